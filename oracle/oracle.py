@@ -1,0 +1,246 @@
+"""ctypes binding of oracle/nnd_oracle.c -- TEST INFRASTRUCTURE ONLY.
+
+Mirrors the reference call sequence of ``NNDescent.__init__`` for the dense
+euclidean / cosine branch (reference pynndescent_.py:1105-1133, 1247-1260):
+RandomState draws -> make_forest -> rptree_leaf_array -> nn_descent.
+The product path (pynndescent_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+INT32_MIN = np.iinfo(np.int32).min + 1  # reference pynndescent_.py:62
+INT32_MAX = np.iinfo(np.int32).max - 1  # reference pynndescent_.py:63
+METRICS = {"euclidean": 0, "l2": 0, "cosine": 1}
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+
+
+class Trace(C.Structure):
+    _fields_ = [
+        ("n_iters_run", C.c_int64),
+        ("c", C.c_int64 * 64),
+        ("pairs", C.c_int64 * 64),
+        ("generated", C.c_int64 * 64),
+    ]
+
+
+def build(force=False):
+    """Compile both oracle libraries (gcc); no-op when they are up to date."""
+    out = os.path.join(_HERE, "_build")
+    src = os.path.join(_HERE, "nnd_oracle.c")
+    libs = [os.path.join(out, "liboracle_strict.so"), os.path.join(out, "liboracle_fast.so")]
+    stale = force or any(
+        (not os.path.exists(p)) or os.path.getmtime(p) < os.path.getmtime(src) for p in libs
+    )
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "all"])
+    return libs
+
+
+_LIBS = {}
+
+
+def load(kind="strict"):
+    """Load ``liboracle_<kind>.so`` (kind: 'strict' for parity pins, 'fast' for timing)."""
+    if kind in _LIBS:
+        return _LIBS[kind]
+    path = os.path.join(_HERE, "_build", "liboracle_%s.so" % kind)
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    lib.orc_tau_rand_int.argtypes = [_i64p]
+    lib.orc_tau_rand_int.restype = C.c_int32
+    lib.orc_tau_rand.argtypes = [_i64p]
+    lib.orc_tau_rand.restype = C.c_float
+    for name in ("orc_squared_euclidean", "orc_alternative_cosine"):
+        fn = getattr(lib, name)
+        fn.argtypes = [_f32p, _f32p, C.c_int]
+        fn.restype = C.c_float
+    for name in ("orc_euclidean", "orc_cosine"):
+        fn = getattr(lib, name)
+        fn.argtypes = [_f32p, _f32p, C.c_int]
+        fn.restype = C.c_double
+    lib.orc_correct_distances.argtypes = [_f32p, _f64p, C.c_int64, C.c_int]
+    lib.orc_make_heap.argtypes = [_i32p, _f32p, _u8p, C.c_int64, C.c_int]
+    lib.orc_checked_flagged_heap_push.argtypes = [_f32p, _i32p, _u8p, C.c_int, C.c_float, C.c_int32, C.c_uint8]
+    lib.orc_checked_flagged_heap_push.restype = C.c_int
+    lib.orc_checked_heap_push.argtypes = [_f32p, _i32p, C.c_int, C.c_float, C.c_int32]
+    lib.orc_checked_heap_push.restype = C.c_int
+    lib.orc_deheap_sort.argtypes = [_i32p, _f32p, C.c_int64, C.c_int]
+    for name in ("orc_euclidean_split", "orc_angular_split"):
+        fn = getattr(lib, name)
+        fn.argtypes = [_f32p, C.c_int, _i32p, C.c_int, _i64p, _i8p, _f32p, C.POINTER(C.c_float)]
+        fn.restype = C.c_int
+    lib.orc_make_forest_leaf_array.argtypes = [
+        _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, C.c_int, C.c_int,
+        C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+    ]
+    lib.orc_make_forest_leaf_array.restype = C.POINTER(C.c_int32)
+    lib.orc_free.argtypes = [C.c_void_p]
+    lib.orc_init_rp_tree.argtypes = [
+        _f32p, C.c_int64, C.c_int, C.c_int, _i32p, _f32p, _u8p, C.c_int, _i32p, C.c_int64, C.c_int, C.c_int,
+    ]
+    lib.orc_init_random.argtypes = [_f32p, C.c_int64, C.c_int, C.c_int, _i32p, _f32p, _u8p, C.c_int, _i64p]
+    lib.orc_init_from_graph.argtypes = [
+        _f32p, C.c_int64, C.c_int, C.c_int, _i32p, _f32p, _u8p, C.c_int, _i32p, C.c_void_p, C.c_int,
+    ]
+    lib.orc_new_build_candidates.argtypes = [
+        _i32p, _u8p, C.c_int64, C.c_int, C.c_int, _i64p, C.c_int, _i32p, _i32p,
+    ]
+    lib.orc_nn_descent_internal.argtypes = [
+        _f32p, C.c_int64, C.c_int, C.c_int, _i32p, _f32p, _u8p, C.c_int, _i64p, C.c_int, C.c_int, C.c_float,
+        C.c_int, C.POINTER(Trace),
+    ]
+    lib.orc_nn_descent.argtypes = [
+        _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, C.c_int, C.c_int, C.c_float, _i32p, C.c_int64,
+        C.c_int, _i32p, _f32p, _u8p, C.c_int, C.c_int, C.POINTER(Trace),
+    ]
+    lib.orc_nn_descent.restype = C.c_int
+    lib.orc_brute_force_knn.argtypes = [
+        _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, _i32p, _f64p,
+    ]
+    lib.orc_num_threads.restype = C.c_int
+    _LIBS[kind] = lib
+    return lib
+
+
+# ----------------------------------------------------------------------------
+# reference-shaped helpers
+
+
+def default_n_trees(n):  # reference pynndescent_.py:1009-1010
+    return max(3, min(12, int(round(2.0 * np.log10(n)))))
+
+
+def default_n_iters(n):  # reference pynndescent_.py:1011-1012
+    return max(5, int(round(np.log2(n))))
+
+
+def default_leaf_size(n_neighbors):  # reference rp_trees.py:2845-2846
+    return max(60, min(256, 5 * int(n_neighbors)))
+
+
+def draw_rng_states(random_state, n_trees, tree_init=True):
+    """The three RandomState draws of the build, in reference order
+    (pynndescent_.py:1105-1110, rp_trees.py:2850)."""
+    rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+    rng_state = rs.randint(INT32_MIN, INT32_MAX, 3).astype(np.int64)
+    search_rng_state = rs.randint(INT32_MIN, INT32_MAX, 3).astype(np.int64)
+    tree_states = (
+        rs.randint(INT32_MIN, INT32_MAX, size=(n_trees, 3)).astype(np.int64)
+        if (tree_init and n_trees > 0)
+        else np.zeros((0, 3), np.int64)
+    )
+    return rng_state, search_rng_state, tree_states
+
+
+def make_leaf_array(data, n_trees, leaf_size, tree_states, angular, max_depth=200, lib=None):
+    """make_forest + rptree_leaf_array (reference rp_trees.py:2815-2922)."""
+    lib = lib or load()
+    data = np.ascontiguousarray(data, np.float32)
+    if n_trees == 0:
+        return np.array([[-1]], dtype=np.int32)
+    nl = C.c_int64()
+    ms = C.c_int32()
+    ptr = lib.orc_make_forest_leaf_array(
+        data, data.shape[0], data.shape[1], n_trees, leaf_size,
+        np.ascontiguousarray(tree_states, np.int64), int(bool(angular)), max_depth, C.byref(nl), C.byref(ms),
+    )
+    arr = np.ctypeslib.as_array(ptr, shape=(max(nl.value, 1), ms.value)).copy()[: nl.value]
+    lib.orc_free(ptr)
+    return arr
+
+
+def nn_descent(data, n_neighbors, rng_state, max_candidates, metric, n_iters, delta, leaf_array,
+               n_threads=8, init=None, lib=None, return_trace=False):
+    """reference pynndescent_.py:323-366. Returns (indices, alt-space distances), rows ascending."""
+    lib = lib or load()
+    data = np.ascontiguousarray(data, np.float32)
+    n, dim = data.shape
+    k = int(n_neighbors)
+    if init is None:
+        hi = np.empty((n, k), np.int32)
+        hd = np.empty((n, k), np.float32)
+        hf = np.empty((n, k), np.uint8)
+        have = 0
+    else:
+        hi, hd, hf = (np.ascontiguousarray(a).copy() for a in init)
+        have = 1
+    la = np.ascontiguousarray(leaf_array, np.int32)
+    tr = Trace()
+    st = np.ascontiguousarray(rng_state, np.int64)
+    lib.orc_nn_descent(data, n, dim, METRICS[metric], k, st, int(max_candidates), int(n_iters), float(delta),
+                       la, la.shape[0], la.shape[1], hi, hd, hf, have, int(n_threads), C.byref(tr))
+    if return_trace:
+        it = tr.n_iters_run
+        return hi, hd, {"iters": it, "c": list(tr.c[:it]), "pairs": list(tr.pairs[:it]),
+                        "generated": list(tr.generated[:it])}
+    return hi, hd
+
+
+def build_index(data, metric="euclidean", n_neighbors=30, n_trees=None, leaf_size=None, random_state=None,
+                max_candidates=None, n_iters=None, delta=0.001, tree_init=True, max_rptree_depth=200,
+                n_threads=8, kind="strict", return_trace=False):
+    """The dense build of ``NNDescent.__init__`` (reference pynndescent_.py:976-1260), CPU oracle.
+    Returns (indices int32 (n,k), alt-space distances f32 (n,k))[, trace]."""
+    lib = load(kind)
+    data = np.ascontiguousarray(data, np.float32)
+    n = data.shape[0]
+    if n_trees is None:
+        n_trees = default_n_trees(n)
+    if n_iters is None:
+        n_iters = default_n_iters(n)
+    tree_init = bool(tree_init) and n_trees > 0
+    rng_state, _, tree_states = draw_rng_states(random_state, n_trees, tree_init)
+    if tree_init:
+        ls = default_leaf_size(n_neighbors) if leaf_size is None else leaf_size
+        leaf_array = make_leaf_array(data, n_trees, ls, tree_states, metric == "cosine", max_rptree_depth, lib)
+    else:
+        leaf_array = np.array([[-1]], dtype=np.int32)
+    mc = min(60, n_neighbors) if max_candidates is None else max_candidates  # pynndescent_.py:1135-1138
+    return nn_descent(data, n_neighbors, rng_state, mc, metric, n_iters, delta, leaf_array,
+                      n_threads=n_threads, lib=lib, return_trace=return_trace)
+
+
+def correct_distances(alt, metric):
+    """``_distance_correction`` (reference distances.py:2170-2173, 704-711)."""
+    lib = load()
+    alt = np.ascontiguousarray(alt, np.float32)
+    out = np.empty(alt.shape, np.float64)
+    lib.orc_correct_distances(alt.reshape(-1), out.reshape(-1), alt.size, METRICS[metric])
+    return out
+
+
+def brute_force_knn(data, k, metric="euclidean", rows=None, kind="fast"):
+    """Exact kNN, self included, true-metric float64 distances (ground truth T2)."""
+    lib = load(kind)
+    data = np.ascontiguousarray(data, np.float32)
+    n, dim = data.shape
+    if rows is None:
+        nr, rp = n, None
+    else:
+        rows = np.ascontiguousarray(rows, np.int64)
+        nr, rp = rows.shape[0], rows.ctypes.data_as(C.c_void_p)
+    oi = np.empty((nr, k), np.int32)
+    od = np.empty((nr, k), np.float64)
+    lib.orc_brute_force_knn(data, n, dim, METRICS[metric], k, rp, nr, oi, od)
+    return oi, od
+
+
+def recall(true_idx, approx_idx, k_true=None):
+    """Reference-test convention (tests/test_pynndescent_.py:27-31): fraction of the true
+    top-``k_true`` found anywhere in the approximate row."""
+    k_true = true_idx.shape[1] if k_true is None else k_true
+    hits = 0
+    for t, a in zip(true_idx[:, :k_true], approx_idx):
+        hits += np.isin(t, a).sum()
+    return hits / float(true_idx.shape[0] * k_true)
