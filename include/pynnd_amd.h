@@ -1,0 +1,156 @@
+/*
+ * pynnd_amd.h -- C ABI of the MI355X (gfx950) NN-Descent index builder.
+ *
+ * This is the drop-in boundary for the BUILD path of lmcinnes/pynndescent 0.6.0.
+ * The reference has no FFI of its own (it is Python + numba); the boundary is the
+ * two call sites inside NNDescent.__init__ (reference pynndescent/pynndescent_.py):
+ *
+ *     make_forest(...) + rptree_leaf_array(...)      pynndescent_.py:1118-1130
+ *     nn_descent(data, n_neighbors, rng_state, max_candidates, dist, n_iters,
+ *                delta, init_graph, rp_tree_init, leaf_array, ...)
+ *                                                    pynndescent_.py:1247-1260
+ *
+ * Each entry point below names the reference function(s) it replaces.  All
+ * pointers are plain host or device pointers, all sizes are explicit, no C++ or
+ * torch types cross the boundary.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Every function returns 0 on success, non-zero on failure; the message is
+ *     available from nnd_last_error(handle) (or nnd_last_global_error() when no
+ *     handle exists yet).  There is NO CPU fallback: without a gfx950 device
+ *     nnd_create fails.
+ *   - "alt space": distances are squared-euclidean (metric 0) or
+ *     log2(|x||y|/<x,y>) (metric 1), exactly what the reference keeps in
+ *     NNDescent._neighbor_graph (distances.py:63-91, 583-630); the caller applies
+ *     sqrt / 1-2^-d itself (distances.py:2170-2173), as NNDescent.neighbor_graph does.
+ *   - Output rows are ascending in distance; missing entries are (-1, +inf) at
+ *     the row tail (utils.py:130-158, 189-218).
+ *   - One handle = one GPU = one HIP stream.  Calls on one handle must be
+ *     serialised by the caller; distinct handles are independent.
+ */
+#ifndef PYNND_AMD_H
+#define PYNND_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NND_METRIC_SQEUCLIDEAN 0 /* reference distances.py:63  squared_euclidean  */
+#define NND_METRIC_ALT_COSINE 1  /* reference distances.py:583 alternative_cosine */
+
+#define NND_ABI_VERSION 1
+
+typedef struct nnd_handle_s *nnd_handle_t;
+
+/* Build parameters; mirrors the NNDescent ctor kwargs that reach the build path
+ * (pynndescent_.py:976-1007) after the ctor's defaulting (pynndescent_.py:1009-1012,
+ * 1135-1138; rp_trees.py:2845-2846).  The host code does the defaulting. */
+typedef struct nnd_params {
+    int64_t n;              /* points */
+    int32_t dim;            /* features */
+    int32_t metric;         /* NND_METRIC_* */
+    int32_t n_neighbors;    /* k, 1..64 */
+    int32_t n_trees;        /* 0 = no RP-forest initialisation */
+    int32_t leaf_size;      /* > 0 */
+    int32_t max_depth;      /* max_rptree_depth (pynndescent_.py:1000) */
+    int32_t max_candidates; /* 1..64 */
+    int32_t n_iters;
+    float delta;            /* stop when c <= delta*k*n (pynndescent_.py:317) */
+    int64_t rng_state[3];   /* NNDescent.rng_state (pynndescent_.py:1105-1107) */
+    int64_t tree_rng[3];    /* first row of make_forest's per-tree draw (rp_trees.py:2850) */
+    int32_t device;         /* HIP device ordinal */
+    int32_t join_blocks;    /* descent sub-steps per iteration (>=1); reference blocks by 16384 vertices (pynndescent_.py:279) */
+    int32_t reserved[6];
+} nnd_params;
+
+/* Run-time statistics for measurement (bench.py roofline). */
+typedef struct nnd_stats {
+    int64_t n_iters_run;
+    int64_t n_leaves;
+    int64_t tree_levels;
+    int64_t leaf_pairs;          /* pair distances evaluated during leaf seeding */
+    int64_t leaf_rows;           /* point rows loaded by the leaf kernel */
+    int64_t join_pairs[64];      /* P_i: pair distances evaluated, per iteration */
+    int64_t join_rows[64];       /* C_i: candidate rows gathered, per iteration */
+    int64_t join_active[64];     /* vertices with >=1 new candidate, per iteration */
+    int64_t proposals[64];       /* proposals emitted by the join, per iteration */
+    int64_t updates[64];         /* c: accepted k-list insertions, per iteration */
+    float ms_prep, ms_forest, ms_leaf_init, ms_random_init, ms_descent, ms_finalize;
+    float ms_sample[64], ms_join[64], ms_merge[64];
+} nnd_stats;
+
+int32_t nnd_abi_version(void);
+const char *nnd_last_global_error(void);
+const char *nnd_last_error(nnd_handle_t h);
+
+/* Create a builder on params->device and allocate its HBM state (k-lists,
+ * candidate lists, proposal buffers).  Fails if the device is not gfx950. */
+int32_t nnd_create(nnd_handle_t *out, const nnd_params *params);
+int32_t nnd_destroy(nnd_handle_t h);
+
+/* Point set, float32 C-contiguous (n, dim) -- NNDescent._raw_data (pynndescent_.py:1054-1057).
+ * Host variant copies H2D; device variant BORROWS the pointer (it must outlive the handle's
+ * build calls).  Both then run the prep kernel (pad to 32 floats, centre / L2-normalise, norms). */
+int32_t nnd_set_data_host(nnd_handle_t h, const float *x);
+int32_t nnd_set_data_device(nnd_handle_t h, const float *x_dev);
+
+/* make_forest (rp_trees.py:2815-2888): builds all n_trees trees level-synchronously on device. */
+int32_t nnd_make_forest(nnd_handle_t h);
+/* rptree_leaf_array (rp_trees.py:2891-2922): shape query then copy, int32 (n_leaves, max_leaf_size), -1 padded. */
+int32_t nnd_leaf_array_shape(nnd_handle_t h, int64_t *n_leaves, int32_t *max_leaf_size);
+int32_t nnd_get_leaf_array(nnd_handle_t h, int32_t *out_host);
+
+/* make_heap (utils.py:130-158): reset the k-lists to (-1, +inf, 0). */
+int32_t nnd_reset_graph(nnd_handle_t h);
+/* init_rp_tree + generate_leaf_updates (pynndescent_.py:73-185): all-pairs inside every leaf. */
+int32_t nnd_init_from_leaves(nnd_handle_t h);
+/* init_random (pynndescent_.py:188-203): top up rows that are not full with random points. */
+int32_t nnd_init_random(nnd_handle_t h);
+/* initalize_heap_from_graph_indices[_and_distances] (utils.py:836-860), used for init_graph /
+ * init_dist (pynndescent_.py:1225-1242).  init_dist may be NULL. Host pointers, (n, width). */
+int32_t nnd_init_from_graph(nnd_handle_t h, const int32_t *init_idx, const float *init_dist, int32_t width);
+
+/* One iteration of nn_descent_internal (pynndescent_.py:296-320):
+ * new_build_candidates (utils.py:221-320) + generate_graph_update_array (utils.py:536-658)
+ * + apply_graph_update_array (utils.py:661-733).  *c_out = number of k-list insertions. */
+int32_t nnd_descent_iter(nnd_handle_t h, int64_t *c_out);
+/* The whole loop with the reference's stop rule (pynndescent_.py:317). */
+int32_t nnd_descent(nnd_handle_t h);
+
+/* deheap_sort (utils.py:189-218) + exact (f64-accumulated) recomputation of the n*k distances.
+ * Writes int32 (n,k) indices and float32 (n,k) alt-space distances. */
+int32_t nnd_finalize_host(nnd_handle_t h, int32_t *out_idx, float *out_dist);
+int32_t nnd_finalize_device(nnd_handle_t h, int32_t *out_idx_dev, float *out_dist_dev);
+
+/* Everything between "data is resident" and "graph is resident":
+ * forest -> leaf init -> random init -> descent -> finalize (device outputs). */
+int32_t nnd_build_device(nnd_handle_t h, int32_t *out_idx_dev, float *out_dist_dev);
+
+/* One-shot host-buffer build == make_forest + rptree_leaf_array + nn_descent of the reference
+ * (pynndescent_.py:1118-1130, 1247-1260).  init_idx/init_dist nullable (init_graph path). */
+int32_t nnd_build(const nnd_params *params, const float *x, const int32_t *init_idx, const float *init_dist,
+                  int32_t init_width, int32_t *out_idx, float *out_dist, nnd_stats *stats, char *err,
+                  int32_t errlen);
+
+int32_t nnd_get_stats(nnd_handle_t h, nnd_stats *out);
+int32_t nnd_synchronize(nnd_handle_t h);
+
+/* ---- introspection used by the parity tests (device state -> host) ---- */
+/* Current k-lists, unsorted-by-contract but kept ascending: int32 idx (-1 empty), f32 dist, u8 new-flag. */
+int32_t nnd_get_graph(nnd_handle_t h, int32_t *idx, float *dist, uint8_t *flags);
+/* Candidate lists of the last nnd_descent_iter: int32 (n, max_candidates) each, -1 padded. */
+int32_t nnd_get_candidates(nnd_handle_t h, int32_t *new_idx, int32_t *old_idx);
+/* Sampling only (no join): fills the candidate lists and clears sampled new-flags. */
+int32_t nnd_sample_candidates(nnd_handle_t h);
+/* Pairwise alt-space distances between listed rows, computed by the same MFMA Gram tile code
+ * the join uses: out (na, nb) float32 host. */
+int32_t nnd_pairwise_gram(nnd_handle_t h, const int32_t *rows_a, int32_t na, const int32_t *rows_b, int32_t nb,
+                          float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYNND_AMD_H */

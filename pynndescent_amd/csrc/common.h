@@ -1,0 +1,112 @@
+// common.h -- shared device helpers for the gfx950 NN-Descent kernels.
+// Wave = 64 lanes everywhere (CDNA4); nothing here is portable to 32-wide warps on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NND_WAVE 64
+#define NND_EMPTY_E 0xFFFFFFFFu           // empty k-list slot (reference: index -1, utils.py:153)
+#define NND_NEW_BIT 0x80000000u           // "new" flag packed into bit 31 of the neighbour word (utils.py:155 flags)
+#define NND_IDX_MASK 0x7FFFFFFFu
+#define NND_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define NND_FLT_MAX 3.402823466e+38f
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- hashing --
+// Counter-based RNG: every random decision is a pure function of (seed, ids), so the build is
+// deterministic for a given seed on any launch geometry.  Replaces the sequential Tausworthe
+// streams of the reference (utils.py:17-57); only statistical equivalence is required
+// (SURVEY.md Appendix A5 "quirk" notes).
+__host__ __device__ __forceinline__ uint32_t nnd_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t nnd_hash2(uint32_t seed, uint32_t a) {
+    return nnd_mix32(seed ^ nnd_mix32(a + 0x9E3779B9u));
+}
+__host__ __device__ __forceinline__ uint32_t nnd_hash3(uint32_t seed, uint32_t a, uint32_t b) {
+    return nnd_mix32(nnd_hash2(seed, a) ^ nnd_mix32(b * 0x85EBCA6Bu + 0xC2B2AE35u));
+}
+
+// ------------------------------------------------------------ wave helpers --
+__device__ __forceinline__ int nnd_lane() { return (int)(threadIdx.x & 63); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int nnd_prefix_popc(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+__device__ __forceinline__ int nnd_wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float nnd_wave_sum_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double nnd_wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over the 16 lanes of an aligned 16-lane group
+__device__ __forceinline__ float nnd_group16_sum_f32(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Make this wave's LDS writes visible to its own later LDS reads (cross-lane through LDS).
+// One wave executes LDS operations in order; this only stops the compiler from reordering
+// and waits for outstanding LDS traffic.
+__device__ __forceinline__ void nnd_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ------------------------------------------------------------ key packing --
+// Non-negative floats order like their bit patterns; every distance this code ranks is clamped >= 0.
+__device__ __forceinline__ uint64_t nnd_make_key(float d, uint32_t idx) {
+    return ((uint64_t)__float_as_uint(d) << 32) | (uint64_t)(idx & NND_IDX_MASK);
+}
+__device__ __forceinline__ float nnd_key_dist(uint64_t key) { return __uint_as_float((uint32_t)(key >> 32)); }
+__device__ __forceinline__ uint32_t nnd_key_idx(uint64_t key) { return (uint32_t)key & NND_IDX_MASK; }
+
+__device__ __forceinline__ float nnd_clamp_dist(float d) { return d > 0.0f ? d : 0.0f; }
+
+// Gram value -> alt-space distance.
+//   euclid: |a|^2 + |b|^2 - 2<a,b>          (reference distances.py:63-91 in Gram form)
+//   cosine: rows are pre-normalised, na/nb are 1 (non-zero row) or 0 (zero row):
+//           0 if both zero, FLT_MAX if one zero or <a,b> <= 0, else -log2(<a,b>) (distances.py:583-630)
+__device__ __forceinline__ float nnd_gram_to_dist(int metric, float g, float na, float nb) {
+    if (metric == 0) return nnd_clamp_dist(na + nb - 2.0f * g);
+    if (na == 0.0f && nb == 0.0f) return 0.0f;
+    if (na == 0.0f || nb == 0.0f || g <= 0.0f) return NND_FLT_MAX;
+    return nnd_clamp_dist(-__log2f(g));
+}
+
+// Swizzled LDS addressing for row tiles read as MFMA operands.
+// A tile row holds DC floats = DC/4 16-byte chunks.  Chunk c of row r is stored at chunk position
+// c ^ (r & SWZ_MASK): rows that differ in their low bits land in different 16-byte bank slots, so
+// the 16 lanes of an MFMA operand group (16 consecutive rows, same chunk) read conflict-free.
+template <int DC>
+__device__ __forceinline__ int nnd_swz(int row, int chunk) {
+    constexpr int NCH = DC / 4;
+    constexpr int MASK = (NCH >= 16) ? 15 : (NCH - 1);
+    return row * DC + ((chunk ^ (row & MASK)) << 2);
+}
+
+#define NND_HIP_CHECK(expr)                                                                         \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            ctx->set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                               \
+        }                                                                                           \
+    } while (0)

@@ -1,0 +1,118 @@
+// prep.hip -- one-time preparation of the point set in HBM, k-list reset, counters.
+//
+// Layout decisions (DESIGN.md "Data layout"):
+//   xp  (n, dp) float32, dp = dim rounded up to 32 floats so every row is a whole number of
+//       128-byte lines; euclidean rows are centred on the column mean (distances are translation
+//       invariant; centring shrinks |x|^2 and with it the cancellation error of the Gram form),
+//       cosine rows are L2-normalised once (the reference recomputes both norms in every
+//       distance call, distances.py:617-620); zero rows stay zero and are flagged in nrm.
+//   nrm (n) float32: |xp_i|^2 for euclidean; 1 (non-zero row) / 0 (zero row) for cosine.
+#include "common.h"
+#include "state.h"
+
+// ---- column means, deterministic two-stage reduction (no float atomics) ----
+__global__ void k_colsum_partial(const float *__restrict__ x, int64_t n, int d, int rows_per_block,
+                                 double *__restrict__ partial) {
+    int j = threadIdx.x;  // column
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    for (; j < d; j += blockDim.x) {
+        double s = 0.0;
+        for (int64_t r = r0; r < r1; r++) s += (double)x[r * d + j];
+        partial[(int64_t)blockIdx.x * d + j] = s;
+    }
+}
+__global__ void k_colsum_final(const double *__restrict__ partial, int nblocks, int d, int dp, int64_t n,
+                               float *__restrict__ mean) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= dp) return;
+    double s = 0.0;
+    if (j < d)
+        for (int b = 0; b < nblocks; b++) s += partial[(int64_t)b * d + j];
+    mean[j] = j < d ? (float)(s / (double)n) : 0.0f;
+}
+
+// ---- one wave per row: pad + centre / normalise + norm ----
+__global__ __launch_bounds__(256) void k_prep_rows(const float *__restrict__ x, int64_t n, int d, int dp, int metric,
+                                                   const float *__restrict__ mean, float *__restrict__ xp,
+                                                   float *__restrict__ nrm) {
+    int lane = nnd_lane();
+    int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *src = x + row * d;
+    float *dst = xp + row * dp;
+    if (metric == 0) {
+        float s = 0.0f;
+        for (int j = lane; j < dp; j += 64) {
+            float v = j < d ? src[j] - mean[j] : 0.0f;
+            dst[j] = v;
+            s += v * v;
+        }
+        s = nnd_wave_sum_f32(s);
+        if (lane == 0) nrm[row] = s;
+    } else {
+        float s = 0.0f;
+        for (int j = lane; j < d; j += 64) {
+            float v = src[j];
+            s += v * v;
+        }
+        s = nnd_wave_sum_f32(s);
+        float inv = s > 0.0f ? 1.0f / sqrtf(s) : 0.0f;
+        for (int j = lane; j < dp; j += 64) dst[j] = j < d ? src[j] * inv : 0.0f;
+        if (lane == 0) nrm[row] = s > 0.0f ? 1.0f : 0.0f;
+    }
+}
+
+int nnd_launch_prep(nnd_ctx *ctx) {
+    int64_t n = ctx->n;
+    int d = ctx->d, dp = ctx->dp;
+    if (ctx->p.metric == 0) {
+        int rows_per_block = 4096;
+        int nblocks = (int)((n + rows_per_block - 1) / rows_per_block);
+        double *partial = nullptr;
+        NND_HIP_CHECK(hipMallocAsync((void **)&partial, sizeof(double) * (size_t)nblocks * d, ctx->stream));
+        hipLaunchKernelGGL(k_colsum_partial, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->x_orig, n, d,
+                           rows_per_block, partial);
+        hipLaunchKernelGGL(k_colsum_final, dim3((dp + 255) / 256), dim3(256), 0, ctx->stream, partial, nblocks, d, dp,
+                           n, ctx->mean);
+        NND_HIP_CHECK(hipFreeAsync(partial, ctx->stream));
+    } else {
+        NND_HIP_CHECK(hipMemsetAsync(ctx->mean, 0, sizeof(float) * dp, ctx->stream));
+    }
+    int64_t blocks = (n + 3) / 4;
+    hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->x_orig, n, d, dp,
+                       ctx->p.metric, ctx->mean, ctx->xp, ctx->nrm);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- make_heap (reference utils.py:130-158): all slots (-1, +inf, flag 0) ----
+__global__ void k_reset_graph(uint32_t *__restrict__ e, float *__restrict__ dd, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        e[i] = NND_EMPTY_E;
+        dd[i] = INFINITY;
+    }
+}
+
+int nnd_launch_reset_graph(nnd_ctx *ctx) {
+    int64_t total = ctx->n * ctx->ks;
+    hipLaunchKernelGGL(k_reset_graph, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e,
+                       ctx->knn_d, total);
+    NND_HIP_CHECK(hipMemsetAsync(ctx->pbuf, 0xFF, sizeof(uint64_t) * (size_t)ctx->n * ctx->pcap, ctx->stream));
+    NND_HIP_CHECK(hipMemsetAsync(ctx->rbuf, 0xFF, sizeof(uint64_t) * (size_t)ctx->n * 2 * ctx->rcap, ctx->stream));
+    NND_HIP_CHECK(hipGetLastError());
+    ctx->iter = 0;
+    return 0;
+}
+
+int nnd_zero_counters(nnd_ctx *ctx) {
+    NND_HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(long long) * CNT_COUNT, ctx->stream));
+    return 0;
+}
+int nnd_read_counters(nnd_ctx *ctx) {
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_counters, ctx->counters, sizeof(long long) * CNT_COUNT, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}

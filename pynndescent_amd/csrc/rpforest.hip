@@ -1,0 +1,435 @@
+// rpforest.hip -- random-projection forest, built level-synchronously for ALL trees at once.
+//
+// Replaces make_forest / make_dense_tree / make_euclidean_tree / make_angular_tree and the
+// *_random_projection_split functions (reference rp_trees.py:41-171, 304-420, 2173-2302,
+// 2515-2554, 2815-2888) and rptree_leaf_array (rp_trees.py:2891-2922).
+//
+// The reference recurses per tree (one joblib thread per tree).  Here every tree lives in one
+// position space of P = n_trees * n slots: perm[g] is the point at position g, each tree node is a
+// contiguous segment of positions, and one level of ALL nodes of ALL trees is processed by a fixed
+// sequence of launches:
+//   k_hyperplane : one wave per splittable segment: two random members -> hyperplane (+offset)
+//   k_margin     : 16 lanes per position: margin = h.x + off -> side bit (coin flip if |m| < 1e-8)
+//   scan         : exclusive scan of "goes left" over all positions (3 launches)
+//   k_seg_count  : per segment n_left; a one-sided split is re-drawn by coin flips (rp_trees.py:393-403)
+//   k_children   : child segments, which of them split again, compacted ids, final-leaf marks
+//   k_scatter    : stable partition of every segment (left block, then right block)
+// Positions stay in depth-first left-to-right order, so the finished permutation IS the leaf
+// array: leaves are the maximal runs between leaf marks.  Only the leaves are consumed by the build
+// (pynndescent_.py:1130); hyperplanes are discarded level by level.
+//
+// Random choices come from the counter hash (common.h), not from a sequential Tausworthe stream:
+// the forest is statistically, not bitwise, the reference's.
+#include "common.h"
+#include "state.h"
+
+#define RP_EPS 1e-8f  // rp_trees.py:23
+
+static constexpr int SCAN_ITEMS = 8;
+static constexpr int SCAN_BLOCK = 256;
+static constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
+
+// ------------------------------------------------------------------ init --
+__global__ void k_forest_init(int32_t *__restrict__ perm, int32_t *__restrict__ pos_seg, uint8_t *__restrict__ leaf_flag,
+                              int64_t n, int64_t P, int splittable) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    int64_t t = g / n;
+    int64_t i = g - t * n;
+    perm[g] = (int32_t)i;
+    pos_seg[g] = splittable ? (int32_t)t : -1;
+    leaf_flag[g] = (!splittable && i == 0) ? 1 : 0;
+}
+__global__ void k_forest_init_segs(int32_t *__restrict__ seg_start, int32_t *__restrict__ seg_len, int n_trees,
+                                   int64_t n) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_trees) {
+        seg_start[t] = (int32_t)(t * n);
+        seg_len[t] = (int32_t)n;
+    }
+}
+
+// ------------------------------------------------------------ hyperplane --
+// One wave per segment.  euclid (rp_trees.py:350-367): h = x_l - x_r, off = -h.(x_l+x_r)/2.
+// angular (rp_trees.py:87-118): h = x_l/|x_l| - x_r/|x_r| normalised, offset 0; xp rows are already
+// L2-normalised (zero rows are zero, matching the reference's "norm := 1" for them).
+__global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp, int dp, const int32_t *__restrict__ perm,
+                                                    const int32_t *__restrict__ seg_start,
+                                                    const int32_t *__restrict__ seg_len, int n_segs, int angular,
+                                                    uint32_t seed, int depth, float *__restrict__ hyper, int hs) {
+    int lane = nnd_lane();
+    int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= n_segs) return;
+    int a = seg_start[s], len = seg_len[s];
+    uint32_t li = nnd_hash3(seed, (uint32_t)a, (uint32_t)(2 * depth)) % (uint32_t)len;
+    uint32_t ri = nnd_hash3(seed, (uint32_t)a, (uint32_t)(2 * depth + 1)) % (uint32_t)len;
+    if (ri == li) ri = (ri + 1) % (uint32_t)len;  // rp_trees.py:353-354
+    const float *xl = xp + (int64_t)perm[a + li] * dp;
+    const float *xr = xp + (int64_t)perm[a + ri] * dp;
+    float *h = hyper + (int64_t)s * hs;
+    float acc = 0.0f;
+    for (int j = lane; j < dp; j += 64) {
+        float l = xl[j], r = xr[j];
+        float v = l - r;
+        h[j] = v;
+        acc += angular ? v * v : v * (l + r);
+    }
+    acc = nnd_wave_sum_f32(acc);
+    if (angular) {
+        float nh = sqrtf(acc);
+        float inv = nh < RP_EPS ? 1.0f : 1.0f / nh;  // rp_trees.py:113-118
+        for (int j = lane; j < dp; j += 64) h[j] *= inv;
+        if (lane == 0) h[dp] = 0.0f;
+    } else if (lane == 0) {
+        h[dp] = -0.5f * acc;
+    }
+}
+
+// ---------------------------------------------------------------- margin --
+__global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, int dp, const int32_t *__restrict__ perm,
+                                                const int32_t *__restrict__ pos_seg, int64_t P,
+                                                const float *__restrict__ hyper, int hs, uint32_t seed, int depth,
+                                                uint8_t *__restrict__ side) {
+    int sub = threadIdx.x & 15;
+    int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    bool live = g < P;
+    int s = live ? pos_seg[g] : -1;
+    float acc = 0.0f;
+    if (s >= 0) {
+        const float4 *x4 = (const float4 *)(xp + (int64_t)perm[g] * dp);
+        const float4 *h4 = (const float4 *)(hyper + (int64_t)s * hs);
+        for (int c = sub; c < (dp >> 2); c += 16) {
+            float4 a = x4[c], b = h4[c];
+            acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+    }
+    acc = nnd_group16_sum_f32(acc);
+    if (s >= 0 && sub == 0) {
+        float m = acc + hyper[(int64_t)s * hs + dp];
+        uint8_t sd;
+        if (fabsf(m) < RP_EPS) sd = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)g, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
+        else sd = m > 0.0f ? 0 : 1;                                                                                // rp_trees.py:386-391
+        side[g] = sd;
+    }
+}
+
+// ------------------------------------------------------------------ scan --
+// exclusive scan over flag(g) = (pos_seg[g] >= 0 && side[g] == 0)  [mode 0]  or  leaf_flag[g] [mode 1]
+__device__ __forceinline__ int scan_flag(int mode, const int32_t *pos_seg, const uint8_t *bytes, int64_t g, int64_t P) {
+    if (g >= P) return 0;
+    if (mode == 0) return (pos_seg[g] >= 0 && bytes[g] == 0) ? 1 : 0;
+    return bytes[g] ? 1 : 0;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(int mode, const int32_t *__restrict__ pos_seg,
+                                                            const uint8_t *__restrict__ bytes, int64_t P,
+                                                            int32_t *__restrict__ blk) {
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) s += scan_flag(mode, pos_seg, bytes, base + i, P);
+    s = nnd_wave_sum_i32(s);
+    if (nnd_lane() == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; w++) t += wsum[w];
+        blk[blockIdx.x] = t;
+    }
+}
+
+// single block: exclusive scan of blk[0..nb) in place; total -> total_out[0]
+__global__ __launch_bounds__(256) void k_scan_blocks(int32_t *__restrict__ blk, int nb, int32_t *__restrict__ total_out) {
+    __shared__ int part[256];
+    int chunk = (nb + 255) / 256;
+    int b0 = threadIdx.x * chunk, b1 = b0 + chunk < nb ? b0 + chunk : nb;
+    int s = 0;
+    for (int b = b0; b < b1; b++) s += blk[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; i++) {
+            int v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        total_out[0] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int b = b0; b < b1; b++) {
+        int v = blk[b];
+        blk[b] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(int mode, const int32_t *__restrict__ pos_seg,
+                                                           const uint8_t *__restrict__ bytes, int64_t P,
+                                                           const int32_t *__restrict__ blk, int32_t *__restrict__ out) {
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    int lane = nnd_lane(), w = threadIdx.x >> 6;
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int f[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        f[i] = scan_flag(mode, pos_seg, bytes, base + i, P);
+        s += f[i];
+    }
+    // inclusive scan of per-thread sums inside the wave
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < w; i++) woff += wsum[i];
+    int run = blk[blockIdx.x] + woff + incl - s;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < P) out[base + i] = run;
+        run += f[i];
+    }
+}
+
+// ------------------------------------------------------------- per segment --
+// n_left from the scan; a one-sided split marks the segment degenerate (side bits are then re-drawn)
+__global__ void k_seg_count(const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_len, int n_segs,
+                            const int32_t *__restrict__ scan, const int32_t *__restrict__ scan_total, int64_t P,
+                            int32_t *__restrict__ nleft, int mark_degenerate, long long *__restrict__ counters) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    int a = seg_start[s], len = seg_len[s];
+    int64_t e = (int64_t)a + len;
+    int hi = e < P ? scan[e] : scan_total[0];
+    int nl = hi - scan[a];
+    if (mark_degenerate && (nl == 0 || nl == len)) {
+        nl = -1;  // marker for k_redraw_sides
+        atomicAdd((unsigned long long *)&counters[CNT_DEGENERATE], 1ull);
+    }
+    nleft[s] = nl;
+}
+
+// rp_trees.py:393-403: every member of a one-sided split is re-assigned by a fair coin
+__global__ void k_redraw_sides(const int32_t *__restrict__ pos_seg, const int32_t *__restrict__ nleft, int64_t P,
+                               uint32_t seed, int depth, uint8_t *__restrict__ side) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    int s = pos_seg[g];
+    if (s >= 0 && nleft[s] < 0) side[g] = (uint8_t)(nnd_hash3(seed ^ 0x1b873593u, (uint32_t)g, (uint32_t)depth) & 1u);
+}
+
+// single block: children of every segment -> next level's segment list (compacted), child ids, leaf marks
+__global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_len,
+                                                  const int32_t *__restrict__ nleft, int n_segs, int leaf_size,
+                                                  int child_can_split, int32_t *__restrict__ next_start,
+                                                  int32_t *__restrict__ next_len, int32_t *__restrict__ seg_child,
+                                                  uint8_t *__restrict__ leaf_flag, long long *__restrict__ counters) {
+    __shared__ int part[256];
+    int chunk = (n_segs + 255) / 256;
+    int s0 = threadIdx.x * chunk, s1 = s0 + chunk < n_segs ? s0 + chunk : n_segs;
+    int cnt = 0;
+    for (int s = s0; s < s1; s++) {
+        int len = seg_len[s], nl = nleft[s];
+        cnt += (child_can_split && nl > leaf_size) + (child_can_split && (len - nl) > leaf_size);
+    }
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; i++) {
+            int v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        counters[CNT_ACTIVE_SEGS] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int s = s0; s < s1; s++) {
+        int a = seg_start[s], len = seg_len[s], nl = nleft[s];
+        int lens[2] = {nl, len - nl};
+        int starts[2] = {a, a + nl};
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (child_can_split && lens[c] > leaf_size) {  // rp_trees.py:2188
+                next_start[run] = starts[c];
+                next_len[run] = lens[c];
+                seg_child[2 * s + c] = run++;
+            } else {
+                seg_child[2 * s + c] = -1;
+                if (lens[c] > 0) leaf_flag[starts[c]] = 1;  // rp_trees.py:2229-2232
+            }
+        }
+    }
+}
+
+// stable partition (rp_trees.py:405-418): lefts keep their order at the front, rights behind them
+__global__ void k_scatter(const int32_t *__restrict__ perm, const int32_t *__restrict__ pos_seg,
+                          const uint8_t *__restrict__ side, const int32_t *__restrict__ scan,
+                          const int32_t *__restrict__ seg_start, const int32_t *__restrict__ nleft,
+                          const int32_t *__restrict__ seg_child, int64_t P, int32_t *__restrict__ perm_out,
+                          int32_t *__restrict__ pos_seg_out) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    int s = pos_seg[g];
+    if (s < 0) {
+        perm_out[g] = perm[g];
+        pos_seg_out[g] = -1;
+        return;
+    }
+    int a = seg_start[s];
+    int L = scan[g] - scan[a];
+    int right = side[g];
+    int64_t dest = right ? (int64_t)a + nleft[s] + ((int)(g - a) - L) : (int64_t)a + L;
+    perm_out[dest] = perm[g];
+    pos_seg_out[dest] = seg_child[2 * s + right];
+}
+
+// ------------------------------------------------------------ leaf tables --
+__global__ void k_leaf_starts(const uint8_t *__restrict__ leaf_flag, const int32_t *__restrict__ scan, int64_t P,
+                              int32_t *__restrict__ leaf_start) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < P && leaf_flag[g]) leaf_start[scan[g]] = (int32_t)g;
+}
+__global__ void k_leaf_lens(const int32_t *__restrict__ leaf_start, int64_t n_leaves, int64_t n, int64_t P,
+                            int32_t *__restrict__ leaf_len) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    int64_t a = leaf_start[i];
+    int64_t e = i + 1 < n_leaves ? leaf_start[i + 1] : P;
+    int64_t tree_end = (a / n + 1) * n;  // leaves never cross a tree boundary
+    if (e > tree_end) e = tree_end;
+    leaf_len[i] = (int32_t)(e - a);
+}
+__global__ void k_fill_leaf_array(const int32_t *__restrict__ perm, const int32_t *__restrict__ leaf_start,
+                                  const int32_t *__restrict__ leaf_len, int64_t n_leaves, int max_leaf,
+                                  int32_t *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_leaves * max_leaf) return;
+    int64_t i = t / max_leaf;
+    int j = (int)(t - i * max_leaf);
+    out[t] = j < leaf_len[i] ? perm[leaf_start[i] + j] : -1;
+}
+
+// -------------------------------------------------------------- host side --
+static int run_scan(nnd_ctx *ctx, int mode, const int32_t *pos_seg, const uint8_t *bytes, int32_t *total_dev) {
+    int64_t P = ctx->P;
+    int nb = (int)((P + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, mode, pos_seg, bytes, P, ctx->scan_blk);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->scan_blk, nb, total_dev);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, mode, pos_seg, bytes, P, ctx->scan_blk,
+                       ctx->scan_out);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int nnd_launch_forest(nnd_ctx *ctx) {
+    const int64_t n = ctx->n, P = ctx->P;
+    const int T = ctx->p.n_trees, dp = ctx->dp, leaf_size = ctx->p.leaf_size, max_depth = ctx->p.max_depth;
+    const int angular = ctx->p.metric == NND_METRIC_ALT_COSINE;
+    const int hs = dp + 4;
+    ctx->forest_built = false;
+    ctx->n_leaves = 0;
+    ctx->max_leaf = leaf_size;
+    ctx->tree_leaf_begin.clear();
+    if (T <= 0) return 0;
+    if (P >= (int64_t)0x7FFFFFF0) {
+        ctx->set_error("n_trees * n = %lld exceeds the int32 position space", (long long)P);
+        return 1;
+    }
+    int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);  // device scratch word(s)
+    int splittable = (n > leaf_size && max_depth > 0) ? 1 : 0;
+    int cur = 0;
+    unsigned gridP = (unsigned)((P + 255) / 256);
+    hipLaunchKernelGGL(k_forest_init, dim3(gridP), dim3(256), 0, ctx->stream, ctx->perm[0], ctx->pos_seg[0],
+                       ctx->leaf_flag, n, P, splittable);
+    hipLaunchKernelGGL(k_forest_init_segs, dim3((T + 63) / 64), dim3(64), 0, ctx->stream, ctx->seg_start[0],
+                       ctx->seg_len[0], T, n);
+    int64_t S = splittable ? T : 0;
+    int depth = 0;
+    while (S > 0) {
+        if (S > ctx->max_segs) {
+            ctx->set_error("rp-forest: %lld segments exceed the allocation of %lld", (long long)S, (long long)ctx->max_segs);
+            return 1;
+        }
+        if (nnd_zero_counters(ctx)) return 1;
+        hipLaunchKernelGGL(k_hyperplane, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, dp,
+                           ctx->perm[cur], ctx->seg_start[cur], ctx->seg_len[cur], (int)S, angular, ctx->tree_seed, depth,
+                           ctx->hyper, hs);
+        hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, dp,
+                           ctx->perm[cur], ctx->pos_seg[cur], P, ctx->hyper, hs, ctx->tree_seed, depth, ctx->side);
+        if (run_scan(ctx, 0, ctx->pos_seg[cur], ctx->side, scan_total)) return 1;
+        hipLaunchKernelGGL(k_seg_count, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, ctx->seg_start[cur],
+                           ctx->seg_len[cur], (int)S, ctx->scan_out, scan_total, P, ctx->seg_nleft, 1, ctx->counters);
+        if (nnd_read_counters(ctx)) return 1;
+        if (ctx->h_counters[CNT_DEGENERATE] > 0) {
+            hipLaunchKernelGGL(k_redraw_sides, dim3(gridP), dim3(256), 0, ctx->stream, ctx->pos_seg[cur], ctx->seg_nleft, P,
+                               ctx->tree_seed, depth, ctx->side);
+            if (run_scan(ctx, 0, ctx->pos_seg[cur], ctx->side, scan_total)) return 1;
+            hipLaunchKernelGGL(k_seg_count, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->seg_start[cur], ctx->seg_len[cur], (int)S, ctx->scan_out, scan_total, P,
+                               ctx->seg_nleft, 0, ctx->counters);
+        }
+        int child_can_split = (max_depth - (depth + 1)) > 0 ? 1 : 0;
+        hipLaunchKernelGGL(k_children, dim3(1), dim3(256), 0, ctx->stream, ctx->seg_start[cur], ctx->seg_len[cur],
+                           ctx->seg_nleft, (int)S, leaf_size, child_can_split, ctx->seg_start[1 - cur],
+                           ctx->seg_len[1 - cur], ctx->seg_child, ctx->leaf_flag, ctx->counters);
+        hipLaunchKernelGGL(k_scatter, dim3(gridP), dim3(256), 0, ctx->stream, ctx->perm[cur], ctx->pos_seg[cur], ctx->side,
+                           ctx->scan_out, ctx->seg_start[cur], ctx->seg_nleft, ctx->seg_child, P, ctx->perm[1 - cur],
+                           ctx->pos_seg[1 - cur]);
+        NND_HIP_CHECK(hipGetLastError());
+        if (nnd_read_counters(ctx)) return 1;
+        S = ctx->h_counters[CNT_ACTIVE_SEGS];
+        cur = 1 - cur;
+        depth++;
+    }
+    ctx->cur = cur;
+    ctx->stats.tree_levels = depth;
+    // leaf tables
+    if (run_scan(ctx, 1, nullptr, ctx->leaf_flag, scan_total)) return 1;
+    int32_t nl = 0;
+    NND_HIP_CHECK(hipMemcpyAsync(&nl, scan_total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->n_leaves = nl;
+    if (ctx->leaf_start) { NND_HIP_CHECK(hipFree(ctx->leaf_start)); ctx->leaf_start = nullptr; }
+    if (ctx->leaf_len) { NND_HIP_CHECK(hipFree(ctx->leaf_len)); ctx->leaf_len = nullptr; }
+    NND_HIP_CHECK(hipMalloc((void **)&ctx->leaf_start, sizeof(int32_t) * (size_t)(nl + 1)));
+    NND_HIP_CHECK(hipMalloc((void **)&ctx->leaf_len, sizeof(int32_t) * (size_t)(nl + 1)));
+    hipLaunchKernelGGL(k_leaf_starts, dim3(gridP), dim3(256), 0, ctx->stream, ctx->leaf_flag, ctx->scan_out, P,
+                       ctx->leaf_start);
+    hipLaunchKernelGGL(k_leaf_lens, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream, ctx->leaf_start,
+                       (int64_t)nl, n, P, ctx->leaf_len);
+    NND_HIP_CHECK(hipGetLastError());
+    std::vector<int32_t> hs_start(nl), hs_len(nl);
+    NND_HIP_CHECK(hipMemcpyAsync(hs_start.data(), ctx->leaf_start, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(hipMemcpyAsync(hs_len.data(), ctx->leaf_len, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    int32_t mx = leaf_size;  // rp_trees.py:2548
+    ctx->tree_leaf_begin.assign(T + 1, nl);
+    int t_next = 0;
+    for (int64_t i = 0; i < nl; i++) {
+        if (hs_len[i] > mx) mx = hs_len[i];
+        int t = (int)(hs_start[i] / n);
+        while (t_next <= t) ctx->tree_leaf_begin[t_next++] = i;
+    }
+    ctx->max_leaf = mx;
+    ctx->stats.n_leaves = nl;
+    ctx->forest_built = true;
+    return 0;
+}
+
+int nnd_launch_leaf_array(nnd_ctx *ctx, int32_t *out_dev) {
+    int64_t total = ctx->n_leaves * ctx->max_leaf;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(k_fill_leaf_array, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->perm[ctx->cur],
+                       ctx->leaf_start, ctx->leaf_len, ctx->n_leaves, ctx->max_leaf, out_dev);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,105 @@
+// state.h -- host-side state of one builder handle (one GPU, one HIP stream) and the
+// launch entry points implemented by the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <vector>
+
+#include "../../include/pynnd_amd.h"
+
+// device-side counters (one int64 each), reset per phase
+enum {
+    CNT_ACCEPT = 0,   // k-list insertions (c of pynndescent_.py:317)
+    CNT_PAIRS,        // pair distances evaluated
+    CNT_ROWS,         // point rows gathered
+    CNT_PROPOSALS,    // proposals emitted by the join
+    CNT_ACTIVE,       // vertices with >=1 new candidate
+    CNT_DEGENERATE,   // rp-forest: segments whose split left one side empty
+    CNT_ACTIVE_SEGS,  // rp-forest: splittable segments for the next level
+    CNT_LEAVES,
+    CNT_SCRATCH,
+    CNT_COUNT = 16
+};
+
+struct nnd_handle_s {
+    nnd_params p{};
+    nnd_stats stats{};
+    char err[512] = {0};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // geometry
+    int64_t n = 0;
+    int d = 0, dp = 0;      // dp = d rounded up to 32 floats (128-byte rows)
+    int k = 0, ks = 0;      // ks = k rounded up to 16 (64-byte k-list rows)
+    int mc = 0, mcp = 0;    // mcp = max_candidates rounded up to 16/32/64
+    int rcap = 0, pcap = 0; // reverse-offer slots per (vertex,class); proposal slots per vertex
+    int iter = 0;
+    uint32_t seed = 0, tree_seed = 0;
+
+    // data
+    const float *x_orig = nullptr; // (n,d) original rows (device); owned iff x_owned
+    bool x_owned = false;
+    float *xp = nullptr;   // (n,dp) prepared rows: centred (euclid) or L2-normalised (cosine), zero padded
+    float *nrm = nullptr;  // (n) |x-mu|^2 (euclid) or 1/0 non-zero flag (cosine)
+    float *mean = nullptr; // (dp)
+
+    // k-lists, rows ascending by (dist, idx)
+    uint32_t *knn_e = nullptr; // (n,ks) neighbour | NEW_BIT ; 0xFFFFFFFF = empty
+    float *knn_d = nullptr;    // (n,ks) alt-space distance ; +inf = empty
+
+    // candidates / proposals
+    int32_t *cand = nullptr;  // (n, 2*mcp): [new | old], -1 padded
+    uint64_t *rbuf = nullptr; // (n, 2, rcap) reverse offers (priority<<32 | source), hashed slots
+    uint64_t *pbuf = nullptr; // (n, pcap) proposals (dist_bits<<32 | source), hashed slots
+
+    // rp forest (all trees in one position space P = n_trees*n)
+    int64_t P = 0;
+    int32_t *perm[2] = {nullptr, nullptr};    // point id per position (ping-pong)
+    int32_t *pos_seg[2] = {nullptr, nullptr}; // active segment index per position or -1
+    uint8_t *side = nullptr;                  // (P) 0 left / 1 right
+    uint8_t *leaf_flag = nullptr;             // (P) 1 at the first position of every final leaf
+    int32_t *scan_out = nullptr;              // (P) exclusive scan scratch
+    int32_t *scan_blk = nullptr;              // block sums
+    int32_t *seg_start[2] = {nullptr, nullptr}, *seg_len[2] = {nullptr, nullptr};
+    int32_t *seg_nleft = nullptr, *seg_child = nullptr; // per active segment scratch
+    float *hyper = nullptr;                   // (max_segs, dp+?) hyperplane + offset
+    int64_t max_segs = 0;
+    int cur = 0; // which ping-pong half holds the finished permutation
+    int32_t *leaf_start = nullptr, *leaf_len = nullptr; // (n_leaves) after the forest is done
+    int64_t n_leaves = 0;
+    int32_t max_leaf = 0;
+    std::vector<int64_t> tree_leaf_begin; // per tree: first leaf index (host)
+    bool forest_built = false;
+
+    long long *counters = nullptr;      // device CNT_COUNT
+    long long h_counters[CNT_COUNT] = {0};
+
+    void set_error(const char *fmt, ...) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(err, sizeof(err), fmt, ap);
+        va_end(ap);
+    }
+};
+typedef nnd_handle_s nnd_ctx;
+
+// ---- implemented in the kernel translation units; each returns 0 / sets ctx->err ----
+int nnd_launch_prep(nnd_ctx *ctx);
+int nnd_launch_reset_graph(nnd_ctx *ctx);
+int nnd_launch_forest(nnd_ctx *ctx);
+int nnd_launch_leaf_array(nnd_ctx *ctx, int32_t *out_dev /* (n_leaves,max_leaf) */);
+int nnd_launch_leaf_init(nnd_ctx *ctx);
+int nnd_launch_random_init(nnd_ctx *ctx);
+int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float *dist_dev, int width);
+int nnd_launch_sample(nnd_ctx *ctx);
+int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end);
+int nnd_launch_merge(nnd_ctx *ctx);
+int nnd_launch_finalize(nnd_ctx *ctx, int32_t *out_idx_dev, float *out_dist_dev);
+int nnd_launch_pairwise(nnd_ctx *ctx, const int32_t *rows_a_dev, int na, const int32_t *rows_b_dev, int nb,
+                        float *out_dev);
+int nnd_read_counters(nnd_ctx *ctx);  // device -> ctx->h_counters (synchronises the stream)
+int nnd_zero_counters(nnd_ctx *ctx);

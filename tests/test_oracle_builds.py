@@ -1,0 +1,161 @@
+"""Whole-pipeline pins of the CPU oracle against reference runs (tests/golden/build_*.npz,
+class_*.npz -- produced by the reference source itself, see tests/golden/make_golden.py).
+
+Euclidean pipelines are reproduced BIT-FOR-BIT at the recorded thread count (sequential f32
+arithmetic, integer RNG).  Cosine pipelines agree statistically: libm's log2f vs numpy's and the
+f64 `norm` accumulator numba uses (utils.py:70) move individual distances by an ulp, which
+changes tie-breaks, so the pin there is recall parity within 0.5 % and distance agreement."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util_data import clustered, nn_data_like
+
+
+def _g(golden_dir, name):
+    path = os.path.join(golden_dir, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture %s missing" % name)
+    return np.load(path)
+
+
+def _oracle_staged(data, metric, g):
+    k, T = int(g["k"]), int(g["n_threads"])
+    return O.build_index(data, metric=metric, n_neighbors=k, n_trees=int(g["n_trees"]), random_state=int(g["seed"]),
+                         n_iters=int(g["n_iters"]), n_threads=T, return_trace=True)
+
+
+@pytest.mark.parametrize("T", [1, 4])
+def test_nndata_euclidean_bit_exact(golden_dir, T):
+    g = _g(golden_dir, "build_nndata_euclidean_T%d" % T)
+    idx, dist, tr = _oracle_staged(nn_data_like(), "euclidean", g)
+    np.testing.assert_array_equal(tr["c"], g["c"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(dist, g["dist"])
+
+
+def test_leaf_array_and_init_bit_exact(golden_dir, oracle_strict):
+    g = _g(golden_dir, "build_nndata_euclidean_T1")
+    x = nn_data_like()
+    rng_state, _, tree_states = O.draw_rng_states(int(g["seed"]), int(g["n_trees"]))
+    la = O.make_leaf_array(x, int(g["n_trees"]), O.default_leaf_size(30), tree_states, False, lib=oracle_strict)
+    np.testing.assert_array_equal(la, g["leaf_array"])
+    n, k = x.shape[0], 30
+    hi = np.empty((n, k), np.int32); hd = np.empty((n, k), np.float32); hf = np.empty((n, k), np.uint8)
+    oracle_strict.orc_make_heap(hi, hd, hf, n, k)
+    oracle_strict.orc_init_rp_tree(x, n, x.shape[1], 0, hi, hd, hf, k, la, la.shape[0], la.shape[1], 8)
+    np.testing.assert_array_equal(hi, g["after_tree_idx"])
+    np.testing.assert_array_equal(hd, g["after_tree_dist"])
+    oracle_strict.orc_init_random(x, n, x.shape[1], 0, hi, hd, hf, k, rng_state)
+    np.testing.assert_array_equal(hi, g["after_init_idx"])
+    np.testing.assert_array_equal(hf, g["after_init_flags"])
+
+
+def test_clustered_euclidean_bit_exact(golden_dir):
+    g = _g(golden_dir, "build_clustered_euclidean_T4")
+    n, d, latent, ncl, seed = (int(v) for v in g["gen"])
+    idx, dist, tr = _oracle_staged(clustered(n, d, latent, ncl, seed), "euclidean", g)
+    np.testing.assert_array_equal(tr["c"], g["c"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(dist, g["dist"])
+
+
+@pytest.mark.slow
+def test_c1_plumbing_config_bit_exact(golden_dir):
+    """BASELINE.json configs[0]: 10k x 64 random, euclidean, k=10, n_iters=5 (reference run, 8 threads)."""
+    g = _g(golden_dir, "build_c1_T8")
+    x = np.random.RandomState(0).standard_normal((10000, 64)).astype(np.float32)
+    idx, dist, tr = _oracle_staged(x, "euclidean", g)
+    np.testing.assert_array_equal(tr["c"], g["c"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(dist, g["dist"])
+
+
+def _recall_pair(x, metric, k_true, ref_idx, got_idx):
+    ti, _ = O.brute_force_knn(x, k_true, metric)
+    return O.recall(ti, ref_idx), O.recall(ti, got_idx)
+
+
+@pytest.mark.parametrize("T", [1, 4])
+def test_nndata_cosine_statistical(golden_dir, T):
+    g = _g(golden_dir, "build_nndata_cosine_T%d" % T)
+    x = nn_data_like()
+    idx, dist, tr = _oracle_staged(x, "cosine", g)
+    r_ref, r_got = _recall_pair(x, "cosine", 10, g["idx"], idx)
+    assert r_ref >= 0.98 and abs(r_ref - r_got) <= 0.005, (r_ref, r_got)
+    same = (idx == g["idx"]) & (g["dist"] < 1e30)
+    assert same.mean() > 0.95
+    np.testing.assert_allclose(dist[same], g["dist"][same], rtol=1e-4, atol=2e-6)
+    # the two all-zero rows are each other's exact neighbour at distance 0 (distances.py:622-623)
+    assert set(idx[1000, :2].tolist()) == {1000, 1001} and dist[1000, 1] == 0.0
+
+
+def test_iid_cosine_statistical(golden_dir):
+    g = _g(golden_dir, "build_iid_cosine_T4")
+    n, d, seed = (int(v) for v in g["gen"])
+    x = np.random.RandomState(seed).standard_normal((n, d)).astype(np.float32)
+    idx, dist, tr = _oracle_staged(x, "cosine", g)
+    r_ref, r_got = _recall_pair(x, "cosine", 10, g["idx"], idx)
+    assert abs(r_ref - r_got) <= 0.005, (r_ref, r_got)
+    assert abs(len(tr["c"]) - len(g["c"])) <= 1
+    assert abs(tr["c"][0] - g["c"][0]) <= 0.02 * g["c"][0]
+
+
+def test_class_level_defaults(golden_dir):
+    """NNDescent(...) with every default, as the reference tests construct it
+    (tests/test_pynndescent_.py:19-53): the oracle's ctor-level defaulting must match."""
+    x = nn_data_like()
+    g = _g(golden_dir, "class_nndata_euclidean")
+    idx, dist = O.build_index(x, "euclidean", n_neighbors=30, random_state=int(g["seed"]), n_threads=1)
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(dist, g["dist"])
+    np.testing.assert_allclose(O.correct_distances(dist, "euclidean"), g["corrected"], rtol=1e-6)
+    g = _g(golden_dir, "class_nndata_cosine")
+    idx, dist = O.build_index(x, "cosine", n_neighbors=30, random_state=int(g["seed"]), n_threads=1)
+    r_ref, r_got = _recall_pair(x, "cosine", 10, g["idx"], idx)
+    assert r_ref >= 0.98 and abs(r_ref - r_got) <= 0.005
+
+
+def test_class_level_no_tree_and_no_split(golden_dir):
+    g = _g(golden_dir, "class_notree_euclidean")
+    x = nn_data_like()[200:]
+    idx, dist = O.build_index(x, "euclidean", n_neighbors=10, random_state=int(g["seed"]), tree_init=False, n_threads=1)
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(dist, g["dist"])
+    g = _g(golden_dir, "class_nosplit_euclidean")
+    idx, dist = O.build_index(g["data"], "euclidean", n_neighbors=9, random_state=int(g["seed"]),
+                              leaf_size=int(g["leaf_size"]), n_threads=1)
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(dist, g["dist"])
+
+
+def test_reference_testdata_duplicates(golden_dir):
+    """Reference tests on duplicate-heavy inputs: rows must hold unique indices
+    (tests/test_pynndescent_.py:299-314, 352-369) and dedup'd data must reach recall 0.95 (317-349)."""
+    g = _g(golden_dir, "reference_testdata_cosine_near_duplicates")
+    idx, _ = O.build_index(g["data"], "cosine", n_neighbors=10, n_trees=20, random_state=int(g["seed"]), n_threads=1)
+    for row in idx:
+        assert len(row) == len(np.unique(row))
+    for row in g["idx"]:
+        assert len(row) == len(np.unique(row))
+    hang = _g(golden_dir, "reference_testdata_cosine_hang")["data"]
+    idx, _ = O.build_index(hang, "cosine", n_neighbors=10, n_trees=20, random_state=189212, n_threads=8, kind="fast")
+    for row in idx:
+        valid = row[row >= 0]
+        assert len(valid) == len(np.unique(valid))
+    data = np.unique(hang, axis=0)
+    data = data[~np.all(data == 0, axis=1)][:1000]
+    gd = _g(golden_dir, "class_dedup_hang_cosine")
+    idx, _ = O.build_index(data, "cosine", n_neighbors=10, n_trees=20, random_state=int(gd["seed"]), n_threads=1)
+    r_ref, r_got = _recall_pair(data, "cosine", 10, gd["idx"], idx)
+    assert r_ref >= 0.95 and r_got >= 0.95 and abs(r_ref - r_got) <= 0.01, (r_ref, r_got)
+
+
+def test_bad_data_smoke(golden_dir):
+    """tests/test_pynndescent_.py:750-756: sqrt of a 1011 x 3500 count matrix, cosine, defaults."""
+    arr = _g(golden_dir, "reference_testdata_bad_data")["arr_0"]
+    data = np.sqrt(arr).astype(np.float32)
+    idx, dist = O.build_index(data, "cosine", n_neighbors=30, random_state=0, n_threads=8, kind="fast")
+    assert idx.shape == (1011, 30) and np.isfinite(dist[idx >= 0]).all()
