@@ -1,0 +1,263 @@
+"""ctypes binding of libpynnd_amd.so (include/pynnd_amd.h).
+
+This is the whole FFI: plain pointers and sizes, no torch types.  The library is built in-tree by
+``__graft_entry__.build()`` / ``make -C pynndescent_amd/csrc``; if it is missing or no gfx950 device
+is present the build path fails loudly -- there is no CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpynnd_amd.so")
+
+NND_METRIC_SQEUCLIDEAN = 0
+NND_METRIC_ALT_COSINE = 1
+
+
+class NNDParams(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("dim", C.c_int32),
+        ("metric", C.c_int32),
+        ("n_neighbors", C.c_int32),
+        ("n_trees", C.c_int32),
+        ("leaf_size", C.c_int32),
+        ("max_depth", C.c_int32),
+        ("max_candidates", C.c_int32),
+        ("n_iters", C.c_int32),
+        ("delta", C.c_float),
+        ("rng_state", C.c_int64 * 3),
+        ("tree_rng", C.c_int64 * 3),
+        ("device", C.c_int32),
+        ("join_blocks", C.c_int32),
+        ("reserved", C.c_int32 * 6),
+    ]
+
+
+class NNDStats(C.Structure):
+    _fields_ = [
+        ("n_iters_run", C.c_int64),
+        ("n_leaves", C.c_int64),
+        ("tree_levels", C.c_int64),
+        ("leaf_pairs", C.c_int64),
+        ("leaf_rows", C.c_int64),
+        ("join_pairs", C.c_int64 * 64),
+        ("join_rows", C.c_int64 * 64),
+        ("join_active", C.c_int64 * 64),
+        ("proposals", C.c_int64 * 64),
+        ("updates", C.c_int64 * 64),
+        ("ms_prep", C.c_float),
+        ("ms_forest", C.c_float),
+        ("ms_leaf_init", C.c_float),
+        ("ms_random_init", C.c_float),
+        ("ms_descent", C.c_float),
+        ("ms_finalize", C.c_float),
+        ("ms_sample", C.c_float * 64),
+        ("ms_join", C.c_float * 64),
+        ("ms_merge", C.c_float * 64),
+    ]
+
+    def as_dict(self):
+        it = int(self.n_iters_run)
+        m = min(it, 64)
+        out = {
+            "n_iters_run": it, "n_leaves": int(self.n_leaves), "tree_levels": int(self.tree_levels),
+            "leaf_pairs": int(self.leaf_pairs), "leaf_rows": int(self.leaf_rows),
+        }
+        for name in ("join_pairs", "join_rows", "join_active", "proposals", "updates"):
+            out[name] = [int(v) for v in getattr(self, name)[:m]]
+        for name in ("ms_prep", "ms_forest", "ms_leaf_init", "ms_random_init", "ms_descent", "ms_finalize"):
+            out[name] = float(getattr(self, name))
+        for name in ("ms_sample", "ms_join", "ms_merge"):
+            out[name] = [float(v) for v in getattr(self, name)[:m]]
+        return out
+
+
+# every symbol include/pynnd_amd.h declares: (name, restype, argtypes)
+_H = C.c_void_p
+_SIGNATURES = [
+    ("nnd_abi_version", C.c_int32, []),
+    ("nnd_last_global_error", C.c_char_p, []),
+    ("nnd_last_error", C.c_char_p, [_H]),
+    ("nnd_create", C.c_int32, [C.POINTER(_H), C.POINTER(NNDParams)]),
+    ("nnd_destroy", C.c_int32, [_H]),
+    ("nnd_set_data_host", C.c_int32, [_H, C.c_void_p]),
+    ("nnd_set_data_device", C.c_int32, [_H, C.c_void_p]),
+    ("nnd_make_forest", C.c_int32, [_H]),
+    ("nnd_leaf_array_shape", C.c_int32, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    ("nnd_get_leaf_array", C.c_int32, [_H, C.c_void_p]),
+    ("nnd_reset_graph", C.c_int32, [_H]),
+    ("nnd_init_from_leaves", C.c_int32, [_H]),
+    ("nnd_init_random", C.c_int32, [_H]),
+    ("nnd_init_from_graph", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int32]),
+    ("nnd_descent_iter", C.c_int32, [_H, C.POINTER(C.c_int64)]),
+    ("nnd_descent", C.c_int32, [_H]),
+    ("nnd_finalize_host", C.c_int32, [_H, C.c_void_p, C.c_void_p]),
+    ("nnd_finalize_device", C.c_int32, [_H, C.c_void_p, C.c_void_p]),
+    ("nnd_build_device", C.c_int32, [_H, C.c_void_p, C.c_void_p]),
+    ("nnd_build", C.c_int32, [C.POINTER(NNDParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                              C.c_void_p, C.POINTER(NNDStats), C.c_char_p, C.c_int32]),
+    ("nnd_get_stats", C.c_int32, [_H, C.POINTER(NNDStats)]),
+    ("nnd_synchronize", C.c_int32, [_H]),
+    ("nnd_get_graph", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nnd_get_candidates", C.c_int32, [_H, C.c_void_p, C.c_void_p]),
+    ("nnd_sample_candidates", C.c_int32, [_H]),
+    ("nnd_pairwise_gram", C.c_int32, [_H, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+]
+EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libpynnd_amd.so and bind every entry point.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C pynndescent_amd/csrc`. pynndescent_amd has no CPU fallback." % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in _SIGNATURES:
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class NNDError(RuntimeError):
+    pass
+
+
+class Builder:
+    """Thin object wrapper over an ``nnd_handle_t`` (one GPU, one stream)."""
+
+    def __init__(self, n, dim, metric, n_neighbors, n_trees, leaf_size, max_depth, max_candidates, n_iters, delta,
+                 rng_state, tree_rng, device=0, join_blocks=1):
+        self.lib = load_library()
+        p = NNDParams()
+        p.n, p.dim, p.metric = int(n), int(dim), int(metric)
+        p.n_neighbors, p.n_trees, p.leaf_size = int(n_neighbors), int(n_trees), int(leaf_size)
+        p.max_depth, p.max_candidates, p.n_iters = int(max_depth), int(max_candidates), int(n_iters)
+        p.delta = float(delta)
+        for i in range(3):
+            p.rng_state[i] = int(rng_state[i])
+            p.tree_rng[i] = int(tree_rng[i])
+        p.device, p.join_blocks = int(device), int(join_blocks)
+        self.params = p
+        self.n, self.dim, self.k, self.mc = int(n), int(dim), int(n_neighbors), int(max_candidates)
+        self._h = _H()
+        if self.lib.nnd_create(C.byref(self._h), C.byref(p)) != 0:
+            raise NNDError(self.lib.nnd_last_global_error().decode())
+        self._keepalive = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NNDError(self.lib.nnd_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.nnd_destroy(self._h)
+            self._h = _H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data -----------------------------------------------------------------------------------
+    def set_data_host(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.shape == (self.n, self.dim)
+        self._check(self.lib.nnd_set_data_host(self._h, _ptr(x)))
+
+    def set_data_device(self, dev_ptr, keepalive=None):
+        """dev_ptr: integer address of a float32 (n, dim) C-contiguous device buffer (e.g. tensor.data_ptr())."""
+        self._keepalive = keepalive
+        self._check(self.lib.nnd_set_data_device(self._h, C.c_void_p(int(dev_ptr))))
+
+    # -- stages ---------------------------------------------------------------------------------
+    def make_forest(self):
+        self._check(self.lib.nnd_make_forest(self._h))
+
+    def leaf_array(self):
+        nl, ms = C.c_int64(), C.c_int32()
+        self._check(self.lib.nnd_leaf_array_shape(self._h, C.byref(nl), C.byref(ms)))
+        out = np.empty((max(nl.value, 1), max(ms.value, 1)), np.int32)
+        self._check(self.lib.nnd_get_leaf_array(self._h, _ptr(out)))
+        return out[: nl.value]
+
+    def reset_graph(self):
+        self._check(self.lib.nnd_reset_graph(self._h))
+
+    def init_from_leaves(self):
+        self._check(self.lib.nnd_init_from_leaves(self._h))
+
+    def init_random(self):
+        self._check(self.lib.nnd_init_random(self._h))
+
+    def init_from_graph(self, idx, dist=None):
+        idx = np.ascontiguousarray(idx, np.int32)
+        dist = None if dist is None else np.ascontiguousarray(dist, np.float32)
+        self._check(self.lib.nnd_init_from_graph(self._h, _ptr(idx), _ptr(dist), idx.shape[1]))
+
+    def descent_iter(self):
+        c = C.c_int64()
+        self._check(self.lib.nnd_descent_iter(self._h, C.byref(c)))
+        return c.value
+
+    def descent(self):
+        self._check(self.lib.nnd_descent(self._h))
+
+    def sample_candidates(self):
+        self._check(self.lib.nnd_sample_candidates(self._h))
+
+    def finalize(self):
+        idx = np.empty((self.n, self.k), np.int32)
+        dist = np.empty((self.n, self.k), np.float32)
+        self._check(self.lib.nnd_finalize_host(self._h, _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def finalize_device(self, idx_ptr, dist_ptr):
+        self._check(self.lib.nnd_finalize_device(self._h, C.c_void_p(int(idx_ptr)), C.c_void_p(int(dist_ptr))))
+
+    def build_device(self, idx_ptr, dist_ptr):
+        self._check(self.lib.nnd_build_device(self._h, C.c_void_p(int(idx_ptr)), C.c_void_p(int(dist_ptr))))
+
+    def synchronize(self):
+        self._check(self.lib.nnd_synchronize(self._h))
+
+    # -- introspection --------------------------------------------------------------------------
+    def stats(self):
+        s = NNDStats()
+        self._check(self.lib.nnd_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def graph(self):
+        idx = np.empty((self.n, self.k), np.int32)
+        dist = np.empty((self.n, self.k), np.float32)
+        flags = np.empty((self.n, self.k), np.uint8)
+        self._check(self.lib.nnd_get_graph(self._h, _ptr(idx), _ptr(dist), _ptr(flags)))
+        return idx, dist, flags
+
+    def candidates(self):
+        new = np.empty((self.n, self.mc), np.int32)
+        old = np.empty((self.n, self.mc), np.int32)
+        self._check(self.lib.nnd_get_candidates(self._h, _ptr(new), _ptr(old)))
+        return new, old
+
+    def pairwise_gram(self, rows_a, rows_b):
+        a = np.ascontiguousarray(rows_a, np.int32)
+        b = np.ascontiguousarray(rows_b, np.int32)
+        out = np.empty((a.shape[0], b.shape[0]), np.float32)
+        self._check(self.lib.nnd_pairwise_gram(self._h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out)))
+        return out

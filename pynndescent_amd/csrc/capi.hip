@@ -1,0 +1,506 @@
+// capi.hip -- extern "C" boundary (include/pynnd_amd.h): handle lifetime, HBM allocation, and
+// the orchestration that mirrors nn_descent / nn_descent_internal (reference pynndescent_.py:266-366).
+#include <string.h>
+
+#include <string>
+
+#include "common.h"
+#include "state.h"
+
+static thread_local char g_err[512] = {0};
+
+static void gerr(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int32_t nnd_abi_version(void) { return NND_ABI_VERSION; }
+extern "C" const char *nnd_last_global_error(void) { return g_err; }
+extern "C" const char *nnd_last_error(nnd_handle_t h) { return h ? h->err : g_err; }
+
+#define API_HIP(expr)                                                                                \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            ctx->set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                                \
+        }                                                                                            \
+    } while (0)
+
+template <typename T>
+static int dalloc(nnd_ctx *ctx, T **p, size_t count) {
+    API_HIP(hipMalloc((void **)p, sizeof(T) * (count ? count : 1)));
+    return 0;
+}
+
+static void free_all(nnd_ctx *ctx) {
+    auto F = [](void *p) {
+        if (p) (void)hipFree(p);
+    };
+    if (ctx->x_owned) F((void *)ctx->x_orig);
+    F(ctx->xp); F(ctx->nrm); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->cand); F(ctx->rbuf); F(ctx->pbuf);
+    F(ctx->pdirty);
+    for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
+    F(ctx->side); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
+    F(ctx->hyper); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->counters);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+}
+
+extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
+    if (!out || !p) { gerr("nnd_create: null argument"); return 1; }
+    *out = nullptr;
+    if (p->n < 1 || p->dim < 1) { gerr("nnd_create: need n >= 1 and dim >= 1 (got n=%lld dim=%d)", (long long)p->n, p->dim); return 1; }
+    if (p->metric != NND_METRIC_SQEUCLIDEAN && p->metric != NND_METRIC_ALT_COSINE) { gerr("nnd_create: unknown metric %d", p->metric); return 1; }
+    if (p->n_neighbors < 1 || p->n_neighbors > 64) { gerr("nnd_create: n_neighbors must be in 1..64 (got %d)", p->n_neighbors); return 1; }
+    if (p->max_candidates < 1 || p->max_candidates > 64) { gerr("nnd_create: max_candidates must be in 1..64 (got %d)", p->max_candidates); return 1; }
+    if (p->n_trees < 0 || p->leaf_size < 1) { gerr("nnd_create: bad n_trees/leaf_size"); return 1; }
+    if (p->n >= (int64_t)0x7FFFFFF0) { gerr("nnd_create: n too large for int32 ids"); return 1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { gerr("nnd_create: no HIP device visible (this library has no CPU path)"); return 1; }
+    if (p->device < 0 || p->device >= ndev) { gerr("nnd_create: device %d out of range (%d visible)", p->device, ndev); return 1; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) { gerr("nnd_create: hipGetDeviceProperties failed"); return 1; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { gerr("nnd_create: device %d is %s; this build targets gfx950 (MI355X) only", p->device, prop.gcnArchName); return 1; }
+    if (hipSetDevice(p->device) != hipSuccess) { gerr("nnd_create: hipSetDevice failed"); return 1; }
+
+    nnd_ctx *ctx = new nnd_ctx();
+    ctx->p = *p;
+    ctx->n = p->n;
+    ctx->d = p->dim;
+    ctx->dp = (p->dim + 31) & ~31;
+    ctx->k = p->n_neighbors;
+    ctx->ks = (p->n_neighbors + 15) & ~15;
+    ctx->mc = p->max_candidates;
+    ctx->mcp = p->max_candidates <= 16 ? 16 : (p->max_candidates <= 32 ? 32 : 64);
+    ctx->rcap = 32;
+    ctx->pcap = 64;
+    if (ctx->p.join_blocks < 1) ctx->p.join_blocks = 1;
+    ctx->seed = nnd_mix32((uint32_t)p->rng_state[0] ^ nnd_mix32((uint32_t)p->rng_state[1] + 0x9E3779B9u) ^
+                          nnd_mix32((uint32_t)p->rng_state[2] + 0x7F4A7C15u));
+    ctx->tree_seed = nnd_mix32((uint32_t)p->tree_rng[0] ^ nnd_mix32((uint32_t)p->tree_rng[1] + 0x9E3779B9u) ^
+                               nnd_mix32((uint32_t)p->tree_rng[2] + 0x7F4A7C15u));
+    int rc = 0;
+    do {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->set_error("hipStreamCreate failed"); rc = 1; break; }
+        (void)hipEventCreate(&ctx->ev0);
+        (void)hipEventCreate(&ctx->ev1);
+        const size_t n = (size_t)ctx->n;
+        if ((rc = dalloc(ctx, &ctx->xp, n * ctx->dp))) break;
+        if ((rc = dalloc(ctx, &ctx->nrm, n))) break;
+        if ((rc = dalloc(ctx, &ctx->mean, (size_t)ctx->dp))) break;
+        if ((rc = dalloc(ctx, &ctx->knn_e, n * ctx->ks))) break;
+        if ((rc = dalloc(ctx, &ctx->knn_d, n * ctx->ks))) break;
+        if ((rc = dalloc(ctx, &ctx->cand, n * 2 * ctx->mcp))) break;
+        if ((rc = dalloc(ctx, &ctx->rbuf, n * 2 * ctx->rcap))) break;
+        if ((rc = dalloc(ctx, &ctx->pbuf, n * ctx->pcap))) break;
+        if ((rc = dalloc(ctx, &ctx->pdirty, n))) break;
+        if ((rc = dalloc(ctx, &ctx->counters, (size_t)CNT_COUNT))) break;
+        if (hipMemset(ctx->pdirty, 0, n) != hipSuccess) { ctx->set_error("hipMemset failed"); rc = 1; break; }
+        if (p->n_trees > 0) {
+            ctx->P = (int64_t)p->n_trees * ctx->n;
+            const size_t P = (size_t)ctx->P;
+            ctx->max_segs = ctx->P / (p->leaf_size + 1) + p->n_trees + 8;
+            const size_t S = (size_t)ctx->max_segs;
+            for (int i = 0; i < 2 && !rc; i++) {
+                if ((rc = dalloc(ctx, &ctx->perm[i], P))) break;
+                if ((rc = dalloc(ctx, &ctx->pos_seg[i], P))) break;
+                if ((rc = dalloc(ctx, &ctx->seg_start[i], S))) break;
+                if ((rc = dalloc(ctx, &ctx->seg_len[i], S))) break;
+            }
+            if (rc) break;
+            if ((rc = dalloc(ctx, &ctx->side, P))) break;
+            if ((rc = dalloc(ctx, &ctx->leaf_flag, P))) break;
+            if ((rc = dalloc(ctx, &ctx->scan_out, P + 1))) break;
+            if ((rc = dalloc(ctx, &ctx->scan_blk, P / 2048 + 2))) break;
+            if ((rc = dalloc(ctx, &ctx->seg_nleft, S))) break;
+            if ((rc = dalloc(ctx, &ctx->seg_child, 2 * S))) break;
+            if ((rc = dalloc(ctx, &ctx->hyper, S * (size_t)(ctx->dp + 4)))) break;
+        }
+    } while (0);
+    if (rc) {
+        gerr("nnd_create: %s", ctx->err);
+        free_all(ctx);
+        delete ctx;
+        return 1;
+    }
+    *out = ctx;
+    return 0;
+}
+
+extern "C" int32_t nnd_destroy(nnd_handle_t ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->p.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx);
+    delete ctx;
+    return 0;
+}
+
+#define ENTER(ctx)                                           \
+    if (!ctx) { gerr("null handle"); return 1; }             \
+    API_HIP(hipSetDevice(ctx->p.device));
+
+static float elapsed_ms(nnd_ctx *ctx) {
+    float ms = 0.f;
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    (void)hipEventSynchronize(ctx->ev1);
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    return ms;
+}
+static void tick(nnd_ctx *ctx) { (void)hipEventRecord(ctx->ev0, ctx->stream); }
+
+static int after_data(nnd_ctx *ctx) {
+    tick(ctx);
+    if (nnd_launch_prep(ctx)) return 1;
+    if (nnd_launch_reset_graph(ctx)) return 1;
+    ctx->stats.ms_prep = elapsed_ms(ctx);
+    return 0;
+}
+
+extern "C" int32_t nnd_set_data_host(nnd_handle_t ctx, const float *x) {
+    ENTER(ctx);
+    if (!x) { ctx->set_error("nnd_set_data_host: null data"); return 1; }
+    if (ctx->x_owned && ctx->x_orig) { API_HIP(hipFree((void *)ctx->x_orig)); }
+    float *dx = nullptr;
+    API_HIP(hipMalloc((void **)&dx, sizeof(float) * (size_t)ctx->n * ctx->d));
+    ctx->x_orig = dx;
+    ctx->x_owned = true;
+    API_HIP(hipMemcpyAsync(dx, x, sizeof(float) * (size_t)ctx->n * ctx->d, hipMemcpyHostToDevice, ctx->stream));
+    return after_data(ctx);
+}
+
+extern "C" int32_t nnd_set_data_device(nnd_handle_t ctx, const float *x_dev) {
+    ENTER(ctx);
+    if (!x_dev) { ctx->set_error("nnd_set_data_device: null data"); return 1; }
+    if (ctx->x_owned && ctx->x_orig) { API_HIP(hipFree((void *)ctx->x_orig)); }
+    ctx->x_orig = x_dev;
+    ctx->x_owned = false;
+    return after_data(ctx);
+}
+
+static int need_data(nnd_ctx *ctx) {
+    if (!ctx->x_orig) { ctx->set_error("no data set (call nnd_set_data_host/device first)"); return 1; }
+    return 0;
+}
+
+extern "C" int32_t nnd_make_forest(nnd_handle_t ctx) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    tick(ctx);
+    if (nnd_launch_forest(ctx)) return 1;
+    ctx->stats.ms_forest = elapsed_ms(ctx);
+    return 0;
+}
+
+extern "C" int32_t nnd_leaf_array_shape(nnd_handle_t ctx, int64_t *n_leaves, int32_t *max_leaf_size) {
+    ENTER(ctx);
+    if (!ctx->forest_built) {  // rp_trees.py:2921-2922: np.array([[-1]])
+        *n_leaves = 1;
+        *max_leaf_size = 1;
+        return 0;
+    }
+    *n_leaves = ctx->n_leaves;
+    *max_leaf_size = ctx->max_leaf;
+    return 0;
+}
+
+extern "C" int32_t nnd_get_leaf_array(nnd_handle_t ctx, int32_t *out_host) {
+    ENTER(ctx);
+    if (!ctx->forest_built) {
+        out_host[0] = -1;
+        return 0;
+    }
+    size_t total = (size_t)ctx->n_leaves * ctx->max_leaf;
+    int32_t *d = nullptr;
+    API_HIP(hipMalloc((void **)&d, sizeof(int32_t) * (total ? total : 1)));
+    if (nnd_launch_leaf_array(ctx, d)) { (void)hipFree(d); return 1; }
+    API_HIP(hipMemcpyAsync(out_host, d, sizeof(int32_t) * total, hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(hipFree(d));
+    return 0;
+}
+
+extern "C" int32_t nnd_reset_graph(nnd_handle_t ctx) {
+    ENTER(ctx);
+    return nnd_launch_reset_graph(ctx);
+}
+
+extern "C" int32_t nnd_init_from_leaves(nnd_handle_t ctx) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    tick(ctx);
+    if (nnd_launch_leaf_init(ctx)) return 1;
+    ctx->stats.ms_leaf_init = elapsed_ms(ctx);
+    return 0;
+}
+
+extern "C" int32_t nnd_init_random(nnd_handle_t ctx) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    tick(ctx);
+    if (nnd_launch_random_init(ctx)) return 1;
+    ctx->stats.ms_random_init = elapsed_ms(ctx);
+    return 0;
+}
+
+extern "C" int32_t nnd_init_from_graph(nnd_handle_t ctx, const int32_t *init_idx, const float *init_dist, int32_t width) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    if (!init_idx || width < 1) { ctx->set_error("nnd_init_from_graph: bad arguments"); return 1; }
+    size_t cnt = (size_t)ctx->n * width;
+    int32_t *di = nullptr;
+    float *dd = nullptr;
+    API_HIP(hipMalloc((void **)&di, sizeof(int32_t) * cnt));
+    API_HIP(hipMemcpyAsync(di, init_idx, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, ctx->stream));
+    if (init_dist) {
+        API_HIP(hipMalloc((void **)&dd, sizeof(float) * cnt));
+        API_HIP(hipMemcpyAsync(dd, init_dist, sizeof(float) * cnt, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int rc = nnd_launch_init_from_graph(ctx, di, dd, width);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(di);
+    if (dd) (void)hipFree(dd);
+    return rc;
+}
+
+extern "C" int32_t nnd_sample_candidates(nnd_handle_t ctx) {
+    ENTER(ctx);
+    return nnd_launch_sample(ctx);
+}
+
+// one iteration of nn_descent_internal (pynndescent_.py:296-320)
+static int descent_iter(nnd_ctx *ctx, int64_t *c_out, bool timed) {
+    const int it = ctx->iter;
+    float ms;
+    if (timed) tick(ctx);
+    if (nnd_launch_sample(ctx)) return 1;
+    if (timed) { ms = elapsed_ms(ctx); if (it < 64) ctx->stats.ms_sample[it] = ms; }
+    if (nnd_zero_counters(ctx)) return 1;
+    // The reference joins vertices in blocks of 16384 and applies updates between blocks
+    // (pynndescent_.py:239-261) so thresholds tighten inside an iteration; join_blocks sub-steps do the same.
+    const int nb = ctx->p.join_blocks;
+    float ms_join = 0.f, ms_merge = 0.f;
+    for (int b = 0; b < nb; b++) {
+        int64_t v0 = ctx->n * b / nb, v1 = ctx->n * (b + 1) / nb;
+        if (timed) tick(ctx);
+        if (nnd_launch_join(ctx, v0, v1)) return 1;
+        if (timed) { ms_join += elapsed_ms(ctx); tick(ctx); }
+        if (nnd_launch_merge(ctx)) return 1;
+        if (timed) ms_merge += elapsed_ms(ctx);
+    }
+    if (nnd_read_counters(ctx)) return 1;
+    if (it < 64) {
+        ctx->stats.ms_join[it] = ms_join;
+        ctx->stats.ms_merge[it] = ms_merge;
+        ctx->stats.join_pairs[it] = ctx->h_counters[CNT_PAIRS];
+        ctx->stats.join_rows[it] = ctx->h_counters[CNT_ROWS];
+        ctx->stats.join_active[it] = ctx->h_counters[CNT_ACTIVE];
+        ctx->stats.proposals[it] = ctx->h_counters[CNT_PROPOSALS];
+        ctx->stats.updates[it] = ctx->h_counters[CNT_ACCEPT];
+    }
+    *c_out = ctx->h_counters[CNT_ACCEPT];
+    ctx->iter++;
+    ctx->stats.n_iters_run = ctx->iter;
+    return 0;
+}
+
+extern "C" int32_t nnd_descent_iter(nnd_handle_t ctx, int64_t *c_out) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    int64_t c = 0;
+    if (descent_iter(ctx, &c, true)) return 1;
+    if (c_out) *c_out = c;
+    return 0;
+}
+
+static int descent_loop(nnd_ctx *ctx, bool timed) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, ctx->stream);
+    int rc = 0;
+    for (int it = 0; it < ctx->p.n_iters; it++) {
+        int64_t c = 0;
+        if ((rc = descent_iter(ctx, &c, timed))) break;
+        if ((double)c <= (double)ctx->p.delta * ctx->k * (double)ctx->n) break;  // pynndescent_.py:317
+    }
+    (void)hipEventRecord(e1, ctx->stream);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ctx->stats.ms_descent, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+extern "C" int32_t nnd_descent(nnd_handle_t ctx) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    return descent_loop(ctx, true);
+}
+
+extern "C" int32_t nnd_finalize_device(nnd_handle_t ctx, int32_t *out_idx_dev, float *out_dist_dev) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    tick(ctx);
+    if (nnd_launch_finalize(ctx, out_idx_dev, out_dist_dev)) return 1;
+    ctx->stats.ms_finalize = elapsed_ms(ctx);
+    return 0;
+}
+
+extern "C" int32_t nnd_finalize_host(nnd_handle_t ctx, int32_t *out_idx, float *out_dist) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    size_t cnt = (size_t)ctx->n * ctx->k;
+    int32_t *di = nullptr;
+    float *dd = nullptr;
+    API_HIP(hipMalloc((void **)&di, sizeof(int32_t) * cnt));
+    API_HIP(hipMalloc((void **)&dd, sizeof(float) * cnt));
+    int rc = nnd_finalize_device(ctx, di, dd);
+    if (!rc) {
+        API_HIP(hipMemcpyAsync(out_idx, di, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+        API_HIP(hipMemcpyAsync(out_dist, dd, sizeof(float) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+        API_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    (void)hipFree(di);
+    (void)hipFree(dd);
+    return rc;
+}
+
+// nn_descent (pynndescent_.py:323-366) on a resident point set: EMPTY_GRAPH branch
+extern "C" int32_t nnd_build_device(nnd_handle_t ctx, int32_t *out_idx_dev, float *out_dist_dev) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    if (nnd_launch_reset_graph(ctx)) return 1;
+    if (ctx->p.n_trees > 0) {
+        tick(ctx);
+        if (nnd_launch_forest(ctx)) return 1;
+        ctx->stats.ms_forest = elapsed_ms(ctx);
+        tick(ctx);
+        if (nnd_launch_leaf_init(ctx)) return 1;
+        ctx->stats.ms_leaf_init = elapsed_ms(ctx);
+    }
+    tick(ctx);
+    if (nnd_launch_random_init(ctx)) return 1;
+    ctx->stats.ms_random_init = elapsed_ms(ctx);
+    if (descent_loop(ctx, true)) return 1;
+    tick(ctx);
+    if (nnd_launch_finalize(ctx, out_idx_dev, out_dist_dev)) return 1;
+    ctx->stats.ms_finalize = elapsed_ms(ctx);
+    return 0;
+}
+
+extern "C" int32_t nnd_build(const nnd_params *params, const float *x, const int32_t *init_idx, const float *init_dist,
+                             int32_t init_width, int32_t *out_idx, float *out_dist, nnd_stats *stats, char *err,
+                             int32_t errlen) {
+    auto fail = [&](const char *msg) {
+        if (err && errlen > 0) { strncpy(err, msg, (size_t)errlen - 1); err[errlen - 1] = 0; }
+        return 1;
+    };
+    nnd_handle_t h = nullptr;
+    nnd_params p = *params;
+    if (init_idx) p.n_trees = 0;  // pynndescent_.py:1059-1062: an init graph disables the forest
+    if (nnd_create(&h, &p)) return fail(g_err);
+    int rc = nnd_set_data_host(h, x);
+    if (!rc) {
+        if (init_idx) {
+            rc = nnd_init_from_graph(h, init_idx, init_dist, init_width);
+            if (!rc) rc = nnd_descent(h);
+            if (!rc) rc = nnd_finalize_host(h, out_idx, out_dist);
+        } else {
+            size_t cnt = (size_t)h->n * h->k;
+            int32_t *di = nullptr;
+            float *dd = nullptr;
+            if (hipMalloc((void **)&di, sizeof(int32_t) * cnt) != hipSuccess || hipMalloc((void **)&dd, sizeof(float) * cnt) != hipSuccess) {
+                h->set_error("hipMalloc of the output buffers failed");
+                rc = 1;
+            }
+            if (!rc) rc = nnd_build_device(h, di, dd);
+            if (!rc) {
+                if (hipMemcpy(out_idx, di, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(out_dist, dd, sizeof(float) * cnt, hipMemcpyDeviceToHost) != hipSuccess) {
+                    h->set_error("copy of the result to the host failed");
+                    rc = 1;
+                }
+            }
+            if (di) (void)hipFree(di);
+            if (dd) (void)hipFree(dd);
+        }
+    }
+    if (stats) *stats = h->stats;
+    std::string msg = h->err;
+    nnd_destroy(h);
+    if (rc) return fail(msg.c_str());
+    return 0;
+}
+
+extern "C" int32_t nnd_get_stats(nnd_handle_t ctx, nnd_stats *out) {
+    if (!ctx || !out) { gerr("null argument"); return 1; }
+    *out = ctx->stats;
+    return 0;
+}
+
+extern "C" int32_t nnd_synchronize(nnd_handle_t ctx) {
+    ENTER(ctx);
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- introspection for the parity tests ----
+extern "C" int32_t nnd_get_graph(nnd_handle_t ctx, int32_t *idx, float *dist, uint8_t *flags) {
+    ENTER(ctx);
+    size_t cnt = (size_t)ctx->n * ctx->ks;
+    std::vector<uint32_t> he(cnt);
+    std::vector<float> hd(cnt);
+    API_HIP(hipMemcpyAsync(he.data(), ctx->knn_e, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(hipMemcpyAsync(hd.data(), ctx->knn_d, sizeof(float) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t v = 0; v < ctx->n; v++)
+        for (int j = 0; j < ctx->k; j++) {
+            uint32_t e = he[v * ctx->ks + j];
+            size_t o = (size_t)v * ctx->k + j;
+            if (idx) idx[o] = e == NND_EMPTY_E ? -1 : (int32_t)(e & NND_IDX_MASK);
+            if (dist) dist[o] = hd[v * ctx->ks + j];
+            if (flags) flags[o] = e == NND_EMPTY_E ? 0 : (uint8_t)(e >> 31);
+        }
+    return 0;
+}
+
+extern "C" int32_t nnd_get_candidates(nnd_handle_t ctx, int32_t *new_idx, int32_t *old_idx) {
+    ENTER(ctx);
+    size_t cnt = (size_t)ctx->n * 2 * ctx->mcp;
+    std::vector<int32_t> hc(cnt);
+    API_HIP(hipMemcpyAsync(hc.data(), ctx->cand, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t v = 0; v < ctx->n; v++)
+        for (int j = 0; j < ctx->mc; j++) {
+            if (new_idx) new_idx[v * ctx->mc + j] = hc[v * 2 * ctx->mcp + j];
+            if (old_idx) old_idx[v * ctx->mc + j] = hc[v * 2 * ctx->mcp + ctx->mcp + j];
+        }
+    return 0;
+}
+
+extern "C" int32_t nnd_pairwise_gram(nnd_handle_t ctx, const int32_t *rows_a, int32_t na, const int32_t *rows_b,
+                                     int32_t nb, float *out) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    int32_t *da = nullptr, *db = nullptr;
+    float *dout = nullptr;
+    API_HIP(hipMalloc((void **)&da, sizeof(int32_t) * na));
+    API_HIP(hipMalloc((void **)&db, sizeof(int32_t) * nb));
+    API_HIP(hipMalloc((void **)&dout, sizeof(float) * (size_t)na * nb));
+    API_HIP(hipMemcpyAsync(da, rows_a, sizeof(int32_t) * na, hipMemcpyHostToDevice, ctx->stream));
+    API_HIP(hipMemcpyAsync(db, rows_b, sizeof(int32_t) * nb, hipMemcpyHostToDevice, ctx->stream));
+    int rc = nnd_launch_pairwise(ctx, da, na, db, nb, dout);
+    if (!rc) {
+        API_HIP(hipMemcpyAsync(out, dout, sizeof(float) * (size_t)na * nb, hipMemcpyDeviceToHost, ctx->stream));
+        API_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dout);
+    return rc;
+}

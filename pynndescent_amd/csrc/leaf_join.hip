@@ -1,0 +1,184 @@
+// leaf_join.hip -- RP-tree leaf seeding: all pairs inside every leaf, merged straight into the
+// k-lists of the leaf's own points.
+//
+// Replaces generate_leaf_updates + init_rp_tree (reference pynndescent_.py:73-185): for every leaf,
+// every pair p != q: d = dist(x_p, x_q); keep if it beats either endpoint's current worst distance;
+// push (q,d) into p's heap and (p,d) into q's heap with the "new" flag.
+//
+// MI355X design: one workgroup per leaf.  The leaf's rows are gathered once into LDS (coalesced
+// 128-byte-line loads, swizzled), the |leaf| x |leaf| distance block is a Gram contraction on the
+// f32 MFMA pipe, and -- because inside ONE tree every point belongs to exactly one leaf -- the
+// workgroup OWNS the k-lists of its points for the duration of the launch: each row of the block
+// is merged into its point's sorted k-list by one wave with no atomics and no update buffer
+// (the reference round-trips 12-byte (p,q,d) triples through memory and scans them once per
+// thread, pynndescent_.py:154-185).  Trees are processed one launch after another, so thresholds
+// tighten between trees exactly like the reference's leaf blocks tighten them (pynndescent_.py:137-152).
+#include "common.h"
+#include "gram.h"
+#include "merge.h"
+#include "state.h"
+
+template <int NT, int NW, int DC>
+struct leaf_cfg {
+    static constexpr int MP = NT * 16;                      // max leaf rows
+    static constexpr int TR = (NT + NW - 1) / NW;           // tile rows per wave
+    static constexpr int DSTRIDE = MP + 1;                  // row stride of the per-wave distance block
+    static constexpr int XS_FLOATS = MP * DC;
+    static constexpr int DB_FLOATS = NW * 16 * DSTRIDE;
+    static constexpr int BIG_FLOATS = XS_FLOATS > DB_FLOATS ? XS_FLOATS : DB_FLOATS;  // Xs and Dblk alias
+};
+
+template <int NT, int NW, int DC>
+__global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
+                                                       int metric, const int32_t *__restrict__ perm,
+                                                       const int32_t *__restrict__ wl_start,
+                                                       const int32_t *__restrict__ wl_len, int64_t leaf0,
+                                                       int64_t n_leaves, int k, int ks, uint32_t *__restrict__ knn_e,
+                                                       float *__restrict__ knn_d, long long *__restrict__ counters) {
+    using C = leaf_cfg<NT, NW, DC>;
+    __shared__ __attribute__((aligned(16))) float big[C::BIG_FLOATS];
+    __shared__ int32_t ids[C::MP];
+    __shared__ float nrs[C::MP];
+    __shared__ nnd_merge_scratch msc[NW];
+
+    const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
+    const int64_t leaf = leaf0 + blockIdx.x;
+    if (leaf >= n_leaves) return;
+    const int start = wl_start[leaf];
+    const int m = wl_len[leaf];
+    if (m < 2) return;  // no pairs
+    const int nt = (m + 15) >> 4;
+    const int mp = nt << 4;
+
+    for (int r = tid; r < C::MP; r += NW * 64) {
+        int id = r < m ? perm[start + r] : -1;
+        ids[r] = id;
+        nrs[r] = id >= 0 ? nrm[id] : 0.0f;
+    }
+    __syncthreads();
+
+    f32x4 acc[C::TR][NT];
+#pragma unroll
+    for (int tr = 0; tr < C::TR; tr++)
+#pragma unroll
+        for (int J = 0; J < NT; J++) acc[tr][J] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float *Xs = big;
+    for (int c0 = 0; c0 < dp; c0 += DC) {
+        const int cw = (dp - c0) < DC ? (dp - c0) : DC;
+        nnd_stage_rows<DC>(xp, dp, ids, mp, c0, cw, Xs, tid, NW * 64);
+        __syncthreads();
+#pragma unroll
+        for (int tr = 0; tr < C::TR; tr++) {
+            const int I = w + tr * NW;
+            if (I < nt) nnd_gram_chunk<DC, NT>(Xs, I * 16, 0, cw, acc[tr], [nt](int J) { return J < nt; });
+        }
+        __syncthreads();  // Xs is overwritten by the next chunk / by the distance blocks below
+    }
+
+    // distances of this wave's tile rows -> per-wave LDS block, then merge each row into its point's k-list
+    float *Dw = big + w * 16 * C::DSTRIDE;
+    const int r16 = lane & 15, g = lane >> 4;
+    int accepted = 0;
+#pragma unroll
+    for (int tr = 0; tr < C::TR; tr++) {
+        const int I = w + tr * NW;
+        if (I >= nt) continue;
+#pragma unroll
+        for (int J = 0; J < NT; J++) {
+            if (J < nt) {
+                const int j = J * 16 + r16;
+                const float nj = nrs[j];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int il = 4 * g + r;
+                    Dw[il * C::DSTRIDE + j] = nnd_gram_to_dist(metric, acc[tr][J][r], nrs[I * 16 + il], nj);
+                }
+            }
+        }
+        nnd_wave_lds_sync();
+        for (int il = 0; il < 16; il++) {
+            const int i = I * 16 + il;
+            if (i >= m) break;
+            const float *Drow = Dw + il * C::DSTRIDE;
+            accepted += nnd_merge_row((int64_t)ids[i], k, ks, knn_e, knn_d, msc[w], m,
+                                      [&](int c, uint32_t &id, float &dc) {
+                                          id = (uint32_t)ids[c];
+                                          dc = Drow[c];
+                                          return c != i;  // pynndescent_.py:97: j starts at i+1, i.e. p != q
+                                      });
+        }
+        nnd_wave_lds_sync();
+    }
+    if (lane == 0 && accepted) atomicAdd((unsigned long long *)&counters[CNT_ACCEPT], (unsigned long long)accepted);
+    if (tid == 0) {
+        atomicAdd((unsigned long long *)&counters[CNT_PAIRS], (unsigned long long)((long long)m * (m - 1) / 2));
+        atomicAdd((unsigned long long *)&counters[CNT_ROWS], (unsigned long long)m);
+    }
+}
+
+// Work list: leaves longer than 256 points (possible only when max_depth cuts the recursion short,
+// rp_trees.py:2188) are cut into runs of <= 256 consecutive positions for seeding purposes.
+static constexpr int LEAF_MAX = 256;
+
+int nnd_launch_leaf_init(nnd_ctx *ctx) {
+    if (!ctx->forest_built || ctx->n_leaves == 0) return 0;
+    const int T = ctx->p.n_trees;
+    // host copies of the leaf table (small) -> per-tree work lists
+    std::vector<int32_t> hs(ctx->n_leaves), hl(ctx->n_leaves);
+    NND_HIP_CHECK(hipMemcpyAsync(hs.data(), ctx->leaf_start, sizeof(int32_t) * ctx->n_leaves, hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(hipMemcpyAsync(hl.data(), ctx->leaf_len, sizeof(int32_t) * ctx->n_leaves, hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> ws, wl;
+    std::vector<int64_t> tb(T + 1, 0);
+    ws.reserve(ctx->n_leaves);
+    wl.reserve(ctx->n_leaves);
+    int maxlen = 0;
+    for (int t = 0; t < T; t++) {
+        tb[t] = (int64_t)ws.size();
+        for (int64_t i = ctx->tree_leaf_begin[t]; i < ctx->tree_leaf_begin[t + 1]; i++) {
+            int32_t a = hs[i], len = hl[i];
+            while (len > 0) {
+                int32_t piece = len > LEAF_MAX ? LEAF_MAX : len;
+                ws.push_back(a);
+                wl.push_back(piece);
+                if (piece > maxlen) maxlen = piece;
+                a += piece;
+                len -= piece;
+            }
+        }
+    }
+    tb[T] = (int64_t)ws.size();
+    int64_t nw = (int64_t)ws.size();
+    if (nw == 0) return 0;
+    int32_t *d_ws = nullptr, *d_wl = nullptr;
+    NND_HIP_CHECK(hipMalloc((void **)&d_ws, sizeof(int32_t) * nw));
+    NND_HIP_CHECK(hipMalloc((void **)&d_wl, sizeof(int32_t) * nw));
+    NND_HIP_CHECK(hipMemcpyAsync(d_ws, ws.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, ctx->stream));
+    NND_HIP_CHECK(hipMemcpyAsync(d_wl, wl.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, ctx->stream));
+    if (nnd_zero_counters(ctx)) return 1;
+    const int32_t *perm = ctx->perm[ctx->cur];
+    for (int t = 0; t < T; t++) {
+        int64_t cnt = tb[t + 1] - tb[t];
+        if (cnt <= 0) continue;
+        dim3 grid((unsigned)cnt);
+#define LEAF_ARGS ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, perm, d_ws, d_wl, tb[t], tb[t + 1], ctx->k, ctx->ks, \
+                  ctx->knn_e, ctx->knn_d, ctx->counters
+        if (maxlen <= 64)
+            hipLaunchKernelGGL((k_leaf_join<4, 4, 128>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 96)
+            hipLaunchKernelGGL((k_leaf_join<6, 4, 128>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 128)
+            hipLaunchKernelGGL((k_leaf_join<8, 4, 64>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+        else
+            hipLaunchKernelGGL((k_leaf_join<16, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+#undef LEAF_ARGS
+    }
+    NND_HIP_CHECK(hipGetLastError());
+    if (nnd_read_counters(ctx)) return 1;
+    ctx->stats.leaf_pairs = ctx->h_counters[CNT_PAIRS];
+    ctx->stats.leaf_rows = ctx->h_counters[CNT_ROWS];
+    NND_HIP_CHECK(hipFree(d_ws));
+    NND_HIP_CHECK(hipFree(d_wl));
+    return 0;
+}

@@ -1,0 +1,128 @@
+// merge.hip -- apply buffered proposals to the k-lists; random and user-graph initialisation.
+//
+// k_merge replaces apply_graph_update_array (reference utils.py:661-733): the reference lets every
+// thread scan ALL (p,q,d) updates and apply those whose endpoint it owns.  Here proposals were
+// already routed to their target by the join (join.hip), so one wave per target row that has
+// pending proposals merges them (merge.h) and re-arms the slots.  c (utils.py:725,731) is the
+// number of proposals that end up in a list.
+//
+// k_random_init replaces init_random (pynndescent_.py:188-203); k_graph_init replaces
+// initalize_heap_from_graph_indices[_and_distances] (utils.py:836-860).  Both write their
+// candidates into the proposal slots and reuse k_merge.
+#include "common.h"
+#include "merge.h"
+#include "state.h"
+
+__global__ __launch_bounds__(256) void k_merge(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
+                                               int64_t n, int k, int ks, uint32_t *__restrict__ knn_e,
+                                               float *__restrict__ knn_d, long long *__restrict__ counters) {
+    __shared__ nnd_merge_scratch msc[4];
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t v = (int64_t)blockIdx.x * 4 + w;
+    if (v >= n) return;
+    if (!pdirty[v]) return;
+    uint64_t *slots = pbuf + v * pcap;
+    int acc = nnd_merge_row(v, k, ks, knn_e, knn_d, msc[w], pcap, [&](int c, uint32_t &id, float &dc) {
+        uint64_t key = slots[c];
+        id = nnd_key_idx(key);
+        dc = nnd_key_dist(key);
+        return key != NND_EMPTY_KEY;
+    });
+    for (int s = lane; s < pcap; s += 64) slots[s] = NND_EMPTY_KEY;
+    if (lane == 0) {
+        pdirty[v] = 0;
+        if (acc) atomicAdd((unsigned long long *)&counters[CNT_ACCEPT], (unsigned long long)acc);
+    }
+}
+
+int nnd_launch_merge(nnd_ctx *ctx) {
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->pbuf, ctx->pdirty,
+                       ctx->pcap, ctx->n, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->counters);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// wave-cooperative alt-space distance between prepared rows a and b (difference form for euclid)
+__device__ __forceinline__ float row_dist(const float *__restrict__ xp, int dp, const float *__restrict__ nrm, int metric,
+                                          int64_t a, int64_t b) {
+    const float *xa = xp + a * dp, *xb = xp + b * dp;
+    float s = 0.0f;
+    for (int j = nnd_lane(); j < dp; j += 64) {
+        float p = xa[j], q = xb[j];
+        s += metric == 0 ? (p - q) * (p - q) : p * q;
+    }
+    s = nnd_wave_sum_f32(s);
+    if (metric == 0) return nnd_clamp_dist(s);
+    return nnd_gram_to_dist(1, s, nrm[a], nrm[b]);
+}
+
+// init_random (pynndescent_.py:188-203): rows that are not full get (k - filled) random candidates
+__global__ __launch_bounds__(256) void k_random_init(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
+                                                     int metric, int64_t n, int k, int ks,
+                                                     const uint32_t *__restrict__ knn_e, uint32_t seed,
+                                                     uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap) {
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t v = (int64_t)blockIdx.x * 4 + w;
+    if (v >= n) return;
+    uint32_t e = lane < k ? knn_e[v * ks + lane] : NND_EMPTY_E;
+    int filled = __popcll(__ballot(lane < k && e != NND_EMPTY_E));
+    int todo = k - filled;  // pynndescent_.py:196
+    if (todo <= 0) return;
+    uint32_t pick = (uint32_t)(nnd_hash3(seed, (uint32_t)v, (uint32_t)lane) % (uint64_t)n);  // pynndescent_.py:197
+    bool mine = lane < todo;
+    for (int j = 0; j < todo; j++) {  // the same id drawn twice is pushed once (utils.py:489-492)
+        uint32_t other = __shfl(pick, j, 64);
+        if (j < lane && other == pick) mine = false;
+    }
+    for (int j = 0; j < todo; j++) {
+        uint32_t id = __shfl(pick, j, 64);
+        bool on = __shfl((int)mine, j, 64);
+        if (!on) continue;
+        float d = row_dist(xp, dp, nrm, metric, v, (int64_t)id);
+        if (lane == 0) pbuf[v * pcap + j] = nnd_make_key(d, id);
+    }
+    if (lane == 0) pdirty[v] = 1;
+}
+
+int nnd_launch_random_init(nnd_ctx *ctx) {
+    hipLaunchKernelGGL(k_random_init, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, ctx->dp,
+                       ctx->nrm, ctx->p.metric, ctx->n, ctx->k, ctx->ks, ctx->knn_e, ctx->seed ^ 0x3C6EF372u, ctx->pbuf,
+                       ctx->pdirty, ctx->pcap);
+    NND_HIP_CHECK(hipGetLastError());
+    return nnd_launch_merge(ctx);
+}
+
+// utils.py:836-860: every valid (i, j=graph[i][c]) is pushed with distance metric(x_i, x_j) or the given one
+__global__ __launch_bounds__(256) void k_graph_init(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
+                                                    int metric, int64_t n, const int32_t *__restrict__ gidx,
+                                                    const float *__restrict__ gdist, int width,
+                                                    uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap) {
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t v = (int64_t)blockIdx.x * 4 + w;
+    if (v >= n) return;
+    int32_t id = lane < width ? gidx[v * width + lane] : -1;
+    bool mine = id >= 0 && (int64_t)id < n;
+    for (int j = 0; j < width; j++) {
+        int32_t other = __shfl(id, j, 64);
+        if (j < lane && other == id) mine = false;
+    }
+    for (int j = 0; j < width; j++) {
+        int32_t q = __shfl(id, j, 64);
+        bool on = __shfl((int)mine, j, 64);
+        if (!on) continue;
+        float d = gdist ? nnd_clamp_dist(gdist[v * width + j]) : row_dist(xp, dp, nrm, metric, v, (int64_t)q);
+        if (lane == 0) pbuf[v * pcap + j] = nnd_make_key(d, (uint32_t)q);
+    }
+    if (lane == 0) pdirty[v] = 1;
+}
+
+int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float *dist_dev, int width) {
+    if (width > ctx->pcap || width > 64) {
+        ctx->set_error("init graph width %d exceeds %d", width, ctx->pcap < 64 ? ctx->pcap : 64);
+        return 1;
+    }
+    hipLaunchKernelGGL(k_graph_init, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, ctx->dp,
+                       ctx->nrm, ctx->p.metric, ctx->n, idx_dev, dist_dev, width, ctx->pbuf, ctx->pdirty, ctx->pcap);
+    NND_HIP_CHECK(hipGetLastError());
+    return nnd_launch_merge(ctx);
+}

@@ -70,12 +70,13 @@ int nnd_launch_prep(nnd_ctx *ctx) {
         int rows_per_block = 4096;
         int nblocks = (int)((n + rows_per_block - 1) / rows_per_block);
         double *partial = nullptr;
-        NND_HIP_CHECK(hipMallocAsync((void **)&partial, sizeof(double) * (size_t)nblocks * d, ctx->stream));
+        NND_HIP_CHECK(hipMalloc((void **)&partial, sizeof(double) * (size_t)nblocks * d));
         hipLaunchKernelGGL(k_colsum_partial, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->x_orig, n, d,
                            rows_per_block, partial);
         hipLaunchKernelGGL(k_colsum_final, dim3((dp + 255) / 256), dim3(256), 0, ctx->stream, partial, nblocks, d, dp,
                            n, ctx->mean);
-        NND_HIP_CHECK(hipFreeAsync(partial, ctx->stream));
+        NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        NND_HIP_CHECK(hipFree(partial));
     } else {
         NND_HIP_CHECK(hipMemsetAsync(ctx->mean, 0, sizeof(float) * dp, ctx->stream));
     }

@@ -1,0 +1,129 @@
+// sample.hip -- new/old candidate sampling for one NN-descent iteration.
+//
+// Replaces new_build_candidates (reference utils.py:221-320): every directed edge v->u of the
+// current graph, with its new/old flag f, draws a uniform priority and is offered to the candidate
+// list of v (forward) and of u (reverse) -- the "new" lists if f = 1, the "old" lists if f = 0;
+// each list keeps the max_candidates smallest priorities with unique ids (utils.py:277-306).
+// Afterwards every forward new edge whose target made it into new[v] has its flag cleared
+// (utils.py:311-318).
+//
+// The reference makes every thread scan all n*k edges and push into the heaps of the vertices it
+// owns.  Here:
+//   k_sample_reverse : one thread per edge scatters the reverse offer into a bank of RCAP hashed
+//                      slots per (target, class) with a 64-bit atomicMin on (priority<<32 | source)
+//                      -- order independent, so the sample is deterministic for a given seed;
+//   k_sample_select  : one wave per vertex gathers its k forward offers and its reverse slots,
+//                      drops reverse offers that duplicate a forward id, ranks by priority and
+//                      writes the max_candidates smallest of each class, clears the flags of the
+//                      sampled forward-new edges and re-arms the reverse slots.
+// Priorities are hash(seed, iteration, v, u): forward and reverse offers of one edge share the
+// priority, as they do in the reference when one thread owns both endpoints (utils.py:275-291).
+#include "common.h"
+#include "state.h"
+
+__global__ void k_sample_reverse(const uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, uint32_t it_seed,
+                                 uint64_t *__restrict__ rbuf, int rcap) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * ks) return;
+    int64_t v = t / ks;
+    int j = (int)(t - v * ks);
+    if (j >= k) return;
+    uint32_t e = knn_e[t];
+    if (e == NND_EMPTY_E) return;
+    uint32_t u = e & NND_IDX_MASK;
+    uint32_t cls = e >> 31;  // 1 = new
+    uint32_t prio = nnd_hash3(it_seed, (uint32_t)v, u);
+    uint32_t slot = nnd_hash2(it_seed ^ 0x68E31DA4u, (uint32_t)v) & (uint32_t)(rcap - 1);
+    atomicMin((unsigned long long *)&rbuf[((int64_t)u * 2 + cls) * rcap + slot],
+              ((unsigned long long)prio << 32) | (unsigned long long)(uint32_t)v);
+}
+
+#define SAMPLE_MAX_ITEMS 128  // k (<=64) forward + rcap (<=64) reverse offers per class
+
+struct sample_scratch {
+    uint64_t key[2][SAMPLE_MAX_ITEMS];  // [class][item] priority<<32 | id
+};
+
+__global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
+                                                       int mcp, uint32_t it_seed, uint64_t *__restrict__ rbuf, int rcap,
+                                                       int32_t *__restrict__ cand) {
+    __shared__ sample_scratch scr[4];
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t v = (int64_t)blockIdx.x * 4 + w;
+    if (v >= n) return;
+    sample_scratch &sc = scr[w];
+
+    uint32_t e = NND_EMPTY_E;
+    if (lane < k) e = knn_e[v * ks + lane];
+    const bool valid = e != NND_EMPTY_E;
+    const uint32_t u = e & NND_IDX_MASK;
+    const uint32_t cls = e >> 31;
+    const uint64_t fkey = ((uint64_t)nnd_hash3(it_seed, (uint32_t)v, u) << 32) | u;
+    int cnt[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        bool mine = valid && cls == (uint32_t)c;
+        unsigned long long m = __ballot(mine);
+        if (mine) sc.key[c][nnd_prefix_popc(m)] = fkey;
+        cnt[c] = __popcll(m);
+    }
+    nnd_wave_lds_sync();
+    const int nfwd[2] = {cnt[0], cnt[1]};
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        uint64_t *slots = rbuf + (v * 2 + c) * rcap;
+        for (int s0 = 0; s0 < rcap; s0 += 64) {
+            int s = s0 + lane;
+            uint64_t rk = NND_EMPTY_KEY;
+            if (s < rcap) {
+                rk = slots[s];
+                if (rk != NND_EMPTY_KEY) slots[s] = NND_EMPTY_KEY;  // re-arm for the next iteration
+            }
+            bool ok = rk != NND_EMPTY_KEY;
+            if (ok) {  // utils.py:427-430: an id already in the list is not pushed again
+                uint32_t src = (uint32_t)rk;
+                for (int j = 0; j < nfwd[c]; j++) ok &= ((uint32_t)sc.key[c][j] != src);
+            }
+            unsigned long long m = __ballot(ok);
+            if (ok) sc.key[c][cnt[c] + nnd_prefix_popc(m)] = rk;
+            cnt[c] += __popcll(m);
+        }
+    }
+    nnd_wave_lds_sync();
+
+    int32_t *out = cand + v * 2 * mcp;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int M = cnt[c];
+        int32_t *dst = out + (c == 1 ? 0 : mcp);  // layout [new | old]
+        for (int i0 = 0; i0 < M; i0 += 64) {
+            int i = i0 + lane;
+            if (i < M) {
+                uint64_t key = sc.key[c][i];
+                int r = 0;
+                for (int j = 0; j < M; j++) r += (sc.key[c][j] < key) ? 1 : 0;
+                if (r < mc) dst[r] = (int32_t)(uint32_t)key;
+            }
+        }
+        int filled = M < mc ? M : mc;
+        for (int j = filled + lane; j < mcp; j += 64) dst[j] = -1;
+    }
+    // flag reset (utils.py:311-318): a forward new edge that was sampled becomes old
+    if (valid && cls == 1u) {
+        int r = 0;
+        for (int j = 0; j < cnt[1]; j++) r += (sc.key[1][j] < fkey) ? 1 : 0;
+        if (r < mc) knn_e[v * ks + lane] = u;
+    }
+}
+
+int nnd_launch_sample(nnd_ctx *ctx) {
+    const int64_t n = ctx->n;
+    uint32_t it_seed = nnd_hash2(ctx->seed ^ 0x9E3779B9u, (uint32_t)ctx->iter + 1u);
+    int64_t total = n * ctx->ks;
+    hipLaunchKernelGGL(k_sample_reverse, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e, n,
+                       ctx->k, ctx->ks, it_seed, ctx->rbuf, ctx->rcap);
+    hipLaunchKernelGGL(k_sample_select, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->knn_e, n, ctx->k,
+                       ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -55,6 +55,7 @@ struct nnd_handle_s {
     int32_t *cand = nullptr;  // (n, 2*mcp): [new | old], -1 padded
     uint64_t *rbuf = nullptr; // (n, 2, rcap) reverse offers (priority<<32 | source), hashed slots
     uint64_t *pbuf = nullptr; // (n, pcap) proposals (dist_bits<<32 | source), hashed slots
+    uint8_t *pdirty = nullptr; // (n) 1 when the row has pending proposals
 
     // rp forest (all trees in one position space P = n_trees*n)
     int64_t P = 0;

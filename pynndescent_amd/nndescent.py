@@ -1,0 +1,280 @@
+"""``NNDescent`` -- drop-in for the BUILD path of ``pynndescent.NNDescent`` on an MI355X.
+
+Mirrors the reference constructor (pynndescent/pynndescent_.py:976-1269): same keyword arguments in
+the same positional order, same derived defaults, same RandomState draw order, same attributes after
+construction, same errors and warnings.  The dense euclidean / cosine branch
+(pynndescent_.py:1221-1260) -- ``make_forest`` + ``rptree_leaf_array`` + ``nn_descent`` -- runs on
+the GPU through the C ABI of ``include/pynnd_amd.h``.  Nothing here computes neighbours on the CPU:
+if the HIP library or a gfx950 device is missing, construction raises.
+
+Out of scope (SURVEY.md section 8 "next"): ``prepare`` / ``query`` / ``update``, sparse input, and
+metrics other than euclidean / l2 / cosine.  Those raise ``NotImplementedError`` naming the
+reference entry point to use instead.
+"""
+import time
+from warnings import warn
+
+import numpy as np
+from sklearn.utils import check_array, check_random_state
+
+from . import _capi
+
+INT32_MIN = np.iinfo(np.int32).min + 1  # pynndescent_.py:62
+INT32_MAX = np.iinfo(np.int32).max - 1  # pynndescent_.py:63
+
+_METRIC_CODES = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN,
+                 "cosine": _capi.NND_METRIC_ALT_COSINE}
+# metrics whose trees are angular in the reference (pynndescent_.py:1075-1086)
+_ANGULAR_METRICS = ("cosine", "dot", "correlation", "dice", "jaccard", "hellinger", "hamming", "bit_hamming",
+                    "bit_jaccard")
+
+
+def ts():
+    """Timestamp used in verbose output (reference utils.py:881-883)."""
+    return time.ctime(time.time())
+
+
+def tau_rand_int(state):
+    """Reference utils.py:17-40 on an int64[3] numpy state (used only to warm up search_rng_state)."""
+    s = [int(v) for v in state]
+    s[0] = (((s[0] & 4294967294) << 12) & 0xFFFFFFFF) ^ ((((s[0] << 13) & 0xFFFFFFFF) ^ s[0]) >> 19)
+    s[1] = (((s[1] & 4294967288) << 4) & 0xFFFFFFFF) ^ ((((s[1] << 2) & 0xFFFFFFFF) ^ s[1]) >> 25)
+    s[2] = (((s[2] & 4294967280) << 17) & 0xFFFFFFFF) ^ ((((s[2] << 3) & 0xFFFFFFFF) ^ s[2]) >> 11)
+    state[0], state[1], state[2] = s
+    r = (s[0] ^ s[1] ^ s[2]) & 0xFFFFFFFF
+    return r - (1 << 32) if r >= (1 << 31) else r
+
+
+def correct_alternative_cosine(d):
+    """1 - 2^-d (reference distances.py:704-711); float64 like the reference's ufunc."""
+    return 1.0 - np.power(2.0, -np.asarray(d, dtype=np.float64))
+
+
+_DISTANCE_CORRECTIONS = {"euclidean": np.sqrt, "l2": np.sqrt, "cosine": correct_alternative_cosine}
+
+
+class _DeviceForestSentinel:
+    """Stands in for ``_rp_forest``: downstream reference code only null-checks it
+    (pynndescent_.py:1353) -- the build consumes nothing but the leaf array."""
+
+    def __init__(self, n_trees, n_leaves, max_leaf_size):
+        self.n_trees, self.n_leaves, self.max_leaf_size = n_trees, n_leaves, max_leaf_size
+
+    def __len__(self):
+        return self.n_trees
+
+
+class NNDescent:
+    """See ``pynndescent.NNDescent``; constructor signature identical (pynndescent_.py:976-1007)."""
+
+    def __init__(
+        self,
+        data,
+        metric="euclidean",
+        metric_kwds=None,
+        bit_metric=False,
+        n_neighbors=30,
+        n_trees=None,
+        angular_trees=False,
+        leaf_size=None,
+        pruning_degree_multiplier=1.5,
+        diversify_prob=1.0,
+        diversify_method="standard",
+        degree_prune_aggressiveness=1.0,
+        n_search_trees=1,
+        search_tree_leaf_size=None,
+        max_search_tree_depth=None,
+        quantization=None,
+        tree_init=True,
+        init_graph=None,
+        init_dist=None,
+        random_state=None,
+        low_memory=True,
+        max_candidates=None,
+        max_rptree_depth=200,
+        n_iters=None,
+        delta=0.001,
+        n_jobs=None,
+        compressed=False,
+        parallel_batch_queries=False,
+        verbose=False,
+        device=0,
+    ):
+        if n_trees is None:
+            n_trees = max(3, min(12, int(round(2.0 * np.log10(data.shape[0])))))  # pynndescent_.py:1009-1010
+        if n_iters is None:
+            n_iters = max(5, int(round(np.log2(data.shape[0]))))  # pynndescent_.py:1011-1012
+
+        self.n_trees = n_trees
+        self.angular_trees = angular_trees
+        self.n_trees_after_update = max(2, int(np.round(self.n_trees / 3)))
+        self.n_neighbors = n_neighbors
+        self.metric = metric
+        self.metric_kwds = metric_kwds
+        self.bit_metric = bit_metric
+        self.leaf_size = leaf_size
+        self.prune_degree_multiplier = pruning_degree_multiplier
+        self.diversify_prob = diversify_prob
+        self.diversify_method = diversify_method
+        self.degree_prune_aggressiveness = degree_prune_aggressiveness
+        self.n_search_trees = n_search_trees
+        self.search_tree_leaf_size = search_tree_leaf_size
+        self.max_search_tree_depth = max_search_tree_depth
+        self.max_rptree_depth = max_rptree_depth
+        self.max_candidates = max_candidates
+        self.quantization = quantization
+        self.low_memory = low_memory
+        self.n_iters = n_iters
+        self.delta = delta
+        self.dim = data.shape[1]
+        self.n_jobs = n_jobs
+        self.compressed = compressed
+        self.parallel_batch_queries = parallel_batch_queries
+        self.verbose = verbose
+        self.device = device
+
+        if callable(metric) or metric not in _METRIC_CODES:
+            if callable(metric) or metric in _KNOWN_REFERENCE_METRICS:
+                raise NotImplementedError(
+                    "pynndescent_amd accelerates the dense euclidean / l2 / cosine build only; "
+                    "use pynndescent.NNDescent for metric %r" % (metric,)
+                )
+            raise ValueError("Metric is neither callable, " + "nor a recognised string")  # pynndescent_.py:1292
+        try:
+            import scipy.sparse
+
+            if scipy.sparse.issparse(data):
+                raise NotImplementedError(
+                    "sparse input is out of scope for pynndescent_amd; use pynndescent.NNDescent (sparse_nndescent)"
+                )
+        except ImportError:  # pragma: no cover
+            pass
+
+        data = check_array(data, dtype=np.float32, order="C")  # pynndescent_.py:1054
+        self._input_dtype = np.float32
+        self._raw_data = data
+
+        if not tree_init or n_trees == 0 or init_graph is not None:  # pynndescent_.py:1059-1062
+            self.tree_init = False
+        else:
+            self.tree_init = True
+
+        metric_kwds = metric_kwds or {}
+        self._dist_args = tuple(metric_kwds.values())
+        self.random_state = random_state
+        current_random_state = check_random_state(self.random_state)
+
+        self._distance_correction = _DISTANCE_CORRECTIONS[metric]
+        self._distance_func = None  # device kernels; see include/pynnd_amd.h NND_METRIC_*
+        self._angular_trees = metric in _ANGULAR_METRICS
+        self._bit_trees = False
+        self._is_sparse = False
+
+        # RandomState draw order of the reference: rng_state, search_rng_state, then the per-tree
+        # states inside make_forest (pynndescent_.py:1105-1113, rp_trees.py:2850)
+        self.rng_state = current_random_state.randint(INT32_MIN, INT32_MAX, 3).astype(np.int64)
+        self.search_rng_state = current_random_state.randint(INT32_MIN, INT32_MAX, 3).astype(np.int64)
+        for _ in range(10):
+            tau_rand_int(self.search_rng_state)
+
+        n = data.shape[0]
+        if self.tree_init:
+            if verbose:
+                print(ts(), "Building RP forest with", str(n_trees), "trees")
+            eff_leaf_size = leaf_size
+            if eff_leaf_size is None:
+                eff_leaf_size = max(60, min(256, 5 * int(n_neighbors)))  # rp_trees.py:2845-2846
+            tree_states = current_random_state.randint(INT32_MIN, INT32_MAX, size=(n_trees, 3)).astype(np.int64)
+            eff_trees = n_trees
+        else:
+            eff_leaf_size = max(60, min(256, 5 * int(n_neighbors))) if leaf_size is None else leaf_size
+            tree_states = np.zeros((1, 3), np.int64)
+            eff_trees = 0
+
+        if self.max_candidates is None:
+            effective_max_candidates = min(60, self.n_neighbors)  # pynndescent_.py:1135-1138
+        else:
+            effective_max_candidates = self.max_candidates
+
+        if init_graph is not None:
+            init_graph = np.asarray(init_graph)
+            if init_graph.shape[0] != n:
+                raise ValueError("Init graph size does not match dataset size!")  # pynndescent_.py:1229
+            if init_dist is not None and init_graph.shape != np.asarray(init_dist).shape:
+                raise ValueError("The shapes of init graph and init distances do not match!")  # pynndescent_.py:1236
+
+        builder = _capi.Builder(
+            n, data.shape[1], _METRIC_CODES[metric], n_neighbors, eff_trees, eff_leaf_size, max_rptree_depth,
+            effective_max_candidates, n_iters, delta, self.rng_state, tree_states[0], device=device,
+        )
+        try:
+            builder.set_data_host(data)
+            if self.tree_init:
+                builder.make_forest()
+                st = builder.stats()
+                self._rp_forest = _DeviceForestSentinel(n_trees, st["n_leaves"], eff_leaf_size)
+            else:
+                self._rp_forest = None
+            if verbose:
+                print(ts(), "NN descent for", str(n_iters), "iterations")
+            if init_graph is None:
+                if self.tree_init:
+                    builder.init_from_leaves()
+                builder.init_random()
+            else:
+                builder.init_from_graph(init_graph, init_dist)
+            # nn_descent_internal (pynndescent_.py:296-320), driven from here so verbose output matches
+            for it in range(n_iters):
+                if verbose:
+                    print("\t", it + 1, " / ", n_iters)
+                c = builder.descent_iter()
+                if c <= delta * n_neighbors * n:
+                    if verbose:
+                        print("\tStopping threshold met -- exiting after", it + 1, "iterations")
+                    break
+            self._neighbor_graph = builder.finalize()
+            self._build_stats = builder.stats()
+        finally:
+            builder.close()
+
+        if np.any(self._neighbor_graph[0] < 0):  # pynndescent_.py:1262-1267
+            warn(
+                "Failed to correctly find n_neighbors for some samples."
+                " Results may be less than ideal. Try re-running with"
+                " different parameters."
+            )
+
+    @property
+    def neighbor_graph(self):
+        """pynndescent_.py:2145-2158: copies, with the distance correction applied."""
+        if self.compressed and not hasattr(self, "_neighbor_graph"):
+            warn("Compressed indexes do not have neighbor graph information.")
+            return None
+        return (self._neighbor_graph[0].copy(), self._distance_correction(self._neighbor_graph[1]))
+
+    def _out_of_scope(self, what):
+        raise NotImplementedError(
+            "%s is out of scope for pynndescent_amd (build path only; SURVEY.md section 8f). "
+            "Hand this index's neighbor_graph to the reference as init_graph, or use pynndescent.NNDescent." % what
+        )
+
+    def prepare(self):
+        self._out_of_scope("NNDescent.prepare (pynndescent_.py:2174)")
+
+    def query(self, query_data, k=10, epsilon=0.1):
+        self._out_of_scope("NNDescent.query (pynndescent_.py:2275)")
+
+    def update(self, xs_fresh=None, xs_updated=None, updated_indices=None):
+        self._out_of_scope("NNDescent.update (pynndescent_.py:2381)")
+
+
+# string metrics the reference recognises (distances.py:2103-2168 named_distances keys) -- used only to
+# decide between NotImplementedError (valid in the reference, not accelerated) and the reference's ValueError.
+_KNOWN_REFERENCE_METRICS = frozenset(
+    """euclidean l2 sqeuclidean manhattan taxicab l1 chebyshev linfinity linfty linf minkowski seuclidean
+    standardised_euclidean wminkowski weighted_minkowski mahalanobis canberra cosine dot inner_product correlation
+    haversine braycurtis spearmanr tsss true_angular hellinger kantorovich wasserstein wasserstein_1d
+    wasserstein-1d kantorovich-1d kantorovich_1d circular_kantorovich circular_wasserstein sinkhorn jensen-shannon
+    jensen_shannon symmetric-kl symmetric_kl symmetric_kullback_liebler hamming jaccard dice matching kulsinski
+    rogerstanimoto russellrao sokalsneath sokalmichener yule bit_hamming bit_jaccard""".split()
+)

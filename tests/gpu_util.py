@@ -1,0 +1,69 @@
+"""Helpers for the -m gpu tests (they call the HIP path through the C ABI only)."""
+import numpy as np
+
+from oracle import oracle as O
+from pynndescent_amd import _capi
+
+
+def alt_dist_matrix(x, rows_a, rows_b, metric):
+    """float64 alt-space distances (reference distances.py:63-91, 583-630)."""
+    a = x[rows_a].astype(np.float64)
+    b = x[rows_b].astype(np.float64)
+    if metric == "euclidean":
+        return ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+    dot = a @ b.T
+    na = (a * a).sum(1)[:, None]
+    nb = (b * b).sum(1)[None, :]
+    out = np.full(dot.shape, 3.402823466e38)
+    ok = (na > 0) & (nb > 0) & (dot > 0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out[ok] = np.log2(np.sqrt(na * nb)[ok] / dot[ok])
+    out[(na == 0) & (nb == 0)] = 0.0
+    return np.maximum(out, 0.0)
+
+
+def make_builder(x, metric="euclidean", k=15, n_trees=8, leaf_size=None, mc=None, n_iters=None, delta=0.001,
+                 seed=1, max_depth=200, join_blocks=1):
+    n, d = x.shape
+    rng_state, _, tree_states = O.draw_rng_states(seed, max(n_trees, 1))
+    ls = O.default_leaf_size(k) if leaf_size is None else leaf_size
+    mc = min(60, k) if mc is None else mc
+    n_iters = O.default_n_iters(n) if n_iters is None else n_iters
+    b = _capi.Builder(n, d, O.METRICS[metric], k, n_trees, ls, max_depth, mc, n_iters, delta, rng_state,
+                      tree_states[0], join_blocks=join_blocks)
+    b.set_data_host(x)
+    return b
+
+
+def check_graph_invariants(x, metric, idx, dist, tol=2e-4, atol=1e-5, name=""):
+    """rows ascending, ids unique, stored alt distances match the true ones for the stored ids."""
+    n, k = idx.shape
+    assert np.all(np.diff(np.where(np.isfinite(dist), dist, np.float32(3e38)).astype(np.float64), axis=1) >= 0), name + ": rows not ascending"
+    for r in range(n):
+        v = idx[r][idx[r] >= 0]
+        assert len(v) == len(np.unique(v)), "%s: duplicate ids in row %d: %s" % (name, r, idx[r])
+    rows = np.arange(n)
+    valid = idx >= 0
+    xi = x.astype(np.float64)
+    if metric == "euclidean":
+        true = ((xi[:, None, :] - xi[np.where(valid, idx, 0)]) ** 2).sum(-1)
+    else:
+        nb = xi[np.where(valid, idx, 0)]
+        dot = (xi[:, None, :] * nb).sum(-1)
+        na = (xi * xi).sum(1)[:, None]
+        nbn = (nb * nb).sum(-1)
+        true = np.full(dot.shape, 3.402823466e38)
+        ok = (na > 0) & (nbn > 0) & (dot > 0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            true[ok] = np.log2(np.sqrt(na * nbn)[ok] / dot[ok])
+        true[(na == 0) & (nbn == 0)] = 0.0
+        true = np.maximum(true, 0)
+    big = true > 1e30
+    m = valid & ~big
+    scale = max(1.0, float(np.abs(true[m]).max())) if m.any() else 1.0
+    err = np.abs(dist[m].astype(np.float64) - true[m])
+    lim = tol * np.abs(true[m]) + atol * scale
+    assert (err <= lim).all(), "%s: stored distances off, max err %g (rel %g)" % (
+        name, err.max(), (err / np.maximum(np.abs(true[m]), 1e-30)).max())
+    assert np.all(dist[valid & big] > 1e30), name + ": FLT_MAX convention"
+    assert np.all(np.isinf(dist[~valid])), name + ": empty slots must be +inf"

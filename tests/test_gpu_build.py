@@ -1,0 +1,199 @@
+"""End-to-end parity of the HIP build path with the CPU oracle / reference fixtures (MI355X)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pynndescent_amd import NNDescent
+from tests.util_data import clustered, nn_data_like
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _true_alt_to_corrected(x, idx, metric):
+    xi = x.astype(np.float64)
+    nb = xi[np.where(idx >= 0, idx, 0)]
+    if metric == "euclidean":
+        return np.sqrt(((xi[:, None, :] - nb) ** 2).sum(-1))
+    dot = (xi[:, None, :] * nb).sum(-1)
+    na = np.sqrt((xi * xi).sum(1))[:, None]
+    nbn = np.sqrt((nb * nb).sum(-1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cosd = 1.0 - dot / (na * nbn)
+    cosd = np.where((na == 0) & (nbn == 0), 0.0, np.where((na == 0) | (nbn == 0) | (dot <= 0), 1.0, cosd))
+    return cosd
+
+
+def _parity(x, metric, k, gpu_idx, ref_idx, band=0.005, k_true=10):
+    ti, _ = O.brute_force_knn(x, k_true, metric)
+    r_gpu, r_ref = O.recall(ti, gpu_idx), O.recall(ti, ref_idx)
+    print("recall@%d: gpu %.4f reference-algorithm %.4f" % (k_true, r_gpu, r_ref))
+    assert r_gpu >= r_ref - band, (r_gpu, r_ref)
+    return r_gpu, r_ref
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_reference_test_shape_nn_data(metric):
+    """tests/test_pynndescent_.py:19-53: positional 10 binds to bit_metric, build runs at k=30; floor 0.98."""
+    x = nn_data_like()
+    idx, dist = NNDescent(x, metric, {}, 10, random_state=np.random.RandomState(189212))._neighbor_graph
+    assert idx.shape == (1002, 30)
+    g = np.load(os.path.join(GOLDEN, "class_nndata_%s.npz" % metric))
+    r_gpu, r_ref = _parity(x, metric, 30, idx, g["idx"])
+    assert r_gpu >= 0.98
+
+
+def test_clustered_against_reference_fixture():
+    g = np.load(os.path.join(GOLDEN, "build_clustered_euclidean_T4.npz"))
+    n, d, latent, ncl, seed = (int(v) for v in g["gen"])
+    x = clustered(n, d, latent, ncl, seed)
+    index = NNDescent(x, "euclidean", n_neighbors=15, n_trees=8, random_state=5)
+    idx, dist = index.neighbor_graph
+    _parity(x, "euclidean", 15, idx, g["idx"])
+    # distances of the returned pairs: exact to 1e-5 relative (north_star)
+    np.testing.assert_allclose(dist, _true_alt_to_corrected(x, idx, "euclidean"), rtol=1e-5, atol=1e-7)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+
+
+def test_iid_cosine_against_reference_fixture():
+    g = np.load(os.path.join(GOLDEN, "build_iid_cosine_T4.npz"))
+    n, d, seed = (int(v) for v in g["gen"])
+    x = np.random.RandomState(seed).standard_normal((n, d)).astype(np.float32)
+    index = NNDescent(x, "cosine", n_neighbors=15, n_trees=8, random_state=6)
+    idx, dist = index.neighbor_graph
+    _parity(x, "cosine", 15, idx, g["idx"], band=0.01)
+    truth = _true_alt_to_corrected(x, idx, "cosine")
+    np.testing.assert_allclose(dist, truth, rtol=1e-5, atol=2e-7)
+
+
+def test_baseline_config1_plumbing():
+    """BASELINE.json configs[0]: 10k x 64 random, euclidean, k=10, n_iters=5 (reference fixture, recall ~0.49)."""
+    g = np.load(os.path.join(GOLDEN, "build_c1_T8.npz"))
+    x = np.random.RandomState(0).standard_normal((10000, 64)).astype(np.float32)
+    idx, _ = NNDescent(x, "euclidean", n_neighbors=10, n_trees=8, n_iters=5, random_state=0)._neighbor_graph
+    r_gpu, r_ref = _parity(x, "euclidean", 10, idx, g["idx"], band=0.02)
+    assert abs(r_gpu - r_ref) < 0.08  # same regime, not merely "at least as good"
+
+
+def test_sift_like_medium_vs_oracle():
+    x = clustered(20000, 128, 16, 256, seed=1, nonneg=True) * 20.0
+    index = NNDescent(x, "euclidean", n_neighbors=15, n_trees=8, random_state=2)
+    idx, dist = index.neighbor_graph
+    oidx, _ = O.build_index(x, "euclidean", n_neighbors=15, n_trees=8, random_state=2, n_threads=8, kind="fast")
+    r_gpu, r_ref = _parity(x, "euclidean", 15, idx, oidx)
+    assert r_gpu >= 0.95
+    np.testing.assert_allclose(dist, _true_alt_to_corrected(x, idx, "euclidean"), rtol=1e-5, atol=1e-6)
+    st = index._build_stats
+    print("stats", {k: st[k] for k in ("n_iters_run", "n_leaves", "tree_levels", "ms_forest", "ms_leaf_init", "ms_descent")})
+
+
+def test_glove_like_cosine_d100_vs_oracle():
+    x = clustered(12000, 100, 24, 128, seed=2)
+    index = NNDescent(x, "cosine", n_neighbors=15, n_trees=8, random_state=3)
+    idx, dist = index.neighbor_graph
+    oidx, _ = O.build_index(x, "cosine", n_neighbors=15, n_trees=8, random_state=3, n_threads=8, kind="fast")
+    _parity(x, "cosine", 15, idx, oidx)
+    np.testing.assert_allclose(dist, _true_alt_to_corrected(x, idx, "cosine"), rtol=1e-5, atol=2e-7)
+
+
+def test_deterministic_for_a_seed():
+    """tests/test_pynndescent_.py:279-291 in spirit: same seed -> identical graph."""
+    x = np.random.RandomState(42).normal(0, 100, (1000, 50)).astype(np.float32)
+    a = NNDescent(x, random_state=np.random.RandomState(42))._neighbor_graph
+    b = NNDescent(x, random_state=np.random.RandomState(42))._neighbor_graph
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_duplicate_heavy_inputs_keep_rows_unique():
+    """tests/test_pynndescent_.py:299-314, 352-369."""
+    near = np.load(os.path.join(GOLDEN, "reference_testdata_cosine_near_duplicates.npz"))["data"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        idx, _ = NNDescent(near, "cosine", {}, 10, random_state=np.random.RandomState(189212), n_trees=20)._neighbor_graph
+    for row in idx:
+        v = row[row >= 0]
+        assert len(v) == len(np.unique(v))
+    hang = np.load(os.path.join(GOLDEN, "reference_testdata_cosine_hang.npz"))["data"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        idx, _ = NNDescent(hang, "cosine", {}, 10, random_state=np.random.RandomState(189212), n_trees=20)._neighbor_graph
+    for row in idx:
+        v = row[row >= 0]
+        assert len(v) == len(np.unique(v))
+
+
+def test_deduplicated_data_behaves_normally():
+    """tests/test_pynndescent_.py:317-349: recall >= 0.95 (k=30 effective, true top-10)."""
+    hang = np.load(os.path.join(GOLDEN, "reference_testdata_cosine_hang.npz"))["data"]
+    data = np.unique(hang, axis=0)
+    data = data[~np.all(data == 0, axis=1)][:1000]
+    idx, _ = NNDescent(data, "cosine", {}, 10, random_state=np.random.RandomState(189212), n_trees=20)._neighbor_graph
+    g = np.load(os.path.join(GOLDEN, "class_dedup_hang_cosine.npz"))
+    # the fixture was generated at n_neighbors=10 (keyword), the reference test shape is k=30: compare like for like
+    idx10, _ = NNDescent(data, "cosine", n_neighbors=10, random_state=np.random.RandomState(189212), n_trees=20)._neighbor_graph
+    r_gpu, r_ref = _parity(data, "cosine", 10, idx10, g["idx"], band=0.01)
+    ti, _ = O.brute_force_knn(data, 10, "cosine")
+    assert O.recall(ti, idx) >= 0.95
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_tree_init_false(metric):
+    x = nn_data_like()[200:]
+    idx, _ = NNDescent(x, metric=metric, n_neighbors=10, random_state=3, tree_init=False)._neighbor_graph
+    oidx, _ = O.build_index(x, metric, n_neighbors=10, random_state=3, tree_init=False, n_threads=1)
+    _parity(x, metric, 10, idx, oidx, band=0.01)
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_leaf_size_larger_than_n(metric):
+    """tests/test_pynndescent_.py:716-747: leaf_size > n, k = n - 1: the graph must be complete."""
+    x = np.random.RandomState(17).uniform(5, 40, size=(10, 5)).astype(np.float32)
+    idx, dist = NNDescent(x, metric=metric, n_neighbors=9, random_state=4, leaf_size=21)._neighbor_graph
+    for r in range(10):
+        assert set(idx[r].tolist()) <= set(range(10)) and len(set(idx[r].tolist())) == 9
+
+
+def test_bad_data_smoke_wide_rows():
+    """tests/test_pynndescent_.py:750-756: 1011 x 3500, cosine, defaults (k=30)."""
+    arr = np.load(os.path.join(GOLDEN, "reference_testdata_bad_data.npz"))["arr_0"]
+    data = np.sqrt(arr).astype(np.float32)
+    index = NNDescent(data, metric="cosine", random_state=0)
+    idx, dist = index.neighbor_graph
+    oidx, _ = O.build_index(data, "cosine", n_neighbors=30, random_state=0, n_threads=8, kind="fast")
+    _parity(data, "cosine", 30, idx, oidx, band=0.01)
+
+
+def test_init_graph_and_errors():
+    x = clustered(1200, 10, 4, 6, seed=23)
+    ti, _ = O.brute_force_knn(x, 10, "euclidean")
+    rs = np.random.RandomState(0)
+    noisy = np.where(rs.uniform(size=ti.shape) < 0.5, rs.randint(0, 1200, ti.shape), ti).astype(np.int32)
+    idx, _ = NNDescent(x, n_neighbors=10, init_graph=noisy, random_state=1)._neighbor_graph
+    assert O.recall(ti, idx) > 0.95
+    with pytest.raises(ValueError, match="Init graph size does not match dataset size!"):
+        NNDescent(x, n_neighbors=10, init_graph=noisy[:50])
+    with pytest.raises(ValueError, match="do not match"):
+        NNDescent(x, n_neighbors=10, init_graph=noisy, init_dist=np.zeros((1200, 3), np.float32))
+    with pytest.raises(ValueError, match="Metric is neither callable"):
+        NNDescent(x, metric="not_a_metric")
+
+
+def test_verbose_output(capsys):
+    """tests/test_pynndescent_.py:372-387."""
+    import re
+
+    x = np.vstack([np.random.RandomState(1).randn(10, 20), np.zeros((2, 20))]).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        NNDescent(data=x, metric="euclidean", metric_kwds={}, n_neighbors=4, random_state=np.random.RandomState(189212),
+                  n_trees=5, n_iters=2, verbose=True)
+    out = capsys.readouterr().out
+    assert re.match("^.*5 trees", out, re.DOTALL) and re.match("^.*2 iterations", out, re.DOTALL)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        NNDescent(data=x, metric="euclidean", n_neighbors=4, random_state=1, n_trees=5, n_iters=2, verbose=False)
+    assert capsys.readouterr().out.strip() == ""

@@ -1,0 +1,205 @@
+"""Kernel-level parity tests on a real MI355X (each stage of the build through the C ABI)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.gpu_util import alt_dist_matrix, check_graph_invariants, make_builder
+from tests.util_data import clustered, nn_data_like
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+@pytest.mark.parametrize("d", [5, 40, 128, 200])
+def test_mfma_gram_tile(metric, d):
+    """The f32 MFMA Gram tile (operand and result lane maps) against float64 numpy, asymmetric row lists."""
+    rs = np.random.RandomState(d)
+    x = (rs.standard_normal((300, d)) * rs.uniform(0.5, 2.0, (1, d)) + 0.7).astype(np.float32)
+    x[17] = 0.0
+    b = make_builder(x, metric, k=10, n_trees=0)
+    rows_a = rs.permutation(300)[:37]
+    rows_b = np.concatenate([rs.permutation(300)[:51], [17, 17]])
+    got = b.pairwise_gram(rows_a, rows_b)
+    want = alt_dist_matrix(x, rows_a, rows_b, metric)
+    fin = want < 1e30
+    assert np.array_equal(got > 1e30, ~fin)
+    scale = np.abs(want[fin]).max()
+    np.testing.assert_allclose(got[fin], want[fin], rtol=2e-4, atol=2e-6 * scale)
+    b.close()
+
+
+@pytest.mark.parametrize("metric,n,d,k,T", [("euclidean", 5000, 24, 15, 4), ("cosine", 3000, 16, 10, 3),
+                                            ("euclidean", 1002, 5, 30, 6)])
+def test_forest_partitions(metric, n, d, k, T):
+    x = clustered(n, d, 6, 30, seed=n) if d > 5 else nn_data_like()
+    b = make_builder(x, metric, k=k, n_trees=T)
+    b.make_forest()
+    la = b.leaf_array()
+    ls = O.default_leaf_size(k)
+    assert la.shape[1] == ls
+    ids = la[la >= 0]
+    assert ids.shape[0] == T * n
+    assert np.all(np.bincount(ids, minlength=n) == T)  # every tree holds every point exactly once
+    lens = (la >= 0).sum(1)
+    assert lens.max() <= ls and lens.min() >= 1
+    # -1 padding only at the row tails
+    assert np.all((la >= 0) == (np.arange(ls)[None, :] < lens[:, None]))
+    # same leaf statistics as the reference algorithm (oracle): mean fill within 15 %
+    _, _, ts = O.draw_rng_states(1, T)
+    ola = O.make_leaf_array(x, T, ls, ts, metric == "cosine")
+    ofill = (ola >= 0).sum(1).mean()
+    assert abs(lens.mean() - ofill) <= 0.15 * ofill, (lens.mean(), ofill)
+    # and the same locality: fraction of true 5-NN that share a leaf with their point
+    ti, _ = O.brute_force_knn(x, 6, metric)
+
+    def colocated(arr):
+        hit = np.zeros(n)
+        leaf_of = {}
+        for row in arr:
+            members = row[row >= 0]
+            s = set(members.tolist())
+            for p in members:
+                hit[p] += sum(1 for q in ti[p, 1:] if q in s)
+        return hit.sum() / (n * 5 * T)
+
+    cg, co = colocated(la), colocated(ola)
+    assert abs(cg - co) <= 0.04, (cg, co)
+    b.close()
+
+
+@pytest.mark.parametrize("metric,n,d,k,T", [("euclidean", 4000, 32, 15, 3), ("cosine", 2500, 20, 10, 2),
+                                            ("euclidean", 1002, 5, 30, 2), ("euclidean", 1500, 130, 12, 2)])
+def test_leaf_init_is_exact_topk_of_leafmates(metric, n, d, k, T):
+    """After init_from_leaves every row must hold exactly the k nearest of the point's leaf-mates
+    (what sequential checked_flagged_heap_push over all leaf pairs produces, pynndescent_.py:73-185)."""
+    x = clustered(n, d, 6, 25, seed=7) if d > 5 else nn_data_like()
+    b = make_builder(x, metric, k=k, n_trees=T)
+    b.make_forest()
+    la = b.leaf_array()
+    b.init_from_leaves()
+    idx, dist, flags = b.graph()
+    check_graph_invariants(x, metric, idx, dist, name="leaf_init")
+    assert np.all(flags[idx >= 0] == 1)
+    mates = [set() for _ in range(n)]
+    for row in la:
+        m = row[row >= 0]
+        for p in m:
+            mates[p].update(m.tolist())
+    bad = 0
+    for p in range(0, n, 7):
+        cand = np.array(sorted(mates[p] - {p}))
+        dd = alt_dist_matrix(x, [p], cand, metric)[0]
+        kk = min(k, len(cand))
+        kth = np.sort(dd)[kk - 1]
+        got = idx[p][idx[p] >= 0]
+        assert len(got) == kk, (p, len(got), kk)
+        gd = alt_dist_matrix(x, [p], got, metric)[0]
+        if not np.all(gd <= kth * (1 + 1e-4) + 1e-6):
+            bad += 1
+    assert bad == 0
+    b.close()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_random_init(metric):
+    x = clustered(2000, 16, 5, 10, seed=5)
+    b = make_builder(x, metric, k=12, n_trees=0)
+    b.init_random()
+    idx, dist, flags = b.graph()
+    check_graph_invariants(x, metric, idx, dist, name="random_init")
+    filled = (idx >= 0).sum(1)
+    assert filled.min() >= 9 and filled.mean() > 11.8  # k draws, collisions are rare at n=2000
+    assert np.all(flags[idx >= 0] == 1)
+    b.close()
+
+
+def test_init_from_graph():
+    x = clustered(1500, 12, 4, 8, seed=9)
+    ti, td = O.brute_force_knn(x, 8, "euclidean")
+    g = ti.copy()
+    g[:, 3] = g[:, 2]  # duplicate entries must be pushed once (utils.py:489-492)
+    g[::5, 5] = -1
+    b = make_builder(x, "euclidean", k=10, n_trees=0)
+    b.init_from_graph(g)
+    idx, dist, flags = b.graph()
+    check_graph_invariants(x, "euclidean", idx, dist, name="init_graph")
+    for r in range(0, 1500, 11):
+        want = set(g[r][g[r] >= 0].tolist())
+        assert set(idx[r][idx[r] >= 0].tolist()) == want
+    b.close()
+
+
+@pytest.mark.parametrize("k,mc", [(15, 15), (30, 30), (10, 6)])
+def test_sample_candidates(k, mc):
+    """Structural contract of new_build_candidates (utils.py:221-320)."""
+    x = clustered(3000, 16, 5, 20, seed=11)
+    b = make_builder(x, "euclidean", k=k, n_trees=3, mc=mc)
+    b.make_forest()
+    b.init_from_leaves()
+    b.init_random()
+    b.descent_iter()  # creates a mix of old and new entries
+    idx0, _, fl0 = b.graph()
+    b.sample_candidates()
+    new, old = b.candidates()
+    idx1, _, fl1 = b.graph()
+    assert np.array_equal(idx0, idx1)
+    n = x.shape[0]
+    fwd = [dict() for _ in range(n)]
+    rev_new = [set() for _ in range(n)]
+    rev_old = [set() for _ in range(n)]
+    for v in range(n):
+        for j in range(k):
+            u = idx0[v, j]
+            if u >= 0:
+                (rev_new if fl0[v, j] else rev_old)[u].add(v)
+    n_new_total = 0
+    for v in range(n):
+        nv = new[v][new[v] >= 0]
+        ov = old[v][old[v] >= 0]
+        assert len(nv) == len(np.unique(nv)) and len(ov) == len(np.unique(ov))
+        f_new = set(idx0[v][(idx0[v] >= 0) & (fl0[v] == 1)].tolist())
+        f_old = set(idx0[v][(idx0[v] >= 0) & (fl0[v] == 0)].tolist())
+        assert set(nv.tolist()) <= (f_new | rev_new[v]), v
+        assert set(ov.tolist()) <= (f_old | rev_old[v]), v
+        assert len(nv) >= min(mc, len(f_new)) and len(ov) >= min(mc, len(f_old))
+        # lists are filled from the front
+        assert np.all(new[v][: len(nv)] >= 0) and np.all(old[v][: len(ov)] >= 0)
+        # flag reset: forward new entries that were sampled are old now, the others stay new (utils.py:311-318)
+        for j in range(k):
+            u = idx0[v, j]
+            if u >= 0 and fl0[v, j] == 1:
+                assert fl1[v, j] == (0 if u in set(nv.tolist()) else 1)
+            elif u >= 0:
+                assert fl1[v, j] == 0
+        n_new_total += len(nv)
+    assert n_new_total > 0
+    b.close()
+
+
+@pytest.mark.parametrize("metric,k", [("euclidean", 15), ("cosine", 15), ("euclidean", 30), ("euclidean", 50)])
+def test_descent_iterations_keep_invariants_and_improve(metric, k):
+    x = clustered(4000, 24, 6, 30, seed=13)
+    b = make_builder(x, metric, k=k, n_trees=2)
+    b.make_forest()
+    b.init_from_leaves()
+    b.init_random()
+    ti, _ = O.brute_force_knn(x, 10, metric)
+    idx, dist, _ = b.graph()
+    r_prev = O.recall(ti, idx)
+    cs = []
+    for it in range(4):
+        c = b.descent_iter()
+        cs.append(c)
+        idx, dist, _ = b.graph()
+        check_graph_invariants(x, metric, idx, dist, name="iter%d" % it)
+        r = O.recall(ti, idx)
+        assert r >= r_prev - 1e-9, (it, r_prev, r)
+        r_prev = r
+    st = b.stats()
+    assert cs[0] > 0 and st["join_pairs"][0] > 0 and st["updates"][0] == cs[0]
+    assert r_prev > 0.97, r_prev
+    # every point is its own nearest neighbour at distance 0 (self pair, utils.py:619)
+    assert np.mean(idx[:, 0] == np.arange(x.shape[0])) > 0.999
+    fidx, fdist = b.finalize()
+    assert np.mean(fidx[:, 0] == np.arange(x.shape[0])) > 0.999 and np.all(fdist[fidx[:, 0] == np.arange(x.shape[0]), 0] == 0)
+    b.close()
