@@ -217,6 +217,9 @@ def main():
             "max_rel_dist_err": float("%.3g" % rel),
             "iters": last["n_iters_run"],
             "stage_ms_per_step": {s: round(v / steps, 3) for s, v in stage.items()},
+            "last_step_iter_ms": {"sample": [round(v, 3) for v in last["ms_sample"]],
+                                  "join": [round(v, 3) for v in last["ms_join"]],
+                                  "merge": [round(v, 3) for v in last["ms_merge"]]},
             "counts": {"leaves": last["n_leaves"], "tree_levels": last["tree_levels"],
                        "leaf_pairs": last["leaf_pairs"], "join_pairs": last["join_pairs"],
                        "join_rows": last["join_rows"], "proposals": last["proposals"], "updates": last["updates"]},

@@ -38,7 +38,8 @@ def make_builder(x, metric="euclidean", k=15, n_trees=8, leaf_size=None, mc=None
 def check_graph_invariants(x, metric, idx, dist, tol=2e-4, atol=1e-5, name=""):
     """rows ascending, ids unique, stored alt distances match the true ones for the stored ids."""
     n, k = idx.shape
-    assert np.all(np.diff(np.where(np.isfinite(dist), dist, np.float32(3e38)).astype(np.float64), axis=1) >= 0), name + ": rows not ascending"
+    d64 = np.where(np.isfinite(dist), dist.astype(np.float64), 1e39)
+    assert np.all(np.diff(d64, axis=1) >= 0), name + ": rows not ascending"
     for r in range(n):
         v = idx[r][idx[r] >= 0]
         assert len(v) == len(np.unique(v)), "%s: duplicate ids in row %d: %s" % (name, r, idx[r])
