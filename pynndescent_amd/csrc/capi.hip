@@ -98,7 +98,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
         if ((rc = dalloc(ctx, &ctx->rbuf, n * 2 * ctx->rcap))) break;
         if ((rc = dalloc(ctx, &ctx->pbuf, n * ctx->pcap))) break;
         if ((rc = dalloc(ctx, &ctx->pdirty, n))) break;
-        if ((rc = dalloc(ctx, &ctx->counters, (size_t)CNT_COUNT))) break;
+        if ((rc = dalloc(ctx, &ctx->counters, (size_t)CNT_COUNT * NND_CNT_STRIPES))) break;
         if (hipMemset(ctx->pdirty, 0, n) != hipSuccess) { ctx->set_error("hipMemset failed"); rc = 1; break; }
         if (p->n_trees > 0) {
             ctx->P = (int64_t)p->n_trees * ctx->n;

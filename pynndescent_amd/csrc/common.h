@@ -102,6 +102,11 @@ __device__ __forceinline__ int nnd_swz(int row, int chunk) {
     return row * DC + ((chunk ^ (row & MASK)) << 2);
 }
 
+// one atomic per workgroup per counter, spread over stripes (see state.h)
+__device__ __forceinline__ void nnd_count(long long *counters, int which, long long v) {
+    if (v) atomicAdd((unsigned long long *)&counters[(size_t)(blockIdx.x & 511u) * 16 + which], (unsigned long long)v);
+}
+
 #define NND_HIP_CHECK(expr)                                                                         \
     do {                                                                                            \
         hipError_t _e = (expr);                                                                     \

@@ -110,10 +110,16 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
         }
         nnd_wave_lds_sync();
     }
-    if (lane == 0 && accepted) atomicAdd((unsigned long long *)&counters[CNT_ACCEPT], (unsigned long long)accepted);
+    __syncthreads();
+    int *wacc = (int *)nrs;  // nrs is dead
+    if (lane == 0) wacc[w] = accepted;
+    __syncthreads();
     if (tid == 0) {
-        atomicAdd((unsigned long long *)&counters[CNT_PAIRS], (unsigned long long)((long long)m * (m - 1) / 2));
-        atomicAdd((unsigned long long *)&counters[CNT_ROWS], (unsigned long long)m);
+        long long a = 0;
+        for (int i = 0; i < NW; i++) a += wacc[i];
+        nnd_count(counters, CNT_ACCEPT, a);
+        nnd_count(counters, CNT_PAIRS, (long long)m * (m - 1) / 2);
+        nnd_count(counters, CNT_ROWS, m);
     }
 }
 

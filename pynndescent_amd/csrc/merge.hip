@@ -17,22 +17,24 @@ __global__ __launch_bounds__(256) void k_merge(uint64_t *__restrict__ pbuf, uint
                                                int64_t n, int k, int ks, uint32_t *__restrict__ knn_e,
                                                float *__restrict__ knn_d, long long *__restrict__ counters) {
     __shared__ nnd_merge_scratch msc[4];
+    __shared__ int wacc[4];
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
     const int64_t v = (int64_t)blockIdx.x * 4 + w;
-    if (v >= n) return;
-    if (!pdirty[v]) return;
-    uint64_t *slots = pbuf + v * pcap;
-    int acc = nnd_merge_row(v, k, ks, knn_e, knn_d, msc[w], pcap, [&](int c, uint32_t &id, float &dc) {
-        uint64_t key = slots[c];
-        id = nnd_key_idx(key);
-        dc = nnd_key_dist(key);
-        return key != NND_EMPTY_KEY;
-    });
-    for (int s = lane; s < pcap; s += 64) slots[s] = NND_EMPTY_KEY;
-    if (lane == 0) {
-        pdirty[v] = 0;
-        if (acc) atomicAdd((unsigned long long *)&counters[CNT_ACCEPT], (unsigned long long)acc);
+    int acc = 0;
+    if (v < n && pdirty[v]) {
+        uint64_t *slots = pbuf + v * pcap;
+        acc = nnd_merge_row(v, k, ks, knn_e, knn_d, msc[w], pcap, [&](int c, uint32_t &id, float &dc) {
+            uint64_t key = slots[c];
+            id = nnd_key_idx(key);
+            dc = nnd_key_dist(key);
+            return key != NND_EMPTY_KEY;
+        });
+        for (int s = lane; s < pcap; s += 64) slots[s] = NND_EMPTY_KEY;
+        if (lane == 0) pdirty[v] = 0;
     }
+    if (lane == 0) wacc[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) nnd_count(counters, CNT_ACCEPT, (long long)wacc[0] + wacc[1] + wacc[2] + wacc[3]);
 }
 
 int nnd_launch_merge(nnd_ctx *ctx) {

@@ -108,12 +108,18 @@ int nnd_launch_reset_graph(nnd_ctx *ctx) {
 }
 
 int nnd_zero_counters(nnd_ctx *ctx) {
-    NND_HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(long long) * CNT_COUNT, ctx->stream));
+    NND_HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(long long) * CNT_COUNT * NND_CNT_STRIPES, ctx->stream));
     return 0;
 }
 int nnd_read_counters(nnd_ctx *ctx) {
-    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_counters, ctx->counters, sizeof(long long) * CNT_COUNT, hipMemcpyDeviceToHost,
-                                 ctx->stream));
+    static thread_local std::vector<long long> host(CNT_COUNT * NND_CNT_STRIPES);
+    NND_HIP_CHECK(hipMemcpyAsync(host.data(), ctx->counters, sizeof(long long) * CNT_COUNT * NND_CNT_STRIPES,
+                                 hipMemcpyDeviceToHost, ctx->stream));
     NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < CNT_COUNT; c++) {
+        long long s = 0;
+        for (int i = 0; i < NND_CNT_STRIPES; i++) s += host[(size_t)i * CNT_COUNT + c];
+        ctx->h_counters[c] = s;
+    }
     return 0;
 }

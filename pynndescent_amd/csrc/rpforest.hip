@@ -210,7 +210,7 @@ __global__ void k_seg_count(const int32_t *__restrict__ seg_start, const int32_t
     int hi = e < P ? scan[e] : scan_total[0];
     int nl = hi - scan[a];
     if (mark_degenerate && (nl == 0 || nl == len)) {
-        nl = -1;  // marker for k_redraw_sides
+        nl = -1;  // marker for k_redraw_sides (rare: one atomic per degenerate segment)
         atomicAdd((unsigned long long *)&counters[CNT_DEGENERATE], 1ull);
     }
     nleft[s] = nl;

@@ -23,6 +23,10 @@ enum {
     CNT_SCRATCH,
     CNT_COUNT = 16
 };
+// Hot kernels add to one of NND_CNT_STRIPES copies of the counter block (stripe = workgroup id), one
+// atomic per workgroup per counter: a single shared word saturates at ~12 ns per atomic on MI355X and
+// would serialise a million-wave launch.  nnd_read_counters sums the stripes.
+#define NND_CNT_STRIPES 512
 
 struct nnd_handle_s {
     nnd_params p{};
@@ -76,7 +80,7 @@ struct nnd_handle_s {
     std::vector<int64_t> tree_leaf_begin; // per tree: first leaf index (host)
     bool forest_built = false;
 
-    long long *counters = nullptr;      // device CNT_COUNT
+    long long *counters = nullptr;      // device NND_CNT_STRIPES x CNT_COUNT (stripe 0 doubles as scratch for single-block kernels)
     long long h_counters[CNT_COUNT] = {0};
 
     void set_error(const char *fmt, ...) {
