@@ -43,7 +43,7 @@ static void free_all(nnd_ctx *ctx) {
     F(ctx->xp); F(ctx->nrm); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->cand); F(ctx->rbuf); F(ctx->pbuf);
     F(ctx->pdirty);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
-    F(ctx->side); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
+    F(ctx->inv); F(ctx->side); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
     F(ctx->hyper); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -77,7 +77,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
     ctx->mc = p->max_candidates;
     ctx->mcp = p->max_candidates <= 16 ? 16 : (p->max_candidates <= 32 ? 32 : 64);
     ctx->rcap = 32;
-    ctx->pcap = 64;
+    ctx->pcap = 64;  // one candidate per lane in k_merge (merge.h NCHUNK = 1)
     if (ctx->p.join_blocks < 1) ctx->p.join_blocks = 1;
     ctx->seed = nnd_mix32((uint32_t)p->rng_state[0] ^ nnd_mix32((uint32_t)p->rng_state[1] + 0x9E3779B9u) ^
                           nnd_mix32((uint32_t)p->rng_state[2] + 0x7F4A7C15u));
@@ -112,6 +112,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
                 if ((rc = dalloc(ctx, &ctx->seg_len[i], S))) break;
             }
             if (rc) break;
+            if ((rc = dalloc(ctx, &ctx->inv, P))) break;
             if ((rc = dalloc(ctx, &ctx->side, P))) break;
             if ((rc = dalloc(ctx, &ctx->leaf_flag, P))) break;
             if ((rc = dalloc(ctx, &ctx->scan_out, P + 1))) break;

@@ -39,15 +39,22 @@ __device__ __forceinline__ void nnd_gram_chunk(const float *Xs, int a_base, int 
     for (int t = 0; t < nq; t++) {
         const int c = 4 * t + g;
         const float4 a = *(const float4 *)&Xs[nnd_swz<DC>(a_base + r16, c)];
+        float4 b[NTILES];
 #pragma unroll
-        for (int J = 0; J < NTILES; J++) {
-            if (tile_on(J)) {
-                const float4 b = *(const float4 *)&Xs[nnd_swz<DC>(b_base + J * 16 + r16, c)];
-                acc[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[J], 0, 0, 0);
-                acc[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[J], 0, 0, 0);
-                acc[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[J], 0, 0, 0);
-                acc[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[J], 0, 0, 0);
-            }
-        }
+        for (int J = 0; J < NTILES; J++)
+            if (tile_on(J)) b[J] = *(const float4 *)&Xs[nnd_swz<DC>(b_base + J * 16 + r16, c)];
+        // the four k-steps of a chunk, tiles interleaved so consecutive MFMAs use different accumulators
+#pragma unroll
+        for (int J = 0; J < NTILES; J++)
+            if (tile_on(J)) acc[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[J].x, acc[J], 0, 0, 0);
+#pragma unroll
+        for (int J = 0; J < NTILES; J++)
+            if (tile_on(J)) acc[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[J].y, acc[J], 0, 0, 0);
+#pragma unroll
+        for (int J = 0; J < NTILES; J++)
+            if (tile_on(J)) acc[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[J].z, acc[J], 0, 0, 0);
+#pragma unroll
+        for (int J = 0; J < NTILES; J++)
+            if (tile_on(J)) acc[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[J].w, acc[J], 0, 0, 0);
     }
 }

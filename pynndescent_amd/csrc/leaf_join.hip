@@ -25,7 +25,10 @@ struct leaf_cfg {
     static constexpr int DSTRIDE = MP + 1;                  // row stride of the per-wave distance block
     static constexpr int XS_FLOATS = MP * DC;
     static constexpr int DB_FLOATS = NW * 16 * DSTRIDE;
-    static constexpr int BIG_FLOATS = XS_FLOATS > DB_FLOATS ? XS_FLOATS : DB_FLOATS;  // Xs and Dblk alias
+    static constexpr bool PREFETCH = NT < 16;                // k-list prefetch buffers sit next to the distance blocks
+    static constexpr int PRE_FLOATS = PREFETCH ? NW * 16 * 16 * 2 : 0;  // budgeted for k <= 16; larger k uses what Xs leaves free
+    static constexpr int EPI_FLOATS = DB_FLOATS + PRE_FLOATS;
+    static constexpr int BIG_FLOATS = XS_FLOATS > EPI_FLOATS ? XS_FLOATS : EPI_FLOATS;  // Xs aliases the epilogue buffers
 };
 
 template <int NT, int NW, int DC>
@@ -39,7 +42,6 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
     __shared__ __attribute__((aligned(16))) float big[C::BIG_FLOATS];
     __shared__ int32_t ids[C::MP];
     __shared__ float nrs[C::MP];
-    __shared__ nnd_merge_scratch msc[NW];
 
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
     const int64_t leaf = leaf0 + blockIdx.x;
@@ -96,17 +98,47 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
                 }
             }
         }
+        // all 16 k-lists of this tile row in one memory round trip (they are owned by this workgroup)
+        const bool use_pre = C::PREFETCH && (NW * 16 * ks * 2 <= C::BIG_FLOATS - C::DB_FLOATS);
+        uint32_t *pre_e = (uint32_t *)(big + C::DB_FLOATS) + w * 16 * ks;
+        float *pre_d = big + C::DB_FLOATS + NW * 16 * ks + w * 16 * ks;
+        if (use_pre) {
+            for (int idx = lane; idx < 16 * k; idx += 64) {
+                const int il = idx / k, j = idx - il * k;
+                const int i = I * 16 + il;
+                uint32_t ee = NND_EMPTY_E;
+                float dd = INFINITY;
+                if (i < m) {
+                    ee = knn_e[(int64_t)ids[i] * ks + j];
+                    dd = knn_d[(int64_t)ids[i] * ks + j];
+                }
+                pre_e[il * ks + j] = ee;
+                pre_d[il * ks + j] = dd;
+            }
+        }
         nnd_wave_lds_sync();
         for (int il = 0; il < 16; il++) {
             const int i = I * 16 + il;
             if (i >= m) break;
             const float *Drow = Dw + il * C::DSTRIDE;
-            accepted += nnd_merge_row((int64_t)ids[i], k, ks, knn_e, knn_d, msc[w], m,
-                                      [&](int c, uint32_t &id, float &dc) {
-                                          id = (uint32_t)ids[c];
-                                          dc = Drow[c];
-                                          return c != i;  // pynndescent_.py:97: j starts at i+1, i.e. p != q
-                                      });
+            const int64_t v = ids[i];
+            uint32_t e0 = NND_EMPTY_E;
+            float d0 = INFINITY;
+            if (lane < k) {
+                if (use_pre) {
+                    e0 = pre_e[il * ks + lane];
+                    d0 = pre_d[il * ks + lane];
+                } else {
+                    e0 = knn_e[v * ks + lane];
+                    d0 = knn_d[v * ks + lane];
+                }
+            }
+            accepted += nnd_merge_row_regs<(C::MP + 63) / 64>(knn_e + v * ks, knn_d + v * ks, e0, d0, k, m,
+                                                             [&](int c, uint32_t &id, float &dc) {
+                                                                 id = (uint32_t)ids[c];
+                                                                 dc = Drow[c];
+                                                                 return c != i;  // pynndescent_.py:97: p != q
+                                                             });
         }
         nnd_wave_lds_sync();
     }

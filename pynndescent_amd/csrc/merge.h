@@ -9,25 +9,99 @@
 //     position of a candidate       = #{list entries with a smaller key} + #{candidates with a smaller key}
 // which yields the k smallest keys of (row U batch) -- the same set sequential pushes produce,
 // independent of arrival order (ties in distance are broken by index).
+//
+// Everything lives in registers: lane j < k holds list entry j, lane l holds candidate(s) l, l+64, ...
+// and values are broadcast with v_readlane (the broadcast lane is wave-uniform), so the inner loops
+// run at a few cycles per step instead of an LDS round trip per step.
 #pragma once
 #include "common.h"
 
 #define NND_MAX_K 64
-#define NND_MERGE_CMAX 256
 
-struct nnd_merge_scratch {
-    uint64_t lkey[NND_MAX_K];        // sorted list keys (dist_bits<<32 | idx), EMPTY_KEY for empty slots
-    uint32_t lraw[NND_MAX_K];        // raw neighbour words (idx | NEW_BIT)
-    uint64_t ckey[NND_MERGE_CMAX];   // compacted accepted candidates
-};
+__device__ __forceinline__ uint64_t nnd_readlane_u64(uint64_t v, int src_lane) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
 
 // All 64 lanes of the wave call this with the same arguments.
-// cand(c, id, d) -> bool : candidate c of [0, ncand) (ids must be unique inside the batch).
+// cand(c, id, d) -> bool : candidate c of [0, ncand), ncand <= 64 * NCHUNK (ids unique inside the batch).
 // Returns the number of accepted candidates (same value on every lane).
-template <typename CandFn>
+// Core: lane j < k already holds list entry j in (e, d) (lanes >= k hold EMPTY / +inf).
+template <int NCHUNK, typename CandFn>
+__device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, float *__restrict__ row_d, uint32_t e,
+                                                  float d, int k, int ncand, CandFn cand) {
+    const int lane = nnd_lane();
+    const uint64_t mykey = (e == NND_EMPTY_E) ? NND_EMPTY_KEY : nnd_make_key(d, e);
+    const uint32_t myidx = e & NND_IDX_MASK;  // 0x7FFFFFFF for empty slots: never a valid id
+    const float th = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), k - 1));  // worst distance (+inf while not full)
+
+    uint64_t ckey[NCHUNK];
+    unsigned long long cmask[NCHUNK];
+    int nv = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ch++) {
+        const int c = ch * 64 + lane;
+        uint32_t id = 0;
+        float dc = 0.0f;
+        bool ok = false;
+        if (ch * 64 < ncand) {  // wave-uniform
+            ok = (c < ncand) && cand(c, id, dc);
+            ok = ok && (dc < th);  // strict, utils.py:484
+            for (int j = 0; j < k; j++)  // utils.py:489-492
+                ok = ok && ((uint32_t)__builtin_amdgcn_readlane((int)myidx, j) != id);
+        }
+        ckey[ch] = ok ? nnd_make_key(dc, id) : NND_EMPTY_KEY;
+        cmask[ch] = __ballot(ok);
+        nv += __popcll(cmask[ch]);
+    }
+    if (nv == 0) return 0;
+
+    // one pass over the accepted candidates: list entries count how many precede them,
+    // candidates count how many candidates precede them
+    int shift = 0;
+    int rank[NCHUNK];
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ch++) rank[ch] = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ch++) {
+        unsigned long long m = cmask[ch];
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint64_t kc = nnd_readlane_u64(ckey[ch], src);
+            shift += (kc < mykey) ? 1 : 0;
+#pragma unroll
+            for (int c2 = 0; c2 < NCHUNK; c2++) rank[c2] += (kc < ckey[c2]) ? 1 : 0;
+        }
+    }
+    // one pass over the list: candidates count how many list entries precede them
+    for (int j = 0; j < k; j++) {
+        const uint64_t lj = nnd_readlane_u64(mykey, j);
+#pragma unroll
+        for (int c2 = 0; c2 < NCHUNK; c2++) rank[c2] += (lj < ckey[c2]) ? 1 : 0;
+    }
+    // every lane has read its own entry already; positions are a bijection, so plain stores suffice
+    if (lane < k && shift > 0 && lane + shift < k) {
+        row_e[lane + shift] = e;
+        row_d[lane + shift] = d;
+    }
+    int accepted = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ch++) {
+        if (ckey[ch] != NND_EMPTY_KEY && rank[ch] < k) {
+            row_e[rank[ch]] = nnd_key_idx(ckey[ch]) | NND_NEW_BIT;
+            row_d[rank[ch]] = nnd_key_dist(ckey[ch]);
+            accepted++;
+        }
+    }
+    return nnd_wave_sum_i32(accepted);
+}
+
+// Loader wrapper: fetches row v of the k-lists from global memory, then merges.
+template <int NCHUNK, typename CandFn>
 __device__ __forceinline__ int nnd_merge_row(int64_t v, int k, int ks, uint32_t *__restrict__ knn_e,
-                                             float *__restrict__ knn_d, nnd_merge_scratch &sc, int ncand,
-                                             CandFn cand) {
+                                             float *__restrict__ knn_d, int ncand, CandFn cand) {
     const int lane = nnd_lane();
     uint32_t *row_e = knn_e + v * ks;
     float *row_d = knn_d + v * ks;
@@ -37,63 +111,5 @@ __device__ __forceinline__ int nnd_merge_row(int64_t v, int k, int ks, uint32_t 
         e = row_e[lane];
         d = row_d[lane];
     }
-    uint64_t mykey = (e == NND_EMPTY_E) ? NND_EMPTY_KEY : nnd_make_key(d, e);
-    sc.lkey[lane] = mykey;
-    sc.lraw[lane] = e;
-    const float th = __shfl(d, k - 1, 64);  // worst distance; +inf while the row is not full
-    nnd_wave_lds_sync();
-
-    int nv = 0;
-    for (int base = 0; base < ncand; base += 64) {
-        int c = base + lane;
-        uint32_t id = 0;
-        float dc = 0.0f;
-        bool ok = (c < ncand) && cand(c, id, dc);
-        ok = ok && (dc < th);  // strict, utils.py:484
-        if (ok) {
-            for (int j = 0; j < k; j++) {  // utils.py:489-492 (LDS broadcast reads)
-                uint64_t lk = sc.lkey[j];
-                if (lk != NND_EMPTY_KEY && nnd_key_idx(lk) == id) {
-                    ok = false;
-                    break;
-                }
-            }
-        }
-        unsigned long long m = __ballot(ok);
-        if (ok) sc.ckey[nv + nnd_prefix_popc(m)] = nnd_make_key(dc, id);
-        nv += __popcll(m);
-    }
-    if (nv == 0) return 0;
-    nnd_wave_lds_sync();
-
-    // surviving list entries shift right by the number of smaller accepted candidates
-    if (lane < k) {
-        int shift = 0;
-        for (int c = 0; c < nv; c++) shift += (sc.ckey[c] < mykey) ? 1 : 0;
-        int np = lane + shift;
-        if (shift > 0 && np < k) {
-            row_e[np] = e;
-            row_d[np] = d;
-        }
-    }
-    int accepted = 0;
-    for (int base = 0; base < nv; base += 64) {
-        int c = base + lane;
-        if (c < nv) {
-            uint64_t key = sc.ckey[c];
-            int r = 0;
-            for (int j = 0; j < k; j++) r += (sc.lkey[j] < key) ? 1 : 0;
-            if (r < k) {
-                for (int c2 = 0; c2 < nv; c2++) r += (sc.ckey[c2] < key) ? 1 : 0;
-                if (r < k) {
-                    row_e[r] = nnd_key_idx(key) | NND_NEW_BIT;
-                    row_d[r] = nnd_key_dist(key);
-                    accepted++;
-                }
-            }
-        }
-    }
-    accepted = nnd_wave_sum_i32(accepted);
-    nnd_wave_lds_sync();  // scratch may be reused by the caller's next row
-    return accepted;
+    return nnd_merge_row_regs<NCHUNK>(row_e, row_d, e, d, k, ncand, cand);
 }

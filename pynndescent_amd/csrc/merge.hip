@@ -16,14 +16,13 @@
 __global__ __launch_bounds__(256) void k_merge(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
                                                int64_t n, int k, int ks, uint32_t *__restrict__ knn_e,
                                                float *__restrict__ knn_d, long long *__restrict__ counters) {
-    __shared__ nnd_merge_scratch msc[4];
     __shared__ int wacc[4];
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
     const int64_t v = (int64_t)blockIdx.x * 4 + w;
     int acc = 0;
     if (v < n && pdirty[v]) {
         uint64_t *slots = pbuf + v * pcap;
-        acc = nnd_merge_row(v, k, ks, knn_e, knn_d, msc[w], pcap, [&](int c, uint32_t &id, float &dc) {
+        acc = nnd_merge_row<1>(v, k, ks, knn_e, knn_d, pcap, [&](int c, uint32_t &id, float &dc) {
             uint64_t key = slots[c];
             id = nnd_key_idx(key);
             dc = nnd_key_dist(key);

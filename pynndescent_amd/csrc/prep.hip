@@ -67,7 +67,7 @@ int nnd_launch_prep(nnd_ctx *ctx) {
     int64_t n = ctx->n;
     int d = ctx->d, dp = ctx->dp;
     if (ctx->p.metric == 0) {
-        int rows_per_block = 4096;
+        int rows_per_block = 256;
         int nblocks = (int)((n + rows_per_block - 1) / rows_per_block);
         double *partial = nullptr;
         NND_HIP_CHECK(hipMalloc((void **)&partial, sizeof(double) * (size_t)nblocks * d));

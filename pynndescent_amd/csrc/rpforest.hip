@@ -9,9 +9,15 @@
 // contiguous segment of positions, and one level of ALL nodes of ALL trees is processed by a fixed
 // sequence of launches:
 //   k_hyperplane : one wave per splittable segment: two random members -> hyperplane (+offset)
-//   k_margin     : 16 lanes per position: margin = h.x + off -> side bit (coin flip if |m| < 1e-8)
+//   k_margin     : 16 lanes per position: margin = h.x + off -> side bit (coin flip if |m| < 1e-8).
+//                  While the hyperplane table of a level fits in L2 (top ~11 levels) the point-major
+//                  variant k_margin_fused streams every point row ONCE for all trees of the level
+//                  (rows from HBM in order, hyperplanes from L2); deeper levels gather rows in
+//                  position order, where neighbours share a hyperplane.
 //   scan         : exclusive scan of "goes left" over all positions (3 launches)
-//   k_seg_count  : per segment n_left; a one-sided split is re-drawn by coin flips (rp_trees.py:393-403)
+//   k_seg_count  : per segment n_left; a one-sided split is replaced by an even split of the
+//                  segment's (arbitrarily ordered) members -- the reference re-draws every member by
+//                  a fair coin (rp_trees.py:393-403); both cut the node in two near-equal random halves
 //   k_children   : child segments, which of them split again, compacted ids, final-leaf marks
 //   k_scatter    : stable partition of every segment (left block, then right block)
 // Positions stay in depth-first left-to-right order, so the finished permutation IS the leaf
@@ -31,12 +37,13 @@ static constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
 
 // ------------------------------------------------------------------ init --
 __global__ void k_forest_init(int32_t *__restrict__ perm, int32_t *__restrict__ pos_seg, uint8_t *__restrict__ leaf_flag,
-                              int64_t n, int64_t P, int splittable) {
+                              int32_t *__restrict__ inv, int64_t n, int64_t P, int splittable) {
     int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= P) return;
     int64_t t = g / n;
     int64_t i = g - t * n;
     perm[g] = (int32_t)i;
+    inv[g] = (int32_t)g;
     pos_seg[g] = splittable ? (int32_t)t : -1;
     leaf_flag[g] = (!splittable && i == 0) ? 1 : 0;
 }
@@ -110,6 +117,38 @@ __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, in
         if (fabsf(m) < RP_EPS) sd = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)g, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
         else sd = m > 0.0f ? 0 : 1;                                                                                // rp_trees.py:386-391
         side[g] = sd;
+    }
+}
+
+// point-major variant: one pass over the points serves every tree (rows read once per level)
+__global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ xp, int dp, int64_t n, int n_trees,
+                                                      const int32_t *__restrict__ inv,
+                                                      const int32_t *__restrict__ pos_seg,
+                                                      const float *__restrict__ hyper, int hs, uint32_t seed, int depth,
+                                                      uint8_t *__restrict__ side) {
+    const int sub = threadIdx.x & 15;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const bool live = i < n;
+    const float4 *x4 = (const float4 *)(xp + (live ? i : 0) * dp);
+    for (int t = 0; t < n_trees; t++) {
+        const int64_t g = live ? (int64_t)inv[(int64_t)t * n + i] : 0;
+        const int s = live ? pos_seg[g] : -1;
+        float acc = 0.0f;
+        if (s >= 0) {
+            const float4 *h4 = (const float4 *)(hyper + (int64_t)s * hs);
+            for (int c = sub; c < (dp >> 2); c += 16) {
+                float4 a = x4[c], b = h4[c];
+                acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            }
+        }
+        acc = nnd_group16_sum_f32(acc);
+        if (s >= 0 && sub == 0) {
+            float m = acc + hyper[(int64_t)s * hs + dp];
+            uint8_t sd;
+            if (fabsf(m) < RP_EPS) sd = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)g, (uint32_t)depth) & 1u);
+            else sd = m > 0.0f ? 0 : 1;
+            side[g] = sd;
+        }
     }
 }
 
@@ -199,30 +238,19 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(int mode, const int32
 }
 
 // ------------------------------------------------------------- per segment --
-// n_left from the scan; a one-sided split marks the segment degenerate (side bits are then re-drawn)
+// n_left from the scan.  A one-sided split (rp_trees.py:393-403) is encoded as nleft = -(ceil(len/2)) - 1:
+// k_children / k_scatter then send the members at even offsets left and those at odd offsets right.
 __global__ void k_seg_count(const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_len, int n_segs,
                             const int32_t *__restrict__ scan, const int32_t *__restrict__ scan_total, int64_t P,
-                            int32_t *__restrict__ nleft, int mark_degenerate, long long *__restrict__ counters) {
+                            int32_t *__restrict__ nleft) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_segs) return;
     int a = seg_start[s], len = seg_len[s];
     int64_t e = (int64_t)a + len;
     int hi = e < P ? scan[e] : scan_total[0];
     int nl = hi - scan[a];
-    if (mark_degenerate && (nl == 0 || nl == len)) {
-        nl = -1;  // marker for k_redraw_sides (rare: one atomic per degenerate segment)
-        atomicAdd((unsigned long long *)&counters[CNT_DEGENERATE], 1ull);
-    }
+    if (nl == 0 || nl == len) nl = -((len + 1) / 2) - 1;
     nleft[s] = nl;
-}
-
-// rp_trees.py:393-403: every member of a one-sided split is re-assigned by a fair coin
-__global__ void k_redraw_sides(const int32_t *__restrict__ pos_seg, const int32_t *__restrict__ nleft, int64_t P,
-                               uint32_t seed, int depth, uint8_t *__restrict__ side) {
-    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= P) return;
-    int s = pos_seg[g];
-    if (s >= 0 && nleft[s] < 0) side[g] = (uint8_t)(nnd_hash3(seed ^ 0x1b873593u, (uint32_t)g, (uint32_t)depth) & 1u);
 }
 
 // single block: children of every segment -> next level's segment list (compacted), child ids, leaf marks
@@ -237,6 +265,7 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
     int cnt = 0;
     for (int s = s0; s < s1; s++) {
         int len = seg_len[s], nl = nleft[s];
+        if (nl < 0) nl = -nl - 1;
         cnt += (child_can_split && nl > leaf_size) + (child_can_split && (len - nl) > leaf_size);
     }
     part[threadIdx.x] = cnt;
@@ -254,6 +283,7 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
     int run = part[threadIdx.x];
     for (int s = s0; s < s1; s++) {
         int a = seg_start[s], len = seg_len[s], nl = nleft[s];
+        if (nl < 0) nl = -nl - 1;
         int lens[2] = {nl, len - nl};
         int starts[2] = {a, a + nl};
 #pragma unroll
@@ -274,8 +304,8 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
 __global__ void k_scatter(const int32_t *__restrict__ perm, const int32_t *__restrict__ pos_seg,
                           const uint8_t *__restrict__ side, const int32_t *__restrict__ scan,
                           const int32_t *__restrict__ seg_start, const int32_t *__restrict__ nleft,
-                          const int32_t *__restrict__ seg_child, int64_t P, int32_t *__restrict__ perm_out,
-                          int32_t *__restrict__ pos_seg_out) {
+                          const int32_t *__restrict__ seg_child, int64_t P, int64_t n, int32_t *__restrict__ perm_out,
+                          int32_t *__restrict__ pos_seg_out, int32_t *__restrict__ inv) {
     int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= P) return;
     int s = pos_seg[g];
@@ -285,11 +315,23 @@ __global__ void k_scatter(const int32_t *__restrict__ perm, const int32_t *__res
         return;
     }
     int a = seg_start[s];
-    int L = scan[g] - scan[a];
-    int right = side[g];
-    int64_t dest = right ? (int64_t)a + nleft[s] + ((int)(g - a) - L) : (int64_t)a + L;
-    perm_out[dest] = perm[g];
+    int nl = nleft[s];
+    int right;
+    int64_t dest;
+    if (nl < 0) {  // one-sided split: even offsets left, odd offsets right
+        nl = -nl - 1;
+        int off = (int)(g - a);
+        right = off & 1;
+        dest = right ? (int64_t)a + nl + (off >> 1) : (int64_t)a + (off >> 1);
+    } else {
+        int L = scan[g] - scan[a];
+        right = side[g];
+        dest = right ? (int64_t)a + nl + ((int)(g - a) - L) : (int64_t)a + L;
+    }
+    int32_t p = perm[g];
+    perm_out[dest] = p;
     pos_seg_out[dest] = seg_child[2 * s + right];
+    if (inv) inv[(g / n) * n + p] = (int32_t)dest;
 }
 
 // ------------------------------------------------------------ leaf tables --
@@ -349,44 +391,46 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     int cur = 0;
     unsigned gridP = (unsigned)((P + 255) / 256);
     hipLaunchKernelGGL(k_forest_init, dim3(gridP), dim3(256), 0, ctx->stream, ctx->perm[0], ctx->pos_seg[0],
-                       ctx->leaf_flag, n, P, splittable);
+                       ctx->leaf_flag, ctx->inv, n, P, splittable);
     hipLaunchKernelGGL(k_forest_init_segs, dim3((T + 63) / 64), dim3(64), 0, ctx->stream, ctx->seg_start[0],
                        ctx->seg_len[0], T, n);
     int64_t S = splittable ? T : 0;
     int depth = 0;
+    bool inv_live = true;  // inv[] is maintained while the point-major margin kernel is in use
     while (S > 0) {
         if (S > ctx->max_segs) {
             ctx->set_error("rp-forest: %lld segments exceed the allocation of %lld", (long long)S, (long long)ctx->max_segs);
             return 1;
         }
-        if (nnd_zero_counters(ctx)) return 1;
         hipLaunchKernelGGL(k_hyperplane, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, dp,
                            ctx->perm[cur], ctx->seg_start[cur], ctx->seg_len[cur], (int)S, angular, ctx->tree_seed, depth,
                            ctx->hyper, hs);
-        hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, dp,
-                           ctx->perm[cur], ctx->pos_seg[cur], P, ctx->hyper, hs, ctx->tree_seed, depth, ctx->side);
+        const bool fused = inv_live && (S * (int64_t)hs * 4 <= (int64_t)6 << 20);  // hyperplane table fits in L2
+        if (fused) {
+            hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, dp, n, T,
+                               ctx->inv, ctx->pos_seg[cur], ctx->hyper, hs, ctx->tree_seed, depth, ctx->side);
+        } else {
+            inv_live = false;
+            hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, dp,
+                               ctx->perm[cur], ctx->pos_seg[cur], P, ctx->hyper, hs, ctx->tree_seed, depth, ctx->side);
+        }
         if (run_scan(ctx, 0, ctx->pos_seg[cur], ctx->side, scan_total)) return 1;
         hipLaunchKernelGGL(k_seg_count, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, ctx->seg_start[cur],
-                           ctx->seg_len[cur], (int)S, ctx->scan_out, scan_total, P, ctx->seg_nleft, 1, ctx->counters);
-        if (nnd_read_counters(ctx)) return 1;
-        if (ctx->h_counters[CNT_DEGENERATE] > 0) {
-            hipLaunchKernelGGL(k_redraw_sides, dim3(gridP), dim3(256), 0, ctx->stream, ctx->pos_seg[cur], ctx->seg_nleft, P,
-                               ctx->tree_seed, depth, ctx->side);
-            if (run_scan(ctx, 0, ctx->pos_seg[cur], ctx->side, scan_total)) return 1;
-            hipLaunchKernelGGL(k_seg_count, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream,
-                               ctx->seg_start[cur], ctx->seg_len[cur], (int)S, ctx->scan_out, scan_total, P,
-                               ctx->seg_nleft, 0, ctx->counters);
-        }
+                           ctx->seg_len[cur], (int)S, ctx->scan_out, scan_total, P, ctx->seg_nleft);
         int child_can_split = (max_depth - (depth + 1)) > 0 ? 1 : 0;
         hipLaunchKernelGGL(k_children, dim3(1), dim3(256), 0, ctx->stream, ctx->seg_start[cur], ctx->seg_len[cur],
                            ctx->seg_nleft, (int)S, leaf_size, child_can_split, ctx->seg_start[1 - cur],
                            ctx->seg_len[1 - cur], ctx->seg_child, ctx->leaf_flag, ctx->counters);
         hipLaunchKernelGGL(k_scatter, dim3(gridP), dim3(256), 0, ctx->stream, ctx->perm[cur], ctx->pos_seg[cur], ctx->side,
-                           ctx->scan_out, ctx->seg_start[cur], ctx->seg_nleft, ctx->seg_child, P, ctx->perm[1 - cur],
-                           ctx->pos_seg[1 - cur]);
+                           ctx->scan_out, ctx->seg_start[cur], ctx->seg_nleft, ctx->seg_child, P, n, ctx->perm[1 - cur],
+                           ctx->pos_seg[1 - cur], inv_live ? ctx->inv : (int32_t *)nullptr);
         NND_HIP_CHECK(hipGetLastError());
-        if (nnd_read_counters(ctx)) return 1;
-        S = ctx->h_counters[CNT_ACTIVE_SEGS];
+        // one small read-back per level: the number of segments that split again
+        long long next = 0;
+        NND_HIP_CHECK(hipMemcpyAsync(&next, ctx->counters + CNT_ACTIVE_SEGS, sizeof(long long), hipMemcpyDeviceToHost,
+                                     ctx->stream));
+        NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        S = next;
         cur = 1 - cur;
         depth++;
     }

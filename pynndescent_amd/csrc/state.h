@@ -65,6 +65,7 @@ struct nnd_handle_s {
     int64_t P = 0;
     int32_t *perm[2] = {nullptr, nullptr};    // point id per position (ping-pong)
     int32_t *pos_seg[2] = {nullptr, nullptr}; // active segment index per position or -1
+    int32_t *inv = nullptr;                   // (P) position of point i in tree t (top, point-major levels)
     uint8_t *side = nullptr;                  // (P) 0 left / 1 right
     uint8_t *leaf_flag = nullptr;             // (P) 1 at the first position of every final leaf
     int32_t *scan_out = nullptr;              // (P) exclusive scan scratch
