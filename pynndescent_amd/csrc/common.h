@@ -12,6 +12,7 @@
 #define NND_FLT_MAX 3.402823466e+38f
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- hashing --
 // Counter-based RNG: every random decision is a pure function of (seed, ids), so the build is

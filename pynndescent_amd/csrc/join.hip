@@ -77,14 +77,18 @@ __global__ __launch_bounds__(256, 2) void k_local_join(const float *__restrict__
     const int nch0 = cw0 >> 2;
 
     // candidate ids of group g for row tid (tid < ROWS)
-    auto load_cand = [&](int64_t g) -> int {
-        if (tid >= ROWS || g >= n_groups) return -1;
-        const int slot = tid / RV, within = tid - slot * RV;
+    // (loads are unconditional with clamped addresses: a "default, then conditional load" pattern makes the
+    //  compiler drain the whole memory queue (s_waitcnt vmcnt(0)) before it may overwrite the default)
+    auto load_cand = [&](int64_t g) __attribute__((always_inline)) -> int {
+        const int row = tid < ROWS ? tid : 0;
+        const int slot = row / RV, within = row - slot * RV;
         const int64_t v = v_begin + g * VPW + slot;
-        return v < v_end ? cand[v * RV + within] : -1;
+        const bool ok = tid < ROWS && g < n_groups && v < v_end;
+        const int c = cand[ok ? v * RV + within : 0];
+        return ok ? c : -1;
     };
     // publish them (and the per-vertex count of new candidates: lists are filled from the front, sample.hip)
-    auto store_cand = [&](int buf, int c) {
+    auto store_cand = [&](int buf, int c) __attribute__((always_inline)) {
         if (tid < ROWS) {
             const int slot = tid / RV, within = tid - slot * RV;
             cidbuf[buf * ROWS + tid] = c;
@@ -98,61 +102,60 @@ __global__ __launch_bounds__(256, 2) void k_local_join(const float *__restrict__
     };
 
     // registers that carry the NEXT group's gather across the current group's MFMA + epilogue
-    float4 rowv[NLD];
-    uint4 klv[KQMAX];
+    f32x4 rowv[NLD];  // native vector types: these arrays must stay in registers
+    u32x4 klv[KQMAX];
     float nx_nrm = 0.0f, nx_th = 0.0f;
     int nx_id = -1;
-    auto issue_gather = [&](int buf) {  // every global load of a group's gather, issued back to back
+    auto issue_gather = [&](int buf) __attribute__((always_inline)) {  // every global load of a group's gather, issued back to back
         const int32_t *cb = cidbuf + buf * ROWS;
         const int32_t *nb = nnewbuf + buf * 4;
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int i = 0; i < NLD; i++) {
             const int idx = tid + i * 256;
             int r, ch;
             if (cw0 == DC) { r = idx / NCH; ch = idx % NCH; } else { r = idx / nch0; ch = idx - r * nch0; }
-            const int id = (r < ROWS && nb[r / RV] > 0) ? cb[r] : -1;
-            rowv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (id >= 0) rowv[i] = *(const float4 *)(xp + (int64_t)id * dp + 4 * ch);
+            const int rr = r < ROWS ? r : 0;
+            const int id = nb[rr / RV] > 0 ? cb[rr] : -1;
+            rowv[i] = *(const f32x4 *)(xp + (int64_t)(id >= 0 ? id : 0) * dp + 4 * ch);  // empty slot: row 0 (an L2 hit), masked later
         }
-        nx_id = -1; nx_nrm = 0.0f; nx_th = 0.0f;
-        if (tid < ROWS) {
-            nx_id = nb[tid / RV] > 0 ? cb[tid] : -1;
-            if (nx_id >= 0) {
-                nx_nrm = nrm[nx_id];
-                nx_th = knn_d[(int64_t)nx_id * ks + (k - 1)];
-            }
+        {
+            const int row = tid < ROWS ? tid : 0;
+            nx_id = (tid < ROWS && nb[row / RV] > 0) ? cb[row] : -1;
+            const int64_t ide = nx_id >= 0 ? nx_id : 0;
+            nx_nrm = nrm[ide];
+            nx_th = knn_d[ide * ks + (k - 1)];
         }
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int i = 0; i < KQMAX; i++) {
             const int idx = tid + i * 256;  // covers every (row, chunk < KQ) exactly once
             const int r = idx / KQ, c = idx % KQ;
-            klv[i] = make_uint4(NND_IDX_MASK, NND_IDX_MASK, NND_IDX_MASK, NND_IDX_MASK);
-            if (c < kq) {
-                const int id = nb[r / RV] > 0 ? cb[r] : -1;
-                if (id >= 0) klv[i] = *(const uint4 *)(knn_e + (int64_t)id * ks + 4 * c);  // padding beyond k is EMPTY
-            }
+            const int id = nb[r / RV] > 0 ? cb[r] : -1;
+            const bool ok = c < kq && id >= 0;
+            klv[i] = *(const u32x4 *)(knn_e + (ok ? (int64_t)id * ks + 4 * c : 0));  // raw; masked when it lands
         }
     };
-    auto land_gather = [&]() {  // registers -> LDS
-#pragma unroll
+    auto land_gather = [&](int buf) __attribute__((always_inline)) {  // registers -> LDS
+        const int32_t *cb = cidbuf + buf * ROWS;
+        const int32_t *nb = nnewbuf + buf * 4;
+#pragma clang loop unroll(full)
         for (int i = 0; i < NLD; i++) {
             const int idx = tid + i * 256;
             int r, ch;
             if (cw0 == DC) { r = idx / NCH; ch = idx % NCH; } else { r = idx / nch0; ch = idx - r * nch0; }
-            if (r < ROWS) *(float4 *)&Xs[nnd_swz<DC>(r, ch)] = rowv[i];
+            if (r < ROWS) *(f32x4 *)&Xs[nnd_swz<DC>(r, ch)] = rowv[i];
         }
         if (tid < ROWS) {
             cid[tid] = nx_id;
             cnrm[tid] = nx_nrm;
             cth[tid] = nx_th;
         }
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int i = 0; i < KQMAX; i++) {
             const int idx = tid + i * 256;
             const int r = idx / KQ, c = idx % KQ;
-            uint4 wv = klv[i];
-            wv.x &= NND_IDX_MASK; wv.y &= NND_IDX_MASK; wv.z &= NND_IDX_MASK; wv.w &= NND_IDX_MASK;
-            *(uint4 *)(klist + r * kls + 4 * c) = wv;
+            const bool ok = c < kq && nb[r / RV] > 0 && cb[r] >= 0;  // padding beyond k is EMPTY already
+            const u32x4 empty = {NND_IDX_MASK, NND_IDX_MASK, NND_IDX_MASK, NND_IDX_MASK};
+            *(u32x4 *)(klist + r * kls + 4 * c) = ok ? (klv[i] & NND_IDX_MASK) : empty;
         }
     };
 
@@ -174,11 +177,12 @@ __global__ __launch_bounds__(256, 2) void k_local_join(const float *__restrict__
         for (int s2 = 0; s2 < VPW; s2++) act += nnewbuf[cur * 4 + s2] > 0;
         const int my_new = nnewbuf[cur * 4 + slot];
         // 1. land this group's gather (issued one iteration ago) in LDS
-        if (act) land_gather();
+        if (act) land_gather(cur);
         __syncthreads();
-        // 2./3. keep the memory system busy: ids two groups ahead, rows one group ahead
-        const int c2 = load_cand(g + 2 * stride);
+        // 2./3. keep the memory system busy: rows one group ahead, ids two groups ahead (issued last, so
+        // that nothing has to wait for it before the end of the iteration: loads return in order)
         if (g + stride < n_groups) issue_gather(cur ^ 1);
+        const int c2 = load_cand(g + 2 * stride);
         // 4. this group's distance block and proposals
         if (act) {
             const int nb_new = (my_new + 15) >> 4;
