@@ -150,6 +150,30 @@ int32_t nnd_sample_candidates(nnd_handle_t h);
 int32_t nnd_pairwise_gram(nnd_handle_t h, const int32_t *rows_a, int32_t na, const int32_t *rows_b, int32_t nb,
                           float *out);
 
+/* ---- row-sharded multi-GPU build (one handle per GPU) ----
+ * The reference is single-process; its sharding idea is the owner-computes rule of
+ * apply_graph_update_array / new_build_candidates (utils.py:709-731, 259-306: each thread owns a contiguous
+ * vertex range).  Here every handle is created with the GLOBAL n and the full (replicated) point set, but
+ * owns rows [lo, hi): sampling, join, merge and finalize act on owned rows only.  The exchange steps
+ * (k-list all-gather, proposal all-to-all-v, update-count all-reduce) are driven by the host over RCCL
+ * (pynndescent_amd/sharded.py); these entry points are their device-side halves.  All pointers below are
+ * DEVICE pointers. */
+int32_t nnd_set_owned_range(nnd_handle_t h, int64_t lo, int64_t hi);
+int32_t nnd_row_stride(nnd_handle_t h); /* ks: uint32/float words per k-list row */
+/* raw k-list rows [lo,hi): neighbour words (idx | new<<31, 0xFFFFFFFF empty) and alt-space distances */
+int32_t nnd_export_graph_rows(nnd_handle_t h, int64_t lo, int64_t hi, uint32_t *e_dst, float *d_dst);
+int32_t nnd_import_graph_rows(nnd_handle_t h, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
+/* merge another handle's rows [lo,hi) into ours (combining per-rank forests' leaf seeding at the owner) */
+int32_t nnd_merge_graph_rows(nnd_handle_t h, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
+/* one descent iteration in three steps, with the proposal exchange between join and merge */
+int32_t nnd_descent_sample(nnd_handle_t h);
+int32_t nnd_descent_join(nnd_handle_t h);
+int32_t nnd_proposal_counts(nnd_handle_t h, int32_t *cnt /* (n) pending records per NON-owned vertex */);
+int32_t nnd_export_proposals(nnd_handle_t h, const int64_t *offsets /* exclusive scan of cnt */, uint64_t *keys_out,
+                             int32_t *targets_out);
+int32_t nnd_import_proposals(nnd_handle_t h, const uint64_t *keys, const int32_t *targets, int64_t count);
+int32_t nnd_descent_merge(nnd_handle_t h, int64_t *c_local);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,17 @@ _SIGNATURES = [
     ("nnd_get_candidates", C.c_int32, [_H, C.c_void_p, C.c_void_p]),
     ("nnd_sample_candidates", C.c_int32, [_H]),
     ("nnd_pairwise_gram", C.c_int32, [_H, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("nnd_set_owned_range", C.c_int32, [_H, C.c_int64, C.c_int64]),
+    ("nnd_row_stride", C.c_int32, [_H]),
+    ("nnd_export_graph_rows", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("nnd_import_graph_rows", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("nnd_merge_graph_rows", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("nnd_descent_sample", C.c_int32, [_H]),
+    ("nnd_descent_join", C.c_int32, [_H]),
+    ("nnd_proposal_counts", C.c_int32, [_H, C.c_void_p]),
+    ("nnd_export_proposals", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nnd_import_proposals", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
+    ("nnd_descent_merge", C.c_int32, [_H, C.POINTER(C.c_int64)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -222,8 +233,9 @@ class Builder:
         self._check(self.lib.nnd_sample_candidates(self._h))
 
     def finalize(self):
-        idx = np.empty((self.n, self.k), np.int32)
-        dist = np.empty((self.n, self.k), np.float32)
+        lo, hi = getattr(self, "own", (0, self.n))
+        idx = np.empty((hi - lo, self.k), np.int32)
+        dist = np.empty((hi - lo, self.k), np.float32)
         self._check(self.lib.nnd_finalize_host(self._h, _ptr(idx), _ptr(dist)))
         return idx, dist
 
@@ -254,6 +266,44 @@ class Builder:
         old = np.empty((self.n, self.mc), np.int32)
         self._check(self.lib.nnd_get_candidates(self._h, _ptr(new), _ptr(old)))
         return new, old
+
+    # -- row-sharded build: device-side halves of the exchange steps (pointers are integer device addresses)
+    def set_owned_range(self, lo, hi):
+        self._check(self.lib.nnd_set_owned_range(self._h, int(lo), int(hi)))
+        self.own = (int(lo), int(hi))
+
+    def row_stride(self):
+        return int(self.lib.nnd_row_stride(self._h))
+
+    def export_graph_rows(self, lo, hi, e_ptr, d_ptr):
+        self._check(self.lib.nnd_export_graph_rows(self._h, int(lo), int(hi), C.c_void_p(int(e_ptr)), C.c_void_p(int(d_ptr))))
+
+    def import_graph_rows(self, lo, hi, e_ptr, d_ptr):
+        self._check(self.lib.nnd_import_graph_rows(self._h, int(lo), int(hi), C.c_void_p(int(e_ptr)), C.c_void_p(int(d_ptr))))
+
+    def merge_graph_rows(self, lo, hi, e_ptr, d_ptr):
+        self._check(self.lib.nnd_merge_graph_rows(self._h, int(lo), int(hi), C.c_void_p(int(e_ptr)), C.c_void_p(int(d_ptr))))
+
+    def descent_sample(self):
+        self._check(self.lib.nnd_descent_sample(self._h))
+
+    def descent_join(self):
+        self._check(self.lib.nnd_descent_join(self._h))
+
+    def proposal_counts(self, cnt_ptr):
+        self._check(self.lib.nnd_proposal_counts(self._h, C.c_void_p(int(cnt_ptr))))
+
+    def export_proposals(self, offsets_ptr, keys_ptr, targets_ptr):
+        self._check(self.lib.nnd_export_proposals(self._h, C.c_void_p(int(offsets_ptr)), C.c_void_p(int(keys_ptr)),
+                                                  C.c_void_p(int(targets_ptr))))
+
+    def import_proposals(self, keys_ptr, targets_ptr, count):
+        self._check(self.lib.nnd_import_proposals(self._h, C.c_void_p(int(keys_ptr)), C.c_void_p(int(targets_ptr)), int(count)))
+
+    def descent_merge(self):
+        c = C.c_int64()
+        self._check(self.lib.nnd_descent_merge(self._h, C.byref(c)))
+        return c.value
 
     def pairwise_gram(self, rows_a, rows_b):
         a = np.ascontiguousarray(rows_a, np.int32)

@@ -70,6 +70,8 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
     nnd_ctx *ctx = new nnd_ctx();
     ctx->p = *p;
     ctx->n = p->n;
+    ctx->own_lo = 0;
+    ctx->own_hi = p->n;
     ctx->d = p->dim;
     ctx->dp = (p->dim + 31) & ~31;
     ctx->k = p->n_neighbors;
@@ -286,7 +288,8 @@ static int descent_iter(nnd_ctx *ctx, int64_t *c_out, bool timed) {
     const int nb = ctx->p.join_blocks;
     float ms_join = 0.f, ms_merge = 0.f;
     for (int b = 0; b < nb; b++) {
-        int64_t v0 = ctx->n * b / nb, v1 = ctx->n * (b + 1) / nb;
+        const int64_t span = ctx->own_hi - ctx->own_lo;
+        int64_t v0 = ctx->own_lo + span * b / nb, v1 = ctx->own_lo + span * (b + 1) / nb;
         if (timed) tick(ctx);
         if (nnd_launch_join(ctx, v0, v1)) return 1;
         if (timed) { ms_join += elapsed_ms(ctx); tick(ctx); }
@@ -355,7 +358,7 @@ extern "C" int32_t nnd_finalize_device(nnd_handle_t ctx, int32_t *out_idx_dev, f
 extern "C" int32_t nnd_finalize_host(nnd_handle_t ctx, int32_t *out_idx, float *out_dist) {
     ENTER(ctx);
     if (need_data(ctx)) return 1;
-    size_t cnt = (size_t)ctx->n * ctx->k;
+    size_t cnt = (size_t)(ctx->own_hi - ctx->own_lo) * ctx->k;  // owned rows only
     int32_t *di = nullptr;
     float *dd = nullptr;
     API_HIP(hipMalloc((void **)&di, sizeof(int32_t) * cnt));
@@ -504,4 +507,92 @@ extern "C" int32_t nnd_pairwise_gram(nnd_handle_t ctx, const int32_t *rows_a, in
     (void)hipFree(db);
     (void)hipFree(dout);
     return rc;
+}
+
+// ---- row-sharded multi-GPU build; host orchestration: pynndescent_amd/sharded.py ----
+extern "C" int32_t nnd_set_owned_range(nnd_handle_t ctx, int64_t lo, int64_t hi) {
+    ENTER(ctx);
+    if (lo < 0 || hi > ctx->n || lo > hi) { ctx->set_error("nnd_set_owned_range: bad range [%lld, %lld)", (long long)lo, (long long)hi); return 1; }
+    ctx->own_lo = lo;
+    ctx->own_hi = hi;
+    return 0;
+}
+extern "C" int32_t nnd_row_stride(nnd_handle_t ctx) { return ctx ? ctx->ks : 0; }
+
+extern "C" int32_t nnd_export_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, uint32_t *e_dst_dev, float *d_dst_dev) {
+    ENTER(ctx);
+    size_t cnt = (size_t)(hi - lo) * ctx->ks;
+    API_HIP(hipMemcpyAsync(e_dst_dev, ctx->knn_e + lo * ctx->ks, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    API_HIP(hipMemcpyAsync(d_dst_dev, ctx->knn_d + lo * ctx->ks, sizeof(float) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int32_t nnd_import_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, const uint32_t *e_src_dev, const float *d_src_dev) {
+    ENTER(ctx);
+    size_t cnt = (size_t)(hi - lo) * ctx->ks;
+    API_HIP(hipMemcpyAsync(ctx->knn_e + lo * ctx->ks, e_src_dev, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    API_HIP(hipMemcpyAsync(ctx->knn_d + lo * ctx->ks, d_src_dev, sizeof(float) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int32_t nnd_merge_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, const uint32_t *e_src_dev, const float *d_src_dev) {
+    ENTER(ctx);
+    if (nnd_launch_merge_graph_rows(ctx, lo, hi, e_src_dev, d_src_dev)) return 1;
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int32_t nnd_descent_sample(nnd_handle_t ctx) {
+    ENTER(ctx);
+    tick(ctx);
+    if (nnd_launch_sample(ctx)) return 1;
+    float ms = elapsed_ms(ctx);
+    if (ctx->iter < 64) ctx->stats.ms_sample[ctx->iter] = ms;
+    return 0;
+}
+extern "C" int32_t nnd_descent_join(nnd_handle_t ctx) {
+    ENTER(ctx);
+    if (nnd_zero_counters(ctx)) return 1;
+    tick(ctx);
+    if (nnd_launch_join(ctx, ctx->own_lo, ctx->own_hi)) return 1;
+    float ms = elapsed_ms(ctx);
+    if (ctx->iter < 64) ctx->stats.ms_join[ctx->iter] = ms;
+    return 0;
+}
+extern "C" int32_t nnd_proposal_counts(nnd_handle_t ctx, int32_t *cnt_dev) {
+    ENTER(ctx);
+    if (nnd_launch_proposal_counts(ctx, cnt_dev)) return 1;
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int32_t nnd_export_proposals(nnd_handle_t ctx, const int64_t *offsets_dev, uint64_t *keys_out_dev, int32_t *targets_out_dev) {
+    ENTER(ctx);
+    if (nnd_launch_export_proposals(ctx, offsets_dev, keys_out_dev, targets_out_dev)) return 1;
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int32_t nnd_import_proposals(nnd_handle_t ctx, const uint64_t *keys_dev, const int32_t *targets_dev, int64_t count) {
+    ENTER(ctx);
+    if (nnd_launch_import_proposals(ctx, keys_dev, targets_dev, count)) return 1;
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int32_t nnd_descent_merge(nnd_handle_t ctx, int64_t *c_local) {
+    ENTER(ctx);
+    const int it = ctx->iter;
+    tick(ctx);
+    if (nnd_launch_merge(ctx)) return 1;
+    float ms = elapsed_ms(ctx);
+    if (nnd_read_counters(ctx)) return 1;
+    if (it < 64) {
+        ctx->stats.ms_merge[it] = ms;
+        ctx->stats.join_pairs[it] = ctx->h_counters[CNT_PAIRS];
+        ctx->stats.join_rows[it] = ctx->h_counters[CNT_ROWS];
+        ctx->stats.join_active[it] = ctx->h_counters[CNT_ACTIVE];
+        ctx->stats.proposals[it] = ctx->h_counters[CNT_PROPOSALS];
+        ctx->stats.updates[it] = ctx->h_counters[CNT_ACCEPT];
+    }
+    if (c_local) *c_local = ctx->h_counters[CNT_ACCEPT];
+    ctx->iter++;
+    ctx->stats.n_iters_run = ctx->iter;
+    return 0;
 }

@@ -8,11 +8,11 @@
 #include "common.h"
 #include "state.h"
 
-__global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, int d, int metric, int64_t n, int k, int ks,
+__global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, int d, int metric, int64_t lo, int64_t n, int k, int ks,
                                                   const uint32_t *__restrict__ knn_e, int32_t *__restrict__ out_idx,
                                                   float *__restrict__ out_dist) {
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t v = (int64_t)blockIdx.x * 4 + w;
+    const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;  // owned rows [lo, n); output row index is v - lo
     if (v >= n) return;
     uint32_t e = lane < k ? knn_e[v * ks + lane] : NND_EMPTY_E;
     const float *xv = x + v * d;
@@ -58,14 +58,14 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, i
         r += (kj < mykey || (kj == mykey && j < lane)) ? 1 : 0;
     }
     if (lane < k) {
-        out_idx[v * k + r] = e == NND_EMPTY_E ? -1 : (int32_t)(e & NND_IDX_MASK);
-        out_dist[v * k + r] = mine;
+        out_idx[(v - lo) * k + r] = e == NND_EMPTY_E ? -1 : (int32_t)(e & NND_IDX_MASK);
+        out_dist[(v - lo) * k + r] = mine;
     }
 }
 
 int nnd_launch_finalize(nnd_ctx *ctx, int32_t *out_idx_dev, float *out_dist_dev) {
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->x_orig, ctx->d,
-                       ctx->p.metric, ctx->n, ctx->k, ctx->ks, ctx->knn_e, out_idx_dev, out_dist_dev);
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream, ctx->x_orig,
+                       ctx->d, ctx->p.metric, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, out_idx_dev, out_dist_dev);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -14,11 +14,11 @@
 #include "state.h"
 
 __global__ __launch_bounds__(256) void k_merge(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
-                                               int64_t n, int k, int ks, uint32_t *__restrict__ knn_e,
+                                               int64_t lo, int64_t n, int k, int ks, uint32_t *__restrict__ knn_e,
                                                float *__restrict__ knn_d, long long *__restrict__ counters) {
     __shared__ int wacc[4];
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t v = (int64_t)blockIdx.x * 4 + w;
+    const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;  // [lo, n): the rows this handle owns
     int acc = 0;
     if (v < n && pdirty[v]) {
         uint64_t *slots = pbuf + v * pcap;
@@ -37,8 +37,8 @@ __global__ __launch_bounds__(256) void k_merge(uint64_t *__restrict__ pbuf, uint
 }
 
 int nnd_launch_merge(nnd_ctx *ctx) {
-    hipLaunchKernelGGL(k_merge, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->pbuf, ctx->pdirty,
-                       ctx->pcap, ctx->n, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->counters);
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream, ctx->pbuf,
+                       ctx->pdirty, ctx->pcap, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->counters);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -59,12 +59,12 @@ __device__ __forceinline__ float row_dist(const float *__restrict__ xp, int dp, 
 
 // init_random (pynndescent_.py:188-203): rows that are not full get (k - filled) random candidates
 __global__ __launch_bounds__(256) void k_random_init(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
-                                                     int metric, int64_t n, int k, int ks,
+                                                     int metric, int64_t n, int64_t lo, int64_t hi, int k, int ks,
                                                      const uint32_t *__restrict__ knn_e, uint32_t seed,
                                                      uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap) {
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t v = (int64_t)blockIdx.x * 4 + w;
-    if (v >= n) return;
+    const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;
+    if (v >= hi) return;
     uint32_t e = lane < k ? knn_e[v * ks + lane] : NND_EMPTY_E;
     int filled = __popcll(__ballot(lane < k && e != NND_EMPTY_E));
     int todo = k - filled;  // pynndescent_.py:196
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void k_random_init(const float *__restrict__ x
 }
 
 int nnd_launch_random_init(nnd_ctx *ctx) {
-    hipLaunchKernelGGL(k_random_init, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, ctx->dp,
-                       ctx->nrm, ctx->p.metric, ctx->n, ctx->k, ctx->ks, ctx->knn_e, ctx->seed ^ 0x3C6EF372u, ctx->pbuf,
+    hipLaunchKernelGGL(k_random_init, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp,
+                       ctx->dp, ctx->nrm, ctx->p.metric, ctx->n, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, ctx->seed ^ 0x3C6EF372u, ctx->pbuf,
                        ctx->pdirty, ctx->pcap);
     NND_HIP_CHECK(hipGetLastError());
     return nnd_launch_merge(ctx);
@@ -126,4 +126,111 @@ int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float
                        ctx->nrm, ctx->p.metric, ctx->n, idx_dev, dist_dev, width, ctx->pbuf, ctx->pdirty, ctx->pcap);
     NND_HIP_CHECK(hipGetLastError());
     return nnd_launch_merge(ctx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-sharded multi-GPU build: every handle keeps global-sized arrays indexed by
+// global vertex id but OWNS the rows [own_lo, own_hi).  Proposals whose target is owned elsewhere are
+// compacted into (key, target) records, shipped to the owner (host side: all-to-all-v over RCCL),
+// and folded into the owner's slots.  This is the cross-process form of the reference's ownership
+// test in apply_graph_update_array (utils.py:721-731).
+
+// records pending for every vertex this handle does NOT own (0 for owned or clean rows)
+__global__ __launch_bounds__(256) void k_proposal_counts(const uint64_t *__restrict__ pbuf, const uint8_t *__restrict__ pdirty,
+                                                         int pcap, int64_t n, int64_t own_lo, int64_t own_hi,
+                                                         int32_t *__restrict__ cnt) {
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t v = (int64_t)blockIdx.x * 4 + w;
+    if (v >= n) return;
+    int c = 0;
+    if ((v < own_lo || v >= own_hi) && pdirty[v]) {
+        for (int s = lane; s < pcap; s += 64) c += pbuf[v * pcap + s] != NND_EMPTY_KEY;
+        c = nnd_wave_sum_i32(c);
+    }
+    if (lane == 0) cnt[v] = c;
+}
+
+// write the records of vertex v at offsets[v] (exclusive scan of the counts), re-arm the slots
+__global__ __launch_bounds__(256) void k_export_proposals(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
+                                                          int64_t n, int64_t own_lo, int64_t own_hi,
+                                                          const int64_t *__restrict__ offsets, uint64_t *__restrict__ keys,
+                                                          int32_t *__restrict__ targets) {
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t v = (int64_t)blockIdx.x * 4 + w;
+    if (v >= n) return;
+    if ((v >= own_lo && v < own_hi) || !pdirty[v]) return;
+    int64_t off = offsets[v];
+    for (int s0 = 0; s0 < pcap; s0 += 64) {
+        const int s = s0 + lane;
+        uint64_t key = s < pcap ? pbuf[v * pcap + s] : NND_EMPTY_KEY;
+        const bool on = key != NND_EMPTY_KEY;
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int64_t o = off + nnd_prefix_popc(m);
+            keys[o] = key;
+            targets[o] = (int32_t)v;
+            pbuf[v * pcap + s] = NND_EMPTY_KEY;
+        }
+        off += __popcll(m);
+    }
+    if (lane == 0) pdirty[v] = 0;
+}
+
+// fold received records into this handle's slots (same hashed-slot atomicMin as the join)
+__global__ void k_import_proposals(const uint64_t *__restrict__ keys, const int32_t *__restrict__ targets, int64_t count,
+                                   uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t key = keys[i];
+    const int64_t t = targets[i];
+    const uint32_t s = nnd_hash2(slot_seed, nnd_key_idx(key)) & (uint32_t)(pcap - 1);
+    atomicMin((unsigned long long *)&pbuf[t * pcap + s], (unsigned long long)key);
+    pdirty[t] = 1;
+}
+
+// merge rows [lo, hi) of another handle's partial k-lists (e_src/d_src: (hi-lo, ks) row blocks) into ours:
+// used to combine the per-rank forests' leaf seeding at the owner
+__global__ __launch_bounds__(256) void k_merge_graph_rows(int64_t lo, int64_t hi, int k, int ks, const uint32_t *__restrict__ e_src,
+                                                          const float *__restrict__ d_src, uint32_t *__restrict__ knn_e,
+                                                          float *__restrict__ knn_d) {
+    const int w = threadIdx.x >> 6;
+    const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;
+    if (v >= hi) return;
+    const uint32_t *es = e_src + (v - lo) * ks;
+    const float *ds = d_src + (v - lo) * ks;
+    nnd_merge_row<1>(v, k, ks, knn_e, knn_d, k, [&](int c, uint32_t &id, float &dc) {
+        const uint32_t e = es[c];
+        id = e & NND_IDX_MASK;
+        dc = ds[c];
+        return e != NND_EMPTY_E;
+    });
+}
+
+int nnd_launch_proposal_counts(nnd_ctx *ctx, int32_t *cnt_dev) {
+    hipLaunchKernelGGL(k_proposal_counts, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->pbuf, ctx->pdirty,
+                       ctx->pcap, ctx->n, ctx->own_lo, ctx->own_hi, cnt_dev);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int nnd_launch_export_proposals(nnd_ctx *ctx, const int64_t *offsets_dev, uint64_t *keys_out, int32_t *targets_out) {
+    hipLaunchKernelGGL(k_export_proposals, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->pbuf, ctx->pdirty,
+                       ctx->pcap, ctx->n, ctx->own_lo, ctx->own_hi, offsets_dev, keys_out, targets_out);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_t *targets, int64_t count) {
+    if (count <= 0) return 0;
+    // same slot hash as the join of the iteration that produced the records (iter was not advanced yet)
+    uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
+    hipLaunchKernelGGL(k_import_proposals, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, keys, targets, count,
+                       ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src) {
+    if (hi <= lo) return 0;
+    hipLaunchKernelGGL(k_merge_graph_rows, dim3((unsigned)((hi - lo + 3) / 4)), dim3(256), 0, ctx->stream, lo, hi, ctx->k, ctx->ks,
+                       e_src, d_src, ctx->knn_e, ctx->knn_d);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
 }

@@ -22,7 +22,7 @@
 #include "state.h"
 
 __global__ void k_sample_reverse(const uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, uint32_t it_seed,
-                                 uint64_t *__restrict__ rbuf, int rcap) {
+                                 uint64_t *__restrict__ rbuf, int rcap, int64_t own_lo, int64_t own_hi) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * ks) return;
     int64_t v = t / ks;
@@ -31,6 +31,7 @@ __global__ void k_sample_reverse(const uint32_t *__restrict__ knn_e, int64_t n, 
     uint32_t e = knn_e[t];
     if (e == NND_EMPTY_E) return;
     uint32_t u = e & NND_IDX_MASK;
+    if ((int64_t)u < own_lo || (int64_t)u >= own_hi) return;  // owner-computes: only targets this handle owns (utils.py:270-273)
     uint32_t cls = e >> 31;  // 1 = new
     uint32_t prio = nnd_hash3(it_seed, (uint32_t)v, u);
     uint32_t slot = nnd_hash2(it_seed ^ 0x68E31DA4u, (uint32_t)v) & (uint32_t)(rcap - 1);
@@ -46,11 +47,11 @@ struct sample_scratch {
 
 __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
                                                        int mcp, uint32_t it_seed, uint64_t *__restrict__ rbuf, int rcap,
-                                                       int32_t *__restrict__ cand) {
+                                                       int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi) {
     __shared__ sample_scratch scr[4];
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t v = (int64_t)blockIdx.x * 4 + w;
-    if (v >= n) return;
+    const int64_t v = own_lo + (int64_t)blockIdx.x * 4 + w;
+    if (v >= own_hi) return;
     sample_scratch &sc = scr[w];
 
     uint32_t e = NND_EMPTY_E;
@@ -121,9 +122,10 @@ int nnd_launch_sample(nnd_ctx *ctx) {
     uint32_t it_seed = nnd_hash2(ctx->seed ^ 0x9E3779B9u, (uint32_t)ctx->iter + 1u);
     int64_t total = n * ctx->ks;
     hipLaunchKernelGGL(k_sample_reverse, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e, n,
-                       ctx->k, ctx->ks, it_seed, ctx->rbuf, ctx->rcap);
-    hipLaunchKernelGGL(k_sample_select, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->knn_e, n, ctx->k,
-                       ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand);
+                       ctx->k, ctx->ks, it_seed, ctx->rbuf, ctx->rcap, ctx->own_lo, ctx->own_hi);
+    hipLaunchKernelGGL(k_sample_select, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream,
+                       ctx->knn_e, n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand, ctx->own_lo,
+                       ctx->own_hi);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

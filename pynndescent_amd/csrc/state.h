@@ -42,6 +42,7 @@ struct nnd_handle_s {
     int mc = 0, mcp = 0;    // mcp = max_candidates rounded up to 16/32/64
     int rcap = 0, pcap = 0; // reverse-offer slots per (vertex,class); proposal slots per vertex
     int iter = 0;
+    int64_t own_lo = 0, own_hi = 0; // rows this handle owns (row-sharded multi-GPU build); default [0, n)
     uint32_t seed = 0, tree_seed = 0;
 
     // data
@@ -107,5 +108,9 @@ int nnd_launch_merge(nnd_ctx *ctx);
 int nnd_launch_finalize(nnd_ctx *ctx, int32_t *out_idx_dev, float *out_dist_dev);
 int nnd_launch_pairwise(nnd_ctx *ctx, const int32_t *rows_a_dev, int na, const int32_t *rows_b_dev, int nb,
                         float *out_dev);
+int nnd_launch_proposal_counts(nnd_ctx *ctx, int32_t *cnt_dev);
+int nnd_launch_export_proposals(nnd_ctx *ctx, const int64_t *offsets_dev, uint64_t *keys_out, int32_t *targets_out);
+int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_t *targets, int64_t count);
+int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
 int nnd_read_counters(nnd_ctx *ctx);  // device -> ctx->h_counters (synchronises the stream)
 int nnd_zero_counters(nnd_ctx *ctx);

@@ -1,0 +1,92 @@
+"""Host side of the row-sharded build, on CPU: partition helpers and the torch.distributed transport
+(gloo, world_size 2) that carries the k-list all-gather and the proposal all-to-all-v."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from pynndescent_amd import sharded
+
+
+def test_partition_helpers():
+    r = sharded.shard_ranges(10, 3)
+    assert r == [(0, 3), (3, 6), (6, 10)]
+    assert sharded.shard_ranges(8, 8) == [(i, i + 1) for i in range(8)]
+    assert sharded.tree_ranges(8, 2) == [(0, 4), (4, 8)]
+    tr = sharded.tree_ranges(3, 8)  # fewer trees than ranks: some ranks get none, every tree is built once
+    assert sum(b - a for a, b in tr) == 3 and all(b - a in (0, 1) for a, b in tr)
+    # records are ordered by target vertex: the exclusive scan at the range edges gives the per-rank segments
+    cnt = np.array([0, 2, 0, 1, 0, 0, 3, 1, 0, 0])
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    seg = sharded.segment_bounds(off, r)
+    assert seg == [(0, 2), (2, 3), (3, 7)]
+    assert sum(b - a for a, b in seg) == cnt.sum()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = sharded.TorchDistComm()
+        # all-gather of shards with different row counts (k-list rows / point-set shards)
+        mine = torch.full((3 + rank, 4), float(rank))
+        got = comm.all_gather_v(mine)
+        ok = len(got) == world and all(g.shape == (3 + r, 4) and bool((g == r).all()) for r, g in enumerate(got))
+        # all-to-all-v with ragged (and empty) segments: the proposal records
+        send = [torch.arange(rank * 100 + dst * 10, rank * 100 + dst * 10 + (dst + rank) % 3, dtype=torch.int64)
+                for dst in range(world)]
+        recv = comm.all_to_all_v(send)
+        for src in range(world):
+            n = (rank + src) % 3
+            want = torch.arange(src * 100 + rank * 10, src * 100 + rank * 10 + n, dtype=torch.int64)
+            ok = ok and torch.equal(recv[src], want)
+        # update-count all-reduce (stop rule, pynndescent_.py:317)
+        ok = ok and comm.all_reduce_sum(5 + rank) == sum(5 + r for r in range(world))
+        comm.barrier()
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_torch_dist_transport_gloo(world):
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def test_thread_comm_matches_the_contract():
+    import threading
+
+    comms = sharded.ThreadComm.make(3)
+    res = [None] * 3
+
+    def run(r):
+        c = comms[r]
+        g = c.all_gather_v(torch.full((r + 1,), r))
+        a = c.all_to_all_v([torch.tensor([r * 10 + d] * ((r + d) % 2)) for d in range(3)])
+        s = c.all_reduce_sum(r + 1)
+        res[r] = (g, a, s)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for r in range(3):
+        g, a, s = res[r]
+        assert [t.tolist() for t in g] == [[0], [1, 1], [2, 2, 2]]
+        assert [t.tolist() for t in a] == [[src * 10 + r] * ((src + r) % 2) for src in range(3)]
+        assert s == 6
