@@ -31,18 +31,22 @@ import torch  # noqa: E402  (device memory, streams, torch.distributed: plumbing
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def sift_like(n, d, seed, device, latent=16, n_clusters=1024, noise=0.3):
+def sift_like(n, d, seed, device, latent=16, n_clusters=1024, noise=0.3, sample_seed=None):
     """SURVEY.md section 8d C2': 1024-component Gaussian mixture in a 16-dim latent, random linear map to
-    d dims, + noise, shifted non-negative, scaled to ~[0, 218]; generated on the device."""
+    d dims, + noise, shifted non-negative, scaled to ~[0, 218]; generated on the device.
+    ``seed`` fixes the mixture (centres, projection); ``sample_seed`` the draws (rank-specific when sharded,
+    so that all shards come from ONE distribution and neighbours cross shard boundaries)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     centres = torch.randn(n_clusters, latent, generator=g, device=device) * 3.0
+    proj = torch.randn(latent, d, generator=g, device=device) / (latent ** 0.5)
+    if sample_seed is not None:
+        g.manual_seed(sample_seed)
     assign = torch.randint(0, n_clusters, (n,), generator=g, device=device)
     z = centres[assign] + torch.randn(n, latent, generator=g, device=device)
-    proj = torch.randn(latent, d, generator=g, device=device) / (latent ** 0.5)
     x = z @ proj + noise * torch.randn(n, d, generator=g, device=device)
-    x = x - x.min()
-    x = x * (218.0 / x.max())
+    x = x + 12.0  # shift non-negative with a fixed offset (identical on every shard)
+    x = x.clamp_min(0.0) * (218.0 / 24.0)
     return x.contiguous().float()
 
 
@@ -64,12 +68,35 @@ def recall_at(true_idx, approx_idx, k_true=10, cols=None):
     return hits / float(t.shape[0] * k_true)
 
 
+def cpu_baseline(O, xs, k, n_trees):
+    """The CPU oracle (restatement of the reference algorithm) on this box's host cores.  The reference's
+    parallel scheme makes every thread scan all edges (utils.py:266-273), so more threads is not always
+    faster: a short probe picks the thread count, then the bounded sample is timed once."""
+    cores = os.cpu_count() or 1
+    O.build()
+    probe = xs[: min(30000, xs.shape[0])]
+    best_t, best = None, None
+    for t in sorted({min(cores, c) for c in (8, 16, 32, 64, 128)}):
+        t1 = time.perf_counter()
+        O.build_index(probe, "euclidean", n_neighbors=k, n_trees=n_trees, random_state=1234, n_threads=t, kind="fast")
+        dt = time.perf_counter() - t1
+        if best is None or dt < best:
+            best_t, best = t, dt
+    t1 = time.perf_counter()
+    O.build_index(xs, "euclidean", n_neighbors=k, n_trees=n_trees, random_state=1234, n_threads=best_t, kind="fast")
+    dt = time.perf_counter() - t1
+    return {"value": round(xs.shape[0] / dt, 1), "unit": "points/s", "cores": best_t, "host_cores": cores, "kind": "port",
+            "sample": "first %d points of the same synthetic set, same k/n_trees/defaults; CPU restatement of the "
+                      "reference algorithm (numba unavailable), gcc -O3 -ffast-math + OpenMP, %d threads "
+                      "(fastest of a probe over 8..128)" % (xs.shape[0], best_t)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--points-per-gpu", dest="n", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=15)
     ap.add_argument("--n-trees", type=int, default=8)
@@ -85,27 +112,50 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # PYNND_BENCH_SHARE_GPU=1 (debug only): all ranks on GPU 0 over gloo, to exercise the multi-process
+        # path on a one-GPU box; the real run is one rank per GPU over nccl (= RCCL)
+        if os.environ.get("PYNND_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    from oracle import oracle as O  # cpu_baseline leg + defaults only
-    from pynndescent_amd import _capi
+    from pynndescent_amd import _capi, sharded
 
     n, d, k = args.n, args.dim, args.k
-    x = sift_like(n, d, seed=1 + rank, device=device)
+    n_total = n * world
+    x = sift_like(n, d, seed=1, device=device, sample_seed=100 + rank)
     torch.cuda.synchronize()
-    out_idx = torch.empty((n, k), dtype=torch.int32, device=device)
-    out_dist = torch.empty((n, k), dtype=torch.float32, device=device)
-    rng_state, _, tree_states = O.draw_rng_states(1234 + rank, args.n_trees)
-    n_iters = O.default_n_iters(n)
-    builder = _capi.Builder(n, d, _capi.NND_METRIC_SQEUCLIDEAN, k, args.n_trees, O.default_leaf_size(k), 200,
-                            min(60, k), n_iters, 0.001, rng_state, tree_states[0], device=local_rank,
-                            join_blocks=args.join_blocks)
+    n_iters = max(5, int(round(np.log2(n_total))))  # pynndescent_.py:1011-1012
+    leaf_size = max(60, min(256, 5 * k))              # rp_trees.py:2845-2846
+    lim = np.iinfo(np.int32)
+    rs = np.random.RandomState(1234)
+    rng_state = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
+    _ = rs.randint(lim.min + 1, lim.max - 1, 3)
+    tree_states = rs.randint(lim.min + 1, lim.max - 1, size=(args.n_trees, 3)).astype(np.int64)
 
-    def step():
-        builder.set_data_device(x.data_ptr(), keepalive=x)
-        builder.build_device(out_idx.data_ptr(), out_dist.data_ptr())
+    if world == 1:
+        out_idx = torch.empty((n, k), dtype=torch.int32, device=device)
+        out_dist = torch.empty((n, k), dtype=torch.float32, device=device)
+        builder = _capi.Builder(n, d, _capi.NND_METRIC_SQEUCLIDEAN, k, args.n_trees, leaf_size, 200, min(60, k), n_iters,
+                                0.001, rng_state, tree_states[0], device=local_rank, join_blocks=args.join_blocks)
+        sb = None
+
+        def step():
+            builder.set_data_device(x.data_ptr(), keepalive=x)
+            builder.build_device(out_idx.data_ptr(), out_dist.data_ptr())
+            return builder.stats(), None
+    else:
+        comm = sharded.TorchDistComm()
+        sb = sharded.ShardedBuilder(comm, [n] * world, d, "euclidean", k, args.n_trees, seed=1234, device_index=local_rank)
+        builder = sb.b
+        out_idx, out_dist = sb.out_idx, sb.out_dist
+
+        def step():
+            _, _, info = sb.build(x)
+            return info["stats"], info
 
     def barrier():
         if world > 1:
@@ -117,22 +167,17 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    stage = {"forest": 0.0, "leaf_init": 0.0, "descent": 0.0, "join": 0.0, "sample": 0.0, "merge": 0.0,
-             "finalize": 0.0, "prep": 0.0, "random_init": 0.0}
-    join_bytes = join_ms = 0.0
-    leaf_bytes = 0.0
+    stage = {"forest": 0.0, "leaf_init": 0.0, "join": 0.0, "sample": 0.0, "merge": 0.0, "finalize": 0.0, "prep": 0.0,
+             "random_init": 0.0}
+    join_bytes = join_ms = leaf_bytes = 0.0
     n_join_launches = 0
-    last = None
+    last = info = None
     for _ in range(args.steps):
-        step()
-        st = builder.stats()  # per-stage HIP-event timings taken on the library's own stream
+        st, info = step()  # per-stage HIP-event timings are taken on the library's own stream
         last = st
-        stage["forest"] += st["ms_forest"]
-        stage["leaf_init"] += st["ms_leaf_init"]
-        stage["descent"] += st["ms_descent"]
-        stage["finalize"] += st["ms_finalize"]
-        stage["prep"] += st["ms_prep"]
-        stage["random_init"] += st["ms_random_init"]
+        for key, name in (("forest", "ms_forest"), ("leaf_init", "ms_leaf_init"), ("finalize", "ms_finalize"),
+                          ("prep", "ms_prep"), ("random_init", "ms_random_init")):
+            stage[key] += st[name]
         stage["join"] += sum(st["ms_join"])
         stage["sample"] += sum(st["ms_sample"])
         stage["merge"] += sum(st["ms_merge"])
@@ -147,53 +192,50 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1000.0 / args.steps
-    value = world * n * args.steps / elapsed
+    value = n_total * args.steps / elapsed
 
-    result = None
+    # recall vs exact brute force on a sample of this rank's rows (outside the timed region)
+    if world > 1:
+        x_all = torch.cat(sharded.TorchDistComm().all_gather_v(x), dim=0)
+    else:
+        x_all = x
     if rank == 0:
-        # recall vs exact brute force on a sample (outside the timed region)
-        rs = np.random.RandomState(0)
-        rows = torch.from_numpy(rs.choice(n, size=min(2000, n), replace=False)).to(device)
-        true_idx = exact_knn_sample(x, rows, 10)
+        rsmp = np.random.RandomState(0)
+        rows = torch.from_numpy(rsmp.choice(n, size=min(2000, n), replace=False)).to(device)  # rank 0 owns rows [0, n)
+        true_idx = exact_knn_sample(x_all, rows, 10)
         rec_all = recall_at(true_idx, out_idx[rows], 10)
         rec_strict = recall_at(true_idx, out_idx[rows], 10, cols=10)
-        # distances: returned (alt-space) vs float64 truth for the returned pairs
-        nb = x[out_idx[rows].long()].double()
-        truth = ((x[rows].double()[:, None, :] - nb) ** 2).sum(-1)
+        nb = x_all[out_idx[rows].long()].double()
+        truth = ((x_all[rows].double()[:, None, :] - nb) ** 2).sum(-1)
         rel = ((out_dist[rows].double() - truth).abs() / truth.clamp_min(1e-30))[truth > 0].max().item()
 
-        # roofline for the dominant kernel (by measured time): the local join gathers C_i candidate rows
-        # of dp*4 bytes each per launch (SURVEY.md section 8d B_iter, dominant term)
-        dominant = max(("join", "leaf_init", "forest"), key=lambda s: stage[s])
+        # roofline of the dominant kernel (by measured time).  Algorithmic bytes:
+        #   k_local_join : C_i gathered candidate rows * dp*4 bytes per launch
+        #   k_leaf_join  : sum of leaf sizes * dp*4 bytes per launch
+        #   rp forest    : n * dp*4 * levels (each row once per level, all trees fused) + 8 B/position/level
         steps = float(args.steps)
+        dominant = max(("join", "leaf_init", "forest"), key=lambda sname: stage[sname])
+        join_gbs = join_bytes / (join_ms * 1e-3) / 1e9 if join_ms > 0 else 0.0
         if dominant == "join":
-            achieved = join_bytes / (join_ms * 1e-3) / 1e9 if join_ms > 0 else 0.0
-            kernel = "k_local_join"
+            achieved, kernel = join_gbs, "k_local_join"
         elif dominant == "leaf_init":
-            achieved = leaf_bytes / (stage["leaf_init"] * 1e-3) / 1e9
-            kernel = "k_leaf_join"
+            achieved, kernel = leaf_bytes / (stage["leaf_init"] * 1e-3) / 1e9, "k_leaf_join"
         else:
-            tree_bytes = steps * (n * 4.0 * builder_dp(d) * last["tree_levels"] + n * 8.0 * last["tree_levels"] * args.n_trees)
-            achieved = tree_bytes / (stage["forest"] * 1e-3) / 1e9
-            kernel = "rp_forest (k_margin et al.)"
-        roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "join_GBps": round(join_bytes / (join_ms * 1e-3) / 1e9, 2) if join_ms > 0 else None,
-                    "join_avg_launch_ms": round(join_ms / max(n_join_launches, 1), 4)}
+            n_here = builder.n
+            tree_bytes = steps * (n_here * 4.0 * builder_dp(d) * last["tree_levels"] +
+                                  n_here * 8.0 * last["tree_levels"] * max(1, args.n_trees // world))
+            achieved, kernel = tree_bytes / (stage["forest"] * 1e-3) / 1e9, "rp_forest (k_margin_fused / k_margin + partition)"
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "k_local_join": {"achieved": round(join_gbs, 2), "frac": round(join_gbs / HBM_PEAK_GBS, 5),
+                                     "avg_launch_ms": round(join_ms / max(n_join_launches, 1), 4),
+                                     "bytes_per_launch": round(join_bytes / max(n_join_launches, 1))}}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            ns = min(args.cpu_sample, n)
-            xs = x[:ns].cpu().numpy()
-            O.build()
-            t1 = time.perf_counter()
-            O.build_index(xs, "euclidean", n_neighbors=k, n_trees=args.n_trees, random_state=1234,
-                          n_threads=cores, kind="fast")
-            dt = time.perf_counter() - t1
-            cpu = {"value": round(ns / dt, 1), "unit": "points/s", "cores": cores, "kind": "port",
-                   "sample": "first %d points of the same synthetic set, same k/n_trees/defaults, CPU restatement of "
-                             "the reference algorithm (numba unavailable), -O3 -ffast-math + OpenMP" % ns}
+            from oracle import oracle as O  # test infrastructure: the cpu_baseline leg only
+
+            cpu = cpu_baseline(O, x[: min(args.cpu_sample, n)].cpu().numpy(), k, args.n_trees)
 
         result = {
             "metric": "index build: points indexed/sec (recall@10 vs brute force reported alongside)",
@@ -209,26 +251,33 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "SIFT-like %dx%d float32 euclidean k=%d n_trees=%d (BASELINE configs[1] stand-in, "
-                                   "SURVEY 8d C2')" % (n, d, k, args.n_trees),
-                       "parallelism": "1 GPU" if world == 1 else "%d independent row shards of %d points" % (world, n),
+                                   "SURVEY 8d C2'); %d points per GPU" % (n_total, d, k, args.n_trees, n),
+                       "parallelism": "1 GPU" if world == 1 else
+                       "rows sharded over %d GPUs (one global index of %d points): point set all-gathered once, forest split "
+                       "by tree, per iteration k-list all-gather + proposal all-to-all-v + count all-reduce over RCCL"
+                       % (world, n_total),
                        "join_blocks": args.join_blocks},
             "recall_at_10": round(rec_all, 4),
             "recall_at_10_strict_first10": round(rec_strict, 4),
             "max_rel_dist_err": float("%.3g" % rel),
             "iters": last["n_iters_run"],
-            "stage_ms_per_step": {s: round(v / steps, 3) for s, v in stage.items()},
+            "stage_ms_per_step": {sname: round(v / steps, 3) for sname, v in stage.items()},
             "last_step_iter_ms": {"sample": [round(v, 3) for v in last["ms_sample"]],
                                   "join": [round(v, 3) for v in last["ms_join"]],
                                   "merge": [round(v, 3) for v in last["ms_merge"]]},
-            "counts": {"leaves": last["n_leaves"], "tree_levels": last["tree_levels"],
-                       "leaf_pairs": last["leaf_pairs"], "join_pairs": last["join_pairs"],
-                       "join_rows": last["join_rows"], "proposals": last["proposals"], "updates": last["updates"]},
+            "counts": {"leaves": last["n_leaves"], "tree_levels": last["tree_levels"], "leaf_pairs": last["leaf_pairs"],
+                       "join_pairs": last["join_pairs"], "join_rows": last["join_rows"], "proposals": last["proposals"],
+                       "updates": last["updates"]},
+            "exchanged_records_rank0": None if info is None else info["exchanged_records"],
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(result))
         sys.stdout.flush()
-    builder.close()
+    if sb is not None:
+        sb.close()
+    else:
+        builder.close()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

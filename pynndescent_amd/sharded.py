@@ -63,6 +63,8 @@ class TorchDistComm:
 
     def all_gather_v(self, t):
         """Gather 1-D/2-D tensors whose first dimension may differ per rank."""
+        if self._host_staged() and t.is_cuda:
+            return [g.to(t.device) for g in self.all_gather_v(t.cpu())]
         n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
         sizes = [torch.zeros_like(n) for _ in range(self.world)]
         self.dist.all_gather(sizes, n, group=self.group)
@@ -78,6 +80,9 @@ class TorchDistComm:
 
     def all_to_all_v(self, send):
         """send[s] goes to rank s (first-dimension sizes arbitrary); returns the list received."""
+        if self._host_staged() and send[0].is_cuda:
+            dev0 = send[0].device
+            return [g.to(dev0) for g in self.all_to_all_v([t.cpu() for t in send])]
         dev = send[0].device
         counts = torch.tensor([t.shape[0] for t in send], dtype=torch.int64, device=dev)
         rcounts = torch.empty_like(counts)
@@ -108,6 +113,10 @@ class TorchDistComm:
 
     def _dev(self):
         return torch.device("cuda", torch.cuda.current_device()) if self.dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+
+    def _host_staged(self):
+        """gloo moves host memory: device tensors are staged through the CPU (tests / debugging only)."""
+        return self.dist.get_backend(self.group) == "gloo"
 
     def barrier(self):
         self.dist.barrier(group=self.group)
@@ -160,60 +169,77 @@ def _sync():
         torch.cuda.current_stream().synchronize()
 
 
-def sharded_build(comm, x_local, metric="euclidean", n_neighbors=15, n_trees=8, leaf_size=None, max_candidates=None,
-                  n_iters=None, delta=0.001, seed=0, max_rptree_depth=200, device_index=None, verbose=False):
-    """Build the rows of the global k-NN graph that this rank owns.
+class ShardedBuilder:
+    """Persistent state of one rank (HBM allocations survive across builds; bench.py times ``build``)."""
 
-    x_local: torch float32 (n_local, d) tensor on this rank's GPU (its shard of the point set).
-    Returns (idx int32 (n_local, k) with GLOBAL neighbour ids, alt-space dist float32 (n_local, k), info dict);
-    the tensors stay resident on the GPU."""
-    dev = x_local.device
-    if device_index is None:
-        device_index = dev.index if dev.index is not None else torch.cuda.current_device()
-    rank, world = comm.rank, comm.world
-    k = int(n_neighbors)
+    def __init__(self, comm, shard_sizes, dim, metric="euclidean", n_neighbors=15, n_trees=8, leaf_size=None,
+                 max_candidates=None, n_iters=None, delta=0.001, seed=0, max_rptree_depth=200, device_index=None):
+        self.comm = comm
+        rank, world = comm.rank, comm.world
+        sizes = [int(v) for v in shard_sizes]
+        assert len(sizes) == world
+        self.n_total = sum(sizes)
+        bounds = np.concatenate([[0], np.cumsum(sizes)])
+        self.ranges = [(int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
+        self.lo, self.hi = self.ranges[rank]
+        self.k = int(n_neighbors)
+        self.d = int(dim)
+        self.delta = float(delta)
+        self.n_trees = int(n_trees)
+        # the reference's derived defaults, on the GLOBAL n (pynndescent_.py:1009-1012, 1135-1138; rp_trees.py:2845)
+        self.n_iters = max(5, int(round(np.log2(self.n_total)))) if n_iters is None else int(n_iters)
+        leaf_size = max(60, min(256, 5 * self.k)) if leaf_size is None else int(leaf_size)
+        mc = min(60, self.k) if max_candidates is None else int(max_candidates)
+        rs = np.random.RandomState(seed)  # identical draws on every rank
+        lim = np.iinfo(np.int32)
+        rng_state = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
+        _search = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
+        tree_states = rs.randint(lim.min + 1, lim.max - 1, size=(max(self.n_trees, 1), 3)).astype(np.int64)
+        t0, t1 = tree_ranges(self.n_trees, world)[rank]
+        self.local_trees = t1 - t0
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        self.dev = torch.device("cuda", device_index)
+        metric_code = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN,
+                       "cosine": _capi.NND_METRIC_ALT_COSINE}[metric]
+        self.b = _capi.Builder(self.n_total, self.d, metric_code, self.k, self.local_trees, leaf_size, max_rptree_depth, mc,
+                               self.n_iters, delta, rng_state, tree_states[min(t0, max(self.n_trees, 1) - 1)],
+                               device=device_index)
+        self.b.set_owned_range(self.lo, self.hi)
+        self.ks = self.b.row_stride()
+        dev, ks = self.dev, self.ks
+        self.own_e = torch.empty(((self.hi - self.lo) * ks,), dtype=torch.int32, device=dev)
+        self.own_d = torch.empty(((self.hi - self.lo) * ks,), dtype=torch.float32, device=dev)
+        self.cnt = torch.zeros((self.n_total,), dtype=torch.int32, device=dev)
+        self.offsets = torch.zeros((self.n_total + 1,), dtype=torch.int64, device=dev)
+        self.edge_index = torch.tensor([v for ab in self.ranges for v in ab], device=dev)
+        self.out_idx = torch.empty((self.hi - self.lo, self.k), dtype=torch.int32, device=dev)
+        self.out_dist = torch.empty((self.hi - self.lo, self.k), dtype=torch.float32, device=dev)
 
-    # ---- replicate the point set once (all-gather over xGMI): candidate vectors never travel again ----
-    shards = comm.all_gather_v(x_local.contiguous())
-    sizes = [int(t.shape[0]) for t in shards]
-    n_total = sum(sizes)
-    bounds = np.concatenate([[0], np.cumsum(sizes)])
-    ranges = [(int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
-    lo, hi = ranges[rank]
-    x_full = torch.cat(shards, dim=0).contiguous()
-    del shards
-    d = int(x_full.shape[1])
+    def close(self):
+        self.b.close()
 
-    # ---- the reference's derived defaults, on the GLOBAL n (pynndescent_.py:1009-1012, 1135-1138; rp_trees.py:2845) ----
-    if n_iters is None:
-        n_iters = max(5, int(round(np.log2(n_total))))
-    if leaf_size is None:
-        leaf_size = max(60, min(256, 5 * k))
-    mc = min(60, k) if max_candidates is None else int(max_candidates)
-    rs = np.random.RandomState(seed)  # identical draws on every rank
-    lim = np.iinfo(np.int32)
-    rng_state = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
-    _search = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
-    tree_states = rs.randint(lim.min + 1, lim.max - 1, size=(max(n_trees, 1), 3)).astype(np.int64)
-    t0, t1 = tree_ranges(n_trees, world)[rank]
-    local_trees = t1 - t0
-
-    metric_code = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN,
-                   "cosine": _capi.NND_METRIC_ALT_COSINE}[metric]
-    b = _capi.Builder(n_total, d, metric_code, k, local_trees, leaf_size, max_rptree_depth, mc, n_iters, delta, rng_state,
-                      tree_states[min(t0, max(n_trees, 1) - 1)], device=device_index)
-    info = {"n_total": n_total, "range": (lo, hi), "local_trees": local_trees, "iters": 0, "c": [], "exchanged_records": []}
-    try:
+    def build(self, x_local, verbose=False):
+        """One complete sharded build.  Returns (idx (n_local,k) GLOBAL ids, alt-space dist, info)."""
+        comm, b, dev, ks, k = self.comm, self.b, self.dev, self.ks, self.k
+        rank, world = comm.rank, comm.world
+        lo, hi, ranges, n_total = self.lo, self.hi, self.ranges, self.n_total
+        info = {"n_total": n_total, "range": (lo, hi), "local_trees": self.local_trees, "iters": 0, "c": [],
+                "exchanged_records": []}
+        # ---- replicate the point set once (all-gather over xGMI): candidate vectors never travel again ----
+        if world > 1:
+            x_full = torch.cat(comm.all_gather_v(x_local.contiguous()), dim=0).contiguous()
+        else:
+            x_full = x_local.contiguous()
+        assert x_full.shape == (n_total, self.d)
         _sync()
-        b.set_data_device(x_full.data_ptr(), keepalive=x_full)
-        b.set_owned_range(lo, hi)
-        ks = b.row_stride()
+        b.set_data_device(x_full.data_ptr(), keepalive=x_full)  # prep kernel + k-list reset
 
         # ---- forest split by tree: every rank seeds ALL rows from its own trees, owners merge the partial lists ----
-        if local_trees > 0:
+        if self.local_trees > 0:
             b.make_forest()
             b.init_from_leaves()
-        if n_trees > 0 and world > 1:
+        if self.n_trees > 0 and world > 1:
             send_e, send_d = [], []
             for (a, z) in ranges:
                 e = torch.empty(((z - a) * ks,), dtype=torch.int32, device=dev)
@@ -230,15 +256,12 @@ def sharded_build(comm, x_local, metric="euclidean", n_neighbors=15, n_trees=8, 
             del send_e, send_d, recv_e, recv_d
         b.init_random()  # owned rows that are still not full (pynndescent_.py:188-203)
 
-        own_e = torch.empty(((hi - lo) * ks,), dtype=torch.int32, device=dev)
-        own_d = torch.empty(((hi - lo) * ks,), dtype=torch.float32, device=dev)
-        cnt = torch.zeros((n_total,), dtype=torch.int32, device=dev)
-        for it in range(n_iters):
+        for it in range(self.n_iters):
             # (1) k-list all-gather: thresholds / neighbour ids / reverse edges of remote rows
             if world > 1:
-                b.export_graph_rows(lo, hi, own_e.data_ptr(), own_d.data_ptr())
-                all_e = comm.all_gather_v(own_e)
-                all_d = comm.all_gather_v(own_d)
+                b.export_graph_rows(lo, hi, self.own_e.data_ptr(), self.own_d.data_ptr())
+                all_e = comm.all_gather_v(self.own_e)
+                all_d = comm.all_gather_v(self.own_d)
                 _sync()
                 for src, (a, z) in enumerate(ranges):
                     if src != rank and z > a:
@@ -250,41 +273,54 @@ def sharded_build(comm, x_local, metric="euclidean", n_neighbors=15, n_trees=8, 
             # (3) proposals for vertices owned elsewhere -> (key, target) records -> owners
             n_sent = 0
             if world > 1:
-                b.proposal_counts(cnt.data_ptr())
-                offsets = torch.zeros((n_total + 1,), dtype=torch.int64, device=dev)
-                torch.cumsum(cnt, dim=0, out=offsets[1:])
-                edge = offsets[torch.tensor([v for ab in ranges for v in ab], device=dev)].tolist()
+                b.proposal_counts(self.cnt.data_ptr())
+                torch.cumsum(self.cnt, dim=0, out=self.offsets[1:])
+                edge = self.offsets[self.edge_index].tolist()
                 seg = [(int(edge[2 * r]), int(edge[2 * r + 1])) for r in range(world)]  # == segment_bounds(offsets, ranges)
-                total = int(offsets[-1].item())
+                total = int(edge[-1]) if ranges[-1][1] == n_total else int(self.offsets[-1].item())
                 keys = torch.empty((max(total, 1),), dtype=torch.int64, device=dev)
                 targets = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
                 _sync()
-                b.export_proposals(offsets.data_ptr(), keys.data_ptr(), targets.data_ptr())
-                send_k = [keys[a:z] for (a, z) in seg]
-                send_t = [targets[a:z] for (a, z) in seg]
-                recv_k = comm.all_to_all_v(send_k)
-                recv_t = comm.all_to_all_v(send_t)
-                rk = torch.cat([t for i, t in enumerate(recv_k) if i != rank]) if world > 1 else keys[:0]
-                rt = torch.cat([t for i, t in enumerate(recv_t) if i != rank]) if world > 1 else targets[:0]
+                b.export_proposals(self.offsets.data_ptr(), keys.data_ptr(), targets.data_ptr())
+                recv_k = comm.all_to_all_v([keys[a:z] for (a, z) in seg])
+                recv_t = comm.all_to_all_v([targets[a:z] for (a, z) in seg])
+                rk = torch.cat([t for i, t in enumerate(recv_k) if i != rank])
+                rt = torch.cat([t for i, t in enumerate(recv_t) if i != rank])
                 _sync()
                 if rk.numel():
                     b.import_proposals(rk.data_ptr(), rt.data_ptr(), rk.numel())
                 n_sent = total
             # (4) owner-side merge, (5) global update count for the stop rule (pynndescent_.py:317)
-            c = comm.all_reduce_sum(b.descent_merge())
+            c = comm.all_reduce_sum(b.descent_merge()) if world > 1 else b.descent_merge()
             info["c"].append(c)
             info["exchanged_records"].append(n_sent)
             info["iters"] = it + 1
             if verbose and rank == 0:
-                print("\t", it + 1, " / ", n_iters, " c =", c)
-            if c <= delta * k * n_total:
+                print("\t", it + 1, " / ", self.n_iters, " c =", c)
+            if c <= self.delta * k * n_total:
                 break
-        out_idx = torch.empty((hi - lo, k), dtype=torch.int32, device=dev)
-        out_dist = torch.empty((hi - lo, k), dtype=torch.float32, device=dev)
         _sync()
-        b.finalize_device(out_idx.data_ptr(), out_dist.data_ptr())
+        b.finalize_device(self.out_idx.data_ptr(), self.out_dist.data_ptr())
         b.synchronize()
         info["stats"] = b.stats()
+        return self.out_idx, self.out_dist, info
+
+
+def sharded_build(comm, x_local, metric="euclidean", n_neighbors=15, n_trees=8, leaf_size=None, max_candidates=None,
+                  n_iters=None, delta=0.001, seed=0, max_rptree_depth=200, device_index=None, verbose=False):
+    """Convenience wrapper: allocate, build the rows this rank owns, release.
+
+    x_local: torch float32 (n_local, d) tensor on this rank's GPU (its shard of the point set).
+    Returns (idx int32 (n_local, k) with GLOBAL neighbour ids, alt-space dist float32 (n_local, k), info dict);
+    the tensors stay resident on the GPU."""
+    n = torch.tensor([x_local.shape[0]], dtype=torch.int64, device=x_local.device)
+    sizes = [int(t.item()) for t in comm.all_gather_v(n)]
+    if device_index is None:
+        device_index = x_local.device.index if x_local.device.index is not None else torch.cuda.current_device()
+    sb = ShardedBuilder(comm, sizes, x_local.shape[1], metric, n_neighbors, n_trees, leaf_size, max_candidates, n_iters,
+                        delta, seed, max_rptree_depth, device_index)
+    try:
+        idx, dist, info = sb.build(x_local, verbose=verbose)
+        return idx.clone(), dist.clone(), info
     finally:
-        b.close()
-    return out_idx, out_dist, info
+        sb.close()
