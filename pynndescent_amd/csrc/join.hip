@@ -263,6 +263,229 @@ __global__ __launch_bounds__(256, 2) void k_local_join(const float *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// max_candidates <= 16 (k <= 16: the BASELINE / UMAP regime): one WAVE per vertex, no workgroup barrier at
+// all.  Each wave owns a private LDS region ([new | old] = 32 rows), runs its own software pipeline
+// (gather of its next vertex in registers while the current vertex is on the MFMA pipe / in the epilogue)
+// and strides over the vertices independently, so a slow epilogue or a late gather in one wave never
+// stalls the other three.
+template <int DC, int KS16>
+__global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
+                                                         int metric, const int32_t *__restrict__ cand, int64_t v_begin,
+                                                         int64_t v_end, int k, int ks, const uint32_t *__restrict__ knn_e,
+                                                         const float *__restrict__ knn_d, uint64_t *__restrict__ pbuf,
+                                                         uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed,
+                                                         long long *__restrict__ counters) {
+    constexpr int MCP = 16, RV = 32;          // rows per vertex: [new(16) | old(16)]
+    constexpr int NCH = DC / 4;               // 16-byte chunks per staged row
+    constexpr int NLD = RV * NCH / 64;        // row chunks per lane
+    constexpr int KQ = KS16 * 4;              // uint4 chunks per neighbour-list row
+    constexpr int KQL = RV * KQ / 64;         // of which per lane
+    constexpr int kls = KS16 * 16 + 4;        // padded neighbour-list row stride (words)
+    constexpr int WAVE_BYTES = RV * DC * 4 + 2 * RV * 4 + 2 * 4 + 3 * RV * 4 + RV * kls * 4 + 8;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
+    unsigned char *mine = smem + (size_t)w * ((WAVE_BYTES + 15) & ~15);
+    float *Xs = (float *)mine;                     // RV * DC floats
+    int32_t *cidbuf = (int32_t *)(Xs + RV * DC);   // 2 * RV
+    int32_t *nnewbuf = cidbuf + 2 * RV;            // 2
+    int32_t *cid = nnewbuf + 2;                    // RV
+    float *cnrm = (float *)(cid + RV);             // RV
+    float *cth = cnrm + RV;                        // RV
+    uint32_t *klist = (uint32_t *)(cth + RV);      // RV * kls
+    const int kq = ks >> 2;
+    const int cw0 = dp < DC ? dp : DC;
+    const int nch0 = cw0 >> 2;
+    const int64_t n_v = v_end - v_begin;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+
+    auto load_cand = [&](int64_t g) __attribute__((always_inline)) -> int {
+        const int row = lane < RV ? lane : 0;
+        const bool ok = lane < RV && g < n_v;
+        const int c = cand[ok ? (v_begin + g) * RV + row : 0];
+        return ok ? c : -1;
+    };
+    auto store_cand = [&](int buf, int c) __attribute__((always_inline)) {
+        const unsigned long long m = __ballot(c >= 0 && lane < MCP);  // lists are filled from the front
+        if (lane < RV) cidbuf[buf * RV + lane] = c;
+        if (lane == 0) nnewbuf[buf] = __popcll(m);
+    };
+    f32x4 rowv[NLD];
+    u32x4 klv[KQL];
+    float nx_nrm = 0.0f, nx_th = 0.0f;
+    int nx_id = -1;
+    auto issue_gather = [&](int buf) __attribute__((always_inline)) {
+        const int32_t *cb = cidbuf + buf * RV;
+        const bool on = nnewbuf[buf] > 0;
+#pragma clang loop unroll(full)
+        for (int i = 0; i < NLD; i++) {
+            const int idx = lane + i * 64;
+            int r, ch;
+            if (cw0 == DC) { r = idx / NCH; ch = idx % NCH; } else { r = idx / nch0; ch = idx - r * nch0; }
+            const int rr = r < RV ? r : 0;
+            const int id = on ? cb[rr] : -1;
+            rowv[i] = *(const f32x4 *)(xp + (int64_t)(id >= 0 ? id : 0) * dp + 4 * ch);  // empty slot: row 0 (L2 hit), masked later
+        }
+        {
+            const int row = lane < RV ? lane : 0;
+            nx_id = (lane < RV && on) ? cb[row] : -1;
+            const int64_t ide = nx_id >= 0 ? nx_id : 0;
+            nx_nrm = nrm[ide];
+            nx_th = knn_d[ide * ks + (k - 1)];
+        }
+#pragma clang loop unroll(full)
+        for (int i = 0; i < KQL; i++) {
+            const int idx = lane + i * 64;
+            const int r = idx / KQ, c = idx % KQ;
+            const int id = on ? cb[r] : -1;
+            const bool ok = c < kq && id >= 0;
+            klv[i] = *(const u32x4 *)(knn_e + (ok ? (int64_t)id * ks + 4 * c : 0));  // raw; masked when it lands
+        }
+    };
+    auto land_gather = [&](int buf) __attribute__((always_inline)) {
+        const int32_t *cb = cidbuf + buf * RV;
+#pragma clang loop unroll(full)
+        for (int i = 0; i < NLD; i++) {
+            const int idx = lane + i * 64;
+            int r, ch;
+            if (cw0 == DC) { r = idx / NCH; ch = idx % NCH; } else { r = idx / nch0; ch = idx - r * nch0; }
+            if (r < RV) *(f32x4 *)&Xs[nnd_swz<DC>(r, ch)] = rowv[i];
+        }
+        if (lane < RV) {
+            cid[lane] = nx_id;
+            cnrm[lane] = nx_nrm;
+            cth[lane] = nx_th;
+        }
+#pragma clang loop unroll(full)
+        for (int i = 0; i < KQL; i++) {
+            const int idx = lane + i * 64;
+            const int r = idx / KQ, c = idx % KQ;
+            const bool ok = c < kq && cb[r] >= 0;  // padding beyond k is EMPTY already
+            const u32x4 empty = {NND_IDX_MASK, NND_IDX_MASK, NND_IDX_MASK, NND_IDX_MASK};
+            *(u32x4 *)(klist + r * kls + 4 * c) = ok ? (klv[i] & NND_IDX_MASK) : empty;
+        }
+    };
+
+    int64_t g = (int64_t)blockIdx.x * 4 + w;
+    store_cand(0, load_cand(g));
+    store_cand(1, load_cand(g + stride));
+    nnd_wave_lds_sync();
+    issue_gather(0);
+
+    int tot_pairs = 0, tot_prop = 0, tot_rows = 0, tot_act = 0;
+    const int r16 = lane & 15, gq = lane >> 4;
+    for (int it = 0; g < n_v; g += stride, it++) {
+        const int cur = it & 1;
+        const int my_new = nnewbuf[cur];
+        if (my_new > 0) land_gather(cur);
+        nnd_wave_lds_sync();
+        if (g + stride < n_v) issue_gather(cur ^ 1);
+        const int c2 = load_cand(g + 2 * stride);
+        if (my_new > 0) {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            for (int c0 = 0; c0 < dp; c0 += DC) {
+                const int cw = (dp - c0) < DC ? (dp - c0) : DC;
+                if (c0 > 0) {  // rows wider than one LDS chunk: remaining chunks staged synchronously by this wave
+                    nnd_wave_lds_sync();
+                    nnd_stage_rows<DC>(xp, dp, cid, RV, c0, cw, Xs, lane, 64);
+                    nnd_wave_lds_sync();
+                }
+                nnd_gram_chunk<DC, 2>(Xs, 0, 0, cw, acc, [](int) { return true; });
+            }
+#pragma unroll
+            for (int J = 0; J < 2; J++) {
+                const int jj = J * 16 + r16;  // index inside [new | old]
+                const int qid = cid[jj];
+                const float qn = cnrm[jj], qth = cth[jj];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = 4 * gq + r;  // index inside new
+                    const int pid = cid[i];
+                    const bool valid = pid >= 0 && qid >= 0 && (jj >= MCP || jj >= i);
+                    if (!valid) continue;
+                    tot_pairs++;
+                    const bool self = (pid == qid);
+                    const float d = self ? 0.0f : nnd_gram_to_dist(metric, acc[J][r], cnrm[i], qn);
+                    const bool need_p = d < cth[i], need_q = !self && d < qth;
+                    if (!(need_p | need_q)) continue;
+                    const bool in_p = klist_has<KS16>(klist + i * kls, (uint32_t)qid);
+                    const bool in_q = klist_has<KS16>(klist + jj * kls, (uint32_t)pid);
+                    if (need_p && !in_p) {  // p <- q
+                        const uint32_t sl = nnd_hash2(slot_seed, (uint32_t)qid) & (uint32_t)(pcap - 1);
+                        atomicMin((unsigned long long *)&pbuf[(int64_t)pid * pcap + sl],
+                                  (unsigned long long)nnd_make_key(d, (uint32_t)qid));
+                        pdirty[pid] = 1;
+                        tot_prop++;
+                    }
+                    if (need_q && !in_q) {  // q <- p
+                        const uint32_t sl = nnd_hash2(slot_seed, (uint32_t)pid) & (uint32_t)(pcap - 1);
+                        atomicMin((unsigned long long *)&pbuf[(int64_t)qid * pcap + sl],
+                                  (unsigned long long)nnd_make_key(d, (uint32_t)pid));
+                        pdirty[qid] = 1;
+                        tot_prop++;
+                    }
+                }
+            }
+            if (lane < RV) tot_rows += cid[lane] >= 0;
+            if (lane == 0) tot_act += 1;
+        }
+        nnd_wave_lds_sync();
+        store_cand(cur, c2);
+    }
+    // ---- statistics: one atomic per workgroup per counter (striped) ----
+    tot_pairs = nnd_wave_sum_i32(tot_pairs);
+    tot_prop = nnd_wave_sum_i32(tot_prop);
+    tot_rows = nnd_wave_sum_i32(tot_rows);
+    tot_act = nnd_wave_sum_i32(tot_act);
+    __syncthreads();
+    int *red = (int *)smem;  // every wave is done with its region
+    if (lane == 0) {
+        red[w * 4 + 0] = tot_pairs; red[w * 4 + 1] = tot_prop; red[w * 4 + 2] = tot_rows; red[w * 4 + 3] = tot_act;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const long long sum = (long long)red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
+        const int which = tid == 0 ? CNT_PAIRS : (tid == 1 ? CNT_PROPOSALS : (tid == 2 ? CNT_ROWS : CNT_ACTIVE));
+        nnd_count(counters, which, sum);
+    }
+}
+
+template <int DC, int KS16>
+static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
+    constexpr int RV = 32, kls = KS16 * 16 + 4;
+    constexpr int WAVE_BYTES = RV * DC * 4 + 2 * RV * 4 + 2 * 4 + 3 * RV * 4 + RV * kls * 4 + 8;
+    size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
+    auto kern = k_local_join16<DC, KS16>;
+    static int wg_per_cu = 0, n_cu = 0;
+    if (wg_per_cu == 0) {
+        NND_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipDeviceProp_t prop;
+        NND_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->p.device));
+        n_cu = prop.multiProcessorCount;
+        int occ = 0;
+        NND_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, 256, smem));
+        wg_per_cu = occ < 1 ? 1 : occ;
+    }
+    int64_t nv = v_end - v_begin;
+    int64_t groups = (nv + 3) / 4;
+    int64_t resident = (int64_t)n_cu * wg_per_cu;
+    unsigned grid = (unsigned)(groups < resident ? groups : resident);
+    uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
+                       v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed,
+                       ctx->counters);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int DC>
+static int launch_join16_ks(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
+    if (ctx->ks <= 16) return launch_join16_t<DC, 1>(ctx, v_begin, v_end);
+    if (ctx->ks <= 32) return launch_join16_t<DC, 2>(ctx, v_begin, v_end);
+    return launch_join16_t<DC, 4>(ctx, v_begin, v_end);
+}
+
 template <int MCP, int DC, int KS16>
 static int launch_join_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     constexpr int VPW = 64 / MCP;
@@ -304,7 +527,7 @@ int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     if (v_end <= v_begin) return 0;
     const bool wide = ctx->dp >= 128;
     switch (ctx->mcp) {
-        case 16: return wide ? launch_join_ks<16, 128>(ctx, v_begin, v_end) : launch_join_ks<16, 32>(ctx, v_begin, v_end);
+        case 16: return wide ? launch_join16_ks<128>(ctx, v_begin, v_end) : launch_join16_ks<32>(ctx, v_begin, v_end);
         case 32: return wide ? launch_join_ks<32, 128>(ctx, v_begin, v_end) : launch_join_ks<32, 32>(ctx, v_begin, v_end);
         case 64: return wide ? launch_join_ks<64, 128>(ctx, v_begin, v_end) : launch_join_ks<64, 32>(ctx, v_begin, v_end);
     }
