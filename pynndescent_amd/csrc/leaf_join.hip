@@ -22,11 +22,14 @@ template <int NT, int NW, int DC>
 struct leaf_cfg {
     static constexpr int MP = NT * 16;                      // max leaf rows
     static constexpr int TR = (NT + NW - 1) / NW;           // tile rows per wave
-    static constexpr int DSTRIDE = MP + 1;                  // row stride of the per-wave distance block
+    static constexpr int DSTRIDE = MP + 1;                  // row stride of the distance block
     static constexpr int XS_FLOATS = MP * DC;
-    static constexpr int DB_FLOATS = NW * 16 * DSTRIDE;
-    static constexpr bool PREFETCH = NT < 16;                // k-list prefetch buffers sit next to the distance blocks
-    static constexpr int PRE_FLOATS = PREFETCH ? NW * 16 * 16 * 2 : 0;  // budgeted for k <= 16; larger k uses what Xs leaves free
+    // NT <= 6: the whole leaf x leaf distance block lives in LDS and its rows are dealt round-robin to ALL waves
+    // (balanced merges); larger leaves: each wave keeps only the 16 rows of the tile row it is working on.
+    static constexpr bool FULLD = NT <= 6;
+    static constexpr int DB_FLOATS = FULLD ? MP * DSTRIDE : NW * 16 * DSTRIDE;
+    static constexpr bool PREFETCH = FULLD;                  // k-list prefetch buffers sit next to the distance block
+    static constexpr int PRE_FLOATS = PREFETCH ? MP * 16 * 2 : 0;  // budgeted for k <= 16; larger k uses what Xs leaves free
     static constexpr int EPI_FLOATS = DB_FLOATS + PRE_FLOATS;
     static constexpr int BIG_FLOATS = XS_FLOATS > EPI_FLOATS ? XS_FLOATS : EPI_FLOATS;  // Xs aliases the epilogue buffers
 };
@@ -78,56 +81,49 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
         __syncthreads();  // Xs is overwritten by the next chunk / by the distance blocks below
     }
 
-    // distances of this wave's tile rows -> per-wave LDS block, then merge each row into its point's k-list
-    float *Dw = big + w * 16 * C::DSTRIDE;
+    // distances -> LDS, then every row is merged into its point's k-list by one wave
     const int r16 = lane & 15, g = lane >> 4;
     int accepted = 0;
+    if constexpr (C::FULLD) {
+        float *Dm = big;  // MP x DSTRIDE; Xs is dead (barrier at the end of the K loop)
 #pragma unroll
-    for (int tr = 0; tr < C::TR; tr++) {
-        const int I = w + tr * NW;
-        if (I >= nt) continue;
+        for (int tr = 0; tr < C::TR; tr++) {
+            const int I = w + tr * NW;
+            if (I >= nt) continue;
 #pragma unroll
-        for (int J = 0; J < NT; J++) {
-            if (J < nt) {
-                const int j = J * 16 + r16;
-                const float nj = nrs[j];
+            for (int J = 0; J < NT; J++) {
+                if (J < nt) {
+                    const int j = J * 16 + r16;
+                    const float nj = nrs[j];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int il = 4 * g + r;
-                    Dw[il * C::DSTRIDE + j] = nnd_gram_to_dist(metric, acc[tr][J][r], nrs[I * 16 + il], nj);
+                    for (int r = 0; r < 4; r++) {
+                        const int il = I * 16 + 4 * g + r;
+                        Dm[il * C::DSTRIDE + j] = nnd_gram_to_dist(metric, acc[tr][J][r], nrs[il], nj);
+                    }
                 }
             }
         }
-        // all 16 k-lists of this tile row in one memory round trip (they are owned by this workgroup)
-        const bool use_pre = C::PREFETCH && (NW * 16 * ks * 2 <= C::BIG_FLOATS - C::DB_FLOATS);
-        uint32_t *pre_e = (uint32_t *)(big + C::DB_FLOATS) + w * 16 * ks;
-        float *pre_d = big + C::DB_FLOATS + NW * 16 * ks + w * 16 * ks;
+        // the k-lists of all m points in one memory round trip (this workgroup owns them for this tree)
+        const bool use_pre = (m * ks * 2 <= C::BIG_FLOATS - C::DB_FLOATS);
+        uint32_t *pre_e = (uint32_t *)(big + C::DB_FLOATS);
+        float *pre_d = big + C::DB_FLOATS + m * ks;
         if (use_pre) {
-            for (int idx = lane; idx < 16 * k; idx += 64) {
-                const int il = idx / k, j = idx - il * k;
-                const int i = I * 16 + il;
-                uint32_t ee = NND_EMPTY_E;
-                float dd = INFINITY;
-                if (i < m) {
-                    ee = knn_e[(int64_t)ids[i] * ks + j];
-                    dd = knn_d[(int64_t)ids[i] * ks + j];
-                }
-                pre_e[il * ks + j] = ee;
-                pre_d[il * ks + j] = dd;
+            for (int idx = tid; idx < m * k; idx += NW * 64) {
+                const int i = idx / k, j = idx - i * k;
+                pre_e[i * ks + j] = knn_e[(int64_t)ids[i] * ks + j];
+                pre_d[i * ks + j] = knn_d[(int64_t)ids[i] * ks + j];
             }
         }
-        nnd_wave_lds_sync();
-        for (int il = 0; il < 16; il++) {
-            const int i = I * 16 + il;
-            if (i >= m) break;
-            const float *Drow = Dw + il * C::DSTRIDE;
+        __syncthreads();
+        for (int i = w; i < m; i += NW) {  // rows dealt round-robin: every wave gets ~m/NW merges
+            const float *Drow = Dm + i * C::DSTRIDE;
             const int64_t v = ids[i];
             uint32_t e0 = NND_EMPTY_E;
             float d0 = INFINITY;
             if (lane < k) {
                 if (use_pre) {
-                    e0 = pre_e[il * ks + lane];
-                    d0 = pre_d[il * ks + lane];
+                    e0 = pre_e[i * ks + lane];
+                    d0 = pre_d[i * ks + lane];
                 } else {
                     e0 = knn_e[v * ks + lane];
                     d0 = knn_d[v * ks + lane];
@@ -140,7 +136,39 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
                                                                  return c != i;  // pynndescent_.py:97: p != q
                                                              });
         }
-        nnd_wave_lds_sync();
+    } else {
+        float *Dw = big + w * 16 * C::DSTRIDE;
+#pragma unroll
+        for (int tr = 0; tr < C::TR; tr++) {
+            const int I = w + tr * NW;
+            if (I >= nt) continue;
+#pragma unroll
+            for (int J = 0; J < NT; J++) {
+                if (J < nt) {
+                    const int j = J * 16 + r16;
+                    const float nj = nrs[j];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int il = 4 * g + r;
+                        Dw[il * C::DSTRIDE + j] = nnd_gram_to_dist(metric, acc[tr][J][r], nrs[I * 16 + il], nj);
+                    }
+                }
+            }
+            nnd_wave_lds_sync();
+            for (int il = 0; il < 16; il++) {
+                const int i = I * 16 + il;
+                if (i >= m) break;
+                const float *Drow = Dw + il * C::DSTRIDE;
+                const int64_t v = ids[i];
+                accepted += nnd_merge_row<(C::MP + 63) / 64>(v, k, ks, knn_e, knn_d, m,
+                                                            [&](int c, uint32_t &id, float &dc) {
+                                                                id = (uint32_t)ids[c];
+                                                                dc = Drow[c];
+                                                                return c != i;  // pynndescent_.py:97: p != q
+                                                            });
+            }
+            nnd_wave_lds_sync();
+        }
     }
     __syncthreads();
     int *wacc = (int *)nrs;  // nrs is dead
