@@ -120,7 +120,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
             if ((rc = dalloc(ctx, &ctx->scan_out, P + 1))) break;
             if ((rc = dalloc(ctx, &ctx->scan_blk, P / 2048 + 2))) break;
             if ((rc = dalloc(ctx, &ctx->seg_nleft, S))) break;
-            if ((rc = dalloc(ctx, &ctx->seg_child, 2 * S))) break;
+            if ((rc = dalloc(ctx, &ctx->seg_child, 5 * S))) break;  // child ids (2S) + finisher work list (3S)
             if ((rc = dalloc(ctx, &ctx->hyper, S * (size_t)(ctx->dp + 4)))) break;
         }
     } while (0);

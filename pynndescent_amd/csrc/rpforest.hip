@@ -256,31 +256,43 @@ __global__ void k_seg_count(const int32_t *__restrict__ seg_start, const int32_t
 // single block: children of every segment -> next level's segment list (compacted), child ids, leaf marks
 __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_len,
                                                   const int32_t *__restrict__ nleft, int n_segs, int leaf_size,
-                                                  int child_can_split, int32_t *__restrict__ next_start,
-                                                  int32_t *__restrict__ next_len, int32_t *__restrict__ seg_child,
-                                                  uint8_t *__restrict__ leaf_flag, long long *__restrict__ counters) {
-    __shared__ int part[256];
+                                                  int child_can_split, int fin_max, int child_depth,
+                                                  int32_t *__restrict__ next_start, int32_t *__restrict__ next_len,
+                                                  int32_t *__restrict__ seg_child, uint8_t *__restrict__ leaf_flag,
+                                                  int32_t *__restrict__ fin_start, int32_t *__restrict__ fin_len,
+                                                  int32_t *__restrict__ fin_depth, long long *__restrict__ counters) {
+    // a child that splits again either stays in the level-synchronous passes (len > fin_max) or is handed to
+    // k_finish_subtrees (len <= fin_max: its whole subtree fits in one workgroup's LDS)
+    __shared__ int part[256], partf[256];
     int chunk = (n_segs + 255) / 256;
     int s0 = threadIdx.x * chunk, s1 = s0 + chunk < n_segs ? s0 + chunk : n_segs;
-    int cnt = 0;
+    int cnt = 0, cntf = 0;
     for (int s = s0; s < s1; s++) {
         int len = seg_len[s], nl = nleft[s];
         if (nl < 0) nl = -nl - 1;
-        cnt += (child_can_split && nl > leaf_size) + (child_can_split && (len - nl) > leaf_size);
+        int lens[2] = {nl, len - nl};
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (child_can_split && lens[c] > leaf_size) {
+                if (lens[c] > fin_max) cnt++; else cntf++;
+            }
+        }
     }
     part[threadIdx.x] = cnt;
+    partf[threadIdx.x] = cntf;
     __syncthreads();
     if (threadIdx.x == 0) {
-        int run = 0;
+        int run = 0, runf = (int)counters[CNT_SCRATCH + 1];  // finisher list grows across levels
         for (int i = 0; i < 256; i++) {
-            int v = part[i];
-            part[i] = run;
-            run += v;
+            int v = part[i]; part[i] = run; run += v;
+            int vf = partf[i]; partf[i] = runf; runf += vf;
         }
         counters[CNT_ACTIVE_SEGS] = run;
+        counters[CNT_SCRATCH + 1] = runf;
     }
     __syncthreads();
-    int run = part[threadIdx.x];
+    int run = part[threadIdx.x], runf = partf[threadIdx.x];
+    long long active_pos = 0;
     for (int s = s0; s < s1; s++) {
         int a = seg_start[s], len = seg_len[s], nl = nleft[s];
         if (nl < 0) nl = -nl - 1;
@@ -289,15 +301,25 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             if (child_can_split && lens[c] > leaf_size) {  // rp_trees.py:2188
-                next_start[run] = starts[c];
-                next_len[run] = lens[c];
-                seg_child[2 * s + c] = run++;
+                if (lens[c] > fin_max) {
+                    next_start[run] = starts[c];
+                    next_len[run] = lens[c];
+                    seg_child[2 * s + c] = run++;
+                    active_pos += lens[c];
+                } else {
+                    fin_start[runf] = starts[c];
+                    fin_len[runf] = lens[c];
+                    fin_depth[runf] = child_depth;
+                    runf++;
+                    seg_child[2 * s + c] = -1;  // leaves the level-synchronous passes
+                }
             } else {
                 seg_child[2 * s + c] = -1;
                 if (lens[c] > 0) leaf_flag[starts[c]] = 1;  // rp_trees.py:2229-2232
             }
         }
     }
+    if (active_pos) atomicAdd((unsigned long long *)&counters[CNT_LEAVES], (unsigned long long)active_pos);  // positions still in the passes
 }
 
 // stable partition (rp_trees.py:405-418): lefts keep their order at the front, rights behind them
@@ -332,6 +354,146 @@ __global__ void k_scatter(const int32_t *__restrict__ perm, const int32_t *__res
     perm_out[dest] = p;
     pos_seg_out[dest] = seg_child[2 * s + right];
     if (inv) inv[(g / n) * n + p] = (int32_t)dest;
+}
+
+// ------------------------------------------------------------ subtree finisher --
+// Once every splittable segment fits in LDS (<= FIN_MAX points) the level-synchronous passes stop and one
+// workgroup per segment finishes its whole subtree on its own: explicit stack of sub-segments, hyperplane and
+// member ids in LDS, margins by 16-lane groups, stable partition by a block-wide scan.  No global
+// synchronisation, no per-level launches; deep unbalanced branches only cost their own workgroup.
+// Same split rule, same hashes (position- and depth-keyed) as the level-synchronous kernels above.
+static constexpr int FIN_MAX = 4096;     // points per finisher segment
+static constexpr int FIN_STACK = 512;    // sub-segments pending (depth budget is 200: a DFS needs <= depth+1 entries)
+
+__global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict__ xp, int dp, int32_t *__restrict__ perm,
+                                                         const int32_t *__restrict__ seg_start,
+                                                         const int32_t *__restrict__ seg_len,
+                                                         const int32_t *__restrict__ seg_depth, int n_segs, int angular,
+                                                         uint32_t seed, int max_depth, int leaf_size,
+                                                         uint8_t *__restrict__ leaf_flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    int32_t *ids = (int32_t *)fsm;                 // FIN_MAX
+    int32_t *tmp = ids + FIN_MAX;                  // FIN_MAX (partition scratch)
+    uint8_t *sd = (uint8_t *)(tmp + FIN_MAX);      // FIN_MAX side bits
+    float *h = (float *)(sd + FIN_MAX);            // dp + 4 hyperplane + offset
+    int32_t *stk = (int32_t *)(h + dp + 4);        // FIN_STACK * 3: (start, len, depth)
+    int32_t *wsum = stk + FIN_STACK * 3;           // 8: per-wave partial sums / scalars
+    const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
+    const int s = blockIdx.x;
+    if (s >= n_segs) return;
+    const int a = seg_start[s], len = seg_len[s];
+    for (int i = tid; i < len; i += 256) ids[i] = perm[a + i];
+    if (tid == 0) {
+        stk[0] = 0; stk[1] = len; stk[2] = seg_depth[s];
+        wsum[7] = 1;  // stack size
+    }
+    __syncthreads();
+    while (true) {
+        const int sp = wsum[7];
+        if (sp == 0) break;
+        const int ss = stk[(sp - 1) * 3], l = stk[(sp - 1) * 3 + 1], dep = stk[(sp - 1) * 3 + 2];
+        __syncthreads();
+        if (tid == 0) wsum[7] = sp - 1;
+        if (!(l > leaf_size && (max_depth - dep) > 0)) {  // rp_trees.py:2188: this node is a leaf
+            if (tid == 0 && l > 0) leaf_flag[a + ss] = 1;
+            __syncthreads();
+            continue;
+        }
+        // two random members -> hyperplane (rp_trees.py:350-367 / 87-118); hashes keyed like k_hyperplane
+        const uint32_t gpos = (uint32_t)(a + ss);
+        uint32_t li = nnd_hash3(seed, gpos, (uint32_t)(2 * dep)) % (uint32_t)l;
+        uint32_t ri = nnd_hash3(seed, gpos, (uint32_t)(2 * dep + 1)) % (uint32_t)l;
+        if (ri == li) ri = (ri + 1) % (uint32_t)l;
+        const float *xl = xp + (int64_t)ids[ss + li] * dp;
+        const float *xr = xp + (int64_t)ids[ss + ri] * dp;
+        float part = 0.0f;
+        for (int j = tid; j < dp; j += 256) {
+            const float lv = xl[j], rv = xr[j];
+            const float v = lv - rv;
+            h[j] = v;
+            part += angular ? v * v : v * (lv + rv);
+        }
+        part = nnd_wave_sum_f32(part);
+        if (lane == 0) ((float *)wsum)[w] = part;
+        __syncthreads();
+        const float tot = ((float *)wsum)[0] + ((float *)wsum)[1] + ((float *)wsum)[2] + ((float *)wsum)[3];
+        float off = 0.0f, scale = 1.0f;
+        if (angular) {
+            const float nh = sqrtf(tot);
+            scale = nh < RP_EPS ? 1.0f : 1.0f / nh;
+        } else {
+            off = -0.5f * tot;
+        }
+        __syncthreads();
+        // margins: 16 lanes per member, 4 members per group per pass so that 4 row gathers are in flight per lane
+        const int sub = tid & 15, grp = tid >> 4;
+        for (int i0 = 0; i0 < l; i0 += 64) {
+            float acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * 16 + grp;
+                acc[u] = 0.0f;
+                if (i < l) {
+                    const float4 *x4 = (const float4 *)(xp + (int64_t)ids[ss + i] * dp);
+                    const float4 *h4 = (const float4 *)h;
+                    for (int c = sub; c < (dp >> 2); c += 16) {
+                        const float4 p = x4[c], q = h4[c];
+                        acc[u] += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * 16 + grp;
+                const float a4 = nnd_group16_sum_f32(acc[u]);
+                if (i < l && sub == 0) {
+                    const float m = a4 * scale + off;
+                    uint8_t side;
+                    if (fabsf(m) < RP_EPS) side = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, gpos + (uint32_t)i, (uint32_t)dep) & 1u);
+                    else side = m > 0.0f ? 0 : 1;
+                    sd[i] = side;
+                }
+            }
+        }
+        __syncthreads();
+        // stable partition: block-wide exclusive scan of "left" over l <= FIN_MAX members (16 per thread)
+        const int per = (l + 255) / 256;
+        const int b0 = tid * per, b1 = b0 + per < l ? b0 + per : l;
+        int cntl = 0;
+        for (int i = b0; i < b1; i++) cntl += sd[i] == 0;
+        int incl = cntl;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int i = 0; i < w; i++) woff += wsum[i];
+        int nl = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const bool one_sided = (nl == 0 || nl == l);  // rp_trees.py:393-403 -> even split by offset parity
+        if (one_sided) nl = (l + 1) / 2;
+        int run = woff + incl - cntl;
+        for (int i = b0; i < b1; i++) {
+            int dest;
+            if (one_sided) dest = (i & 1) ? nl + (i >> 1) : (i >> 1);
+            else if (sd[i] == 0) dest = run++;
+            else dest = nl + (i - run);
+            tmp[dest] = ids[ss + i];
+        }
+        __syncthreads();
+        for (int i = tid; i < l; i += 256) ids[ss + i] = tmp[i];
+        if (tid == 0) {  // right child first so that the left one is processed next (order is immaterial)
+            int top = wsum[7];
+            stk[top * 3] = ss + nl; stk[top * 3 + 1] = l - nl; stk[top * 3 + 2] = dep + 1;
+            top++;
+            stk[top * 3] = ss; stk[top * 3 + 1] = nl; stk[top * 3 + 2] = dep + 1;
+            wsum[7] = top + 1;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < len; i += 256) perm[a + i] = ids[i];
 }
 
 // ------------------------------------------------------------ leaf tables --
@@ -397,6 +559,25 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     int64_t S = splittable ? T : 0;
     int depth = 0;
     bool inv_live = true;  // inv[] is maintained while the point-major margin kernel is in use
+    long long active_pos = P;
+    const int fin_max = FIN_MAX;
+    const size_t fin_smem = sizeof(int32_t) * 2 * FIN_MAX + FIN_MAX + sizeof(float) * (dp + 4) +
+                            sizeof(int32_t) * (FIN_STACK * 3 + 8);
+    int32_t *fin_start = ctx->seg_child + 2 * ctx->max_segs;  // finisher work list lives behind seg_child
+    int32_t *fin_len = fin_start + ctx->max_segs;
+    int32_t *fin_depth = fin_len + ctx->max_segs;
+    NND_HIP_CHECK(hipMemsetAsync(ctx->counters + CNT_SCRATCH + 1, 0, sizeof(long long), ctx->stream));
+    if (S > 0 && n <= fin_max) {  // small point sets: the roots go straight to the finisher
+        std::vector<int32_t> hs(T), hl(T), hd(T, 0);
+        for (int t = 0; t < T; t++) { hs[t] = (int32_t)(t * n); hl[t] = (int32_t)n; }
+        NND_HIP_CHECK(hipMemcpyAsync(fin_start, hs.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
+        NND_HIP_CHECK(hipMemcpyAsync(fin_len, hl.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
+        NND_HIP_CHECK(hipMemcpyAsync(fin_depth, hd.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
+        long long cntf = T;
+        NND_HIP_CHECK(hipMemcpyAsync(ctx->counters + CNT_SCRATCH + 1, &cntf, sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+        NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        S = 0;
+    }
     while (S > 0) {
         if (S > ctx->max_segs) {
             ctx->set_error("rp-forest: %lld segments exceed the allocation of %lld", (long long)S, (long long)ctx->max_segs);
@@ -405,7 +586,9 @@ int nnd_launch_forest(nnd_ctx *ctx) {
         hipLaunchKernelGGL(k_hyperplane, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, dp,
                            ctx->perm[cur], ctx->seg_start[cur], ctx->seg_len[cur], (int)S, angular, ctx->tree_seed, depth,
                            ctx->hyper, hs);
-        const bool fused = inv_live && (S * (int64_t)hs * 4 <= (int64_t)6 << 20);  // hyperplane table fits in L2
+        // point-major pass: hyperplane table fits in L2 AND enough positions are still active to amortise
+        // streaming every row once (it costs n rows regardless of how many positions are active)
+        const bool fused = inv_live && (S * (int64_t)hs * 4 <= (int64_t)6 << 20) && (active_pos * 2 >= 3 * n);
         if (fused) {
             hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, dp, n, T,
                                ctx->inv, ctx->pos_seg[cur], ctx->hyper, hs, ctx->tree_seed, depth, ctx->side);
@@ -418,21 +601,46 @@ int nnd_launch_forest(nnd_ctx *ctx) {
         hipLaunchKernelGGL(k_seg_count, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, ctx->seg_start[cur],
                            ctx->seg_len[cur], (int)S, ctx->scan_out, scan_total, P, ctx->seg_nleft);
         int child_can_split = (max_depth - (depth + 1)) > 0 ? 1 : 0;
+        NND_HIP_CHECK(hipMemsetAsync(ctx->counters + CNT_LEAVES, 0, sizeof(long long), ctx->stream));
         hipLaunchKernelGGL(k_children, dim3(1), dim3(256), 0, ctx->stream, ctx->seg_start[cur], ctx->seg_len[cur],
-                           ctx->seg_nleft, (int)S, leaf_size, child_can_split, ctx->seg_start[1 - cur],
-                           ctx->seg_len[1 - cur], ctx->seg_child, ctx->leaf_flag, ctx->counters);
+                           ctx->seg_nleft, (int)S, leaf_size, child_can_split, fin_max, depth + 1, ctx->seg_start[1 - cur],
+                           ctx->seg_len[1 - cur], ctx->seg_child, ctx->leaf_flag, fin_start, fin_len, fin_depth, ctx->counters);
         hipLaunchKernelGGL(k_scatter, dim3(gridP), dim3(256), 0, ctx->stream, ctx->perm[cur], ctx->pos_seg[cur], ctx->side,
                            ctx->scan_out, ctx->seg_start[cur], ctx->seg_nleft, ctx->seg_child, P, n, ctx->perm[1 - cur],
                            ctx->pos_seg[1 - cur], inv_live ? ctx->inv : (int32_t *)nullptr);
         NND_HIP_CHECK(hipGetLastError());
-        // one small read-back per level: the number of segments that split again
-        long long next = 0;
-        NND_HIP_CHECK(hipMemcpyAsync(&next, ctx->counters + CNT_ACTIVE_SEGS, sizeof(long long), hipMemcpyDeviceToHost,
+        // one small read-back per level: the number of segments that stay in the level-synchronous passes
+        long long next[2] = {0, 0};  // CNT_ACTIVE_SEGS, CNT_LEAVES are adjacent
+        static_assert(CNT_LEAVES == CNT_ACTIVE_SEGS + 1, "counter layout");
+        NND_HIP_CHECK(hipMemcpyAsync(next, ctx->counters + CNT_ACTIVE_SEGS, 2 * sizeof(long long), hipMemcpyDeviceToHost,
                                      ctx->stream));
         NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        S = next;
+        S = next[0];
+        active_pos = next[1];
         cur = 1 - cur;
         depth++;
+    }
+    {  // subtrees that fit in LDS: one workgroup each, no more global passes
+        long long nfin = 0;
+        NND_HIP_CHECK(hipMemcpyAsync(&nfin, ctx->counters + CNT_SCRATCH + 1, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (nfin > ctx->max_segs) {
+            ctx->set_error("rp-forest: %lld finisher segments exceed the allocation of %lld", nfin, (long long)ctx->max_segs);
+            return 1;
+        }
+        if (nfin > 0) {
+            static bool configured = false;
+            if (!configured) {
+                NND_HIP_CHECK(hipFuncSetAttribute((const void *)k_finish_subtrees, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)fin_smem));
+                configured = true;
+            }
+            hipLaunchKernelGGL(k_finish_subtrees, dim3((unsigned)nfin), dim3(256), fin_smem, ctx->stream, ctx->xp, dp,
+                               ctx->perm[cur], fin_start, fin_len, fin_depth, (int)nfin, angular, ctx->tree_seed, max_depth,
+                               leaf_size, ctx->leaf_flag);
+            NND_HIP_CHECK(hipGetLastError());
+        }
+        ctx->stats.n_leaves = nfin;  // overwritten below; kept for debugging
     }
     ctx->cur = cur;
     ctx->stats.tree_levels = depth;
