@@ -40,7 +40,7 @@ static void free_all(nnd_ctx *ctx) {
         if (p) (void)hipFree(p);
     };
     if (ctx->x_owned) F((void *)ctx->x_orig);
-    F(ctx->xp); F(ctx->nrm); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->cand); F(ctx->rbuf); F(ctx->pbuf);
+    F(ctx->xp); F(ctx->nrm); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->cand); F(ctx->rbuf); F(ctx->pbuf);
     F(ctx->pdirty);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
@@ -96,6 +96,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
         if ((rc = dalloc(ctx, &ctx->mean, (size_t)ctx->dp))) break;
         if ((rc = dalloc(ctx, &ctx->knn_e, n * ctx->ks))) break;
         if ((rc = dalloc(ctx, &ctx->knn_d, n * ctx->ks))) break;
+        if ((rc = dalloc(ctx, &ctx->th, n))) break;
         if ((rc = dalloc(ctx, &ctx->cand, n * 2 * ctx->mcp))) break;
         if ((rc = dalloc(ctx, &ctx->rbuf, n * 2 * ctx->rcap))) break;
         if ((rc = dalloc(ctx, &ctx->pbuf, n * ctx->pcap))) break;
@@ -532,6 +533,7 @@ extern "C" int32_t nnd_import_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t h
     size_t cnt = (size_t)(hi - lo) * ctx->ks;
     API_HIP(hipMemcpyAsync(ctx->knn_e + lo * ctx->ks, e_src_dev, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
     API_HIP(hipMemcpyAsync(ctx->knn_d + lo * ctx->ks, d_src_dev, sizeof(float) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    if (nnd_launch_refresh_th(ctx, lo, hi)) return 1;
     API_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }

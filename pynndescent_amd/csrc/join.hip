@@ -47,7 +47,7 @@ template <int MCP, int DC, int KS16>
 __global__ __launch_bounds__(256, 2) void k_local_join(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
                                                     int metric, const int32_t *__restrict__ cand, int64_t v_begin,
                                                     int64_t v_end, int64_t n_groups, int k, int ks,
-                                                    const uint32_t *__restrict__ knn_e, const float *__restrict__ knn_d,
+                                                    const uint32_t *__restrict__ knn_e, const float *__restrict__ th,
                                                     uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
                                                     uint32_t slot_seed, long long *__restrict__ counters) {
     constexpr int NA = MCP / 16;      // A tile rows per vertex == waves per vertex
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_local_join(const float *__restrict__
             nx_id = (tid < ROWS && nb[row / RV] > 0) ? cb[row] : -1;
             const int64_t ide = nx_id >= 0 ? nx_id : 0;
             nx_nrm = nrm[ide];
-            nx_th = knn_d[ide * ks + (k - 1)];
+            nx_th = th[ide];  // compact per-row worst distance (L2 resident), not a 128-byte line per candidate
         }
 #pragma clang loop unroll(full)
         for (int i = 0; i < KQMAX; i++) {
@@ -273,7 +273,7 @@ template <int DC, int KS16>
 __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
                                                          int metric, const int32_t *__restrict__ cand, int64_t v_begin,
                                                          int64_t v_end, int k, int ks, const uint32_t *__restrict__ knn_e,
-                                                         const float *__restrict__ knn_d, uint64_t *__restrict__ pbuf,
+                                                         const float *__restrict__ th, uint64_t *__restrict__ pbuf,
                                                          uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed,
                                                          long long *__restrict__ counters) {
     constexpr int MCP = 16, RV = 32;          // rows per vertex: [new(16) | old(16)]
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
             nx_id = (lane < RV && on) ? cb[row] : -1;
             const int64_t ide = nx_id >= 0 ? nx_id : 0;
             nx_nrm = nrm[ide];
-            nx_th = knn_d[ide * ks + (k - 1)];
+            nx_th = th[ide];  // compact per-row worst distance (L2 resident), not a 128-byte line per candidate
         }
 #pragma clang loop unroll(full)
         for (int i = 0; i < KQL; i++) {
@@ -473,7 +473,7 @@ static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     unsigned grid = (unsigned)(groups < resident ? groups : resident);
     uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
-                       v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed,
+                       v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed,
                        ctx->counters);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
@@ -510,7 +510,7 @@ static int launch_join_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     unsigned grid = (unsigned)(n_groups < resident ? n_groups : resident);
     uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
-                       v_begin, v_end, n_groups, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->pbuf, ctx->pdirty, ctx->pcap,
+                       v_begin, v_end, n_groups, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty, ctx->pcap,
                        slot_seed, ctx->counters);
     NND_HIP_CHECK(hipGetLastError());
     return 0;

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
                                                        const int32_t *__restrict__ wl_start,
                                                        const int32_t *__restrict__ wl_len, int64_t leaf0,
                                                        int64_t n_leaves, int k, int ks, uint32_t *__restrict__ knn_e,
-                                                       float *__restrict__ knn_d, long long *__restrict__ counters) {
+                                                       float *__restrict__ knn_d, float *__restrict__ th,
+                                                       long long *__restrict__ counters) {
     using C = leaf_cfg<NT, NW, DC>;
     __shared__ __attribute__((aligned(16))) float big[C::BIG_FLOATS];
     __shared__ int32_t ids[C::MP];
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
                     d0 = knn_d[v * ks + lane];
                 }
             }
-            accepted += nnd_merge_row_regs<(C::MP + 63) / 64>(knn_e + v * ks, knn_d + v * ks, e0, d0, k, m,
+            accepted += nnd_merge_row_regs<(C::MP + 63) / 64>(knn_e + v * ks, knn_d + v * ks, th + v, e0, d0, k, m,
                                                              [&](int c, uint32_t &id, float &dc) {
                                                                  id = (uint32_t)ids[c];
                                                                  dc = Drow[c];
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
                 if (i >= m) break;
                 const float *Drow = Dw + il * C::DSTRIDE;
                 const int64_t v = ids[i];
-                accepted += nnd_merge_row<(C::MP + 63) / 64>(v, k, ks, knn_e, knn_d, m,
+                accepted += nnd_merge_row<(C::MP + 63) / 64>(v, k, ks, knn_e, knn_d, th, m,
                                                             [&](int c, uint32_t &id, float &dc) {
                                                                 id = (uint32_t)ids[c];
                                                                 dc = Drow[c];
@@ -229,7 +230,7 @@ int nnd_launch_leaf_init(nnd_ctx *ctx) {
         if (cnt <= 0) continue;
         dim3 grid((unsigned)cnt);
 #define LEAF_ARGS ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, perm, d_ws, d_wl, tb[t], tb[t + 1], ctx->k, ctx->ks, \
-                  ctx->knn_e, ctx->knn_d, ctx->counters
+                  ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters
         if (maxlen <= 64)
             hipLaunchKernelGGL((k_leaf_join<4, 4, 128>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 96)

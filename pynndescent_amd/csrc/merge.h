@@ -29,8 +29,9 @@ __device__ __forceinline__ uint64_t nnd_readlane_u64(uint64_t v, int src_lane) {
 // Returns the number of accepted candidates (same value on every lane).
 // Core: lane j < k already holds list entry j in (e, d) (lanes >= k hold EMPTY / +inf).
 template <int NCHUNK, typename CandFn>
-__device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, float *__restrict__ row_d, uint32_t e,
-                                                  float d, int k, int ncand, CandFn cand) {
+__device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, float *__restrict__ row_d,
+                                                  float *__restrict__ th_slot, uint32_t e, float d, int k, int ncand,
+                                                  CandFn cand) {
     const int lane = nnd_lane();
     const uint64_t mykey = (e == NND_EMPTY_E) ? NND_EMPTY_KEY : nnd_make_key(d, e);
     const uint32_t myidx = e & NND_IDX_MASK;  // 0x7FFFFFFF for empty slots: never a valid id
@@ -85,6 +86,7 @@ __device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, 
     if (lane < k && shift > 0 && lane + shift < k) {
         row_e[lane + shift] = e;
         row_d[lane + shift] = d;
+        if (lane + shift == k - 1) *th_slot = d;  // new worst distance of the row
     }
     int accepted = 0;
 #pragma unroll
@@ -92,6 +94,7 @@ __device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, 
         if (ckey[ch] != NND_EMPTY_KEY && rank[ch] < k) {
             row_e[rank[ch]] = nnd_key_idx(ckey[ch]) | NND_NEW_BIT;
             row_d[rank[ch]] = nnd_key_dist(ckey[ch]);
+            if (rank[ch] == k - 1) *th_slot = nnd_key_dist(ckey[ch]);
             accepted++;
         }
     }
@@ -101,7 +104,7 @@ __device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, 
 // Loader wrapper: fetches row v of the k-lists from global memory, then merges.
 template <int NCHUNK, typename CandFn>
 __device__ __forceinline__ int nnd_merge_row(int64_t v, int k, int ks, uint32_t *__restrict__ knn_e,
-                                             float *__restrict__ knn_d, int ncand, CandFn cand) {
+                                             float *__restrict__ knn_d, float *__restrict__ th, int ncand, CandFn cand) {
     const int lane = nnd_lane();
     uint32_t *row_e = knn_e + v * ks;
     float *row_d = knn_d + v * ks;
@@ -111,5 +114,5 @@ __device__ __forceinline__ int nnd_merge_row(int64_t v, int k, int ks, uint32_t 
         e = row_e[lane];
         d = row_d[lane];
     }
-    return nnd_merge_row_regs<NCHUNK>(row_e, row_d, e, d, k, ncand, cand);
+    return nnd_merge_row_regs<NCHUNK>(row_e, row_d, th + v, e, d, k, ncand, cand);
 }

@@ -15,14 +15,15 @@
 
 __global__ __launch_bounds__(256) void k_merge(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
                                                int64_t lo, int64_t n, int k, int ks, uint32_t *__restrict__ knn_e,
-                                               float *__restrict__ knn_d, long long *__restrict__ counters) {
+                                               float *__restrict__ knn_d, float *__restrict__ th,
+                                               long long *__restrict__ counters) {
     __shared__ int wacc[4];
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
     const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;  // [lo, n): the rows this handle owns
     int acc = 0;
     if (v < n && pdirty[v]) {
         uint64_t *slots = pbuf + v * pcap;
-        acc = nnd_merge_row<1>(v, k, ks, knn_e, knn_d, pcap, [&](int c, uint32_t &id, float &dc) {
+        acc = nnd_merge_row<1>(v, k, ks, knn_e, knn_d, th, pcap, [&](int c, uint32_t &id, float &dc) {
             uint64_t key = slots[c];
             id = nnd_key_idx(key);
             dc = nnd_key_dist(key);
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void k_merge(uint64_t *__restrict__ pbuf, uint
 
 int nnd_launch_merge(nnd_ctx *ctx) {
     hipLaunchKernelGGL(k_merge, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream, ctx->pbuf,
-                       ctx->pdirty, ctx->pcap, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->counters);
+                       ctx->pdirty, ctx->pcap, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -192,13 +193,13 @@ __global__ void k_import_proposals(const uint64_t *__restrict__ keys, const int3
 // used to combine the per-rank forests' leaf seeding at the owner
 __global__ __launch_bounds__(256) void k_merge_graph_rows(int64_t lo, int64_t hi, int k, int ks, const uint32_t *__restrict__ e_src,
                                                           const float *__restrict__ d_src, uint32_t *__restrict__ knn_e,
-                                                          float *__restrict__ knn_d) {
+                                                          float *__restrict__ knn_d, float *__restrict__ th) {
     const int w = threadIdx.x >> 6;
     const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;
     if (v >= hi) return;
     const uint32_t *es = e_src + (v - lo) * ks;
     const float *ds = d_src + (v - lo) * ks;
-    nnd_merge_row<1>(v, k, ks, knn_e, knn_d, k, [&](int c, uint32_t &id, float &dc) {
+    nnd_merge_row<1>(v, k, ks, knn_e, knn_d, th, k, [&](int c, uint32_t &id, float &dc) {
         const uint32_t e = es[c];
         id = e & NND_IDX_MASK;
         dc = ds[c];
@@ -230,7 +231,20 @@ int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_
 int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src) {
     if (hi <= lo) return 0;
     hipLaunchKernelGGL(k_merge_graph_rows, dim3((unsigned)((hi - lo + 3) / 4)), dim3(256), 0, ctx->stream, lo, hi, ctx->k, ctx->ks,
-                       e_src, d_src, ctx->knn_e, ctx->knn_d);
+                       e_src, d_src, ctx->knn_e, ctx->knn_d, ctx->th);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// th[v] = worst distance of row v, for rows whose k-lists were overwritten wholesale (imported rows)
+__global__ void k_refresh_th(const float *__restrict__ knn_d, int ks, int k, int64_t lo, int64_t hi, float *__restrict__ th) {
+    const int64_t v = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < hi) th[v] = knn_d[v * ks + (k - 1)];
+}
+int nnd_launch_refresh_th(nnd_ctx *ctx, int64_t lo, int64_t hi) {
+    if (hi <= lo) return 0;
+    hipLaunchKernelGGL(k_refresh_th, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_d, ctx->ks, ctx->k,
+                       lo, hi, ctx->th);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

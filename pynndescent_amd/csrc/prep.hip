@@ -22,14 +22,21 @@ __global__ void k_colsum_partial(const float *__restrict__ x, int64_t n, int d, 
         partial[(int64_t)blockIdx.x * d + j] = s;
     }
 }
-__global__ void k_colsum_final(const double *__restrict__ partial, int nblocks, int d, int dp, int64_t n,
-                               float *__restrict__ mean) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= dp) return;
+// one workgroup per column; fixed summation order (tree over a fixed partition) keeps the mean deterministic
+__global__ __launch_bounds__(256) void k_colsum_final(const double *__restrict__ partial, int nblocks, int d, int dp, int64_t n,
+                                                      float *__restrict__ mean) {
+    __shared__ double red[256];
+    const int j = blockIdx.x;
     double s = 0.0;
     if (j < d)
-        for (int b = 0; b < nblocks; b++) s += partial[(int64_t)b * d + j];
-    mean[j] = j < d ? (float)(s / (double)n) : 0.0f;
+        for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * d + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mean[j] = j < d ? (float)(red[0] / (double)n) : 0.0f;
 }
 
 // ---- one wave per row: pad + centre / normalise + norm ----
@@ -73,7 +80,7 @@ int nnd_launch_prep(nnd_ctx *ctx) {
         NND_HIP_CHECK(hipMalloc((void **)&partial, sizeof(double) * (size_t)nblocks * d));
         hipLaunchKernelGGL(k_colsum_partial, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->x_orig, n, d,
                            rows_per_block, partial);
-        hipLaunchKernelGGL(k_colsum_final, dim3((dp + 255) / 256), dim3(256), 0, ctx->stream, partial, nblocks, d, dp,
+        hipLaunchKernelGGL(k_colsum_final, dim3(dp), dim3(256), 0, ctx->stream, partial, nblocks, d, dp,
                            n, ctx->mean);
         NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         NND_HIP_CHECK(hipFree(partial));
@@ -88,18 +95,20 @@ int nnd_launch_prep(nnd_ctx *ctx) {
 }
 
 // ---- make_heap (reference utils.py:130-158): all slots (-1, +inf, flag 0) ----
-__global__ void k_reset_graph(uint32_t *__restrict__ e, float *__restrict__ dd, int64_t total) {
+__global__ void k_reset_graph(uint32_t *__restrict__ e, float *__restrict__ dd, int64_t total, float *__restrict__ th,
+                              int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
         e[i] = NND_EMPTY_E;
         dd[i] = INFINITY;
     }
+    if (i < n) th[i] = INFINITY;
 }
 
 int nnd_launch_reset_graph(nnd_ctx *ctx) {
     int64_t total = ctx->n * ctx->ks;
     hipLaunchKernelGGL(k_reset_graph, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e,
-                       ctx->knn_d, total);
+                       ctx->knn_d, total, ctx->th, ctx->n);
     NND_HIP_CHECK(hipMemsetAsync(ctx->pbuf, 0xFF, sizeof(uint64_t) * (size_t)ctx->n * ctx->pcap, ctx->stream));
     NND_HIP_CHECK(hipMemsetAsync(ctx->rbuf, 0xFF, sizeof(uint64_t) * (size_t)ctx->n * 2 * ctx->rcap, ctx->stream));
     NND_HIP_CHECK(hipGetLastError());

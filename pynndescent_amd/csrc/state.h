@@ -55,6 +55,7 @@ struct nnd_handle_s {
     // k-lists, rows ascending by (dist, idx)
     uint32_t *knn_e = nullptr; // (n,ks) neighbour | NEW_BIT ; 0xFFFFFFFF = empty
     float *knn_d = nullptr;    // (n,ks) alt-space distance ; +inf = empty
+    float *th = nullptr;       // (n) worst distance of every row (= knn_d[v][k-1]); compact so that threshold gathers stay in L2
 
     // candidates / proposals
     int32_t *cand = nullptr;  // (n, 2*mcp): [new | old], -1 padded
@@ -112,5 +113,6 @@ int nnd_launch_proposal_counts(nnd_ctx *ctx, int32_t *cnt_dev);
 int nnd_launch_export_proposals(nnd_ctx *ctx, const int64_t *offsets_dev, uint64_t *keys_out, int32_t *targets_out);
 int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_t *targets, int64_t count);
 int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
+int nnd_launch_refresh_th(nnd_ctx *ctx, int64_t lo, int64_t hi);
 int nnd_read_counters(nnd_ctx *ctx);  // device -> ctx->h_counters (synchronises the stream)
 int nnd_zero_counters(nnd_ctx *ctx);
