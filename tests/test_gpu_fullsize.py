@@ -1,0 +1,101 @@
+"""BASELINE.json full-size configurations on one MI355X, checked through size-independent properties
+(rows ascending, unique ids, self first at distance 0, exact distances for the returned ids) and recall against
+exact brute force on a sample; medium-size runs are also compared with the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from pynndescent_amd import _capi
+from tests.util_data import clustered
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(n, d, latent, seed, dev, nonneg):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    centres = torch.randn(1024, latent, generator=g, device=dev) * 3.0
+    proj = torch.randn(latent, d, generator=g, device=dev) / latent ** 0.5
+    assign = torch.randint(0, 1024, (n,), generator=g, device=dev)
+    x = (centres[assign] + torch.randn(n, latent, generator=g, device=dev)) @ proj
+    x = x + 0.3 * torch.randn(n, d, generator=g, device=dev)
+    if nonneg:
+        x = (x + 12.0).clamp_min(0) * 9.0
+    return x.contiguous()
+
+
+def _build(x, metric, k, n_trees, seed=1):
+    n, d = x.shape
+    rng_state, _, ts = O.draw_rng_states(seed, n_trees)
+    b = _capi.Builder(n, d, O.METRICS[metric], k, n_trees, O.default_leaf_size(k), 200, min(60, k), O.default_n_iters(n),
+                      0.001, rng_state, ts[0])
+    idx = torch.empty((n, k), dtype=torch.int32, device=x.device)
+    dist = torch.empty((n, k), dtype=torch.float32, device=x.device)
+    torch.cuda.synchronize()
+    b.set_data_device(x.data_ptr(), keepalive=x)
+    b.build_device(idx.data_ptr(), dist.data_ptr())
+    st = b.stats()
+    b.close()
+    return idx, dist, st
+
+
+def _check(x, metric, idx, dist, k, floor):
+    n = x.shape[0]
+    assert bool((idx >= 0).all())
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all()), "rows not ascending"
+    srt = idx.sort(dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all()), "duplicate ids in a row"
+    ar = torch.arange(n, device=x.device, dtype=torch.int32)
+    self_first = (idx[:, 0] == ar)
+    assert self_first.float().mean().item() > 0.999
+    assert bool((dist[self_first, 0] == 0).all())
+    rows = torch.from_numpy(np.random.RandomState(0).choice(n, 1500, replace=False)).to(x.device)
+    q = x[rows].double()
+    nb = x[idx[rows].long()].double()
+    if metric == "euclidean":
+        truth = ((q[:, None, :] - nb) ** 2).sum(-1)
+        full = (x[rows] * x[rows]).sum(1, keepdim=True) + (x * x).sum(1)[None, :] - 2.0 * (x[rows] @ x.T)
+    else:
+        dot = (q[:, None, :] * nb).sum(-1)
+        truth = torch.log2((q.norm(dim=1)[:, None] * nb.norm(dim=2)) / dot).clamp_min(0)
+        xn = x / x.norm(dim=1, keepdim=True)
+        full = 1.0 - xn[rows] @ xn.T
+    rel = ((dist[rows].double() - truth).abs() / truth.clamp_min(1e-12))
+    assert rel[truth > 1e-9].max().item() < 1e-5, rel[truth > 1e-9].max().item()
+    true10 = full.topk(10, dim=1, largest=False).indices.cpu().numpy()
+    got = idx[rows].cpu().numpy()
+    rec = sum(np.isin(t, g).sum() for t, g in zip(true10, got)) / (len(got) * 10.0)
+    assert rec >= floor, rec
+    return rec
+
+
+def test_config2_sift_like_1m_euclidean():
+    """BASELINE configs[1]: 1e6 x 128 euclidean k=15, RP-tree init n_trees=8; recall@10 >= 0.95."""
+    x = _gen(1_000_000, 128, 16, 1, torch.device("cuda", 0), True)
+    idx, dist, st = _build(x, "euclidean", 15, 8)
+    rec = _check(x, "euclidean", idx, dist, 15, 0.95)
+    print("C2' recall@10 %.4f iters %d" % (rec, st["n_iters_run"]))
+
+
+def test_config3_glove_like_1p2m_cosine_d100():
+    """BASELINE configs[2]: 1.2e6 x 100 cosine k=15 (rows not normalised, d padded to 128 on device)."""
+    x = _gen(1_200_000, 100, 24, 2, torch.device("cuda", 0), False)
+    idx, dist, st = _build(x, "cosine", 15, 12)
+    rec = _check(x, "cosine", idx, dist, 15, 0.90)
+    print("C3' recall@10 %.4f iters %d" % (rec, st["n_iters_run"]))
+
+
+@pytest.mark.parametrize("metric,n,d,latent,k", [("euclidean", 150_000, 128, 16, 15), ("cosine", 120_000, 100, 24, 15),
+                                                 ("cosine", 60_000, 256, 32, 15), ("euclidean", 50_000, 784, 20, 30)])
+def test_medium_sizes_against_oracle(metric, n, d, latent, k):
+    """Same inputs through the CPU oracle (reference algorithm): recall within 0.5 %."""
+    x = clustered(n, d, latent, 256, seed=n % 97, nonneg=(metric == "euclidean"))
+    xt = torch.from_numpy(x).cuda()
+    idx, dist, st = _build(xt, metric, k, 8, seed=3)
+    oidx, _ = O.build_index(x, metric, n_neighbors=k, n_trees=8, random_state=3, n_threads=32, kind="fast")
+    rows = np.random.RandomState(1).choice(n, 2000, replace=False)
+    ti, _ = O.brute_force_knn(x, 10, metric, rows=rows)
+    r_gpu, r_cpu = O.recall(ti, idx.cpu().numpy()[rows]), O.recall(ti, oidx[rows])
+    print("%s %dx%d k=%d: recall gpu %.4f oracle %.4f" % (metric, n, d, k, r_gpu, r_cpu))
+    assert r_gpu >= r_cpu - 0.005
