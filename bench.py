@@ -225,8 +225,18 @@ def main():
             tree_bytes = steps * (n_here * 4.0 * builder_dp(d) * last["tree_levels"] +
                                   n_here * 8.0 * last["tree_levels"] * max(1, args.n_trees // world))
             achieved, kernel = tree_bytes / (stage["forest"] * 1e-3) / 1e9, "rp_forest (k_margin_fused / k_margin + partition)"
+        # HBM traffic per launch from the committed PMC passes (tools/pmc_traffic.py; separate --pmc runs, gfx950
+        # FETCH_SIZE correction applied); null if no profile of this kernel has been committed
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            key = {"join": "k_local_join", "leaf_init": "k_leaf_join", "forest": "k_margin_fused"}[dominant]
+            for name, rec in tj.items():
+                if isinstance(rec, dict) and key in name:
+                    traffic = rec["traffic_bytes_per_launch"]
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "k_local_join": {"achieved": round(join_gbs, 2), "frac": round(join_gbs / HBM_PEAK_GBS, 5),
                                      "avg_launch_ms": round(join_ms / max(n_join_launches, 1), 4),
                                      "bytes_per_launch": round(join_bytes / max(n_join_launches, 1))}}
