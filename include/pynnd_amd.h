@@ -163,6 +163,10 @@ int32_t nnd_row_stride(nnd_handle_t h); /* ks: uint32/float words per k-list row
 /* raw k-list rows [lo,hi): neighbour words (idx | new<<31, 0xFFFFFFFF empty) and alt-space distances */
 int32_t nnd_export_graph_rows(nnd_handle_t h, int64_t lo, int64_t hi, uint32_t *e_dst, float *d_dst);
 int32_t nnd_import_graph_rows(nnd_handle_t h, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
+/* d_dst / d_src may be NULL: then only the neighbour words move and the per-row worst distances (the only part of
+ * a remote row's distances the join needs) travel as 4 bytes per row through the two calls below */
+int32_t nnd_export_thresholds(nnd_handle_t h, int64_t lo, int64_t hi, float *th_dst);
+int32_t nnd_import_thresholds(nnd_handle_t h, int64_t lo, int64_t hi, const float *th_src);
 /* merge another handle's rows [lo,hi) into ours (combining per-rank forests' leaf seeding at the owner) */
 int32_t nnd_merge_graph_rows(nnd_handle_t h, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
 /* one descent iteration in three steps, with the proposal exchange between join and merge */

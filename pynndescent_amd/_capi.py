@@ -109,6 +109,8 @@ _SIGNATURES = [
     ("nnd_export_graph_rows", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     ("nnd_import_graph_rows", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     ("nnd_merge_graph_rows", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("nnd_export_thresholds", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p]),
+    ("nnd_import_thresholds", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p]),
     ("nnd_descent_sample", C.c_int32, [_H]),
     ("nnd_descent_join", C.c_int32, [_H]),
     ("nnd_proposal_counts", C.c_int32, [_H, C.c_void_p]),
@@ -275,11 +277,19 @@ class Builder:
     def row_stride(self):
         return int(self.lib.nnd_row_stride(self._h))
 
-    def export_graph_rows(self, lo, hi, e_ptr, d_ptr):
-        self._check(self.lib.nnd_export_graph_rows(self._h, int(lo), int(hi), C.c_void_p(int(e_ptr)), C.c_void_p(int(d_ptr))))
+    def export_graph_rows(self, lo, hi, e_ptr, d_ptr=None):
+        self._check(self.lib.nnd_export_graph_rows(self._h, int(lo), int(hi), C.c_void_p(int(e_ptr)),
+                                                   None if d_ptr is None else C.c_void_p(int(d_ptr))))
 
-    def import_graph_rows(self, lo, hi, e_ptr, d_ptr):
-        self._check(self.lib.nnd_import_graph_rows(self._h, int(lo), int(hi), C.c_void_p(int(e_ptr)), C.c_void_p(int(d_ptr))))
+    def import_graph_rows(self, lo, hi, e_ptr, d_ptr=None):
+        self._check(self.lib.nnd_import_graph_rows(self._h, int(lo), int(hi), C.c_void_p(int(e_ptr)),
+                                                   None if d_ptr is None else C.c_void_p(int(d_ptr))))
+
+    def export_thresholds(self, lo, hi, th_ptr):
+        self._check(self.lib.nnd_export_thresholds(self._h, int(lo), int(hi), C.c_void_p(int(th_ptr))))
+
+    def import_thresholds(self, lo, hi, th_ptr):
+        self._check(self.lib.nnd_import_thresholds(self._h, int(lo), int(hi), C.c_void_p(int(th_ptr))))
 
     def merge_graph_rows(self, lo, hi, e_ptr, d_ptr):
         self._check(self.lib.nnd_merge_graph_rows(self._h, int(lo), int(hi), C.c_void_p(int(e_ptr)), C.c_void_p(int(d_ptr))))

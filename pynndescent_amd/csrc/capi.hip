@@ -524,7 +524,8 @@ extern "C" int32_t nnd_export_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t h
     ENTER(ctx);
     size_t cnt = (size_t)(hi - lo) * ctx->ks;
     API_HIP(hipMemcpyAsync(e_dst_dev, ctx->knn_e + lo * ctx->ks, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-    API_HIP(hipMemcpyAsync(d_dst_dev, ctx->knn_d + lo * ctx->ks, sizeof(float) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_dst_dev)
+        API_HIP(hipMemcpyAsync(d_dst_dev, ctx->knn_d + lo * ctx->ks, sizeof(float) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
     API_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -532,8 +533,23 @@ extern "C" int32_t nnd_import_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t h
     ENTER(ctx);
     size_t cnt = (size_t)(hi - lo) * ctx->ks;
     API_HIP(hipMemcpyAsync(ctx->knn_e + lo * ctx->ks, e_src_dev, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-    API_HIP(hipMemcpyAsync(ctx->knn_d + lo * ctx->ks, d_src_dev, sizeof(float) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-    if (nnd_launch_refresh_th(ctx, lo, hi)) return 1;
+    if (d_src_dev) {  // full rows; d_src_dev == NULL: neighbour words only (thresholds come through nnd_import_thresholds)
+        API_HIP(hipMemcpyAsync(ctx->knn_d + lo * ctx->ks, d_src_dev, sizeof(float) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+        if (nnd_launch_refresh_th(ctx, lo, hi)) return 1;
+    }
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+// per-row worst distances (thresholds): 4 bytes per row instead of the 4*ks-byte distance rows
+extern "C" int32_t nnd_export_thresholds(nnd_handle_t ctx, int64_t lo, int64_t hi, float *th_dst_dev) {
+    ENTER(ctx);
+    API_HIP(hipMemcpyAsync(th_dst_dev, ctx->th + lo, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" int32_t nnd_import_thresholds(nnd_handle_t ctx, int64_t lo, int64_t hi, const float *th_src_dev) {
+    ENTER(ctx);
+    API_HIP(hipMemcpyAsync(ctx->th + lo, th_src_dev, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
     API_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }

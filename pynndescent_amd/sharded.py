@@ -209,7 +209,7 @@ class ShardedBuilder:
         self.ks = self.b.row_stride()
         dev, ks = self.dev, self.ks
         self.own_e = torch.empty(((self.hi - self.lo) * ks,), dtype=torch.int32, device=dev)
-        self.own_d = torch.empty(((self.hi - self.lo) * ks,), dtype=torch.float32, device=dev)
+        self.own_th = torch.empty((self.hi - self.lo,), dtype=torch.float32, device=dev)
         self.cnt = torch.zeros((self.n_total,), dtype=torch.int32, device=dev)
         self.offsets = torch.zeros((self.n_total + 1,), dtype=torch.int64, device=dev)
         self.edge_index = torch.tensor([v for ab in self.ranges for v in ab], device=dev)
@@ -257,16 +257,19 @@ class ShardedBuilder:
         b.init_random()  # owned rows that are still not full (pynndescent_.py:188-203)
 
         for it in range(self.n_iters):
-            # (1) k-list all-gather: thresholds / neighbour ids / reverse edges of remote rows
+            # (1) k-list all-gather: neighbour words (ids + new flags: dedup and reverse edges) and the per-row
+            #     worst distances (thresholds) of remote rows -- 4*ks + 4 bytes per row, not the distance rows
             if world > 1:
-                b.export_graph_rows(lo, hi, self.own_e.data_ptr(), self.own_d.data_ptr())
+                b.export_graph_rows(lo, hi, self.own_e.data_ptr(), None)
+                b.export_thresholds(lo, hi, self.own_th.data_ptr())
                 all_e = comm.all_gather_v(self.own_e)
-                all_d = comm.all_gather_v(self.own_d)
+                all_t = comm.all_gather_v(self.own_th)
                 _sync()
                 for src, (a, z) in enumerate(ranges):
                     if src != rank and z > a:
-                        b.import_graph_rows(a, z, all_e[src].data_ptr(), all_d[src].data_ptr())
-                del all_e, all_d
+                        b.import_graph_rows(a, z, all_e[src].data_ptr(), None)
+                        b.import_thresholds(a, z, all_t[src].data_ptr())
+                del all_e, all_t
             # (2) local sampling and join of the owned vertices
             b.descent_sample()
             b.descent_join()
