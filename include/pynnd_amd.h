@@ -178,6 +178,16 @@ int32_t nnd_export_proposals(nnd_handle_t h, const int64_t *offsets /* exclusive
 int32_t nnd_import_proposals(nnd_handle_t h, const uint64_t *keys, const int32_t *targets, int64_t count);
 int32_t nnd_descent_merge(nnd_handle_t h, int64_t *c_local);
 
+/* ---- search-graph pruning pass (BASELINE config 5; reference NNDescent._init_search_graph, pynndescent_.py:1451-1611) ----
+ * Standard diversify method at diversify_prob = 1.  Host arrays in / out: like the reference, the conversions
+ * between these kernels (COO->CSR, transpose, maximum, binarise) are scipy calls on the host. */
+/* diversify (pynndescent_.py:369-403): (n,k) rows ascending in alt space; pruned slots -> (-1, +inf) */
+int32_t nnd_diversify_host(nnd_handle_t h, int32_t *idx, float *dist);
+/* diversify_csr (pynndescent_.py:549-588) on CSR rows of <= 64 entries; pruned entries get weight 0 */
+int32_t nnd_diversify_csr_host(nnd_handle_t h, const int32_t *indptr, const int32_t *indices, float *data, int64_t nnz);
+/* degree_prune_internal (pynndescent_.py:728-738): rows longer than max_degree keep entries <= sorted(row)[max_degree] */
+int32_t nnd_degree_prune_host(nnd_handle_t h, const int32_t *indptr, float *data, int64_t nnz, int32_t max_degree);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,9 @@ def load(kind="strict"):
         _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, _i32p, _f64p,
     ]
     lib.orc_num_threads.restype = C.c_int
+    lib.orc_diversify.argtypes = [_i32p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_int]
+    lib.orc_diversify_csr.argtypes = [_i32p, _i32p, _f32p, C.c_int64, _f32p, C.c_int, C.c_int]
+    lib.orc_degree_prune.argtypes = [_i32p, _f32p, C.c_int64, C.c_int]
     _LIBS[kind] = lib
     return lib
 
@@ -244,3 +247,63 @@ def recall(true_idx, approx_idx, k_true=None):
     for t, a in zip(true_idx[:, :k_true], approx_idx):
         hits += np.isin(t, a).sum()
     return hits / float(true_idx.shape[0] * k_true)
+
+
+# ----------------------------------------------------------------------------
+# search-graph pruning pass (BASELINE config 5): reference pynndescent_.py:1451-1611 without the tree reordering
+
+FLOAT32_EPS = np.finfo(np.float32).eps
+
+
+def diversify(indices, distances, data, metric, lib=None):
+    """reference pynndescent_.py:369-403 (standard method, diversify_prob = 1). Returns new arrays."""
+    lib = lib or load()
+    i = np.ascontiguousarray(indices, np.int32).copy()
+    d = np.ascontiguousarray(distances, np.float32).copy()
+    x = np.ascontiguousarray(data, np.float32)
+    lib.orc_diversify(i, d, i.shape[0], i.shape[1], x, x.shape[1], METRICS[metric])
+    return i, d
+
+
+def search_graph(data, indices, distances, metric, n_neighbors, pruning_degree_multiplier=1.5, lib=None,
+                 return_stages=False):
+    """The pruning pass of ``NNDescent._init_search_graph`` (pynndescent_.py:1451-1611) on an (indices,
+    alt-space distances) neighbour graph: forward diversify -> CSR -> reverse diversify -> union by maximum ->
+    no diagonal -> degree prune to round(multiplier * k) -> binarise.  Vertex reordering by the search tree
+    (pynndescent_.py:1629-1651) is NOT applied.  Returns a scipy CSR uint8 matrix."""
+    import scipy.sparse as sp
+
+    lib = lib or load()
+    x = np.ascontiguousarray(data, np.float32)
+    n = x.shape[0]
+    rows, dd = diversify(indices, distances, x, metric, lib)
+    dd = dd.copy()
+    dd[dd == 0.0] = FLOAT32_EPS  # pynndescent_.py:1517
+    # COO -> CSR as scipy builds it (pynndescent_.py:1520-1527): entries stay in row order, i.e. ascending
+    # distance, -1 slots dropped; the forward graph is NOT index-sorted at this point
+    keep = rows >= 0
+    indptr = np.concatenate([[0], np.cumsum(keep.sum(1))]).astype(np.int32)
+    fwd = sp.csr_array((dd[keep].astype(np.float32), rows[keep].astype(np.int32), indptr), shape=(n, n))
+    # "Reverse graph" (pynndescent_.py:1541-1577): scipy's transpose of a CSR matrix is a CSC matrix over the SAME
+    # (indptr, indices, data) arrays, so what the reference hands to diversify_csr are the forward rows again;
+    # the pruned weights are then read as the transposed matrix.
+    rdata = np.ascontiguousarray(fwd.data, np.float32).copy()
+    lib.orc_diversify_csr(np.ascontiguousarray(fwd.indptr, np.int32), np.ascontiguousarray(fwd.indices, np.int32),
+                          rdata, n, x, x.shape[1], METRICS[metric])
+    rev = sp.csr_array((rdata, fwd.indices.copy(), fwd.indptr.copy()), shape=(n, n)).transpose().tocsr()
+    rev.eliminate_zeros()
+    rev.sort_indices()
+    fwd.sort_indices()
+    u = fwd.maximum(rev).tocsr()
+    u.setdiag(0.0)
+    u.eliminate_zeros()
+    udata = np.ascontiguousarray(u.data, np.float32)
+    lib.orc_degree_prune(np.ascontiguousarray(u.indptr, np.int32), udata, n,
+                         int(np.round(pruning_degree_multiplier * n_neighbors)))
+    u = sp.csr_array((udata, u.indices, u.indptr), shape=(n, n))
+    u.eliminate_zeros()
+    out = (u != 0).astype(np.uint8).tocsr()
+    out.sort_indices()
+    if return_stages:
+        return out, {"forward_rows": rows, "forward_dist": dd, "reverse_nnz": int(rev.nnz), "union_nnz": int(u.nnz)}
+    return out

@@ -117,6 +117,9 @@ _SIGNATURES = [
     ("nnd_export_proposals", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nnd_import_proposals", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
     ("nnd_descent_merge", C.c_int32, [_H, C.POINTER(C.c_int64)]),
+    ("nnd_diversify_host", C.c_int32, [_H, C.c_void_p, C.c_void_p]),
+    ("nnd_diversify_csr_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    ("nnd_degree_prune_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -314,6 +317,28 @@ class Builder:
         c = C.c_int64()
         self._check(self.lib.nnd_descent_merge(self._h, C.byref(c)))
         return c.value
+
+    # -- search-graph pruning pass (numpy arrays in / out, like the reference's numba kernels)
+    def diversify(self, idx, dist):
+        idx = np.ascontiguousarray(idx, np.int32).copy()
+        dist = np.ascontiguousarray(dist, np.float32).copy()
+        assert idx.shape == (self.n, self.k) and dist.shape == idx.shape
+        self._check(self.lib.nnd_diversify_host(self._h, _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def diversify_csr(self, indptr, indices, data):
+        indptr = np.ascontiguousarray(indptr, np.int32)
+        indices = np.ascontiguousarray(indices, np.int32)
+        data = np.ascontiguousarray(data, np.float32).copy()
+        assert indptr.shape[0] == self.n + 1
+        self._check(self.lib.nnd_diversify_csr_host(self._h, _ptr(indptr), _ptr(indices), _ptr(data), data.shape[0]))
+        return data
+
+    def degree_prune(self, indptr, data, max_degree):
+        indptr = np.ascontiguousarray(indptr, np.int32)
+        data = np.ascontiguousarray(data, np.float32).copy()
+        self._check(self.lib.nnd_degree_prune_host(self._h, _ptr(indptr), _ptr(data), data.shape[0], int(max_degree)))
+        return data
 
     def pairwise_gram(self, rows_a, rows_b):
         a = np.ascontiguousarray(rows_a, np.int32)

@@ -614,3 +614,75 @@ extern "C" int32_t nnd_descent_merge(nnd_handle_t ctx, int64_t *c_local) {
     ctx->stats.n_iters_run = ctx->iter;
     return 0;
 }
+
+// ---- search-graph pruning pass (BASELINE config 5); host glue: pynndescent_amd/search_graph.py ----
+// Host-buffer entry points: the graph of this stage is handed over and taken back as numpy arrays by the
+// reference as well (its glue between the numba kernels is scipy on the host, pynndescent_.py:1509-1611).
+extern "C" int32_t nnd_diversify_host(nnd_handle_t ctx, int32_t *idx /* (n,k) in/out */, float *dist /* (n,k) in/out */) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    size_t cnt = (size_t)ctx->n * ctx->k;
+    int32_t *di = nullptr;
+    float *dd = nullptr;
+    API_HIP(hipMalloc((void **)&di, sizeof(int32_t) * cnt));
+    API_HIP(hipMalloc((void **)&dd, sizeof(float) * cnt));
+    API_HIP(hipMemcpyAsync(di, idx, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, ctx->stream));
+    API_HIP(hipMemcpyAsync(dd, dist, sizeof(float) * cnt, hipMemcpyHostToDevice, ctx->stream));
+    int rc = nnd_launch_diversify_rows(ctx, di, dd);
+    if (!rc) {
+        API_HIP(hipMemcpyAsync(idx, di, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+        API_HIP(hipMemcpyAsync(dist, dd, sizeof(float) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+        API_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    (void)hipFree(di);
+    (void)hipFree(dd);
+    return rc;
+}
+
+extern "C" int32_t nnd_diversify_csr_host(nnd_handle_t ctx, const int32_t *indptr /* n+1 */, const int32_t *indices,
+                                          float *data /* nnz in/out */, int64_t nnz) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    int32_t *dp = nullptr, *di = nullptr;
+    float *dd = nullptr;
+    int *flag = nullptr;
+    API_HIP(hipMalloc((void **)&dp, sizeof(int32_t) * (size_t)(ctx->n + 1)));
+    API_HIP(hipMalloc((void **)&di, sizeof(int32_t) * (size_t)(nnz ? nnz : 1)));
+    API_HIP(hipMalloc((void **)&dd, sizeof(float) * (size_t)(nnz ? nnz : 1)));
+    API_HIP(hipMalloc((void **)&flag, sizeof(int)));
+    API_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+    API_HIP(hipMemcpyAsync(dp, indptr, sizeof(int32_t) * (size_t)(ctx->n + 1), hipMemcpyHostToDevice, ctx->stream));
+    API_HIP(hipMemcpyAsync(di, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+    API_HIP(hipMemcpyAsync(dd, data, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+    int rc = nnd_launch_diversify_csr(ctx, dp, di, dd, flag);
+    int too_long = 0;
+    if (!rc) {
+        API_HIP(hipMemcpyAsync(data, dd, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+        API_HIP(hipMemcpyAsync(&too_long, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        API_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    (void)hipFree(dp); (void)hipFree(di); (void)hipFree(dd); (void)hipFree(flag);
+    if (!rc && too_long) {
+        ctx->set_error("nnd_diversify_csr_host: %d rows are longer than 64 entries (rows of a diversified k-NN graph have <= k <= 64)", too_long);
+        return 1;
+    }
+    return rc;
+}
+
+extern "C" int32_t nnd_degree_prune_host(nnd_handle_t ctx, const int32_t *indptr /* n+1 */, float *data /* nnz in/out */,
+                                         int64_t nnz, int32_t max_degree) {
+    ENTER(ctx);
+    int32_t *dp = nullptr;
+    float *dd = nullptr;
+    API_HIP(hipMalloc((void **)&dp, sizeof(int32_t) * (size_t)(ctx->n + 1)));
+    API_HIP(hipMalloc((void **)&dd, sizeof(float) * (size_t)(nnz ? nnz : 1)));
+    API_HIP(hipMemcpyAsync(dp, indptr, sizeof(int32_t) * (size_t)(ctx->n + 1), hipMemcpyHostToDevice, ctx->stream));
+    API_HIP(hipMemcpyAsync(dd, data, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+    int rc = nnd_launch_degree_prune(ctx, dp, dd, max_degree);
+    if (!rc) {
+        API_HIP(hipMemcpyAsync(data, dd, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+        API_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    (void)hipFree(dp); (void)hipFree(dd);
+    return rc;
+}

@@ -114,5 +114,9 @@ int nnd_launch_export_proposals(nnd_ctx *ctx, const int64_t *offsets_dev, uint64
 int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_t *targets, int64_t count);
 int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
 int nnd_launch_refresh_th(nnd_ctx *ctx, int64_t lo, int64_t hi);
+int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev);
+int nnd_launch_diversify_csr(nnd_ctx *ctx, const int32_t *indptr_dev, const int32_t *indices_dev, float *data_dev,
+                             int *too_long_dev);
+int nnd_launch_degree_prune(nnd_ctx *ctx, const int32_t *indptr_dev, float *data_dev, int max_degree);
 int nnd_read_counters(nnd_ctx *ctx);  // device -> ctx->h_counters (synchronises the stream)
 int nnd_zero_counters(nnd_ctx *ctx);

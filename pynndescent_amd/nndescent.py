@@ -252,6 +252,17 @@ class NNDescent:
             return None
         return (self._neighbor_graph[0].copy(), self._distance_correction(self._neighbor_graph[1]))
 
+    def build_search_graph(self):
+        """The pruning pass of ``_init_search_graph`` (pynndescent_.py:1451-1611: diversify, reverse diversify,
+        degree prune) on the GPU; sets and returns ``_search_graph`` (CSR uint8, NOT yet reordered by a search
+        tree: hub tree / reordering / query stay with the reference)."""
+        from .search_graph import build_search_graph
+
+        self._search_graph = build_search_graph(
+            self._raw_data, self._neighbor_graph[0], self._neighbor_graph[1], self.metric, self.n_neighbors,
+            self.prune_degree_multiplier, self.diversify_prob, self.diversify_method, device=self.device)
+        return self._search_graph
+
     def _out_of_scope(self, what):
         raise NotImplementedError(
             "%s is out of scope for pynndescent_amd (build path only; SURVEY.md section 8f). "

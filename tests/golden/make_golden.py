@@ -350,6 +350,55 @@ def gen_reference_testdata(ref):
     save("class_dedup_hang_cosine", seed=np.int64(189212), k=np.int32(10), **r)
 
 
+def gen_search_graph(ref):
+    """BASELINE config 5's extra pass: the pruning part of NNDescent._init_search_graph (pynndescent_.py:1451-1611),
+    executed with the reference's own functions and scipy glue on a reference-built graph; the tree-order
+    reordering (1629-1651) is left out."""
+    import numba
+    import scipy.sparse as sp
+    from pynndescent import distances as D
+    from pynndescent import pynndescent_ as P
+
+    numba.set_num_threads(1)
+    out = {}
+    for metric, seed in (("euclidean", 41), ("cosine", 42)):
+        x = clustered(1200, 12, 5, 15, seed=seed)
+        index = ref.NNDescent(x, metric=metric, n_neighbors=15, random_state=np.random.RandomState(7))
+        idx, dst = index._neighbor_graph
+        dist = D.fast_distance_alternatives[metric]["dist"]
+        rows, dd = P.diversify(idx.copy(), dst.copy(), x, dist, index.rng_state, 1.0)
+        fwd_rows, fwd_dist = rows.copy(), dd.copy()
+        n = x.shape[0]
+        g = sp.coo_array((n, n), dtype=np.float32)
+        dd[dd == 0.0] = P.FLOAT32_EPS
+        g.row = np.repeat(np.arange(n, dtype=np.int32), rows.shape[1])
+        g.col = rows.ravel()
+        g.data = dd.ravel()
+        g = g.tocsr()
+        g.data[g.indices == -1] = 0.0
+        g.eliminate_zeros()
+        rev = g.transpose()
+        P.diversify_csr(rev.indptr, rev.indices, rev.data, x, dist, index.rng_state, 1.0)
+        rev.eliminate_zeros()
+        rev = rev.tocsr()
+        rev.sort_indices()
+        g = g.tocsr()
+        g.sort_indices()
+        u = g.maximum(rev).tocsr()
+        u.setdiag(0.0)
+        u.eliminate_zeros()
+        pre_prune = u.nnz
+        u = P.degree_prune(u, int(np.round(1.5 * 15)))
+        u.eliminate_zeros()
+        u = (u != 0).astype(np.uint8).tocsr()
+        u.sort_indices()
+        out.update({metric + "_gen": np.array([1200, 12, 5, 15, seed]), metric + "_idx": idx, metric + "_dist": dst,
+                    metric + "_fwd_rows": fwd_rows, metric + "_fwd_dist": fwd_dist, metric + "_rev_nnz": np.int64(rev.nnz),
+                    metric + "_pre_prune_nnz": np.int64(pre_prune), metric + "_indptr": u.indptr.astype(np.int32),
+                    metric + "_indices": u.indices.astype(np.int32)})
+    save("search_graph", **out)
+
+
 GENERATORS = {
     "primitives": gen_primitives,
     "rp": gen_rp,
@@ -358,6 +407,7 @@ GENERATORS = {
     "build_clustered": gen_build_clustered,
     "build_c1": gen_build_c1,
     "reference_testdata": gen_reference_testdata,
+    "search_graph": gen_search_graph,
 }
 
 

@@ -197,3 +197,39 @@ def test_verbose_output(capsys):
         warnings.simplefilter("ignore")
         NNDescent(data=x, metric="euclidean", n_neighbors=4, random_state=1, n_trees=5, n_iters=2, verbose=False)
     assert capsys.readouterr().out.strip() == ""
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_search_graph_pruning_pass_vs_reference_fixture(metric):
+    """BASELINE config 5's pass: the reference's own diversify / diversify_csr / degree_prune run (fixture) on a
+    reference-built graph vs the HIP kernels on the same graph; and the class-level entry point vs the oracle."""
+    from pynndescent_amd.search_graph import build_search_graph
+
+    g = np.load(os.path.join(GOLDEN, "search_graph.npz"))
+    n, d, latent, ncl, seed = (int(v) for v in g[metric + "_gen"])
+    x = clustered(n, d, latent, ncl, seed)
+    sg, st = build_search_graph(x, g[metric + "_idx"], g[metric + "_dist"], metric, 15, return_stages=True)
+    fr = g[metric + "_fwd_rows"]
+    agree = (st["forward_rows"] == fr).mean()
+    print("forward diversify agreement %.5f; nnz %d -> %d -> %d" % (agree, st["forward_nnz"], st["union_nnz"], st["final_nnz"]))
+    assert agree > 0.995
+    a = set(zip(np.repeat(np.arange(n), np.diff(sg.indptr)).tolist(), sg.indices.tolist()))
+    b = set(zip(np.repeat(np.arange(n), np.diff(g[metric + "_indptr"])).tolist(), g[metric + "_indices"].tolist()))
+    assert len(a ^ b) <= 0.01 * len(b), (len(a ^ b), len(b))
+    assert sg.dtype == np.uint8 and np.diff(sg.indptr).max() <= int(np.round(1.5 * 15)) + 1
+    assert sg.diagonal().sum() == 0
+
+
+def test_search_graph_nytimes_like_cosine_d256():
+    """Config-5 shape (angular, d=256, k=15) at reduced n: GPU build + GPU pruning pass vs the oracle's pass on the
+    SAME neighbour graph (edge sets within 1 %), plus degree bound and symmetry of the union."""
+    x = clustered(20000, 256, 32, 200, seed=4)
+    index = NNDescent(x, "cosine", n_neighbors=15, random_state=4)
+    sg = index.build_search_graph()
+    osg = O.search_graph(x, index._neighbor_graph[0], index._neighbor_graph[1], "cosine", 15)
+    n = x.shape[0]
+    a = set(zip(np.repeat(np.arange(n), np.diff(sg.indptr)).tolist(), sg.indices.tolist()))
+    b = set(zip(np.repeat(np.arange(n), np.diff(osg.indptr)).tolist(), osg.indices.tolist()))
+    print("search graph nnz gpu %d oracle %d symmetric difference %d" % (len(a), len(b), len(a ^ b)))
+    assert len(a ^ b) <= 0.01 * len(b)
+    assert np.diff(sg.indptr).max() <= 23 + 1 and sg.shape == (n, n)

@@ -159,3 +159,29 @@ def test_bad_data_smoke(golden_dir):
     data = np.sqrt(arr).astype(np.float32)
     idx, dist = O.build_index(data, "cosine", n_neighbors=30, random_state=0, n_threads=8, kind="fast")
     assert idx.shape == (1011, 30) and np.isfinite(dist[idx >= 0]).all()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_search_graph_pruning_pass(golden_dir, metric):
+    """BASELINE config 5's pass: diversify -> reverse diversify_csr -> union -> degree prune
+    (pynndescent_.py:369-403, 549-588, 728-760, glue 1451-1611), oracle vs the reference's own run."""
+    g = _g(golden_dir, "search_graph")
+    n, d, latent, ncl, seed = (int(v) for v in g[metric + "_gen"])
+    x = clustered(n, d, latent, ncl, seed)
+    rows, dd = O.diversify(g[metric + "_idx"], g[metric + "_dist"], x, metric)
+    if metric == "euclidean":  # sequential f32 distances: bit-exact decisions
+        np.testing.assert_array_equal(rows, g[metric + "_fwd_rows"])
+        np.testing.assert_array_equal(dd, g[metric + "_fwd_dist"])
+    else:
+        assert (rows == g[metric + "_fwd_rows"]).mean() > 0.995
+    sg, st = O.search_graph(x, g[metric + "_idx"], g[metric + "_dist"], metric, 15, return_stages=True)
+    ref_indptr, ref_indices = g[metric + "_indptr"], g[metric + "_indices"]
+    if metric == "euclidean":
+        assert st["reverse_nnz"] == int(g[metric + "_rev_nnz"]) and st["union_nnz"] == int(g[metric + "_pre_prune_nnz"])
+        np.testing.assert_array_equal(sg.indptr, ref_indptr)
+        np.testing.assert_array_equal(sg.indices, ref_indices)
+    else:
+        a = set(zip(np.repeat(np.arange(n), np.diff(sg.indptr)).tolist(), sg.indices.tolist()))
+        b = set(zip(np.repeat(np.arange(n), np.diff(ref_indptr)).tolist(), ref_indices.tolist()))
+        assert len(a ^ b) <= 0.01 * len(b), (len(a ^ b), len(b))
+    assert np.diff(sg.indptr).max() <= int(np.round(1.5 * 15)) + 1
