@@ -102,8 +102,12 @@ class TorchDistComm:
                     ops.append(self.dist.irecv(recv[peer], peer, group=self.group))
             for op in ops:
                 op.wait()
-        else:
-            self.dist.all_to_all(recv, [t.contiguous() for t in send], group=self.group)
+        else:  # nccl (= RCCL): one all_to_all_single with split sizes, the canonical all-to-all-v
+            sc = [int(c) for c in counts.tolist()]
+            inp = torch.cat([t.reshape((t.shape[0],) + tail) for t in send], dim=0).contiguous()
+            out = torch.empty((sum(rc),) + tail, dtype=send[0].dtype, device=dev)
+            self.dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+            recv = list(torch.split(out, rc, dim=0))
         return recv
 
     def all_reduce_sum(self, value):
