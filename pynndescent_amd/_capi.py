@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpynnd_amd.so")
+LIB_PATH = os.environ.get("PYNND_AMD_LIB", os.path.join(_HERE, "libpynnd_amd.so"))  # override: A/B experiments only
 
 NND_METRIC_SQEUCLIDEAN = 0
 NND_METRIC_ALT_COSINE = 1

@@ -40,7 +40,7 @@ static void free_all(nnd_ctx *ctx) {
         if (p) (void)hipFree(p);
     };
     if (ctx->x_owned) F((void *)ctx->x_orig);
-    F(ctx->xp); F(ctx->nrm); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->cand); F(ctx->rbuf); F(ctx->pbuf);
+    F(ctx->xp); F(ctx->nrm); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->cand); F(ctx->rbuf); F(ctx->pbuf);
     F(ctx->pdirty);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
@@ -93,6 +93,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
         const size_t n = (size_t)ctx->n;
         if ((rc = dalloc(ctx, &ctx->xp, n * ctx->dp))) break;
         if ((rc = dalloc(ctx, &ctx->nrm, n))) break;
+        if (p->n_trees > 0 && (rc = dalloc(ctx, &ctx->xh, n * ctx->dp))) break;
         if ((rc = dalloc(ctx, &ctx->mean, (size_t)ctx->dp))) break;
         if ((rc = dalloc(ctx, &ctx->knn_e, n * ctx->ks))) break;
         if ((rc = dalloc(ctx, &ctx->knn_d, n * ctx->ks))) break;

@@ -79,6 +79,13 @@ __device__ __forceinline__ uint64_t nnd_make_key(float d, uint32_t idx) {
 __device__ __forceinline__ float nnd_key_dist(uint64_t key) { return __uint_as_float((uint32_t)(key >> 32)); }
 __device__ __forceinline__ uint32_t nnd_key_idx(uint64_t key) { return (uint32_t)key & NND_IDX_MASK; }
 
+// round-to-nearest-even f32 -> bf16 (finite inputs)
+__device__ __forceinline__ uint16_t nnd_f32_to_bf16(float v) {
+    uint32_t u = __float_as_uint(v);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
 __device__ __forceinline__ float nnd_clamp_dist(float d) { return d > 0.0f ? d : 0.0f; }
 
 // Gram value -> alt-space distance.

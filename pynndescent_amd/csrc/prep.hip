@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_colsum_final(const double *__restrict__
 // ---- one wave per row: pad + centre / normalise + norm ----
 __global__ __launch_bounds__(256) void k_prep_rows(const float *__restrict__ x, int64_t n, int d, int dp, int metric,
                                                    const float *__restrict__ mean, float *__restrict__ xp,
-                                                   float *__restrict__ nrm) {
+                                                   float *__restrict__ nrm, uint16_t *__restrict__ xh) {
     int lane = nnd_lane();
     int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void k_prep_rows(const float *__restrict__ x, 
         for (int j = lane; j < dp; j += 64) {
             float v = j < d ? src[j] - mean[j] : 0.0f;
             dst[j] = v;
+            if (xh) xh[row * dp + j] = nnd_f32_to_bf16(v);
             s += v * v;
         }
         s = nnd_wave_sum_f32(s);
@@ -65,7 +66,11 @@ __global__ __launch_bounds__(256) void k_prep_rows(const float *__restrict__ x, 
         }
         s = nnd_wave_sum_f32(s);
         float inv = s > 0.0f ? 1.0f / sqrtf(s) : 0.0f;
-        for (int j = lane; j < dp; j += 64) dst[j] = j < d ? src[j] * inv : 0.0f;
+        for (int j = lane; j < dp; j += 64) {
+            const float v = j < d ? src[j] * inv : 0.0f;
+            dst[j] = v;
+            if (xh) xh[row * dp + j] = nnd_f32_to_bf16(v);
+        }
         if (lane == 0) nrm[row] = s > 0.0f ? 1.0f : 0.0f;
     }
 }
@@ -89,7 +94,7 @@ int nnd_launch_prep(nnd_ctx *ctx) {
     }
     int64_t blocks = (n + 3) / 4;
     hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->x_orig, n, d, dp,
-                       ctx->p.metric, ctx->mean, ctx->xp, ctx->nrm);
+                       ctx->p.metric, ctx->mean, ctx->xp, ctx->nrm, ctx->xh);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

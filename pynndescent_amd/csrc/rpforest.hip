@@ -74,45 +74,83 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
     const float *xl = xp + (int64_t)perm[a + li] * dp;
     const float *xr = xp + (int64_t)perm[a + ri] * dp;
     float *h = hyper + (int64_t)s * hs;
-    float acc = 0.0f;
+    float acc = 0.0f, sq = 0.0f;
     for (int j = lane; j < dp; j += 64) {
         float l = xl[j], r = xr[j];
         float v = l - r;
         h[j] = v;
         acc += angular ? v * v : v * (l + r);
+        sq += v * v;
     }
     acc = nnd_wave_sum_f32(acc);
+    sq = nnd_wave_sum_f32(sq);
     if (angular) {
         float nh = sqrtf(acc);
         float inv = nh < RP_EPS ? 1.0f : 1.0f / nh;  // rp_trees.py:113-118
         for (int j = lane; j < dp; j += 64) h[j] *= inv;
-        if (lane == 0) h[dp] = 0.0f;
+        if (lane == 0) {
+            h[dp] = 0.0f;
+            h[dp + 1] = nh * inv;  // |h| after normalisation (1, or |h| itself when degenerate)
+        }
     } else if (lane == 0) {
         h[dp] = -0.5f * acc;
+        h[dp + 1] = sqrtf(sq);
     }
 }
 
 // ---------------------------------------------------------------- margin --
-__global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, int dp, const int32_t *__restrict__ perm,
-                                                const int32_t *__restrict__ pos_seg, int64_t P,
-                                                const float *__restrict__ hyper, int hs, uint32_t seed, int depth,
-                                                uint8_t *__restrict__ side) {
+// margin = h . x + off for one point, computed by the 16 lanes of a group (all 16 enter together).
+// Screening pass: the row is read from the bf16 copy (half the bytes).  bf16 rounding moves each product by at
+// most 2^-8 relative, so |margin_bf16 - margin_f32| <= 2^-8 |h| |x|; if the screened margin is further from zero
+// than twice that bound its SIGN is already the f32 sign and the f32 row is never touched.  The (rare) points
+// inside the band are recomputed from the f32 row, so the split is exactly the f32 split.
+__device__ __forceinline__ float rp_margin16(const uint16_t *__restrict__ xh_row, const float *__restrict__ xf_row,
+                                             const float *__restrict__ h, int dp, int sub, float xnorm, bool live) {
+    float acc = 0.0f;
+    if (live) {
+        const uint4 *x8 = (const uint4 *)xh_row;  // 8 bf16 per 16-byte chunk
+        const float4 *h4 = (const float4 *)h;
+        for (int c = sub; c < (dp >> 3); c += 16) {
+            const uint4 q = x8[c];
+            const float4 a = h4[2 * c], b = h4[2 * c + 1];
+            acc += __uint_as_float(q.x << 16) * a.x + __uint_as_float(q.x & 0xFFFF0000u) * a.y +
+                   __uint_as_float(q.y << 16) * a.z + __uint_as_float(q.y & 0xFFFF0000u) * a.w +
+                   __uint_as_float(q.z << 16) * b.x + __uint_as_float(q.z & 0xFFFF0000u) * b.y +
+                   __uint_as_float(q.w << 16) * b.z + __uint_as_float(q.w & 0xFFFF0000u) * b.w;
+        }
+    }
+    acc = nnd_group16_sum_f32(acc);
+    const float off = live ? h[dp] : 0.0f, hnorm = live ? h[dp + 1] : 0.0f;
+    float m = acc + off;
+    const float band = 0.0078125f * hnorm * xnorm + 1e-30f;  // 2 * 2^-8 |h||x|
+    if (live && !(fabsf(m) > band)) {  // uniform inside the 16-lane group
+        float acc2 = 0.0f;
+        const float4 *x4 = (const float4 *)xf_row;
+        const float4 *h4 = (const float4 *)h;
+        for (int c = sub; c < (dp >> 2); c += 16) {
+            const float4 a = x4[c], b = h4[c];
+            acc2 += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        acc2 = nnd_group16_sum_f32(acc2);
+        m = acc2 + off;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
+                                                const float *__restrict__ nrm, int metric, int dp,
+                                                const int32_t *__restrict__ perm, const int32_t *__restrict__ pos_seg,
+                                                int64_t P, const float *__restrict__ hyper, int hs, uint32_t seed,
+                                                int depth, uint8_t *__restrict__ side) {
     int sub = threadIdx.x & 15;
     int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     bool live = g < P;
     int s = live ? pos_seg[g] : -1;
-    float acc = 0.0f;
-    if (s >= 0) {
-        const float4 *x4 = (const float4 *)(xp + (int64_t)perm[g] * dp);
-        const float4 *h4 = (const float4 *)(hyper + (int64_t)s * hs);
-        for (int c = sub; c < (dp >> 2); c += 16) {
-            float4 a = x4[c], b = h4[c];
-            acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-        }
-    }
-    acc = nnd_group16_sum_f32(acc);
-    if (s >= 0 && sub == 0) {
-        float m = acc + hyper[(int64_t)s * hs + dp];
+    live = s >= 0;
+    const int64_t pt = live ? perm[g] : 0;
+    const float xnorm = live ? (metric == 0 ? sqrtf(nrm[pt]) : nrm[pt]) : 0.0f;
+    const float m = rp_margin16(xh + pt * dp, xp + pt * dp, hyper + (int64_t)(live ? s : 0) * hs, dp, sub, xnorm, live);
+    if (live && sub == 0) {
         uint8_t sd;
         if (fabsf(m) < RP_EPS) sd = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)g, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
         else sd = m > 0.0f ? 0 : 1;                                                                                // rp_trees.py:386-391
@@ -121,33 +159,36 @@ __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, in
 }
 
 // point-major variant: one pass over the points serves every tree (rows read once per level)
-__global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ xp, int dp, int64_t n, int n_trees,
-                                                      const int32_t *__restrict__ inv,
+__global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
+                                                      const float *__restrict__ nrm, int metric, int dp, int64_t n,
+                                                      int n_trees, const int32_t *__restrict__ inv,
                                                       const int32_t *__restrict__ pos_seg,
                                                       const float *__restrict__ hyper, int hs, uint32_t seed, int depth,
                                                       uint8_t *__restrict__ side) {
     const int sub = threadIdx.x & 15;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
-    const bool live = i < n;
-    const float4 *x4 = (const float4 *)(xp + (live ? i : 0) * dp);
-    for (int t = 0; t < n_trees; t++) {
-        const int64_t g = live ? (int64_t)inv[(int64_t)t * n + i] : 0;
-        const int s = live ? pos_seg[g] : -1;
-        float acc = 0.0f;
-        if (s >= 0) {
-            const float4 *h4 = (const float4 *)(hyper + (int64_t)s * hs);
-            for (int c = sub; c < (dp >> 2); c += 16) {
-                float4 a = x4[c], b = h4[c];
-                acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    const bool in = i < n;
+    const int64_t pt = in ? i : 0;
+    const float xnorm = in ? (metric == 0 ? sqrtf(nrm[pt]) : nrm[pt]) : 0.0f;
+    // trees in batches of 4: the position and segment look-ups of a batch are independent loads issued together,
+    // so a point pays one dependent (inv -> pos_seg -> hyperplane) latency per batch instead of one per tree
+    for (int t0 = 0; t0 < n_trees; t0 += 4) {
+        int64_t g[4];
+        int sg[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) g[u] = (in && t0 + u < n_trees) ? (int64_t)inv[(int64_t)(t0 + u) * n + i] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; u++) sg[u] = g[u] >= 0 ? pos_seg[g[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool live = sg[u] >= 0;
+            const float m = rp_margin16(xh + pt * dp, xp + pt * dp, hyper + (int64_t)(live ? sg[u] : 0) * hs, dp, sub, xnorm, live);
+            if (live && sub == 0) {
+                uint8_t sd;
+                if (fabsf(m) < RP_EPS) sd = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)g[u], (uint32_t)depth) & 1u);
+                else sd = m > 0.0f ? 0 : 1;
+                side[g[u]] = sd;
             }
-        }
-        acc = nnd_group16_sum_f32(acc);
-        if (s >= 0 && sub == 0) {
-            float m = acc + hyper[(int64_t)s * hs + dp];
-            uint8_t sd;
-            if (fabsf(m) < RP_EPS) sd = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)g, (uint32_t)depth) & 1u);
-            else sd = m > 0.0f ? 0 : 1;
-            side[g] = sd;
         }
     }
 }
@@ -362,10 +403,15 @@ __global__ void k_scatter(const int32_t *__restrict__ perm, const int32_t *__res
 // member ids in LDS, margins by 16-lane groups, stable partition by a block-wide scan.  No global
 // synchronisation, no per-level launches; deep unbalanced branches only cost their own workgroup.
 // Same split rule, same hashes (position- and depth-keyed) as the level-synchronous kernels above.
-static constexpr int FIN_MAX = 4096;     // points per finisher segment
+#ifndef NND_FIN_MAX
+#define NND_FIN_MAX 2048
+#endif
+static constexpr int FIN_MAX = NND_FIN_MAX;     // points per finisher segment
 static constexpr int FIN_STACK = 512;    // sub-segments pending (depth budget is 200: a DFS needs <= depth+1 entries)
 
-__global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict__ xp, int dp, int32_t *__restrict__ perm,
+__global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
+                                                         const float *__restrict__ nrm, int metric, int dp,
+                                                         int32_t *__restrict__ perm,
                                                          const int32_t *__restrict__ seg_start,
                                                          const int32_t *__restrict__ seg_len,
                                                          const int32_t *__restrict__ seg_depth, int n_segs, int angular,
@@ -406,53 +452,49 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
         if (ri == li) ri = (ri + 1) % (uint32_t)l;
         const float *xl = xp + (int64_t)ids[ss + li] * dp;
         const float *xr = xp + (int64_t)ids[ss + ri] * dp;
-        float part = 0.0f;
+        float part = 0.0f, psq = 0.0f;
         for (int j = tid; j < dp; j += 256) {
             const float lv = xl[j], rv = xr[j];
             const float v = lv - rv;
             h[j] = v;
             part += angular ? v * v : v * (lv + rv);
+            psq += v * v;
         }
         part = nnd_wave_sum_f32(part);
-        if (lane == 0) ((float *)wsum)[w] = part;
-        __syncthreads();
-        const float tot = ((float *)wsum)[0] + ((float *)wsum)[1] + ((float *)wsum)[2] + ((float *)wsum)[3];
-        float off = 0.0f, scale = 1.0f;
-        if (angular) {
-            const float nh = sqrtf(tot);
-            scale = nh < RP_EPS ? 1.0f : 1.0f / nh;
-        } else {
-            off = -0.5f * tot;
+        psq = nnd_wave_sum_f32(psq);
+        if (lane == 0) {
+            ((float *)wsum)[w] = part;
         }
         __syncthreads();
-        // margins: 16 lanes per member, 4 members per group per pass so that 4 row gathers are in flight per lane
+        const float tot = ((float *)wsum)[0] + ((float *)wsum)[1] + ((float *)wsum)[2] + ((float *)wsum)[3];
+        __syncthreads();
+        if (lane == 0) ((float *)wsum)[w] = psq;
+        __syncthreads();
+        const float totsq = ((float *)wsum)[0] + ((float *)wsum)[1] + ((float *)wsum)[2] + ((float *)wsum)[3];
+        __syncthreads();
+        if (angular) {  // normalise in place (rp_trees.py:113-118); offset 0
+            const float nh = sqrtf(tot);
+            const float inv = nh < RP_EPS ? 1.0f : 1.0f / nh;
+            for (int j = tid; j < dp; j += 256) h[j] *= inv;
+            if (tid == 0) { h[dp] = 0.0f; h[dp + 1] = nh * inv; }
+        } else if (tid == 0) {
+            h[dp] = -0.5f * tot;
+            h[dp + 1] = sqrtf(totsq);
+        }
+        __syncthreads();
+        // margins: 16 lanes per member (bf16-screened, see rp_margin16)
         const int sub = tid & 15, grp = tid >> 4;
-        for (int i0 = 0; i0 < l; i0 += 64) {
-            float acc[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = i0 + u * 16 + grp;
-                acc[u] = 0.0f;
-                if (i < l) {
-                    const float4 *x4 = (const float4 *)(xp + (int64_t)ids[ss + i] * dp);
-                    const float4 *h4 = (const float4 *)h;
-                    for (int c = sub; c < (dp >> 2); c += 16) {
-                        const float4 p = x4[c], q = h4[c];
-                        acc[u] += p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w;
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = i0 + u * 16 + grp;
-                const float a4 = nnd_group16_sum_f32(acc[u]);
-                if (i < l && sub == 0) {
-                    const float m = a4 * scale + off;
-                    uint8_t side;
-                    if (fabsf(m) < RP_EPS) side = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, gpos + (uint32_t)i, (uint32_t)dep) & 1u);
-                    else side = m > 0.0f ? 0 : 1;
-                    sd[i] = side;
-                }
+        for (int i0 = 0; i0 < l; i0 += 16) {
+            const int i = i0 + grp;
+            const bool live = i < l;
+            const int64_t pt = live ? ids[ss + i] : 0;
+            const float xnorm = live ? (metric == 0 ? sqrtf(nrm[pt]) : nrm[pt]) : 0.0f;
+            const float m = rp_margin16(xh + pt * dp, xp + pt * dp, h, dp, sub, xnorm, live);
+            if (live && sub == 0) {
+                uint8_t side;
+                if (fabsf(m) < RP_EPS) side = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, gpos + (uint32_t)i, (uint32_t)dep) & 1u);
+                else side = m > 0.0f ? 0 : 1;
+                sd[i] = side;
             }
         }
         __syncthreads();
@@ -590,12 +632,13 @@ int nnd_launch_forest(nnd_ctx *ctx) {
         // streaming every row once (it costs n rows regardless of how many positions are active)
         const bool fused = inv_live && (S * (int64_t)hs * 4 <= (int64_t)6 << 20) && (active_pos * 2 >= 3 * n);
         if (fused) {
-            hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, dp, n, T,
-                               ctx->inv, ctx->pos_seg[cur], ctx->hyper, hs, ctx->tree_seed, depth, ctx->side);
+            hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
+                               ctx->p.metric, dp, n, T, ctx->inv, ctx->pos_seg[cur], ctx->hyper, hs, ctx->tree_seed, depth, ctx->side);
         } else {
             inv_live = false;
-            hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, dp,
-                               ctx->perm[cur], ctx->pos_seg[cur], P, ctx->hyper, hs, ctx->tree_seed, depth, ctx->side);
+            hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
+                               ctx->p.metric, dp, ctx->perm[cur], ctx->pos_seg[cur], P, ctx->hyper, hs, ctx->tree_seed, depth,
+                               ctx->side);
         }
         if (run_scan(ctx, 0, ctx->pos_seg[cur], ctx->side, scan_total)) return 1;
         hipLaunchKernelGGL(k_seg_count, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, ctx->seg_start[cur],
@@ -635,8 +678,8 @@ int nnd_launch_forest(nnd_ctx *ctx) {
                                                   (int)fin_smem));
                 configured = true;
             }
-            hipLaunchKernelGGL(k_finish_subtrees, dim3((unsigned)nfin), dim3(256), fin_smem, ctx->stream, ctx->xp, dp,
-                               ctx->perm[cur], fin_start, fin_len, fin_depth, (int)nfin, angular, ctx->tree_seed, max_depth,
+            hipLaunchKernelGGL(k_finish_subtrees, dim3((unsigned)nfin), dim3(256), fin_smem, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
+                               ctx->p.metric, dp, ctx->perm[cur], fin_start, fin_len, fin_depth, (int)nfin, angular, ctx->tree_seed, max_depth,
                                leaf_size, ctx->leaf_flag);
             NND_HIP_CHECK(hipGetLastError());
         }

@@ -50,6 +50,7 @@ struct nnd_handle_s {
     bool x_owned = false;
     float *xp = nullptr;   // (n,dp) prepared rows: centred (euclid) or L2-normalised (cosine), zero padded
     float *nrm = nullptr;  // (n) |x-mu|^2 (euclid) or 1/0 non-zero flag (cosine)
+    uint16_t *xh = nullptr; // (n,dp) bf16 copy of xp: screening pass of the rp-forest margins (half the bytes)
     float *mean = nullptr; // (dp)
 
     // k-lists, rows ascending by (dist, idx)
