@@ -41,7 +41,7 @@ static void free_all(nnd_ctx *ctx) {
     };
     if (ctx->x_owned) F((void *)ctx->x_orig);
     F(ctx->xp); F(ctx->nrm); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->cand); F(ctx->rbuf); F(ctx->pbuf);
-    F(ctx->pdirty);
+    F(ctx->pdirty); F(ctx->active);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
     F(ctx->hyper); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->counters);
@@ -102,6 +102,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
         if ((rc = dalloc(ctx, &ctx->rbuf, n * 2 * ctx->rcap))) break;
         if ((rc = dalloc(ctx, &ctx->pbuf, n * ctx->pcap))) break;
         if ((rc = dalloc(ctx, &ctx->pdirty, n))) break;
+        if ((rc = dalloc(ctx, &ctx->active, n))) break;
         if ((rc = dalloc(ctx, &ctx->counters, (size_t)CNT_COUNT * NND_CNT_STRIPES))) break;
         if (hipMemset(ctx->pdirty, 0, n) != hipSuccess) { ctx->set_error("hipMemset failed"); rc = 1; break; }
         if (p->n_trees > 0) {

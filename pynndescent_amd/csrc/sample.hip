@@ -21,8 +21,13 @@
 #include "common.h"
 #include "state.h"
 
+// Two passes over the edges.  pass 0: NEW edges -- reverse offer into the target's "new" slots, and both endpoints are
+// marked active (they will hold at least one new candidate).  pass 1: OLD edges -- offered only to ACTIVE targets: a
+// vertex without new candidates does no join (utils.py:611-613), so its old list is never read; late iterations, where
+// almost every edge is old and almost every vertex inactive, then cost a scan instead of n*k atomics.
 __global__ void k_sample_reverse(const uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, uint32_t it_seed,
-                                 uint64_t *__restrict__ rbuf, int rcap, int64_t own_lo, int64_t own_hi) {
+                                 uint64_t *__restrict__ rbuf, int rcap, int64_t own_lo, int64_t own_hi, int pass,
+                                 uint8_t *__restrict__ active) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * ks) return;
     int64_t v = t / ks;
@@ -31,8 +36,12 @@ __global__ void k_sample_reverse(const uint32_t *__restrict__ knn_e, int64_t n, 
     uint32_t e = knn_e[t];
     if (e == NND_EMPTY_E) return;
     uint32_t u = e & NND_IDX_MASK;
-    if ((int64_t)u < own_lo || (int64_t)u >= own_hi) return;  // owner-computes: only targets this handle owns (utils.py:270-273)
     uint32_t cls = e >> 31;  // 1 = new
+    if (cls != (uint32_t)(pass == 0)) return;
+    if (pass == 0 && v >= own_lo && v < own_hi) active[v] = 1;  // forward new edge
+    if ((int64_t)u < own_lo || (int64_t)u >= own_hi) return;  // owner-computes: only targets this handle owns (utils.py:270-273)
+    if (pass == 0) active[u] = 1;
+    else if (!active[u]) return;
     uint32_t prio = nnd_hash3(it_seed, (uint32_t)v, u);
     uint32_t slot = nnd_hash2(it_seed ^ 0x68E31DA4u, (uint32_t)v) & (uint32_t)(rcap - 1);
     atomicMin((unsigned long long *)&rbuf[((int64_t)u * 2 + cls) * rcap + slot],
@@ -47,12 +56,17 @@ struct sample_scratch {
 
 __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
                                                        int mcp, uint32_t it_seed, uint64_t *__restrict__ rbuf, int rcap,
-                                                       int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi) {
+                                                       int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
+                                                       const uint8_t *__restrict__ active) {
     __shared__ sample_scratch scr[4];
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
     const int64_t v = own_lo + (int64_t)blockIdx.x * 4 + w;
     if (v >= own_hi) return;
     sample_scratch &sc = scr[w];
+    if (!active[v]) {  // no new candidate can reach v: empty new list, nothing else to do (no offers were stored for it)
+        for (int j = lane; j < mcp; j += 64) cand[v * 2 * mcp + j] = -1;
+        return;
+    }
 
     uint32_t e = NND_EMPTY_E;
     if (lane < k) e = knn_e[v * ks + lane];
@@ -121,11 +135,13 @@ int nnd_launch_sample(nnd_ctx *ctx) {
     const int64_t n = ctx->n;
     uint32_t it_seed = nnd_hash2(ctx->seed ^ 0x9E3779B9u, (uint32_t)ctx->iter + 1u);
     int64_t total = n * ctx->ks;
-    hipLaunchKernelGGL(k_sample_reverse, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e, n,
-                       ctx->k, ctx->ks, it_seed, ctx->rbuf, ctx->rcap, ctx->own_lo, ctx->own_hi);
+    NND_HIP_CHECK(hipMemsetAsync(ctx->active, 0, (size_t)n, ctx->stream));
+    for (int pass = 0; pass < 2; pass++)
+        hipLaunchKernelGGL(k_sample_reverse, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e, n,
+                           ctx->k, ctx->ks, it_seed, ctx->rbuf, ctx->rcap, ctx->own_lo, ctx->own_hi, pass, ctx->active);
     hipLaunchKernelGGL(k_sample_select, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream,
                        ctx->knn_e, n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand, ctx->own_lo,
-                       ctx->own_hi);
+                       ctx->own_hi, ctx->active);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

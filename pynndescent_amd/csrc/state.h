@@ -63,6 +63,7 @@ struct nnd_handle_s {
     uint64_t *rbuf = nullptr; // (n, 2, rcap) reverse offers (priority<<32 | source), hashed slots
     uint64_t *pbuf = nullptr; // (n, pcap) proposals (dist_bits<<32 | source), hashed slots
     uint8_t *pdirty = nullptr; // (n) 1 when the row has pending proposals
+    uint8_t *active = nullptr; // (n) 1 when the vertex will hold >= 1 new candidate this iteration
 
     // rp forest (all trees in one position space P = n_trees*n)
     int64_t P = 0;
