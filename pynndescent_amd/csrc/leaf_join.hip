@@ -130,12 +130,15 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
                     d0 = knn_d[v * ks + lane];
                 }
             }
-            accepted += nnd_merge_row_regs<(C::MP + 63) / 64>(knn_e + v * ks, knn_d + v * ks, th + v, e0, d0, k, m,
-                                                             [&](int c, uint32_t &id, float &dc) {
-                                                                 id = (uint32_t)ids[c];
-                                                                 dc = Drow[c];
-                                                                 return c != i;  // pynndescent_.py:97: p != q
-                                                             });
+            auto cf = [&](int c, uint32_t &id, float &dc) {
+                id = (uint32_t)ids[c];
+                dc = Drow[c];
+                return c != i;  // pynndescent_.py:97: p != q
+            };
+            if (C::MP > 64 && m <= 64)  // wave-uniform: one candidate per lane is enough for this leaf
+                accepted += nnd_merge_row_regs<1>(knn_e + v * ks, knn_d + v * ks, th + v, e0, d0, k, m, cf);
+            else
+                accepted += nnd_merge_row_regs<(C::MP + 63) / 64>(knn_e + v * ks, knn_d + v * ks, th + v, e0, d0, k, m, cf);
         }
     } else {
         float *Dw = big + w * 16 * C::DSTRIDE;

@@ -27,7 +27,14 @@ __device__ __forceinline__ uint64_t nnd_readlane_u64(uint64_t v, int src_lane) {
 // All 64 lanes of the wave call this with the same arguments.
 // cand(c, id, d) -> bool : candidate c of [0, ncand), ncand <= 64 * NCHUNK (ids unique inside the batch).
 // Returns the number of accepted candidates (same value on every lane).
-// Core: lane j < k already holds list entry j in (e, d) (lanes >= k hold EMPTY / +inf).
+// Core: lane j < k already holds list entry j in (e, d) (lanes >= k hold EMPTY / +inf; filled entries are packed
+// at the front of the row).
+//
+// The work is VALU instruction count (this routine is what bounds the leaf-seeding kernel), so every loop is sized
+// by what is actually there: the number of filled list entries, the number of candidates that survive the threshold;
+// and a batch much larger than k (first tree: every leaf-mate beats an empty row) is cut down to ~k + a few by a
+// sampled EXACT bound before the rank pass: a candidate with >= k keys at or below it among (batch U list) is an
+// upper bound of the final worst key, so everything above it can be dropped without changing the result.
 template <int NCHUNK, typename CandFn>
 __device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, float *__restrict__ row_d,
                                                   float *__restrict__ th_slot, uint32_t e, float d, int k, int ncand,
@@ -36,8 +43,10 @@ __device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, 
     const uint64_t mykey = (e == NND_EMPTY_E) ? NND_EMPTY_KEY : nnd_make_key(d, e);
     const uint32_t myidx = e & NND_IDX_MASK;  // 0x7FFFFFFF for empty slots: never a valid id
     const float th = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), k - 1));  // worst distance (+inf while not full)
+    const int nlist = __popcll(__ballot(e != NND_EMPTY_E));
 
-    uint64_t ckey[NCHUNK];
+    uint32_t cid[NCHUNK];
+    float cd[NCHUNK];
     unsigned long long cmask[NCHUNK];
     int nv = 0;
 #pragma unroll
@@ -49,21 +58,81 @@ __device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, 
         if (ch * 64 < ncand) {  // wave-uniform
             ok = (c < ncand) && cand(c, id, dc);
             ok = ok && (dc < th);  // strict, utils.py:484
-            for (int j = 0; j < k; j++)  // utils.py:489-492
-                ok = ok && ((uint32_t)__builtin_amdgcn_readlane((int)myidx, j) != id);
         }
-        ckey[ch] = ok ? nnd_make_key(dc, id) : NND_EMPTY_KEY;
+        cid[ch] = id;
+        cd[ch] = dc;
         cmask[ch] = __ballot(ok);
         nv += __popcll(cmask[ch]);
     }
     if (nv == 0) return 0;
 
-    // one pass over the accepted candidates: list entries count how many precede them,
-    // candidates count how many candidates precede them
+    // utils.py:489-492: drop candidates already in the row -- walk whichever side is shorter
+    if (nlist > 0) {
+        if (nv < nlist) {
+#pragma unroll
+            for (int ch = 0; ch < NCHUNK; ch++) {
+                unsigned long long m = cmask[ch];
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t ids = (uint32_t)__builtin_amdgcn_readlane((int)cid[ch], src);
+                    if (__ballot(myidx == ids)) cmask[ch] &= ~(1ull << src);
+                }
+            }
+        } else {
+            bool ok[NCHUNK];
+#pragma unroll
+            for (int ch = 0; ch < NCHUNK; ch++) ok[ch] = (cmask[ch] >> lane) & 1ull;
+            for (int j = 0; j < nlist; j++) {
+                const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)myidx, j);
+#pragma unroll
+                for (int ch = 0; ch < NCHUNK; ch++) ok[ch] = ok[ch] && (cid[ch] != idj);
+            }
+#pragma unroll
+            for (int ch = 0; ch < NCHUNK; ch++) cmask[ch] = __ballot(ok[ch]);
+        }
+        nv = 0;
+#pragma unroll
+        for (int ch = 0; ch < NCHUNK; ch++) nv += __popcll(cmask[ch]);
+        if (nv == 0) return 0;
+    }
+
+    uint64_t ckey[NCHUNK];
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ch++) ckey[ch] = ((cmask[ch] >> lane) & 1ull) ? nnd_make_key(cd[ch], cid[ch]) : NND_EMPTY_KEY;
+
+    // batch much larger than k: tighten with an exact sampled bound (see above)
+    if (nv > k + 12) {
+        uint64_t bound = NND_EMPTY_KEY;
+        unsigned long long m = cmask[0];
+        for (int t = 0; t < 16 && m; t++) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint64_t kc = nnd_readlane_u64(ckey[0], src);
+            int cnt = __popcll(__ballot(mykey <= kc));
+#pragma unroll
+            for (int ch = 0; ch < NCHUNK; ch++) cnt += __popcll(__ballot(ckey[ch] <= kc));
+            if (cnt >= k && kc < bound) bound = kc;
+        }
+        if (bound != NND_EMPTY_KEY) {
+            nv = 0;
+#pragma unroll
+            for (int ch = 0; ch < NCHUNK; ch++) {
+                if (ckey[ch] > bound) ckey[ch] = NND_EMPTY_KEY;
+                cmask[ch] = __ballot(ckey[ch] != NND_EMPTY_KEY);
+                nv += __popcll(cmask[ch]);
+            }
+        }
+    }
+
+    // rank pass over the surviving candidates: list entries count how many precede them (shift), candidates count
+    // how many candidates precede them; a short batch also picks up its list rank here (ballot), a long one in a
+    // second pass over the filled list entries
     int shift = 0;
     int rank[NCHUNK];
 #pragma unroll
     for (int ch = 0; ch < NCHUNK; ch++) rank[ch] = 0;
+    const bool fused = nv <= nlist;
 #pragma unroll
     for (int ch = 0; ch < NCHUNK; ch++) {
         unsigned long long m = cmask[ch];
@@ -71,19 +140,26 @@ __device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, 
             const int src = __builtin_ctzll(m);
             m &= m - 1;
             const uint64_t kc = nnd_readlane_u64(ckey[ch], src);
-            shift += (kc < mykey) ? 1 : 0;
+            const bool before = kc < mykey;
+            shift += before ? 1 : 0;
 #pragma unroll
             for (int c2 = 0; c2 < NCHUNK; c2++) rank[c2] += (kc < ckey[c2]) ? 1 : 0;
+            if (fused) {
+                // list keys are distinct from candidate keys (dedupe above), so #list < kc = nlist - #(kc < list)
+                const int below = nlist - __popcll(__ballot(before && lane < nlist));
+                if (lane == src) rank[ch] += below;
+            }
         }
     }
-    // one pass over the list: candidates count how many list entries precede them
-    for (int j = 0; j < k; j++) {
-        const uint64_t lj = nnd_readlane_u64(mykey, j);
+    if (!fused) {
+        for (int j = 0; j < nlist; j++) {
+            const uint64_t lj = nnd_readlane_u64(mykey, j);
 #pragma unroll
-        for (int c2 = 0; c2 < NCHUNK; c2++) rank[c2] += (lj < ckey[c2]) ? 1 : 0;
+            for (int c2 = 0; c2 < NCHUNK; c2++) rank[c2] += (lj < ckey[c2]) ? 1 : 0;
+        }
     }
     // every lane has read its own entry already; positions are a bijection, so plain stores suffice
-    if (lane < k && shift > 0 && lane + shift < k) {
+    if (lane < nlist && shift > 0 && lane + shift < k) {
         row_e[lane + shift] = e;
         row_d[lane + shift] = d;
         if (lane + shift == k - 1) *th_slot = d;  // new worst distance of the row
