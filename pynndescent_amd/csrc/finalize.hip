@@ -9,11 +9,16 @@
 #include "state.h"
 
 __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, int d, int metric, int64_t lo, int64_t n, int k, int ks,
-                                                  const uint32_t *__restrict__ knn_e, int32_t *__restrict__ out_idx,
-                                                  float *__restrict__ out_dist) {
+                                                  const uint32_t *__restrict__ knn_e, const int32_t *__restrict__ order,
+                                                  int32_t *__restrict__ out_idx, float *__restrict__ out_dist) {
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;  // owned rows [lo, n); output row index is v - lo
-    if (v >= n) return;
+    // rows are visited in `order` (spatially coherent, see nnd_vertex_order), one contiguous eighth per XCD, so the
+    // neighbour rows of concurrently running waves overlap in L2
+    int64_t b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int64_t g = lo + b * 4 + w;  // owned rows [lo, n); output row index is v - lo
+    if (g >= n) return;
+    const int64_t v = order ? (int64_t)order[g] : g;
     uint32_t e = lane < k ? knn_e[v * ks + lane] : NND_EMPTY_E;
     const float *xv = x + v * d;
     float mine = INFINITY;
@@ -64,8 +69,10 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, i
 }
 
 int nnd_launch_finalize(nnd_ctx *ctx, int32_t *out_idx_dev, float *out_dist_dev) {
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream, ctx->x_orig,
-                       ctx->d, ctx->p.metric, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, out_idx_dev, out_dist_dev);
+    unsigned grid = (unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4);
+    grid = (grid + 7u) & ~7u;  // whole multiples of the XCD count
+    hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, ctx->stream, ctx->x_orig, ctx->d, ctx->p.metric, ctx->own_lo,
+                       ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, nnd_vertex_order(ctx), out_idx_dev, out_dist_dev);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256, 2) void k_local_join(const float *__restrict__
 // stalls the other three.
 template <int DC, int KS16>
 __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
-                                                         int metric, const int32_t *__restrict__ cand, int64_t v_begin,
+                                                         int metric, const int32_t *__restrict__ cand,
+                                                         const int32_t *__restrict__ order, int64_t v_begin,
                                                          int64_t v_end, int k, int ks, const uint32_t *__restrict__ knn_e,
                                                          const float *__restrict__ th, uint64_t *__restrict__ pbuf,
                                                          uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed,
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
     constexpr int KQ = KS16 * 4;              // uint4 chunks per neighbour-list row
     constexpr int KQL = RV * KQ / 64;         // of which per lane
     constexpr int kls = KS16 * 16 + 4;        // padded neighbour-list row stride (words)
-    constexpr int WAVE_BYTES = RV * DC * 4 + 2 * RV * 4 + 2 * 4 + 3 * RV * 4 + RV * kls * 4 + 8;
+    constexpr int WAVE_BYTES = RV * DC * 4 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;
+    static_assert(RV * DC * 4 >= 8 * 64 * 8, "the pair queue (8 combos x 64 lanes x 8 bytes) reuses the row tile");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
@@ -293,33 +295,60 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
     int32_t *cid = nnewbuf + 2;                    // RV
     float *cnrm = (float *)(cid + RV);             // RV
     float *cth = cnrm + RV;                        // RV
-    uint32_t *klist = (uint32_t *)(cth + RV);      // RV * kls
+    uint32_t *cslot = (uint32_t *)(cth + RV);      // RV: proposal slot of each candidate id (hashed once per vertex)
+    uint32_t *cflag = cslot + RV;                  // RV: 1 when a proposal was stored for the row (-> pdirty)
+    uint32_t *klist = cflag + RV;                  // RV * kls
     const int kq = ks >> 2;
     const int cw0 = dp < DC ? dp : DC;
     const int nch0 = cw0 >> 2;
-    const int64_t n_v = v_end - v_begin;
-    const int64_t stride = (int64_t)gridDim.x * 4;
+    // Vertices are visited in `order` (the first tree's leaf order when there is a forest): vertices that are close
+    // in space run at the same time, and their candidate sets overlap heavily, so most row / neighbour-list gathers
+    // and proposal atomics of a window hit L2 instead of HBM.  Each XCD (own L2; workgroups are dealt round-robin to
+    // the 8 XCDs) walks its own contiguous eighth of the order.
+    int64_t n_v = v_end - v_begin;
+    int64_t g, stride;
+    if ((gridDim.x & 7) == 0) {
+        const int64_t per = (((n_v + 7) >> 3) + 3) & ~(int64_t)3;
+        const int64_t g0 = (int64_t)(blockIdx.x & 7) * per;
+        n_v = n_v < g0 + per ? n_v : g0 + per;  // this XCD's range is [g0, n_v)
+        g = g0 + (int64_t)(blockIdx.x >> 3) * 4 + w;
+        stride = (int64_t)(gridDim.x >> 3) * 4;
+    } else {
+        g = (int64_t)blockIdx.x * 4 + w;
+        stride = (int64_t)gridDim.x * 4;
+    }
 
     auto load_cand = [&](int64_t g) __attribute__((always_inline)) -> int {
         const int row = lane < RV ? lane : 0;
         const bool ok = lane < RV && g < n_v;
-        const int c = cand[ok ? (v_begin + g) * RV + row : 0];
+        const int64_t v = ok ? (order ? (int64_t)order[v_begin + g] : v_begin + g) : 0;
+        const int c = cand[v * RV + row];
         return ok ? c : -1;
     };
     auto store_cand = [&](int buf, int c) __attribute__((always_inline)) {
-        const unsigned long long m = __ballot(c >= 0 && lane < MCP);  // lists are filled from the front
+        const unsigned long long m = __ballot(c >= 0 && lane < RV);  // both lists are filled from the front
         if (lane < RV) cidbuf[buf * RV + lane] = c;
-        if (lane == 0) nnewbuf[buf] = __popcll(m);
+        if (lane == 0) nnewbuf[buf] = __popcll(m & 0xFFFFull) | (__popcll(m >> MCP) << 8);  // n_new | n_old << 8
     };
     f32x4 rowv[NLD];
     u32x4 klv[KQL];
     float nx_nrm = 0.0f, nx_th = 0.0f;
     int nx_id = -1;
+    // Only the filled part of each list is fetched and staged: load i of a lane covers rows [i*RPL, (i+1)*RPL), so the
+    // trip counts are wave-uniform (scalar branches, no exec masking).  Rows that are not staged keep stale LDS
+    // contents; the pairs they take part in are masked in the epilogue.
+    constexpr int RPL = 64 / NCH;             // rows per row-chunk load
+    constexpr int RPK = 64 / KQ;              // rows per neighbour-list load
+    auto slot_live = [&](int r0, int nn, int no) __attribute__((always_inline)) -> bool {
+        return nn > 0 && (cw0 != DC || (r0 < MCP ? r0 < nn : r0 - MCP < no));
+    };
     auto issue_gather = [&](int buf) __attribute__((always_inline)) {
         const int32_t *cb = cidbuf + buf * RV;
-        const bool on = nnewbuf[buf] > 0;
+        const int cnt = nnewbuf[buf], nn = cnt & 255, no = cnt >> 8;
+        const bool on = nn > 0;
 #pragma clang loop unroll(full)
         for (int i = 0; i < NLD; i++) {
+            if (!slot_live(i * RPL, nn, no)) continue;
             const int idx = lane + i * 64;
             int r, ch;
             if (cw0 == DC) { r = idx / NCH; ch = idx % NCH; } else { r = idx / nch0; ch = idx - r * nch0; }
@@ -336,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
         }
 #pragma clang loop unroll(full)
         for (int i = 0; i < KQL; i++) {
+            if (!slot_live(i * RPK, nn, no)) continue;
             const int idx = lane + i * 64;
             const int r = idx / KQ, c = idx % KQ;
             const int id = on ? cb[r] : -1;
@@ -345,8 +375,10 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
     };
     auto land_gather = [&](int buf) __attribute__((always_inline)) {
         const int32_t *cb = cidbuf + buf * RV;
+        const int cnt = nnewbuf[buf], nn = cnt & 255, no = cnt >> 8;
 #pragma clang loop unroll(full)
         for (int i = 0; i < NLD; i++) {
+            if (!slot_live(i * RPL, nn, no)) continue;
             const int idx = lane + i * 64;
             int r, ch;
             if (cw0 == DC) { r = idx / NCH; ch = idx % NCH; } else { r = idx / nch0; ch = idx - r * nch0; }
@@ -356,9 +388,12 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
             cid[lane] = nx_id;
             cnrm[lane] = nx_nrm;
             cth[lane] = nx_th;
+            cslot[lane] = nnd_hash2(slot_seed, (uint32_t)nx_id) & (uint32_t)(pcap - 1);
+            cflag[lane] = 0;
         }
 #pragma clang loop unroll(full)
         for (int i = 0; i < KQL; i++) {
+            if (!slot_live(i * RPK, nn, no)) continue;
             const int idx = lane + i * 64;
             const int r = idx / KQ, c = idx % KQ;
             const bool ok = c < kq && cb[r] >= 0;  // padding beyond k is EMPTY already
@@ -367,7 +402,6 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
         }
     };
 
-    int64_t g = (int64_t)blockIdx.x * 4 + w;
     store_cand(0, load_cand(g));
     store_cand(1, load_cand(g + stride));
     nnd_wave_lds_sync();
@@ -377,7 +411,8 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
     const int r16 = lane & 15, gq = lane >> 4;
     for (int it = 0; g < n_v; g += stride, it++) {
         const int cur = it & 1;
-        const int my_new = nnewbuf[cur];
+        const int my_cnt = nnewbuf[cur], my_new = my_cnt & 255;
+        const bool has_old = (my_cnt >> 8) > 0;
         if (my_new > 0) land_gather(cur);
         nnd_wave_lds_sync();
         if (g + stride < n_v) issue_gather(cur ^ 1);
@@ -391,42 +426,82 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
                     nnd_stage_rows<DC>(xp, dp, cid, RV, c0, cw, Xs, lane, 64);
                     nnd_wave_lds_sync();
                 }
-                nnd_gram_chunk<DC, 2>(Xs, 0, 0, cw, acc, [](int) { return true; });
+#ifdef NND_JOIN_NOGRAM
+                if (cw == 12345)
+#endif
+                if (has_old) nnd_gram_chunk<DC, 2>(Xs, 0, 0, cw, acc, [](int) { return true; });
+                else nnd_gram_chunk<DC, 1>(Xs, 0, 0, cw, *(f32x4(*)[1]) & acc[0], [](int) { return true; });
             }
+            // Epilogue in two steps.  (a) every lane screens its 8 pairs against the two thresholds and pushes the few
+            // that pass into a wave-private queue (the row tile is dead after the Gram); (b) the queue is drained 64
+            // entries at a time, so the neighbour-list membership tests and the atomics run on full waves instead of
+            // once per (tile, row) combination with a handful of live lanes -- past the first iteration only a few
+            // percent of the pairs get this far.
+            int pid4[4];
+            float pn4[4], pth4[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                pid4[r] = cid[4 * gq + r];
+                pn4[r] = cnrm[4 * gq + r];
+                pth4[r] = cth[4 * gq + r];
+            }
+            nnd_wave_lds_sync();  // all Gram operand reads of Xs are done
+            uint2 *queue = (uint2 *)Xs;
+            int qn = 0;
 #pragma unroll
             for (int J = 0; J < 2; J++) {
+                if (J == 1 && !has_old) break;  // first iteration: there are no old candidates at all
                 const int jj = J * 16 + r16;  // index inside [new | old]
                 const int qid = cid[jj];
-                const float qn = cnrm[jj], qth = cth[jj];
+                const float qn_ = cnrm[jj], qth = cth[jj];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int i = 4 * gq + r;  // index inside new
-                    const int pid = cid[i];
+                    const int pid = pid4[r];
                     const bool valid = pid >= 0 && qid >= 0 && (jj >= MCP || jj >= i);
-                    if (!valid) continue;
-                    tot_pairs++;
+                    tot_pairs += valid ? 1 : 0;
                     const bool self = (pid == qid);
-                    const float d = self ? 0.0f : nnd_gram_to_dist(metric, acc[J][r], cnrm[i], qn);
-                    const bool need_p = d < cth[i], need_q = !self && d < qth;
-                    if (!(need_p | need_q)) continue;
-                    const bool in_p = klist_has<KS16>(klist + i * kls, (uint32_t)qid);
-                    const bool in_q = klist_has<KS16>(klist + jj * kls, (uint32_t)pid);
-                    if (need_p && !in_p) {  // p <- q
-                        const uint32_t sl = nnd_hash2(slot_seed, (uint32_t)qid) & (uint32_t)(pcap - 1);
-                        atomicMin((unsigned long long *)&pbuf[(int64_t)pid * pcap + sl],
+                    const float d = self ? 0.0f : nnd_gram_to_dist(metric, acc[J][r], pn4[r], qn_);
+#ifdef NND_JOIN_NOEPI
+                    const bool need_p = valid && d == -12345.0f, need_q = false;
+#else
+                    const bool need_p = valid && d < pth4[r], need_q = valid && !self && d < qth;
+#endif
+                    const unsigned long long pm = __ballot(need_p | need_q);
+                    if (pm) {  // wave-uniform
+                        if (need_p | need_q) {
+                            const int off = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                            queue[off] = make_uint2((uint32_t)i | ((uint32_t)jj << 5) | (need_p ? 1024u : 0u) | (need_q ? 2048u : 0u),
+                                                    __float_as_uint(d));
+                        }
+                        qn += __popcll(pm);
+                    }
+                }
+            }
+            nnd_wave_lds_sync();
+            for (int base = 0; base < qn; base += 64) {
+                const int t = base + lane;
+                if (t < qn) {
+                    const uint2 en = queue[t];
+                    const int a = en.x & 31, b = (en.x >> 5) & 31;
+                    const float d = __uint_as_float(en.y);
+                    const int pid = cid[a], qid = cid[b];
+                    if ((en.x & 1024u) && !klist_has<KS16>(klist + a * kls, (uint32_t)qid)) {  // p <- q
+                        atomicMin((unsigned long long *)&pbuf[(int64_t)pid * pcap + cslot[b]],
                                   (unsigned long long)nnd_make_key(d, (uint32_t)qid));
-                        pdirty[pid] = 1;
+                        cflag[a] = 1;
                         tot_prop++;
                     }
-                    if (need_q && !in_q) {  // q <- p
-                        const uint32_t sl = nnd_hash2(slot_seed, (uint32_t)pid) & (uint32_t)(pcap - 1);
-                        atomicMin((unsigned long long *)&pbuf[(int64_t)qid * pcap + sl],
+                    if ((en.x & 2048u) && !klist_has<KS16>(klist + b * kls, (uint32_t)pid)) {  // q <- p
+                        atomicMin((unsigned long long *)&pbuf[(int64_t)qid * pcap + cslot[a]],
                                   (unsigned long long)nnd_make_key(d, (uint32_t)pid));
-                        pdirty[qid] = 1;
+                        cflag[b] = 1;
                         tot_prop++;
                     }
                 }
             }
+            nnd_wave_lds_sync();
+            if (lane < RV && cflag[lane]) pdirty[cid[lane]] = 1;
             if (lane < RV) tot_rows += cid[lane] >= 0;
             if (lane == 0) tot_act += 1;
         }
@@ -454,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
 template <int DC, int KS16>
 static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     constexpr int RV = 32, kls = KS16 * 16 + 4;
-    constexpr int WAVE_BYTES = RV * DC * 4 + 2 * RV * 4 + 2 * 4 + 3 * RV * 4 + RV * kls * 4 + 8;
+    constexpr int WAVE_BYTES = RV * DC * 4 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;
     size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
     auto kern = k_local_join16<DC, KS16>;
     static int wg_per_cu = 0, n_cu = 0;
@@ -471,9 +546,10 @@ static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     int64_t groups = (nv + 3) / 4;
     int64_t resident = (int64_t)n_cu * wg_per_cu;
     unsigned grid = (unsigned)(groups < resident ? groups : resident);
+    if (grid > 8) grid &= ~7u;  // whole multiples of the XCD count: every XCD walks its own slice of the order
     uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
-                       v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed,
+                       nnd_vertex_order(ctx), v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed,
                        ctx->counters);
     NND_HIP_CHECK(hipGetLastError());
     return 0;

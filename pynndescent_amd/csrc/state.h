@@ -122,3 +122,11 @@ int nnd_launch_diversify_csr(nnd_ctx *ctx, const int32_t *indptr_dev, const int3
 int nnd_launch_degree_prune(nnd_ctx *ctx, const int32_t *indptr_dev, float *data_dev, int max_degree);
 int nnd_read_counters(nnd_ctx *ctx);  // device -> ctx->h_counters (synchronises the stream)
 int nnd_zero_counters(nnd_ctx *ctx);
+
+// Visiting order for the vertex-parallel kernels (join, finalize): the first tree's leaf order -- a permutation of
+// [0, n) in which consecutive entries are close in space -- or nullptr (identity) when there is no forest or the
+// handle owns only a slice of the rows.
+static inline const int32_t *nnd_vertex_order(const nnd_ctx *ctx) {
+    if (!ctx->forest_built || ctx->p.n_trees <= 0 || ctx->own_lo != 0 || ctx->own_hi != ctx->n) return nullptr;
+    return ctx->perm[ctx->cur];
+}
