@@ -264,13 +264,19 @@ __global__ __launch_bounds__(256, 2) void k_local_join(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// max_candidates <= 16 (k <= 16: the BASELINE / UMAP regime): one WAVE per vertex, no workgroup barrier at
-// all.  Each wave owns a private LDS region ([new | old] = 32 rows), runs its own software pipeline
-// (gather of its next vertex in registers while the current vertex is on the MFMA pipe / in the epilogue)
-// and strides over the vertices independently, so a slow epilogue or a late gather in one wave never
-// stalls the other three.
+// max_candidates <= 16 (k <= 16: the BASELINE / UMAP regime): one WAVE per vertex, no workgroup barrier and no
+// LDS row tile at all.  One wave computes the whole [new] x [new | old] block, so nothing is shared between waves
+// and staging rows in LDS would be pure overhead: every lane loads its MFMA operands STRAIGHT from global memory
+// in MFMA layout -- lane (r16, g) holds 16-byte chunks 4t+g of candidate row r16 (new) and 16+r16 (old); the
+// new x new tile uses the same registers for both operands.  The register budget (<= 128) lets 4 waves share a
+// SIMD; LDS per wave is ~7.5 KB (ids, norms, thresholds, neighbour lists, the pair queue).  Right after the last
+// MFMA has consumed the row registers the gather of the wave's next vertex is issued into them, so it is in
+// flight during the whole epilogue.
+#ifndef NND_J16_WAVES
+#define NND_J16_WAVES 3
+#endif
 template <int DC, int KS16>
-__global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
+__global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
                                                          int metric, const int32_t *__restrict__ cand,
                                                          const int32_t *__restrict__ order, int64_t v_begin,
                                                          int64_t v_end, int k, int ks, const uint32_t *__restrict__ knn_e,
@@ -278,29 +284,28 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
                                                          uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed,
                                                          long long *__restrict__ counters) {
     constexpr int MCP = 16, RV = 32;          // rows per vertex: [new(16) | old(16)]
-    constexpr int NCH = DC / 4;               // 16-byte chunks per staged row
-    constexpr int NLD = RV * NCH / 64;        // row chunks per lane
+    constexpr int NT = DC / 16;               // 16-byte chunks per lane, row and K block
     constexpr int KQ = KS16 * 4;              // uint4 chunks per neighbour-list row
     constexpr int KQL = RV * KQ / 64;         // of which per lane
+    constexpr int RPK = 64 / KQ;              // rows per neighbour-list load
     constexpr int kls = KS16 * 16 + 4;        // padded neighbour-list row stride (words)
-    constexpr int WAVE_BYTES = RV * DC * 4 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;
-    static_assert(RV * DC * 4 >= 8 * 64 * 8, "the pair queue (8 combos x 64 lanes x 8 bytes) reuses the row tile");
+    constexpr int QCAP = 8 * 64;              // pair queue: 8 (tile, row) combinations x 64 lanes
+    constexpr int WAVE_BYTES = QCAP * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
     unsigned char *mine = smem + (size_t)w * ((WAVE_BYTES + 15) & ~15);
-    float *Xs = (float *)mine;                     // RV * DC floats
-    int32_t *cidbuf = (int32_t *)(Xs + RV * DC);   // 2 * RV
-    int32_t *nnewbuf = cidbuf + 2 * RV;            // 2
-    int32_t *cid = nnewbuf + 2;                    // RV
-    float *cnrm = (float *)(cid + RV);             // RV
-    float *cth = cnrm + RV;                        // RV
-    uint32_t *cslot = (uint32_t *)(cth + RV);      // RV: proposal slot of each candidate id (hashed once per vertex)
-    uint32_t *cflag = cslot + RV;                  // RV: 1 when a proposal was stored for the row (-> pdirty)
-    uint32_t *klist = cflag + RV;                  // RV * kls
+    uint2 *queue = (uint2 *)mine;                       // QCAP
+    int32_t *cidbuf = (int32_t *)(queue + QCAP);        // 2 * RV
+    int32_t *nnewbuf = cidbuf + 2 * RV;                 // 2
+    int32_t *cid = nnewbuf + 2;                         // RV
+    float *cnrm = (float *)(cid + RV);                  // RV
+    float *cth = cnrm + RV;                             // RV
+    uint32_t *cslot = (uint32_t *)(cth + RV);           // RV: proposal slot of each candidate id (hashed once per vertex)
+    uint32_t *cflag = cslot + RV;                       // RV: 1 when a proposal was stored for the row (-> pdirty)
+    uint32_t *klist = cflag + RV;                       // RV * kls
     const int kq = ks >> 2;
-    const int cw0 = dp < DC ? dp : DC;
-    const int nch0 = cw0 >> 2;
+    const int r16 = lane & 15, gq = lane >> 4;
     // Vertices are visited in `order` (the first tree's leaf order when there is a forest): vertices that are close
     // in space run at the same time, and their candidate sets overlap heavily, so most row / neighbour-list gathers
     // and proposal atomics of a window hit L2 instead of HBM.  Each XCD (own L2; workgroups are dealt round-robin to
@@ -330,45 +335,43 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
         if (lane < RV) cidbuf[buf * RV + lane] = c;
         if (lane == 0) nnewbuf[buf] = __popcll(m & 0xFFFFull) | (__popcll(m >> MCP) << 8);  // n_new | n_old << 8
     };
-    f32x4 rowv[NLD];
+    f32x4 ra[NT], rb[NT];  // this lane's chunks of its new row / its old row (one K block)
     u32x4 klv[KQL];
     float nx_nrm = 0.0f, nx_th = 0.0f;
     int nx_id = -1;
-    // Only the filled part of each list is fetched and staged: load i of a lane covers rows [i*RPL, (i+1)*RPL), so the
-    // trip counts are wave-uniform (scalar branches, no exec masking).  Rows that are not staged keep stale LDS
-    // contents; the pairs they take part in are masked in the epilogue.
-    constexpr int RPL = 64 / NCH;             // rows per row-chunk load
-    constexpr int RPK = 64 / KQ;              // rows per neighbour-list load
-    auto slot_live = [&](int r0, int nn, int no) __attribute__((always_inline)) -> bool {
-        return nn > 0 && (cw0 != DC || (r0 < MCP ? r0 < nn : r0 - MCP < no));
+    // rows of K block [c0, c0 + cw) of the vertex whose ids are in cb[]; empty slots read row 0 (cache hit, masked later)
+    auto load_rows = [&](const int32_t *cb, int c0, int cw, bool with_old) __attribute__((always_inline)) {
+        const int ida = cb[r16], idb = cb[MCP + r16];
+        const float *pa = xp + (int64_t)(ida >= 0 ? ida : 0) * dp + c0 + 4 * gq;
+        const float *pb = xp + (int64_t)(idb >= 0 ? idb : 0) * dp + c0 + 4 * gq;
+#pragma clang loop unroll(full)
+        for (int t = 0; t < NT; t++)
+            if (16 * t < cw) ra[t] = *(const f32x4 *)(pa + 16 * t);
+        if (with_old) {
+#pragma clang loop unroll(full)
+            for (int t = 0; t < NT; t++)
+                if (16 * t < cw) rb[t] = *(const f32x4 *)(pb + 16 * t);
+        }
     };
     auto issue_gather = [&](int buf) __attribute__((always_inline)) {
         const int32_t *cb = cidbuf + buf * RV;
         const int cnt = nnewbuf[buf], nn = cnt & 255, no = cnt >> 8;
-        const bool on = nn > 0;
-#pragma clang loop unroll(full)
-        for (int i = 0; i < NLD; i++) {
-            if (!slot_live(i * RPL, nn, no)) continue;
-            const int idx = lane + i * 64;
-            int r, ch;
-            if (cw0 == DC) { r = idx / NCH; ch = idx % NCH; } else { r = idx / nch0; ch = idx - r * nch0; }
-            const int rr = r < RV ? r : 0;
-            const int id = on ? cb[rr] : -1;
-            rowv[i] = *(const f32x4 *)(xp + (int64_t)(id >= 0 ? id : 0) * dp + 4 * ch);  // empty slot: row 0 (L2 hit), masked later
-        }
+        if (nn == 0) return;  // wave-uniform: the vertex has no new candidate, no join (utils.py:611-613)
+        load_rows(cb, 0, dp < DC ? dp : DC, no > 0);
         {
             const int row = lane < RV ? lane : 0;
-            nx_id = (lane < RV && on) ? cb[row] : -1;
+            nx_id = lane < RV ? cb[row] : -1;
             const int64_t ide = nx_id >= 0 ? nx_id : 0;
             nx_nrm = nrm[ide];
             nx_th = th[ide];  // compact per-row worst distance (L2 resident), not a 128-byte line per candidate
         }
 #pragma clang loop unroll(full)
         for (int i = 0; i < KQL; i++) {
-            if (!slot_live(i * RPK, nn, no)) continue;
+            const int r0 = i * RPK;  // neighbour lists of the filled slots only (wave-uniform trip counts)
+            if (!(r0 < MCP ? r0 < nn : r0 - MCP < no)) continue;
             const int idx = lane + i * 64;
             const int r = idx / KQ, c = idx % KQ;
-            const int id = on ? cb[r] : -1;
+            const int id = cb[r];
             const bool ok = c < kq && id >= 0;
             klv[i] = *(const u32x4 *)(knn_e + (ok ? (int64_t)id * ks + 4 * c : 0));  // raw; masked when it lands
         }
@@ -376,14 +379,6 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
     auto land_gather = [&](int buf) __attribute__((always_inline)) {
         const int32_t *cb = cidbuf + buf * RV;
         const int cnt = nnewbuf[buf], nn = cnt & 255, no = cnt >> 8;
-#pragma clang loop unroll(full)
-        for (int i = 0; i < NLD; i++) {
-            if (!slot_live(i * RPL, nn, no)) continue;
-            const int idx = lane + i * 64;
-            int r, ch;
-            if (cw0 == DC) { r = idx / NCH; ch = idx % NCH; } else { r = idx / nch0; ch = idx - r * nch0; }
-            if (r < RV) *(f32x4 *)&Xs[nnd_swz<DC>(r, ch)] = rowv[i];
-        }
         if (lane < RV) {
             cid[lane] = nx_id;
             cnrm[lane] = nx_nrm;
@@ -393,7 +388,8 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
         }
 #pragma clang loop unroll(full)
         for (int i = 0; i < KQL; i++) {
-            if (!slot_live(i * RPK, nn, no)) continue;
+            const int r0 = i * RPK;
+            if (!(r0 < MCP ? r0 < nn : r0 - MCP < no)) continue;
             const int idx = lane + i * 64;
             const int r = idx / KQ, c = idx % KQ;
             const bool ok = c < kq && cb[r] >= 0;  // padding beyond k is EMPTY already
@@ -408,35 +404,48 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
     issue_gather(0);
 
     int tot_pairs = 0, tot_prop = 0, tot_rows = 0, tot_act = 0;
-    const int r16 = lane & 15, gq = lane >> 4;
     for (int it = 0; g < n_v; g += stride, it++) {
         const int cur = it & 1;
         const int my_cnt = nnewbuf[cur], my_new = my_cnt & 255;
         const bool has_old = (my_cnt >> 8) > 0;
-        if (my_new > 0) land_gather(cur);
-        nnd_wave_lds_sync();
-        if (g + stride < n_v) issue_gather(cur ^ 1);
         const int c2 = load_cand(g + 2 * stride);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         if (my_new > 0) {
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            land_gather(cur);
+            nnd_wave_lds_sync();
             for (int c0 = 0; c0 < dp; c0 += DC) {
                 const int cw = (dp - c0) < DC ? (dp - c0) : DC;
-                if (c0 > 0) {  // rows wider than one LDS chunk: remaining chunks staged synchronously by this wave
-                    nnd_wave_lds_sync();
-                    nnd_stage_rows<DC>(xp, dp, cid, RV, c0, cw, Xs, lane, 64);
-                    nnd_wave_lds_sync();
+                if (c0 > 0) load_rows(cid, c0, cw, has_old);  // rows wider than one K block: the rest is fetched in turn
+#ifndef NND_JOIN_NOGRAM
+#pragma clang loop unroll(full)
+                for (int t = 0; t < NT; t++) {
+                    if (16 * t >= cw) continue;
+                    if (has_old) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].x, ra[t].x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].x, rb[t].x, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].y, ra[t].y, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].y, rb[t].y, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].z, ra[t].z, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].z, rb[t].z, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].w, ra[t].w, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].w, rb[t].w, acc[1], 0, 0, 0);
+                    } else {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].x, ra[t].x, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].y, ra[t].y, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].z, ra[t].z, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t].w, ra[t].w, acc[0], 0, 0, 0);
+                    }
                 }
-#ifdef NND_JOIN_NOGRAM
-                if (cw == 12345)
 #endif
-                if (has_old) nnd_gram_chunk<DC, 2>(Xs, 0, 0, cw, acc, [](int) { return true; });
-                else nnd_gram_chunk<DC, 1>(Xs, 0, 0, cw, *(f32x4(*)[1]) & acc[0], [](int) { return true; });
             }
+        }
+        // the row registers are free: the gather of this wave's next vertex flies during the epilogue
+        if (g + stride < n_v) issue_gather(cur ^ 1);
+        if (my_new > 0) {
             // Epilogue in two steps.  (a) every lane screens its 8 pairs against the two thresholds and pushes the few
-            // that pass into a wave-private queue (the row tile is dead after the Gram); (b) the queue is drained 64
-            // entries at a time, so the neighbour-list membership tests and the atomics run on full waves instead of
-            // once per (tile, row) combination with a handful of live lanes -- past the first iteration only a few
-            // percent of the pairs get this far.
+            // that pass into a wave-private queue; (b) the queue is drained 64 entries at a time, so the neighbour-list
+            // membership tests and the atomics run on full waves instead of once per (tile, row) combination with a
+            // handful of live lanes -- past the first iteration only a few percent of the pairs get this far.
             int pid4[4];
             float pn4[4], pth4[4];
 #pragma unroll
@@ -445,8 +454,6 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
                 pn4[r] = cnrm[4 * gq + r];
                 pth4[r] = cth[4 * gq + r];
             }
-            nnd_wave_lds_sync();  // all Gram operand reads of Xs are done
-            uint2 *queue = (uint2 *)Xs;
             int qn = 0;
 #pragma unroll
             for (int J = 0; J < 2; J++) {
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void k_local_join16(const float *__restrict
 template <int DC, int KS16>
 static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     constexpr int RV = 32, kls = KS16 * 16 + 4;
-    constexpr int WAVE_BYTES = RV * DC * 4 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;
+    constexpr int WAVE_BYTES = 8 * 64 * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;
     size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
     auto kern = k_local_join16<DC, KS16>;
     static int wg_per_cu = 0, n_cu = 0;
@@ -603,7 +610,10 @@ int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     if (v_end <= v_begin) return 0;
     const bool wide = ctx->dp >= 128;
     switch (ctx->mcp) {
-        case 16: return wide ? launch_join16_ks<128>(ctx, v_begin, v_end) : launch_join16_ks<32>(ctx, v_begin, v_end);
+#ifndef NND_J16_DCW
+#define NND_J16_DCW 64
+#endif
+        case 16: return wide ? launch_join16_ks<NND_J16_DCW>(ctx, v_begin, v_end) : launch_join16_ks<32>(ctx, v_begin, v_end);
         case 32: return wide ? launch_join_ks<32, 128>(ctx, v_begin, v_end) : launch_join_ks<32, 32>(ctx, v_begin, v_end);
         case 64: return wide ? launch_join_ks<64, 128>(ctx, v_begin, v_end) : launch_join_ks<64, 32>(ctx, v_begin, v_end);
     }
