@@ -8,6 +8,16 @@
 #include "common.h"
 #include "state.h"
 
+// sum over the 16 lanes of an aligned 16-lane group
+__device__ __forceinline__ double fin_group16_sum_f64(double v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One wave per row.  The 64 lanes work as 4 groups of 16: group g takes neighbours g, 4+g, 8+g, ... so four distances
+// are accumulated side by side and up to 16 neighbour rows are in flight per wave (the gather is latency bound when
+// the rows are fetched one after another).
 __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, int d, int metric, int64_t lo, int64_t n, int k, int ks,
                                                   const uint32_t *__restrict__ knn_e, const int32_t *__restrict__ order,
                                                   int32_t *__restrict__ out_idx, float *__restrict__ out_dist) {
@@ -21,38 +31,75 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, i
     const int64_t v = order ? (int64_t)order[g] : g;
     uint32_t e = lane < k ? knn_e[v * ks + lane] : NND_EMPTY_E;
     const float *xv = x + v * d;
+    const int grp = lane >> 4, l16 = lane & 15;
+    const bool vec = (d & 3) == 0;  // rows 16-byte aligned
     float mine = INFINITY;
-    for (int j = 0; j < k; j++) {
-        uint32_t ej = __shfl(e, j, 64);
-        if (ej == NND_EMPTY_E) continue;  // wave-uniform
-        const float *xu = x + (int64_t)(ej & NND_IDX_MASK) * d;
-        float val;
-        if (metric == 0) {
-            double s = 0.0;
-            for (int t = lane; t < d; t += 64) {
-                double df = (double)xv[t] - (double)xu[t];
-                s += df * df;
+    const int nsteps = (k + 3) >> 2;
+    for (int s0 = 0; s0 < nsteps; s0 += 4) {
+        const float *xu[4];
+        bool on[4];
+        double s[4], dot[4], nx[4], ny[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = 4 * (s0 + u) + grp;
+            const uint32_t ej = __shfl(e, j & 63, 64);
+            on[u] = j < k && ej != NND_EMPTY_E;
+            xu[u] = x + (int64_t)(on[u] ? (ej & NND_IDX_MASK) : 0) * d;
+            s[u] = dot[u] = nx[u] = ny[u] = 0.0;
+        }
+        if (vec) {
+            for (int t = 4 * l16; t < d; t += 64) {
+                const float4 a = *(const float4 *)(xv + t);
+                float4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) q[u] = *(const float4 *)(xu[u] + t);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const double a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w;
+                    const double b0 = q[u].x, b1 = q[u].y, b2 = q[u].z, b3 = q[u].w;
+                    if (metric == 0) {
+                        s[u] += (a0 - b0) * (a0 - b0) + (a1 - b1) * (a1 - b1) + (a2 - b2) * (a2 - b2) + (a3 - b3) * (a3 - b3);
+                    } else {
+                        dot[u] += a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3;
+                        nx[u] += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+                        ny[u] += b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
+                    }
+                }
             }
-            val = (float)nnd_wave_sum_f64(s);
         } else {
-            double dot = 0.0, nx = 0.0, ny = 0.0;
-            for (int t = lane; t < d; t += 64) {
-                double a = xv[t], b = xu[t];
-                dot += a * b;
-                nx += a * a;
-                ny += b * b;
-            }
-            dot = nnd_wave_sum_f64(dot);
-            nx = nnd_wave_sum_f64(nx);
-            ny = nnd_wave_sum_f64(ny);
-            if (nx == 0.0 && ny == 0.0) val = 0.0f;
-            else if (nx == 0.0 || ny == 0.0 || dot <= 0.0) val = NND_FLT_MAX;
-            else {
-                double r = log2(sqrt(nx * ny) / dot);
-                val = r > 0.0 ? (float)r : 0.0f;
+            for (int t = l16; t < d; t += 16) {
+                const double a0 = xv[t];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const double b0 = xu[u][t];
+                    if (metric == 0) s[u] += (a0 - b0) * (a0 - b0);
+                    else {
+                        dot[u] += a0 * b0;
+                        nx[u] += a0 * a0;
+                        ny[u] += b0 * b0;
+                    }
+                }
             }
         }
-        if (lane == j) mine = val;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float val;
+            if (metric == 0) {
+                val = (float)fin_group16_sum_f64(s[u]);
+            } else {
+                const double dt = fin_group16_sum_f64(dot[u]), ax = fin_group16_sum_f64(nx[u]), ay = fin_group16_sum_f64(ny[u]);
+                if (ax == 0.0 && ay == 0.0) val = 0.0f;
+                else if (ax == 0.0 || ay == 0.0 || dt <= 0.0) val = NND_FLT_MAX;
+                else {
+                    const double r = log2(sqrt(ax * ay) / dt);
+                    val = r > 0.0 ? (float)r : 0.0f;
+                }
+            }
+            if (!on[u]) val = INFINITY;
+            // neighbour j = 4 * (s0 + u) + group: lane j takes it from (any lane of) group j & 3
+            const float got = __shfl(val, 16 * (lane & 3), 64);
+            if ((lane >> 2) == s0 + u) mine = got;
+        }
     }
     // rank by (distance, index); empty entries are (+inf, 0x7FFFFFFF) and land at the tail
     const uint32_t myidx = e == NND_EMPTY_E ? NND_IDX_MASK : (e & NND_IDX_MASK);
