@@ -532,6 +532,7 @@ extern "C" int32_t nnd_export_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t h
     return 0;
 }
 extern "C" int32_t nnd_import_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, const uint32_t *e_src_dev, const float *d_src_dev) {
+    if (ctx) ctx->all_new = false;  // imported rows may carry cleared flags
     ENTER(ctx);
     size_t cnt = (size_t)(hi - lo) * ctx->ks;
     API_HIP(hipMemcpyAsync(ctx->knn_e + lo * ctx->ks, e_src_dev, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
@@ -556,6 +557,7 @@ extern "C" int32_t nnd_import_thresholds(nnd_handle_t ctx, int64_t lo, int64_t h
     return 0;
 }
 extern "C" int32_t nnd_merge_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, const uint32_t *e_src_dev, const float *d_src_dev) {
+    if (ctx) ctx->all_new = false;  // imported rows may carry cleared flags
     ENTER(ctx);
     if (nnd_launch_merge_graph_rows(ctx, lo, hi, e_src_dev, d_src_dev)) return 1;
     API_HIP(hipStreamSynchronize(ctx->stream));

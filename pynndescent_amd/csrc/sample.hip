@@ -25,15 +25,19 @@
 // marked active (they will hold at least one new candidate).  pass 1: OLD edges -- offered only to ACTIVE targets: a
 // vertex without new candidates does no join (utils.py:611-613), so its old list is never read; late iterations, where
 // almost every edge is old and almost every vertex inactive, then cost a scan instead of n*k atomics.
-__global__ void k_sample_reverse(const uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, uint32_t it_seed,
-                                 uint64_t *__restrict__ rbuf, int rcap, int64_t own_lo, int64_t own_hi, int pass,
-                                 uint8_t *__restrict__ active) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * ks) return;
-    int64_t v = t / ks;
-    int j = (int)(t - v * ks);
-    if (j >= k) return;
-    uint32_t e = knn_e[t];
+// Thread layout: blockDim = (KSP, 256 / KSP) with KSP = the row stride rounded up to a power of two, x = slot, y = row:
+// no division per edge.  Rows are visited in `order` (spatially coherent, one contiguous eighth per XCD): the targets
+// of a window of rows are each other's neighbours, so the offers of a window land in a few slot banks that stay in L2.
+__global__ __launch_bounds__(256) void k_sample_reverse(const uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, uint32_t it_seed,
+                                                        uint64_t *__restrict__ rbuf, int rcap, int64_t own_lo, int64_t own_hi, int pass,
+                                                        uint8_t *__restrict__ active, const int32_t *__restrict__ order) {
+    int64_t b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int64_t g = b * blockDim.y + threadIdx.y;
+    const int j = threadIdx.x;
+    if (g >= n || j >= k) return;
+    const int64_t v = order ? (int64_t)order[g] : g;
+    uint32_t e = knn_e[v * ks + j];
     if (e == NND_EMPTY_E) return;
     uint32_t u = e & NND_IDX_MASK;
     uint32_t cls = e >> 31;  // 1 = new
@@ -134,11 +138,21 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
 int nnd_launch_sample(nnd_ctx *ctx) {
     const int64_t n = ctx->n;
     uint32_t it_seed = nnd_hash2(ctx->seed ^ 0x9E3779B9u, (uint32_t)ctx->iter + 1u);
-    int64_t total = n * ctx->ks;
     NND_HIP_CHECK(hipMemsetAsync(ctx->active, 0, (size_t)n, ctx->stream));
-    for (int pass = 0; pass < 2; pass++)
-        hipLaunchKernelGGL(k_sample_reverse, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e, n,
-                           ctx->k, ctx->ks, it_seed, ctx->rbuf, ctx->rcap, ctx->own_lo, ctx->own_hi, pass, ctx->active);
+    int ksp = 16;
+    while (ksp < ctx->ks) ksp <<= 1;
+    const int rows = 256 / ksp;
+    unsigned grid = (unsigned)((n + rows - 1) / rows);
+    grid = (grid + 7u) & ~7u;  // whole multiples of the XCD count
+    // the spatial order is a permutation of ALL rows: usable whenever there is a forest (the edge scan covers every row
+    // of the graph, also on a handle that owns only a slice of the targets)
+    const int32_t *order = (ctx->forest_built && ctx->p.n_trees > 0) ? ctx->perm[ctx->cur] : nullptr;
+    // every edge still carries the "new" flag before the first sampling pass: there are no old edges to offer
+    const int n_pass = ctx->all_new ? 1 : 2;
+    for (int pass = 0; pass < n_pass; pass++)
+        hipLaunchKernelGGL(k_sample_reverse, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->knn_e, n, ctx->k, ctx->ks,
+                           it_seed, ctx->rbuf, ctx->rcap, ctx->own_lo, ctx->own_hi, pass, ctx->active, order);
+    ctx->all_new = false;
     hipLaunchKernelGGL(k_sample_select, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream,
                        ctx->knn_e, n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand, ctx->own_lo,
                        ctx->own_hi, ctx->active);

@@ -84,6 +84,7 @@ struct nnd_handle_s {
     int32_t max_leaf = 0;
     std::vector<int64_t> tree_leaf_begin; // per tree: first leaf index (host)
     bool forest_built = false;
+    bool all_new = false;  // every edge of the graph still carries the "new" flag (true from reset until the first sampling pass)
 
     long long *counters = nullptr;      // device NND_CNT_STRIPES x CNT_COUNT (stripe 0 doubles as scratch for single-block kernels)
     long long h_counters[CNT_COUNT] = {0};
