@@ -56,31 +56,73 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
     const int nt = (m + 15) >> 4;
     const int mp = nt << 4;
 
-    for (int r = tid; r < C::MP; r += NW * 64) {
-        int id = r < m ? perm[start + r] : -1;
-        ids[r] = id;
-        nrs[r] = id >= 0 ? nrm[id] : 0.0f;
-    }
+    for (int r = tid; r < C::MP; r += NW * 64) ids[r] = r < m ? perm[start + r] : -1;
     __syncthreads();
 
+    // One burst of global loads once the ids are known: the rows of the first K block (registers, then LDS), the
+    // norms, and -- when they fit the register budget -- the k-lists of all m points, which are only needed after the
+    // Gram.  A leaf then pays one exposed memory latency instead of three.
+    constexpr int NTHR = NW * 64;
+    constexpr int NLD = (C::MP * (DC / 4) + NTHR - 1) / NTHR;  // 16-byte row chunks per thread
+    constexpr int NKL = (C::MP * 16 + NTHR - 1) / NTHR;        // k-list words per thread (row stride <= 16)
+    const bool use_pre = C::PREFETCH && ks <= 16 && (m * ks * 2 <= C::BIG_FLOATS - C::DB_FLOATS);
+    float *Xs = big;
+    uint32_t pe[NKL];
+    float pd[NKL];
     f32x4 acc[C::TR][NT];
 #pragma unroll
     for (int tr = 0; tr < C::TR; tr++)
 #pragma unroll
         for (int J = 0; J < NT; J++) acc[tr][J] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float *Xs = big;
     for (int c0 = 0; c0 < dp; c0 += DC) {
         const int cw = (dp - c0) < DC ? (dp - c0) : DC;
-        nnd_stage_rows<DC>(xp, dp, ids, mp, c0, cw, Xs, tid, NW * 64);
+        {
+            const int nch = cw >> 2, total = mp * nch;
+            f32x4 rv[NLD];
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                // unconditional (clamped) loads: a conditionally assigned register array costs whole-array copies
+                const int idx = tid + q * NTHR, idc = idx < total ? idx : 0;
+                const int r = idc / nch, ch = idc - r * nch;
+                const int id = ids[r];
+                rv[q] = *(const f32x4 *)(xp + (int64_t)(id >= 0 ? id : 0) * dp + c0 + 4 * ch);  // rows >= m: row 0, never used
+            }
+            float my_nrm = 0.0f;
+            if (c0 == 0) {
+                if (tid < C::MP) {
+                    const int id = ids[tid];
+                    my_nrm = nrm[id >= 0 ? id : 0];
+                }
+                if (use_pre) {
+#pragma unroll
+                    for (int q = 0; q < NKL; q++) {
+                        const int idx = tid + q * NTHR, idc = idx < m * ks ? idx : 0;
+                        const int i = idc / ks, j = idc - i * ks;
+                        pe[q] = knn_e[(int64_t)ids[i] * ks + j];
+                        pd[q] = knn_d[(int64_t)ids[i] * ks + j];
+                    }
+                }
+            }
+            if (c0 > 0) __syncthreads();  // the previous block's operand reads are done
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                const int idx = tid + q * NTHR;
+                if (idx < total) {
+                    const int r = idx / nch, ch = idx - r * nch;
+                    *(f32x4 *)&Xs[nnd_swz<DC>(r, ch)] = rv[q];
+                }
+            }
+            if (c0 == 0 && tid < C::MP) nrs[tid] = my_nrm;
+        }
         __syncthreads();
 #pragma unroll
         for (int tr = 0; tr < C::TR; tr++) {
             const int I = w + tr * NW;
             if (I < nt) nnd_gram_chunk<DC, NT>(Xs, I * 16, 0, cw, acc[tr], [nt](int J) { return J < nt; });
         }
-        __syncthreads();  // Xs is overwritten by the next chunk / by the distance blocks below
     }
+    __syncthreads();  // Xs is overwritten by the distance blocks below
 
     // distances -> LDS, then every row is merged into its point's k-list by one wave
     const int r16 = lane & 15, g = lane >> 4;
@@ -104,15 +146,17 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
                 }
             }
         }
-        // the k-lists of all m points in one memory round trip (this workgroup owns them for this tree)
-        const bool use_pre = (m * ks * 2 <= C::BIG_FLOATS - C::DB_FLOATS);
+        // the k-lists fetched with the rows (this workgroup owns them for this tree) land next to the distance block
         uint32_t *pre_e = (uint32_t *)(big + C::DB_FLOATS);
         float *pre_d = big + C::DB_FLOATS + m * ks;
         if (use_pre) {
-            for (int idx = tid; idx < m * k; idx += NW * 64) {
-                const int i = idx / k, j = idx - i * k;
-                pre_e[i * ks + j] = knn_e[(int64_t)ids[i] * ks + j];
-                pre_d[i * ks + j] = knn_d[(int64_t)ids[i] * ks + j];
+#pragma unroll
+            for (int q = 0; q < NKL; q++) {
+                const int idx = tid + q * NTHR;
+                if (idx < m * ks) {
+                    pre_e[idx] = pe[q];
+                    pre_d[idx] = pd[q];
+                }
             }
         }
         __syncthreads();
@@ -236,6 +280,8 @@ int nnd_launch_leaf_init(nnd_ctx *ctx) {
                   ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters
         if (maxlen <= 64)
             hipLaunchKernelGGL((k_leaf_join<4, 4, 128>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 80)  // the default leaf_size (<= 75 points): 36 KB of LDS, 4 workgroups per CU
+            hipLaunchKernelGGL((k_leaf_join<5, 4, 64>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 96)
             hipLaunchKernelGGL((k_leaf_join<6, 4, 128>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 128)
