@@ -43,8 +43,8 @@ static void free_all(nnd_ctx *ctx) {
     F(ctx->xp); F(ctx->nrm); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->cand); F(ctx->rbuf); F(ctx->pbuf);
     F(ctx->pdirty); F(ctx->active);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
-    F(ctx->inv); F(ctx->side); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
-    F(ctx->hyper); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->counters);
+    F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
+    F(ctx->hyper); F(ctx->hyper_h); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -119,12 +119,14 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
             if (rc) break;
             if ((rc = dalloc(ctx, &ctx->inv, P))) break;
             if ((rc = dalloc(ctx, &ctx->side, P))) break;
+            if ((rc = dalloc(ctx, &ctx->side_pt, P))) break;
             if ((rc = dalloc(ctx, &ctx->leaf_flag, P))) break;
             if ((rc = dalloc(ctx, &ctx->scan_out, P + 1))) break;
             if ((rc = dalloc(ctx, &ctx->scan_blk, P / 2048 + 2))) break;
             if ((rc = dalloc(ctx, &ctx->seg_nleft, S))) break;
             if ((rc = dalloc(ctx, &ctx->seg_child, 5 * S))) break;  // child ids (2S) + finisher work list (3S)
             if ((rc = dalloc(ctx, &ctx->hyper, S * (size_t)(ctx->dp + 4)))) break;
+            if ((rc = dalloc(ctx, &ctx->hyper_h, S * (size_t)ctx->dp))) break;
         }
     } while (0);
     if (rc) {

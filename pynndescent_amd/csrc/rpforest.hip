@@ -43,7 +43,7 @@ __global__ void k_forest_init(int32_t *__restrict__ perm, int32_t *__restrict__ 
     int64_t t = g / n;
     int64_t i = g - t * n;
     perm[g] = (int32_t)i;
-    inv[g] = (int32_t)g;
+    inv[g] = splittable ? (int32_t)t : -1;  // point-major: segment of point i in tree t (here: the root)
     pos_seg[g] = splittable ? (int32_t)t : -1;
     leaf_flag[g] = (!splittable && i == 0) ? 1 : 0;
 }
@@ -63,7 +63,8 @@ __global__ void k_forest_init_segs(int32_t *__restrict__ seg_start, int32_t *__r
 __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp, int dp, const int32_t *__restrict__ perm,
                                                     const int32_t *__restrict__ seg_start,
                                                     const int32_t *__restrict__ seg_len, int n_segs, int angular,
-                                                    uint32_t seed, int depth, float *__restrict__ hyper, int hs) {
+                                                    uint32_t seed, int depth, float *__restrict__ hyper, int hs,
+                                                    uint16_t *__restrict__ hyper_h) {
     int lane = nnd_lane();
     int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (s >= n_segs) return;
@@ -74,11 +75,13 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
     const float *xl = xp + (int64_t)perm[a + li] * dp;
     const float *xr = xp + (int64_t)perm[a + ri] * dp;
     float *h = hyper + (int64_t)s * hs;
+    uint16_t *hb = hyper_h + (int64_t)s * dp;  // bf16 copy read by the screening pass of the margin kernels
     float acc = 0.0f, sq = 0.0f;
     for (int j = lane; j < dp; j += 64) {
         float l = xl[j], r = xr[j];
         float v = l - r;
         h[j] = v;
+        if (!angular) hb[j] = nnd_f32_to_bf16(v);
         acc += angular ? v * v : v * (l + r);
         sq += v * v;
     }
@@ -87,7 +90,11 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
     if (angular) {
         float nh = sqrtf(acc);
         float inv = nh < RP_EPS ? 1.0f : 1.0f / nh;  // rp_trees.py:113-118
-        for (int j = lane; j < dp; j += 64) h[j] *= inv;
+        for (int j = lane; j < dp; j += 64) {
+            const float v = h[j] * inv;
+            h[j] = v;
+            hb[j] = nnd_f32_to_bf16(v);
+        }
         if (lane == 0) {
             h[dp] = 0.0f;
             h[dp + 1] = nh * inv;  // |h| after normalisation (1, or |h| itself when degenerate)
@@ -105,7 +112,43 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
 // than twice that bound its SIGN is already the f32 sign and the f32 row is never touched.  The (rare) points
 // inside the band are recomputed from the f32 row, so the split is exactly the f32 split.
 __device__ __forceinline__ float rp_margin16(const uint16_t *__restrict__ xh_row, const float *__restrict__ xf_row,
-                                             const float *__restrict__ h, int dp, int sub, float xnorm, bool live) {
+                                             const float *__restrict__ h, const uint16_t *__restrict__ hb, int dp, int sub,
+                                             float xnorm, bool live) {
+    float acc = 0.0f;
+    if (live) {
+        const uint4 *x8 = (const uint4 *)xh_row;  // 8 bf16 per 16-byte chunk
+        const uint4 *h8 = (const uint4 *)hb;
+        for (int c = sub; c < (dp >> 3); c += 16) {
+            const uint4 q = x8[c], p = h8[c];
+            acc += __uint_as_float(q.x << 16) * __uint_as_float(p.x << 16) + __uint_as_float(q.x & 0xFFFF0000u) * __uint_as_float(p.x & 0xFFFF0000u) +
+                   __uint_as_float(q.y << 16) * __uint_as_float(p.y << 16) + __uint_as_float(q.y & 0xFFFF0000u) * __uint_as_float(p.y & 0xFFFF0000u) +
+                   __uint_as_float(q.z << 16) * __uint_as_float(p.z << 16) + __uint_as_float(q.z & 0xFFFF0000u) * __uint_as_float(p.z & 0xFFFF0000u) +
+                   __uint_as_float(q.w << 16) * __uint_as_float(p.w << 16) + __uint_as_float(q.w & 0xFFFF0000u) * __uint_as_float(p.w & 0xFFFF0000u);
+        }
+    }
+    acc = nnd_group16_sum_f32(acc);
+    const float off = live ? h[dp] : 0.0f, hnorm = live ? h[dp + 1] : 0.0f;
+    float m = acc + off;
+    // both operands are round-to-nearest bf16 (relative error <= 2^-9 each): |m_bf16 - m_f32| <= ~2^-8 |h||x|; the
+    // band is twice that
+    const float band = 0.0078125f * hnorm * xnorm + 1e-30f;
+    if (live && !(fabsf(m) > band)) {  // uniform inside the 16-lane group
+        float acc2 = 0.0f;
+        const float4 *x4 = (const float4 *)xf_row;
+        const float4 *h4 = (const float4 *)h;
+        for (int c = sub; c < (dp >> 2); c += 16) {
+            const float4 a = x4[c], b = h4[c];
+            acc2 += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        acc2 = nnd_group16_sum_f32(acc2);
+        m = acc2 + off;
+    }
+    return m;
+}
+
+// same screen with the hyperplane in f32 (the subtree finisher keeps it in LDS, where its size does not matter)
+__device__ __forceinline__ float rp_margin16_f32h(const uint16_t *__restrict__ xh_row, const float *__restrict__ xf_row,
+                                                  const float *__restrict__ h, int dp, int sub, float xnorm, bool live) {
     float acc = 0.0f;
     if (live) {
         const uint4 *x8 = (const uint4 *)xh_row;  // 8 bf16 per 16-byte chunk
@@ -140,8 +183,9 @@ __device__ __forceinline__ float rp_margin16(const uint16_t *__restrict__ xh_row
 __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
                                                 const float *__restrict__ nrm, int metric, int dp,
                                                 const int32_t *__restrict__ perm, const int32_t *__restrict__ pos_seg,
-                                                int64_t P, const float *__restrict__ hyper, int hs, uint32_t seed,
-                                                int depth, uint8_t *__restrict__ side) {
+                                                int64_t P, const float *__restrict__ hyper, int hs,
+                                                const uint16_t *__restrict__ hyper_h, uint32_t seed, int depth,
+                                                uint8_t *__restrict__ side) {
     int sub = threadIdx.x & 15;
     int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     bool live = g < P;
@@ -149,7 +193,8 @@ __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, co
     live = s >= 0;
     const int64_t pt = live ? perm[g] : 0;
     const float xnorm = live ? (metric == 0 ? sqrtf(nrm[pt]) : nrm[pt]) : 0.0f;
-    const float m = rp_margin16(xh + pt * dp, xp + pt * dp, hyper + (int64_t)(live ? s : 0) * hs, dp, sub, xnorm, live);
+    const float m = rp_margin16(xh + pt * dp, xp + pt * dp, hyper + (int64_t)(live ? s : 0) * hs,
+                                hyper_h + (int64_t)(live ? s : 0) * dp, dp, sub, xnorm, live);
     if (live && sub == 0) {
         uint8_t sd;
         if (fabsf(m) < RP_EPS) sd = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)g, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
@@ -158,36 +203,37 @@ __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, co
     }
 }
 
-// point-major variant: one pass over the points serves every tree (rows read once per level)
+// point-major variant: one pass over the points serves every tree (rows read once per level).  Everything it touches
+// is point-major too -- seg_pt[t*n + i] = the point's segment in tree t (-1 once its segment is final), the side goes
+// to side_pt[t*n + i] -- so apart from the hyperplane look-ups (a table that sits in L2) all its traffic is sequential.
+// The scan that follows brings the sides into position order (k_scan_reduce mode 2).
 __global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
                                                       const float *__restrict__ nrm, int metric, int dp, int64_t n,
-                                                      int n_trees, const int32_t *__restrict__ inv,
-                                                      const int32_t *__restrict__ pos_seg,
-                                                      const float *__restrict__ hyper, int hs, uint32_t seed, int depth,
-                                                      uint8_t *__restrict__ side) {
+                                                      int n_trees, const int32_t *__restrict__ seg_pt,
+                                                      const float *__restrict__ hyper, int hs,
+                                                      const uint16_t *__restrict__ hyper_h, uint32_t seed, int depth,
+                                                      uint8_t *__restrict__ side_pt) {
     const int sub = threadIdx.x & 15;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     const bool in = i < n;
     const int64_t pt = in ? i : 0;
     const float xnorm = in ? (metric == 0 ? sqrtf(nrm[pt]) : nrm[pt]) : 0.0f;
-    // trees in batches of 4: the position and segment look-ups of a batch are independent loads issued together,
-    // so a point pays one dependent (inv -> pos_seg -> hyperplane) latency per batch instead of one per tree
+    // trees in batches of 4: the segment look-ups of a batch are independent loads issued together
     for (int t0 = 0; t0 < n_trees; t0 += 4) {
-        int64_t g[4];
         int sg[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) g[u] = (in && t0 + u < n_trees) ? (int64_t)inv[(int64_t)(t0 + u) * n + i] : -1;
-#pragma unroll
-        for (int u = 0; u < 4; u++) sg[u] = g[u] >= 0 ? pos_seg[g[u]] : -1;
+        for (int u = 0; u < 4; u++) sg[u] = (in && t0 + u < n_trees) ? seg_pt[(int64_t)(t0 + u) * n + i] : -1;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const bool live = sg[u] >= 0;
-            const float m = rp_margin16(xh + pt * dp, xp + pt * dp, hyper + (int64_t)(live ? sg[u] : 0) * hs, dp, sub, xnorm, live);
+            const float m = rp_margin16(xh + pt * dp, xp + pt * dp, hyper + (int64_t)(live ? sg[u] : 0) * hs,
+                                        hyper_h + (int64_t)(live ? sg[u] : 0) * dp, dp, sub, xnorm, live);
             if (live && sub == 0) {
+                const int64_t slot = (int64_t)(t0 + u) * n + i;
                 uint8_t sd;
-                if (fabsf(m) < RP_EPS) sd = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)g[u], (uint32_t)depth) & 1u);
+                if (fabsf(m) < RP_EPS) sd = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)slot, (uint32_t)depth) & 1u);
                 else sd = m > 0.0f ? 0 : 1;
-                side[g[u]] = sd;
+                side_pt[slot] = sd;
             }
         }
     }
@@ -201,14 +247,31 @@ __device__ __forceinline__ int scan_flag(int mode, const int32_t *pos_seg, const
     return bytes[g] ? 1 : 0;
 }
 
+// mode 2 = mode 0 after a point-major margin pass: the side of position g is side_pt[tree(g)*n + perm[g]]; it is
+// gathered here once and stored to bytes[g] (position order), which k_scan_apply and k_scatter then read as in mode 0.
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(int mode, const int32_t *__restrict__ pos_seg,
-                                                            const uint8_t *__restrict__ bytes, int64_t P,
-                                                            int32_t *__restrict__ blk) {
+                                                            uint8_t *__restrict__ bytes, int64_t P,
+                                                            int32_t *__restrict__ blk, const int32_t *__restrict__ perm,
+                                                            const uint8_t *__restrict__ side_pt, int64_t n) {
     __shared__ int wsum[SCAN_BLOCK / 64];
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int s = 0;
+    if (mode == 2) {
+        int64_t tb = base < P ? (base / n) * n : 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) s += scan_flag(mode, pos_seg, bytes, base + i, P);
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            const int64_t g = base + i;
+            if (g < P && pos_seg[g] >= 0) {
+                if (g >= tb + n) tb += n;
+                const uint8_t sd = side_pt[tb + perm[g]];
+                bytes[g] = sd;
+                s += sd == 0;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) s += scan_flag(mode, pos_seg, bytes, base + i, P);
+    }
     s = nnd_wave_sum_i32(s);
     if (nnd_lane() == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -394,7 +457,7 @@ __global__ void k_scatter(const int32_t *__restrict__ perm, const int32_t *__res
     int32_t p = perm[g];
     perm_out[dest] = p;
     pos_seg_out[dest] = seg_child[2 * s + right];
-    if (inv) inv[(g / n) * n + p] = (int32_t)dest;
+    if (inv) inv[(g / n) * n + p] = seg_child[2 * s + right];  // point-major segment table of the next level
 }
 
 // ------------------------------------------------------------ subtree finisher --
@@ -489,7 +552,7 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
             const bool live = i < l;
             const int64_t pt = live ? ids[ss + i] : 0;
             const float xnorm = live ? (metric == 0 ? sqrtf(nrm[pt]) : nrm[pt]) : 0.0f;
-            const float m = rp_margin16(xh + pt * dp, xp + pt * dp, h, dp, sub, xnorm, live);
+            const float m = rp_margin16_f32h(xh + pt * dp, xp + pt * dp, h, dp, sub, xnorm, live);
             if (live && sub == 0) {
                 uint8_t side;
                 if (fabsf(m) < RP_EPS) side = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, gpos + (uint32_t)i, (uint32_t)dep) & 1u);
@@ -565,13 +628,15 @@ __global__ void k_fill_leaf_array(const int32_t *__restrict__ perm, const int32_
 }
 
 // -------------------------------------------------------------- host side --
-static int run_scan(nnd_ctx *ctx, int mode, const int32_t *pos_seg, const uint8_t *bytes, int32_t *total_dev) {
+static int run_scan(nnd_ctx *ctx, int mode, const int32_t *pos_seg, uint8_t *bytes, int32_t *total_dev,
+                    const int32_t *perm = nullptr) {
     int64_t P = ctx->P;
     int nb = (int)((P + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, mode, pos_seg, bytes, P, ctx->scan_blk);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, mode, pos_seg, bytes, P, ctx->scan_blk, perm,
+                       ctx->side_pt, ctx->n);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->scan_blk, nb, total_dev);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, mode, pos_seg, bytes, P, ctx->scan_blk,
-                       ctx->scan_out);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, mode == 2 ? 0 : mode, pos_seg, bytes, P,
+                       ctx->scan_blk, ctx->scan_out);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -627,20 +692,20 @@ int nnd_launch_forest(nnd_ctx *ctx) {
         }
         hipLaunchKernelGGL(k_hyperplane, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, dp,
                            ctx->perm[cur], ctx->seg_start[cur], ctx->seg_len[cur], (int)S, angular, ctx->tree_seed, depth,
-                           ctx->hyper, hs);
+                           ctx->hyper, hs, ctx->hyper_h);
         // point-major pass: hyperplane table fits in L2 AND enough positions are still active to amortise
         // streaming every row once (it costs n rows regardless of how many positions are active)
-        const bool fused = inv_live && (S * (int64_t)hs * 4 <= (int64_t)6 << 20) && (active_pos * 2 >= 3 * n);
+        const bool fused = inv_live && (S * (int64_t)dp * 2 <= (int64_t)6 << 20) && (active_pos * 2 >= 3 * n);
         if (fused) {
             hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
-                               ctx->p.metric, dp, n, T, ctx->inv, ctx->pos_seg[cur], ctx->hyper, hs, ctx->tree_seed, depth, ctx->side);
+                               ctx->p.metric, dp, n, T, ctx->inv, ctx->hyper, hs, ctx->hyper_h, ctx->tree_seed, depth, ctx->side_pt);
         } else {
             inv_live = false;
             hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
-                               ctx->p.metric, dp, ctx->perm[cur], ctx->pos_seg[cur], P, ctx->hyper, hs, ctx->tree_seed, depth,
+                               ctx->p.metric, dp, ctx->perm[cur], ctx->pos_seg[cur], P, ctx->hyper, hs, ctx->hyper_h, ctx->tree_seed, depth,
                                ctx->side);
         }
-        if (run_scan(ctx, 0, ctx->pos_seg[cur], ctx->side, scan_total)) return 1;
+        if (run_scan(ctx, fused ? 2 : 0, ctx->pos_seg[cur], ctx->side, scan_total, ctx->perm[cur])) return 1;
         hipLaunchKernelGGL(k_seg_count, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, ctx->seg_start[cur],
                            ctx->seg_len[cur], (int)S, ctx->scan_out, scan_total, P, ctx->seg_nleft);
         int child_can_split = (max_depth - (depth + 1)) > 0 ? 1 : 0;

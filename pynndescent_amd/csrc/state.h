@@ -71,12 +71,14 @@ struct nnd_handle_s {
     int32_t *pos_seg[2] = {nullptr, nullptr}; // active segment index per position or -1
     int32_t *inv = nullptr;                   // (P) position of point i in tree t (top, point-major levels)
     uint8_t *side = nullptr;                  // (P) 0 left / 1 right
+    uint8_t *side_pt = nullptr;               // (P) the same, point-major [tree][point] (written by the fused margin pass)
     uint8_t *leaf_flag = nullptr;             // (P) 1 at the first position of every final leaf
     int32_t *scan_out = nullptr;              // (P) exclusive scan scratch
     int32_t *scan_blk = nullptr;              // block sums
     int32_t *seg_start[2] = {nullptr, nullptr}, *seg_len[2] = {nullptr, nullptr};
     int32_t *seg_nleft = nullptr, *seg_child = nullptr; // per active segment scratch
     float *hyper = nullptr;                   // (max_segs, dp+?) hyperplane + offset
+    uint16_t *hyper_h = nullptr;              // (max_segs, dp) bf16 copy of the normals (screening pass)
     int64_t max_segs = 0;
     int cur = 0; // which ping-pong half holds the finished permutation
     int32_t *leaf_start = nullptr, *leaf_len = nullptr; // (n_leaves) after the forest is done
