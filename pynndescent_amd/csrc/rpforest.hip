@@ -106,101 +106,79 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
 }
 
 // ---------------------------------------------------------------- margin --
-// margin = h . x + off for one point, computed by the 16 lanes of a group (all 16 enter together).
-// Screening pass: the row is read from the bf16 copy (half the bytes).  bf16 rounding moves each product by at
-// most 2^-8 relative, so |margin_bf16 - margin_f32| <= 2^-8 |h| |x|; if the screened margin is further from zero
-// than twice that bound its SIGN is already the f32 sign and the f32 row is never touched.  The (rare) points
-// inside the band are recomputed from the f32 row, so the split is exactly the f32 split.
-__device__ __forceinline__ float rp_margin16(const uint16_t *__restrict__ xh_row, const float *__restrict__ xf_row,
-                                             const float *__restrict__ h, const uint16_t *__restrict__ hb, int dp, int sub,
-                                             float xnorm, bool live) {
+// margin = h . x + off for one point, computed by the 4 lanes of a quad (lane `sub` takes the 16-byte chunks
+// sub, sub+4, ... of the row, i.e. 64 contiguous bytes per 4-chunk step).
+// Screening pass: row AND hyperplane are read from their bf16 copies (half the bytes) and multiplied with the packed
+// v_dot2_f32_bf16 (two products per instruction, no conversions).  Round-to-nearest bf16 moves each operand by at
+// most 2^-9 relative, so |margin_bf16 - margin_f32| <= ~2^-8 |h||x|; if the screened margin is further from zero than
+// twice that bound its SIGN is already the f32 sign and the f32 row is never touched.  The (rare) points inside the
+// band are recomputed from the f32 row and the f32 hyperplane, so the split is exactly the f32 split.
+typedef __attribute__((ext_vector_type(2))) __bf16 rp_bf16x2;
+__device__ __forceinline__ float rp_dot8(uint4 q, uint4 p, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2, q.x), __builtin_bit_cast(rp_bf16x2, p.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2, q.y), __builtin_bit_cast(rp_bf16x2, p.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2, q.z), __builtin_bit_cast(rp_bf16x2, p.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2, q.w), __builtin_bit_cast(rp_bf16x2, p.w), acc, false);
+    return acc;
+}
+// sum over the 4 lanes of an aligned quad (DPP quad permutes; every lane ends with the same value)
+__device__ __forceinline__ float rp_quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+    return v;
+}
+// exact f32 margin (without the offset) of one point by its quad
+__device__ __forceinline__ float rp_exact_quad(const float *__restrict__ xf_row, const float *h, int dp, int sub) {
     float acc = 0.0f;
-    if (live) {
-        const uint4 *x8 = (const uint4 *)xh_row;  // 8 bf16 per 16-byte chunk
-        const uint4 *h8 = (const uint4 *)hb;
-        for (int c = sub; c < (dp >> 3); c += 16) {
-            const uint4 q = x8[c], p = h8[c];
-            acc += __uint_as_float(q.x << 16) * __uint_as_float(p.x << 16) + __uint_as_float(q.x & 0xFFFF0000u) * __uint_as_float(p.x & 0xFFFF0000u) +
-                   __uint_as_float(q.y << 16) * __uint_as_float(p.y << 16) + __uint_as_float(q.y & 0xFFFF0000u) * __uint_as_float(p.y & 0xFFFF0000u) +
-                   __uint_as_float(q.z << 16) * __uint_as_float(p.z << 16) + __uint_as_float(q.z & 0xFFFF0000u) * __uint_as_float(p.z & 0xFFFF0000u) +
-                   __uint_as_float(q.w << 16) * __uint_as_float(p.w << 16) + __uint_as_float(q.w & 0xFFFF0000u) * __uint_as_float(p.w & 0xFFFF0000u);
-        }
+    const float4 *x4 = (const float4 *)xf_row;
+    const float4 *h4 = (const float4 *)h;
+    for (int c = sub; c < (dp >> 2); c += 4) {
+        const float4 a = x4[c], b = h4[c];
+        acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
     }
-    acc = nnd_group16_sum_f32(acc);
-    const float off = live ? h[dp] : 0.0f, hnorm = live ? h[dp + 1] : 0.0f;
-    float m = acc + off;
-    // both operands are round-to-nearest bf16 (relative error <= 2^-9 each): |m_bf16 - m_f32| <= ~2^-8 |h||x|; the
-    // band is twice that
-    const float band = 0.0078125f * hnorm * xnorm + 1e-30f;
-    if (live && !(fabsf(m) > band)) {  // uniform inside the 16-lane group
-        float acc2 = 0.0f;
-        const float4 *x4 = (const float4 *)xf_row;
-        const float4 *h4 = (const float4 *)h;
-        for (int c = sub; c < (dp >> 2); c += 16) {
-            const float4 a = x4[c], b = h4[c];
-            acc2 += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-        }
-        acc2 = nnd_group16_sum_f32(acc2);
-        m = acc2 + off;
-    }
-    return m;
+    return rp_quad_sum(acc);
+}
+// side of the split from a screened margin; `key` feeds the coin flip of rp_trees.py:380-385
+__device__ __forceinline__ uint8_t rp_side(float m, float band, const float *__restrict__ xf_row, const float *h, float off,
+                                           int dp, int sub, uint32_t seed, uint32_t key, int depth) {
+    if (!(fabsf(m) > band)) m = rp_exact_quad(xf_row, h, dp, sub) + off;  // uniform inside the quad
+    if (fabsf(m) < RP_EPS) return (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, key, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
+    return m > 0.0f ? 0 : 1;                                                                              // rp_trees.py:386-391
 }
 
-// same screen with the hyperplane in f32 (the subtree finisher keeps it in LDS, where its size does not matter)
-__device__ __forceinline__ float rp_margin16_f32h(const uint16_t *__restrict__ xh_row, const float *__restrict__ xf_row,
-                                                  const float *__restrict__ h, int dp, int sub, float xnorm, bool live) {
-    float acc = 0.0f;
-    if (live) {
-        const uint4 *x8 = (const uint4 *)xh_row;  // 8 bf16 per 16-byte chunk
-        const float4 *h4 = (const float4 *)h;
-        for (int c = sub; c < (dp >> 3); c += 16) {
-            const uint4 q = x8[c];
-            const float4 a = h4[2 * c], b = h4[2 * c + 1];
-            acc += __uint_as_float(q.x << 16) * a.x + __uint_as_float(q.x & 0xFFFF0000u) * a.y +
-                   __uint_as_float(q.y << 16) * a.z + __uint_as_float(q.y & 0xFFFF0000u) * a.w +
-                   __uint_as_float(q.z << 16) * b.x + __uint_as_float(q.z & 0xFFFF0000u) * b.y +
-                   __uint_as_float(q.w << 16) * b.z + __uint_as_float(q.w & 0xFFFF0000u) * b.w;
-        }
-    }
-    acc = nnd_group16_sum_f32(acc);
-    const float off = live ? h[dp] : 0.0f, hnorm = live ? h[dp + 1] : 0.0f;
-    float m = acc + off;
-    const float band = 0.0078125f * hnorm * xnorm + 1e-30f;  // 2 * 2^-8 |h||x|
-    if (live && !(fabsf(m) > band)) {  // uniform inside the 16-lane group
-        float acc2 = 0.0f;
-        const float4 *x4 = (const float4 *)xf_row;
-        const float4 *h4 = (const float4 *)h;
-        for (int c = sub; c < (dp >> 2); c += 16) {
-            const float4 a = x4[c], b = h4[c];
-            acc2 += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-        }
-        acc2 = nnd_group16_sum_f32(acc2);
-        m = acc2 + off;
-    }
-    return m;
-}
-
+// position-major: neighbouring positions share a hyperplane; rows are gathered through perm
 __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
                                                 const float *__restrict__ nrm, int metric, int dp,
                                                 const int32_t *__restrict__ perm, const int32_t *__restrict__ pos_seg,
                                                 int64_t P, const float *__restrict__ hyper, int hs,
                                                 const uint16_t *__restrict__ hyper_h, uint32_t seed, int depth,
                                                 uint8_t *__restrict__ side) {
-    int sub = threadIdx.x & 15;
-    int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
-    bool live = g < P;
-    int s = live ? pos_seg[g] : -1;
-    live = s >= 0;
-    const int64_t pt = live ? perm[g] : 0;
-    const float xnorm = live ? (metric == 0 ? sqrtf(nrm[pt]) : nrm[pt]) : 0.0f;
-    const float m = rp_margin16(xh + pt * dp, xp + pt * dp, hyper + (int64_t)(live ? s : 0) * hs,
-                                hyper_h + (int64_t)(live ? s : 0) * dp, dp, sub, xnorm, live);
-    if (live && sub == 0) {
-        uint8_t sd;
-        if (fabsf(m) < RP_EPS) sd = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)g, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
-        else sd = m > 0.0f ? 0 : 1;                                                                                // rp_trees.py:386-391
-        side[g] = sd;
+    const int sub = threadIdx.x & 3;
+    const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
+    const int s = g < P ? pos_seg[g] : -1;
+    if (s < 0) return;  // whole quad
+    const int64_t pt = perm[g];
+    const uint4 *x8 = (const uint4 *)(xh + pt * dp);
+    const uint4 *h8 = (const uint4 *)(hyper_h + (int64_t)s * dp);
+    const float *h = hyper + (int64_t)s * hs;
+    const float xn = nrm[pt], off = h[dp], hnorm = h[dp + 1];
+    float acc = 0.0f;
+    for (int c = sub; c < (dp >> 3); c += 16) {  // 4 chunks per lane and step: the 8 loads are issued together
+        uint4 q[4], p[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int cc = c + 4 * j < (dp >> 3) ? c + 4 * j : c;
+            q[j] = x8[cc];
+            p[j] = h8[cc];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (c + 4 * j < (dp >> 3)) acc = rp_dot8(q[j], p[j], acc);
     }
+    const float m = rp_quad_sum(acc) + off;
+    const float band = 0.0078125f * hnorm * (metric == 0 ? sqrtf(xn) : xn) + 1e-30f;  // 2 * 2^-8 |h||x|
+    const uint8_t sd = rp_side(m, band, xp + pt * dp, h, off, dp, sub, seed, (uint32_t)g, depth);
+    if (sub == 0) side[g] = sd;
 }
 
 // point-major variant: one pass over the points serves every tree (rows read once per level).  Everything it touches
@@ -213,28 +191,48 @@ __global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ 
                                                       const float *__restrict__ hyper, int hs,
                                                       const uint16_t *__restrict__ hyper_h, uint32_t seed, int depth,
                                                       uint8_t *__restrict__ side_pt) {
-    const int sub = threadIdx.x & 15;
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
-    const bool in = i < n;
-    const int64_t pt = in ? i : 0;
-    const float xnorm = in ? (metric == 0 ? sqrtf(nrm[pt]) : nrm[pt]) : 0.0f;
-    // trees in batches of 4: the segment look-ups of a batch are independent loads issued together
+    const int sub = threadIdx.x & 3;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
+    if (i >= n) return;  // whole quad
+    const uint4 *x8 = (const uint4 *)(xh + i * dp);
+    const float xn = nrm[i];
+    const float xnorm = metric == 0 ? sqrtf(xn) : xn;
+    const int nch = dp >> 3;
+    // trees in batches of 4: segment ids, then hyperplane chunks of the whole batch, are independent loads issued together
     for (int t0 = 0; t0 < n_trees; t0 += 4) {
         int sg[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) sg[u] = (in && t0 + u < n_trees) ? seg_pt[(int64_t)(t0 + u) * n + i] : -1;
+        float acc[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const bool live = sg[u] >= 0;
-            const float m = rp_margin16(xh + pt * dp, xp + pt * dp, hyper + (int64_t)(live ? sg[u] : 0) * hs,
-                                        hyper_h + (int64_t)(live ? sg[u] : 0) * dp, dp, sub, xnorm, live);
-            if (live && sub == 0) {
-                const int64_t slot = (int64_t)(t0 + u) * n + i;
-                uint8_t sd;
-                if (fabsf(m) < RP_EPS) sd = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)slot, (uint32_t)depth) & 1u);
-                else sd = m > 0.0f ? 0 : 1;
-                side_pt[slot] = sd;
+            sg[u] = t0 + u < n_trees ? seg_pt[(int64_t)(t0 + u) * n + i] : -1;
+            acc[u] = 0.0f;
+        }
+        if (sg[0] < 0 && sg[1] < 0 && sg[2] < 0 && sg[3] < 0) continue;  // whole quad
+        for (int c = sub; c < nch; c += 16) {
+            uint4 q[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) q[j] = x8[c + 4 * j < nch ? c + 4 * j : c];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint4 *h8 = (const uint4 *)(hyper_h + (int64_t)(sg[u] >= 0 ? sg[u] : 0) * dp);
+                uint4 p[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) p[j] = h8[c + 4 * j < nch ? c + 4 * j : c];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (c + 4 * j < nch) acc[u] = rp_dot8(q[j], p[j], acc[u]);
             }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (sg[u] < 0) continue;  // whole quad
+            const float *h = hyper + (int64_t)sg[u] * hs;
+            const float off = h[dp], hnorm = h[dp + 1];
+            const float m = rp_quad_sum(acc[u]) + off;
+            const float band = 0.0078125f * hnorm * xnorm + 1e-30f;
+            const int64_t slot = (int64_t)(t0 + u) * n + i;
+            const uint8_t sd = rp_side(m, band, xp + i * dp, h, off, dp, sub, seed, (uint32_t)slot, depth);
+            if (sub == 0) side_pt[slot] = sd;
         }
     }
 }
@@ -485,7 +483,8 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
     int32_t *tmp = ids + FIN_MAX;                  // FIN_MAX (partition scratch)
     uint8_t *sd = (uint8_t *)(tmp + FIN_MAX);      // FIN_MAX side bits
     float *h = (float *)(sd + FIN_MAX);            // dp + 4 hyperplane + offset
-    int32_t *stk = (int32_t *)(h + dp + 4);        // FIN_STACK * 3: (start, len, depth)
+    uint16_t *hb = (uint16_t *)(h + dp + 4);       // dp: bf16 copy of the normal (dp is a multiple of 32)
+    int32_t *stk = (int32_t *)(hb + dp);           // FIN_STACK * 3: (start, len, depth)
     int32_t *wsum = stk + FIN_STACK * 3;           // 8: per-wave partial sums / scalars
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
     const int s = blockIdx.x;
@@ -545,19 +544,47 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
             h[dp + 1] = sqrtf(totsq);
         }
         __syncthreads();
-        // margins: 16 lanes per member (bf16-screened, see rp_margin16)
-        const int sub = tid & 15, grp = tid >> 4;
-        for (int i0 = 0; i0 < l; i0 += 16) {
-            const int i = i0 + grp;
-            const bool live = i < l;
-            const int64_t pt = live ? ids[ss + i] : 0;
-            const float xnorm = live ? (metric == 0 ? sqrtf(nrm[pt]) : nrm[pt]) : 0.0f;
-            const float m = rp_margin16_f32h(xh + pt * dp, xp + pt * dp, h, dp, sub, xnorm, live);
-            if (live && sub == 0) {
-                uint8_t side;
-                if (fabsf(m) < RP_EPS) side = (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, gpos + (uint32_t)i, (uint32_t)dep) & 1u);
-                else side = m > 0.0f ? 0 : 1;
-                sd[i] = side;
+        // margins: one quad per member (bf16-screened like k_margin), two members per quad and step so that 8 row
+        // fetches are in flight per lane; the bf16 hyperplane comes from LDS
+        for (int j = tid; j < dp; j += 256) hb[j] = nnd_f32_to_bf16(h[j]);
+        __syncthreads();
+        const int sub = tid & 3, grp = tid >> 2;
+        const int nch = dp >> 3;
+        const float off = h[dp], hnorm = h[dp + 1];
+        const uint4 *h8 = (const uint4 *)hb;
+        for (int i0 = 0; i0 < l; i0 += 128) {
+            int64_t pt[2];
+            float acc[2], xn[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = i0 + u * 64 + grp;
+                pt[u] = ids[ss + (i < l ? i : 0)];
+                acc[u] = 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) xn[u] = nrm[pt[u]];
+            for (int c = sub; c < nch; c += 16) {
+                uint4 q[2][4], p[4];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) q[u][j] = ((const uint4 *)(xh + pt[u] * dp))[c + 4 * j < nch ? c + 4 * j : c];
+#pragma unroll
+                for (int j = 0; j < 4; j++) p[j] = h8[c + 4 * j < nch ? c + 4 * j : c];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (c + 4 * j < nch) acc[u] = rp_dot8(q[u][j], p[j], acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = i0 + u * 64 + grp;
+                if (i >= l) continue;  // whole quad
+                const float m = rp_quad_sum(acc[u]) + off;
+                const float band = 0.0078125f * hnorm * (metric == 0 ? sqrtf(xn[u]) : xn[u]) + 1e-30f;
+                const uint8_t side = rp_side(m, band, xp + pt[u] * dp, h, off, dp, sub, seed, gpos + (uint32_t)i, dep);
+                if (sub == 0) sd[i] = side;
             }
         }
         __syncthreads();
@@ -668,7 +695,7 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     bool inv_live = true;  // inv[] is maintained while the point-major margin kernel is in use
     long long active_pos = P;
     const int fin_max = FIN_MAX;
-    const size_t fin_smem = sizeof(int32_t) * 2 * FIN_MAX + FIN_MAX + sizeof(float) * (dp + 4) +
+    const size_t fin_smem = sizeof(int32_t) * 2 * FIN_MAX + FIN_MAX + sizeof(float) * (dp + 4) + sizeof(uint16_t) * dp +
                             sizeof(int32_t) * (FIN_STACK * 3 + 8);
     int32_t *fin_start = ctx->seg_child + 2 * ctx->max_segs;  // finisher work list lives behind seg_child
     int32_t *fin_len = fin_start + ctx->max_segs;
@@ -697,11 +724,11 @@ int nnd_launch_forest(nnd_ctx *ctx) {
         // streaming every row once (it costs n rows regardless of how many positions are active)
         const bool fused = inv_live && (S * (int64_t)dp * 2 <= (int64_t)6 << 20) && (active_pos * 2 >= 3 * n);
         if (fused) {
-            hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
+            hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
                                ctx->p.metric, dp, n, T, ctx->inv, ctx->hyper, hs, ctx->hyper_h, ctx->tree_seed, depth, ctx->side_pt);
         } else {
             inv_live = false;
-            hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
+            hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
                                ctx->p.metric, dp, ctx->perm[cur], ctx->pos_seg[cur], P, ctx->hyper, hs, ctx->hyper_h, ctx->tree_seed, depth,
                                ctx->side);
         }
