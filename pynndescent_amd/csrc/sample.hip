@@ -88,51 +88,80 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
     }
     nnd_wave_lds_sync();
     const int nfwd[2] = {cnt[0], cnt[1]};
+    // reverse offers: when both classes' slot banks fit one wave (2 * rcap <= 64) they are fetched and screened together
+    if (2 * rcap <= 64) {
+        const int c = lane >= rcap ? 1 : 0, s = lane - c * rcap;
+        uint64_t *slots = rbuf + v * 2 * rcap;  // [class 0 | class 1] are adjacent
+        uint64_t rk = NND_EMPTY_KEY;
+        if (lane < 2 * rcap) {
+            rk = slots[lane];
+            if (rk != NND_EMPTY_KEY) slots[lane] = NND_EMPTY_KEY;  // re-arm for the next iteration
+        }
+        bool ok = rk != NND_EMPTY_KEY;
+        if (ok) {  // utils.py:427-430: an id already in the list is not pushed again
+            const uint32_t src = (uint32_t)rk;
+            const int nf = c ? nfwd[1] : nfwd[0];
+            for (int j = 0; j < nf; j++) ok &= ((uint32_t)sc.key[c][j] != src);
+        }
+        (void)s;
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        uint64_t *slots = rbuf + (v * 2 + c) * rcap;
-        for (int s0 = 0; s0 < rcap; s0 += 64) {
-            int s = s0 + lane;
-            uint64_t rk = NND_EMPTY_KEY;
-            if (s < rcap) {
-                rk = slots[s];
-                if (rk != NND_EMPTY_KEY) slots[s] = NND_EMPTY_KEY;  // re-arm for the next iteration
+        for (int cc = 0; cc < 2; cc++) {
+            const bool mine = ok && c == cc;
+            const unsigned long long m = __ballot(mine);
+            if (mine) sc.key[cc][cnt[cc] + nnd_prefix_popc(m)] = rk;
+            cnt[cc] += __popcll(m);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            uint64_t *slots = rbuf + (v * 2 + c) * rcap;
+            for (int s0 = 0; s0 < rcap; s0 += 64) {
+                int s = s0 + lane;
+                uint64_t rk = NND_EMPTY_KEY;
+                if (s < rcap) {
+                    rk = slots[s];
+                    if (rk != NND_EMPTY_KEY) slots[s] = NND_EMPTY_KEY;  // re-arm for the next iteration
+                }
+                bool ok = rk != NND_EMPTY_KEY;
+                if (ok) {  // utils.py:427-430: an id already in the list is not pushed again
+                    uint32_t src = (uint32_t)rk;
+                    for (int j = 0; j < nfwd[c]; j++) ok &= ((uint32_t)sc.key[c][j] != src);
+                }
+                unsigned long long m = __ballot(ok);
+                if (ok) sc.key[c][cnt[c] + nnd_prefix_popc(m)] = rk;
+                cnt[c] += __popcll(m);
             }
-            bool ok = rk != NND_EMPTY_KEY;
-            if (ok) {  // utils.py:427-430: an id already in the list is not pushed again
-                uint32_t src = (uint32_t)rk;
-                for (int j = 0; j < nfwd[c]; j++) ok &= ((uint32_t)sc.key[c][j] != src);
-            }
-            unsigned long long m = __ballot(ok);
-            if (ok) sc.key[c][cnt[c] + nnd_prefix_popc(m)] = rk;
-            cnt[c] += __popcll(m);
         }
     }
     nnd_wave_lds_sync();
 
     int32_t *out = cand + v * 2 * mcp;
+    int my_rank = 1 << 30;  // rank of this lane's forward new edge among the new offers
+    const int my_item = (valid && cls == 1u) ? nnd_prefix_popc(__ballot(valid && cls == 1u)) : -1;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const int M = cnt[c];
         int32_t *dst = out + (c == 1 ? 0 : mcp);  // layout [new | old]
         for (int i0 = 0; i0 < M; i0 += 64) {
             int i = i0 + lane;
+            int r = 1 << 30;
+            uint64_t key = 0;
             if (i < M) {
-                uint64_t key = sc.key[c][i];
-                int r = 0;
+                key = sc.key[c][i];
+                r = 0;
                 for (int j = 0; j < M; j++) r += (sc.key[c][j] < key) ? 1 : 0;
                 if (r < mc) dst[r] = (int32_t)(uint32_t)key;
+            }
+            if (c == 1 && i0 == 0) {  // forward items sit at the front in lane order: hand each its rank (k <= 64)
+                const int got = __shfl(r, my_item >= 0 ? my_item : 0, 64);
+                if (my_item >= 0) my_rank = got;
             }
         }
         int filled = M < mc ? M : mc;
         for (int j = filled + lane; j < mcp; j += 64) dst[j] = -1;
     }
     // flag reset (utils.py:311-318): a forward new edge that was sampled becomes old
-    if (valid && cls == 1u) {
-        int r = 0;
-        for (int j = 0; j < cnt[1]; j++) r += (sc.key[1][j] < fkey) ? 1 : 0;
-        if (r < mc) knn_e[v * ks + lane] = u;
-    }
+    if (valid && cls == 1u && my_rank < mc) knn_e[v * ks + lane] = u;
 }
 
 int nnd_launch_sample(nnd_ctx *ctx) {
