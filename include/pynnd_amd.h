@@ -112,6 +112,10 @@ int32_t nnd_init_random(nnd_handle_t h);
 /* initalize_heap_from_graph_indices[_and_distances] (utils.py:836-860), used for init_graph /
  * init_dist (pynndescent_.py:1225-1242).  init_dist may be NULL. Host pointers, (n, width). */
 int32_t nnd_init_from_graph(nnd_handle_t h, const int32_t *init_idx, const float *init_dist, int32_t width);
+/* init_from_neighbor_graph (pynndescent_.py:206-214), the warm start of NNDescent.update
+ * (pynndescent_.py:2512-2517): the entries of an existing graph -- host (n, width) indices (-1 = none) and
+ * alt-space distances (required) -- are inserted with flag 0 ("old").  Call after nnd_reset_graph. */
+int32_t nnd_init_from_neighbor_graph(nnd_handle_t h, const int32_t *init_idx, const float *init_dist, int32_t width);
 
 /* One iteration of nn_descent_internal (pynndescent_.py:296-320):
  * new_build_candidates (utils.py:221-320) + generate_graph_update_array (utils.py:536-658)

@@ -93,6 +93,7 @@ def load(kind="strict"):
     lib.orc_init_from_graph.argtypes = [
         _f32p, C.c_int64, C.c_int, C.c_int, _i32p, _f32p, _u8p, C.c_int, _i32p, C.c_void_p, C.c_int,
     ]
+    lib.orc_init_from_neighbor_graph.argtypes = [_i32p, _f32p, _u8p, C.c_int, _i32p, _f32p, C.c_int64, C.c_int]
     lib.orc_new_build_candidates.argtypes = [
         _i32p, _u8p, C.c_int64, C.c_int, C.c_int, _i64p, C.c_int, _i32p, _i32p,
     ]
@@ -212,6 +213,54 @@ def build_index(data, metric="euclidean", n_neighbors=30, n_trees=None, leaf_siz
     mc = min(60, n_neighbors) if max_candidates is None else max_candidates  # pynndescent_.py:1135-1138
     return nn_descent(data, n_neighbors, rng_state, mc, metric, n_iters, delta, leaf_array,
                       n_threads=n_threads, lib=lib, return_trace=return_trace)
+
+
+def update_index(raw_data, graph, rng_state, random_state, metric="euclidean", n_neighbors=30, n_trees_after_update=2,
+                 leaf_size=None, max_candidates=None, n_iters=None, delta=0.001, max_rptree_depth=200,
+                 xs_fresh=None, xs_updated=None, updated_indices=None, n_threads=8, kind="strict"):
+    """``NNDescent.update`` (reference pynndescent_.py:2381-2553) for a dense index that has not been prepared.
+
+    raw_data: the index's current data; graph: its (indices, alt-space distances); rng_state: the index's
+    ``rng_state`` array AS LEFT BY THE BUILD (init_random advanced it in place); random_state: the index's
+    ``random_state`` (a RandomState object continues its stream, an int restarts it -- check_random_state).
+    Returns (new raw data, (indices, alt-space distances))."""
+    lib = load(kind)
+    rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+    _unused = rs.randint(INT32_MIN, INT32_MAX, 3).astype(np.int64)  # pynndescent_.py:2408-2411 (handed to make_forest, unused there)
+    raw = np.array(raw_data, np.float32, copy=True)
+    gi = np.array(graph[0], np.int32, copy=True)
+    gd = np.array(graph[1], np.float32, copy=True)
+    upd = [] if updated_indices is None else [int(i) for i in updated_indices]
+    if xs_updated is not None:  # pynndescent_.py:2476-2493
+        for row, i in zip(np.asarray(xs_updated, np.float32), upd):
+            raw[i] = row
+        hit = np.zeros(raw.shape[0], bool)
+        hit[upd] = True
+        gd[hit] = np.inf
+        gi[hit] = -1
+        stale = (gi >= 0) & hit[np.clip(gi, 0, None)]
+        gi[stale] = -1
+        gd[stale] = np.inf
+    fresh = np.zeros((0, raw.shape[1]), np.float32) if xs_fresh is None else np.asarray(xs_fresh, np.float32)
+    raw = np.ascontiguousarray(np.vstack([raw, fresh]))
+    n, dim = raw.shape
+    k = int(n_neighbors)
+    tree_states = rs.randint(INT32_MIN, INT32_MAX, size=(n_trees_after_update, 3)).astype(np.int64)  # rp_trees.py:2850
+    ls = default_leaf_size(k) if leaf_size is None else leaf_size
+    leaf_array = make_leaf_array(raw, n_trees_after_update, ls, tree_states, metric == "cosine", max_rptree_depth, lib)
+    hi = np.empty((n, k), np.int32)
+    hd = np.empty((n, k), np.float32)
+    hf = np.empty((n, k), np.uint8)
+    lib.orc_make_heap(hi, hd, hf, n, k)
+    lib.orc_init_from_neighbor_graph(hi, hd, hf, k, gi, gd, gi.shape[0], gi.shape[1])  # pynndescent_.py:2513-2516
+    la = np.ascontiguousarray(leaf_array, np.int32)
+    lib.orc_init_rp_tree(raw, n, dim, METRICS[metric], hi, hd, hf, k, la, la.shape[0], la.shape[1], 8)  # :2517
+    mc = min(60, k) if max_candidates is None else max_candidates
+    if n_iters is None:
+        n_iters = default_n_iters(n)
+    out = nn_descent(raw, k, rng_state, mc, metric, n_iters, delta, np.array([[-1], [-1]], np.int32),
+                     n_threads=n_threads, init=(hi, hd, hf), lib=lib)
+    return raw, out
 
 
 def correct_distances(alt, metric):

@@ -91,6 +91,7 @@ _SIGNATURES = [
     ("nnd_init_from_leaves", C.c_int32, [_H]),
     ("nnd_init_random", C.c_int32, [_H]),
     ("nnd_init_from_graph", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int32]),
+    ("nnd_init_from_neighbor_graph", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int32]),
     ("nnd_descent_iter", C.c_int32, [_H, C.POINTER(C.c_int64)]),
     ("nnd_descent", C.c_int32, [_H]),
     ("nnd_finalize_host", C.c_int32, [_H, C.c_void_p, C.c_void_p]),
@@ -225,6 +226,11 @@ class Builder:
         idx = np.ascontiguousarray(idx, np.int32)
         dist = None if dist is None else np.ascontiguousarray(dist, np.float32)
         self._check(self.lib.nnd_init_from_graph(self._h, _ptr(idx), _ptr(dist), idx.shape[1]))
+
+    def init_from_neighbor_graph(self, idx, dist):
+        idx = np.ascontiguousarray(idx, np.int32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        self._check(self.lib.nnd_init_from_neighbor_graph(self._h, _ptr(idx), _ptr(dist), idx.shape[1]))
 
     def descent_iter(self):
         c = C.c_int64()

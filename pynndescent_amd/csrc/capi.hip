@@ -275,6 +275,18 @@ extern "C" int32_t nnd_init_from_graph(nnd_handle_t ctx, const int32_t *init_idx
     return rc;
 }
 
+// init_from_neighbor_graph (pynndescent_.py:206-214), the warm start of NNDescent.update: the entries of an existing
+// graph (alt-space distances given) are inserted with flag 0 ("old").  Call on a freshly reset graph.
+extern "C" int32_t nnd_init_from_neighbor_graph(nnd_handle_t ctx, const int32_t *init_idx, const float *init_dist, int32_t width) {
+    if (!ctx) return 1;
+    if (!init_dist) { ENTER(ctx); ctx->set_error("nnd_init_from_neighbor_graph: distances are required"); return 1; }
+    if (nnd_init_from_graph(ctx, init_idx, init_dist, width)) return 1;
+    if (nnd_launch_clear_new_flags(ctx)) return 1;
+    ctx->all_new = false;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->set_error("nnd_init_from_neighbor_graph: synchronize failed"); return 1; }
+    return 0;
+}
+
 extern "C" int32_t nnd_sample_candidates(nnd_handle_t ctx) {
     ENTER(ctx);
     return nnd_launch_sample(ctx);

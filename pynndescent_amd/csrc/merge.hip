@@ -129,6 +129,22 @@ int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float
     return nnd_launch_merge(ctx);
 }
 
+// every entry of the owned rows becomes "old" (init_from_neighbor_graph pushes with flag 0, pynndescent_.py:213)
+__global__ void k_clear_new_flags(uint32_t *__restrict__ knn_e, int64_t lo, int64_t hi, int ks) {
+    int64_t t = lo * ks + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= hi * ks) return;
+    const uint32_t e = knn_e[t];
+    if (e != NND_EMPTY_E) knn_e[t] = e & NND_IDX_MASK;
+}
+int nnd_launch_clear_new_flags(nnd_ctx *ctx) {
+    const int64_t total = (ctx->own_hi - ctx->own_lo) * ctx->ks;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_clear_new_flags, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e,
+                       ctx->own_lo, ctx->own_hi, ctx->ks);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Row-sharded multi-GPU build: every handle keeps global-sized arrays indexed by
 // global vertex id but OWNS the rows [own_lo, own_hi).  Proposals whose target is owned elsewhere are

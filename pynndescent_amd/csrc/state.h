@@ -119,6 +119,7 @@ int nnd_launch_export_proposals(nnd_ctx *ctx, const int64_t *offsets_dev, uint64
 int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_t *targets, int64_t count);
 int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
 int nnd_launch_refresh_th(nnd_ctx *ctx, int64_t lo, int64_t hi);
+int nnd_launch_clear_new_flags(nnd_ctx *ctx);
 int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev);
 int nnd_launch_diversify_csr(nnd_ctx *ctx, const int32_t *indptr_dev, const int32_t *indices_dev, float *data_dev,
                              int *too_long_dev);

@@ -276,7 +276,96 @@ class NNDescent:
         self._out_of_scope("NNDescent.query (pynndescent_.py:2275)")
 
     def update(self, xs_fresh=None, xs_updated=None, updated_indices=None):
-        self._out_of_scope("NNDescent.update (pynndescent_.py:2381)")
+        """``pynndescent.NNDescent.update`` (pynndescent_.py:2381-2553) on the GPU: fresh rows are appended, updated
+        rows replaced (their graph rows and every edge pointing at them are dropped), then the graph is rebuilt from
+        a warm start -- the old graph inserted as "old" edges (init_from_neighbor_graph, flag 0), a forest of
+        ``n_trees_after_update`` trees seeding "new" edges, no random fill -- and NN-descent runs to the stop rule."""
+        current_random_state = check_random_state(self.random_state)
+        # drawn and handed to make_forest by the reference (pynndescent_.py:2408-2411); kept for the stream position
+        current_random_state.randint(INT32_MIN, INT32_MAX, 3)
+        if xs_updated is not None:
+            xs_updated = check_array(xs_updated, dtype=self._input_dtype, order="C")
+            if updated_indices is None:
+                raise ValueError("If xs_updated are provided, updated_indices must also be provided!")
+            try:
+                updated_indices = list(map(int, updated_indices))
+            except (TypeError, ValueError):
+                raise ValueError("Could not convert updated indices to list of int(s).")
+            n1, n2 = len(updated_indices), xs_updated.shape[0]
+            if n1 != n2:
+                raise ValueError(
+                    f"Number of updated indices ({n1}) must match " f"number of rows of xs_updated ({n2})."
+                )
+        else:
+            if updated_indices is not None:
+                warn("xs_updated not provided, while update_indices provided. " "They will be ignored.")
+            updated_indices = None
+        if updated_indices is None:
+            xs_updated = np.zeros((0, self._raw_data.shape[1]), self._input_dtype)
+            updated_indices = []
+        if xs_fresh is None:
+            xs_fresh = np.zeros((0, self._raw_data.shape[1]), dtype=self._input_dtype)
+        else:
+            xs_fresh = check_array(xs_fresh, dtype=self._input_dtype, order="C")
+
+        # data and graph invalidation (pynndescent_.py:2476-2493), vectorised
+        raw = np.array(self._raw_data, copy=True)
+        for x_updated, i_fresh in zip(xs_updated, updated_indices):
+            raw[i_fresh] = x_updated
+        n_old = raw.shape[0]
+        raw = np.ascontiguousarray(np.vstack([raw, xs_fresh]))
+        ns, ds = (np.array(a, copy=True) for a in self._neighbor_graph)
+        if updated_indices:
+            hit = np.zeros(n_old, bool)
+            hit[updated_indices] = True
+            ns[hit] = -1
+            ds[hit] = np.inf
+            stale = (ns >= 0) & hit[np.clip(ns, 0, None)]
+            ns[stale] = -1
+            ds[stale] = np.inf
+        n = raw.shape[0]
+        pad_i = np.full((n, ns.shape[1]), -1, np.int32)
+        pad_d = np.full((n, ns.shape[1]), np.inf, np.float32)
+        pad_i[:n_old] = ns
+        pad_d[:n_old] = ds
+
+        self.n_trees = self.n_trees_after_update  # pynndescent_.py:2498
+        eff_leaf_size = self.leaf_size
+        if eff_leaf_size is None:
+            eff_leaf_size = max(60, min(256, 5 * int(self.n_neighbors)))  # rp_trees.py:2845-2846
+        tree_states = current_random_state.randint(INT32_MIN, INT32_MAX, size=(self.n_trees, 3)).astype(np.int64)
+        if self.max_candidates is None:
+            effective_max_candidates = min(60, self.n_neighbors)
+        else:
+            effective_max_candidates = self.max_candidates
+        builder = _capi.Builder(
+            n, raw.shape[1], _METRIC_CODES[self.metric], self.n_neighbors, self.n_trees, eff_leaf_size,
+            self.max_rptree_depth, effective_max_candidates, self.n_iters, self.delta, self.rng_state, tree_states[0],
+            device=self.device,
+        )
+        try:
+            builder.set_data_host(raw)
+            builder.make_forest()
+            self._rp_forest = _DeviceForestSentinel(self.n_trees, builder.stats()["n_leaves"], eff_leaf_size)
+            builder.reset_graph()
+            builder.init_from_neighbor_graph(pad_i, pad_d)  # pynndescent_.py:2512-2516
+            builder.init_from_leaves()                      # pynndescent_.py:2517
+            for it in range(self.n_iters):                  # nn_descent with init_graph: no random fill (P_:346-350)
+                if self.verbose:
+                    print("\t", it + 1, " / ", self.n_iters)
+                c = builder.descent_iter()
+                if c <= self.delta * self.n_neighbors * n:
+                    if self.verbose:
+                        print("\tStopping threshold met -- exiting after", it + 1, "iterations")
+                    break
+            self._neighbor_graph = builder.finalize()
+            self._build_stats = builder.stats()
+        finally:
+            builder.close()
+        self._raw_data = raw
+        if hasattr(self, "_search_graph"):  # pynndescent_.py:2538-2553: the derived structures are rebuilt
+            del self._search_graph
+            self.build_search_graph()
 
 
 # string metrics the reference recognises (distances.py:2103-2168 named_distances keys) -- used only to

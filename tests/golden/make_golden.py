@@ -399,6 +399,33 @@ def gen_search_graph(ref):
     save("search_graph", **out)
 
 
+def gen_update(ref):
+    """NNDescent.update (pynndescent_.py:2381-2553): fresh rows appended + some rows replaced, warm start from the
+    old graph (flag 0) + a smaller forest, no random init."""
+    import numba
+
+    for metric, seed in (("euclidean", 11), ("cosine", 12)):
+        x = clustered(1500, 12, 5, 25, seed=31)
+        rs = np.random.RandomState(1000 + seed)
+        fresh = (x[rs.choice(1500, 200, replace=False)] + 0.05 * rs.standard_normal((200, 12))).astype(np.float32)
+        upd_idx = np.sort(rs.choice(1500, 30, replace=False)).astype(np.int64)
+        upd = (x[rs.choice(1500, 30, replace=False)] + 0.05 * rs.standard_normal((30, 12))).astype(np.float32)
+        numba.set_num_threads(2)
+        t0 = time.time()
+        index = ref.NNDescent(x.copy(), metric=metric, n_neighbors=10, n_trees=6, random_state=np.random.RandomState(seed),
+                              n_iters=8)
+        before = (np.asarray(index._neighbor_graph[0], np.int32).copy(), np.asarray(index._neighbor_graph[1], np.float32).copy())
+        rng_after_build = np.asarray(index.rng_state, np.int64).copy()
+        index.update(xs_fresh=fresh, xs_updated=upd, updated_indices=upd_idx)
+        after = (np.asarray(index._neighbor_graph[0], np.int32), np.asarray(index._neighbor_graph[1], np.float32))
+        numba.set_num_threads(1)
+        print("update", metric, "%.1fs" % (time.time() - t0), "n after", after[0].shape)
+        save("update_%s_T2" % metric, gen=np.array([1500, 12, 5, 25, 31]), seed=np.int64(seed), k=np.int32(10),
+             n_trees=np.int32(6), n_iters=np.int32(8), n_threads=np.int32(2), fresh=fresh, upd=upd, upd_idx=upd_idx,
+             before_idx=before[0], before_dist=before[1], after_idx=after[0], after_dist=after[1],
+             rng_after_build=rng_after_build, raw_after=np.asarray(index._raw_data, np.float32))
+
+
 GENERATORS = {
     "primitives": gen_primitives,
     "rp": gen_rp,
@@ -408,6 +435,7 @@ GENERATORS = {
     "build_c1": gen_build_c1,
     "reference_testdata": gen_reference_testdata,
     "search_graph": gen_search_graph,
+    "update": gen_update,
 }
 
 

@@ -233,3 +233,46 @@ def test_search_graph_nytimes_like_cosine_d256():
     print("search graph nnz gpu %d oracle %d symmetric difference %d" % (len(a), len(b), len(a ^ b)))
     assert len(a ^ b) <= 0.01 * len(b)
     assert np.diff(sg.indptr).max() <= 23 + 1 and sg.shape == (n, n)
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_update_against_reference_fixture(metric):
+    """NNDescent.update (pynndescent_.py:2381-2553): same inputs as the reference run recorded in the fixture; the
+    updated graph must reach the reference's recall on the NEW data, hold exact distances and no stale edges."""
+    g = np.load(os.path.join(GOLDEN, "update_%s_T2.npz" % metric))
+    n, d, latent, ncl, seed = (int(v) for v in g["gen"])
+    x = clustered(n, d, latent, ncl, seed)
+    index = NNDescent(x.copy(), metric, n_neighbors=int(g["k"]), n_trees=int(g["n_trees"]), n_iters=int(g["n_iters"]),
+                      random_state=np.random.RandomState(int(g["seed"])))
+    before = index._neighbor_graph[0].copy()
+    index.update(xs_fresh=g["fresh"], xs_updated=g["upd"], updated_indices=g["upd_idx"])
+    np.testing.assert_array_equal(index._raw_data, g["raw_after"])
+    idx, dist = index.neighbor_graph
+    assert idx.shape == g["after_idx"].shape == (n + g["fresh"].shape[0], int(g["k"]))
+    assert index.n_trees == index.n_trees_after_update == 2
+    raw = g["raw_after"]
+    _parity(raw, metric, int(g["k"]), idx, g["after_idx"], k_true=int(g["k"]))
+    np.testing.assert_allclose(dist, _true_alt_to_corrected(raw, idx, metric), rtol=1e-5, atol=1e-6)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    for row in idx[::17]:
+        assert len(set(row.tolist())) == len(row)
+    # the warm start matters: untouched rows keep most of their old neighbours
+    keep = np.setdiff1d(np.arange(n), g["upd_idx"])[::7]
+    same = np.mean([len(np.intersect1d(before[i], idx[i])) / before.shape[1] for i in keep])
+    assert same > 0.8, same
+
+
+def test_update_errors_and_plain_refresh():
+    x = clustered(600, 8, 4, 10, seed=3)
+    index = NNDescent(x, "euclidean", n_neighbors=8, random_state=1)
+    with pytest.raises(ValueError, match="updated_indices must also be provided"):
+        index.update(xs_updated=x[:3])
+    with pytest.raises(ValueError, match="must match"):
+        index.update(xs_updated=x[:3], updated_indices=[1, 2])
+    with pytest.warns(UserWarning, match="will be ignored"):
+        index.update(updated_indices=[1, 2])  # nothing to do: graph rebuilt from its own warm start
+    idx, _ = index.neighbor_graph
+    ti, _ = O.brute_force_knn(x, 8, "euclidean")
+    assert O.recall(ti, idx) > 0.97
+    index.update(xs_fresh=x[:50] + 0.01)
+    assert index.neighbor_graph[0].shape == (650, 8)

@@ -185,3 +185,25 @@ def test_search_graph_pruning_pass(golden_dir, metric):
         b = set(zip(np.repeat(np.arange(n), np.diff(ref_indptr)).tolist(), ref_indices.tolist()))
         assert len(a ^ b) <= 0.01 * len(b), (len(a ^ b), len(b))
     assert np.diff(sg.indptr).max() <= int(np.round(1.5 * 15)) + 1
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_update_matches_reference(golden_dir, metric):
+    """NNDescent.update (pynndescent_.py:2381-2553): warm start from the old graph (flag 0) + a smaller forest."""
+    g = _g(golden_dir, "update_%s_T2" % metric)
+    n, d, latent, ncl, seed = (int(v) for v in g["gen"])
+    x = clustered(n, d, latent, ncl, seed=seed)
+    # replay the RandomState stream of the fixture: ctor draws, then update's draws
+    rs = np.random.RandomState(int(g["seed"]))
+    O.draw_rng_states(rs, int(g["n_trees"]))
+    raw, (idx, dist) = O.update_index(
+        x, (g["before_idx"], g["before_dist"]), g["rng_after_build"].copy(), rs, metric=metric,
+        n_neighbors=int(g["k"]), n_trees_after_update=2, n_iters=int(g["n_iters"]), xs_fresh=g["fresh"],
+        xs_updated=g["upd"], updated_indices=g["upd_idx"], n_threads=int(g["n_threads"]))
+    np.testing.assert_array_equal(raw, g["raw_after"])
+    if metric == "euclidean":
+        np.testing.assert_array_equal(idx, g["after_idx"])
+        np.testing.assert_allclose(dist, g["after_dist"], rtol=1e-6)
+    else:  # cosine distances differ in the last bits between C and numpy -> ties may resolve differently
+        same = np.mean([len(np.intersect1d(a, b)) / len(a) for a, b in zip(idx, g["after_idx"])])
+        assert same > 0.97, same
