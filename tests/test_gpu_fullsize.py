@@ -40,7 +40,7 @@ def _build(x, metric, k, n_trees, seed=1):
     return idx, dist, st
 
 
-def _check(x, metric, idx, dist, k, floor):
+def _check(x, metric, idx, dist, k, floor, n_sample=1500):
     n = x.shape[0]
     assert bool((idx >= 0).all())
     assert bool((dist[:, 1:] >= dist[:, :-1]).all()), "rows not ascending"
@@ -50,20 +50,37 @@ def _check(x, metric, idx, dist, k, floor):
     self_first = (idx[:, 0] == ar)
     assert self_first.float().mean().item() > 0.999
     assert bool((dist[self_first, 0] == 0).all())
-    rows = torch.from_numpy(np.random.RandomState(0).choice(n, 1500, replace=False)).to(x.device)
+    rows = torch.from_numpy(np.random.RandomState(0).choice(n, n_sample, replace=False)).to(x.device)
     q = x[rows].double()
     nb = x[idx[rows].long()].double()
     if metric == "euclidean":
         truth = ((q[:, None, :] - nb) ** 2).sum(-1)
-        full = (x[rows] * x[rows]).sum(1, keepdim=True) + (x * x).sum(1)[None, :] - 2.0 * (x[rows] @ x.T)
+        xc = x - x.mean(0, keepdim=True)
     else:
         dot = (q[:, None, :] * nb).sum(-1)
         truth = torch.log2((q.norm(dim=1)[:, None] * nb.norm(dim=2)) / dot).clamp_min(0)
-        xn = x / x.norm(dim=1, keepdim=True)
-        full = 1.0 - xn[rows] @ xn.T
+        xc = x / x.norm(dim=1, keepdim=True)
     rel = ((dist[rows].double() - truth).abs() / truth.clamp_min(1e-12))
     assert rel[truth > 1e-9].max().item() < 1e-5, rel[truth > 1e-9].max().item()
-    true10 = full.topk(10, dim=1, largest=False).indices.cpu().numpy()
+    # exact 10-NN: Gram pre-selection in chunks of 1M columns (torch.topk over rows of several million columns is not
+    # reliable on this stack), 64 best candidates refined in float64
+    bv = bi = None
+    for c0 in range(0, n, 1_000_000):
+        xs = xc[c0:c0 + 1_000_000]
+        if metric == "euclidean":
+            dch = (xc[rows] * xc[rows]).sum(1, keepdim=True) + (xs * xs).sum(1)[None, :] - 2.0 * (xc[rows] @ xs.T)
+        else:
+            dch = 1.0 - xc[rows] @ xs.T
+        tk = dch.topk(32, dim=1, largest=False)
+        bv = tk.values if bv is None else torch.cat([bv, tk.values], 1)
+        bi = tk.indices + c0 if bi is None else torch.cat([bi, tk.indices + c0], 1)
+    cand = torch.gather(bi, 1, bv.argsort(dim=1)[:, :64])
+    cnb = x[cand].double()
+    if metric == "euclidean":
+        dd = ((q[:, None, :] - cnb) ** 2).sum(-1)
+    else:
+        dd = 1.0 - (q[:, None, :] * cnb).sum(-1) / (q.norm(dim=1)[:, None] * cnb.norm(dim=2))
+    true10 = torch.gather(cand, 1, dd.argsort(dim=1)[:, :10]).cpu().numpy()
     got = idx[rows].cpu().numpy()
     rec = sum(np.isin(t, g).sum() for t, g in zip(true10, got)) / (len(got) * 10.0)
     assert rec >= floor, rec
@@ -84,6 +101,15 @@ def test_config3_glove_like_1p2m_cosine_d100():
     idx, dist, st = _build(x, "cosine", 15, 12)
     rec = _check(x, "cosine", idx, dist, 15, 0.90)
     print("C3' recall@10 %.4f iters %d" % (rec, st["n_iters_run"]))
+
+
+def test_config4_size_10m_on_one_gpu():
+    """BASELINE configs[3] is 10M x 128 euclidean k=15 over 8 GPUs; the whole set also fits ONE MI355X (288 GB), which
+    checks the 64-bit index arithmetic at that size: 12 trees x 10M = 1.2e8 positions, 6.4e8 proposal slots."""
+    x = _gen(10_000_000, 128, 16, 3, torch.device("cuda", 0), True)
+    idx, dist, st = _build(x, "euclidean", 15, 12)
+    rec = _check(x, "euclidean", idx, dist, 15, 0.95, n_sample=300)
+    print("C4' (one GPU) recall@10 %.4f iters %d" % (rec, st["n_iters_run"]))
 
 
 @pytest.mark.parametrize("metric,n,d,latent,k", [("euclidean", 150_000, 128, 16, 15), ("cosine", 120_000, 100, 24, 15),
