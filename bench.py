@@ -51,10 +51,18 @@ def sift_like(n, d, seed, device, latent=16, n_clusters=1024, noise=0.3, sample_
 
 
 def exact_knn_sample(x, rows, k):
-    """Brute-force ground truth (self included) for a sample of rows, float64 refinement of the top 4k."""
+    """Brute-force ground truth (self included) for a sample of rows: f32 Gram pre-selection in chunks of 1M columns
+    (torch.topk over rows of several million columns returned wrong answers on this stack), float64 refinement of
+    the best 4k candidates."""
     q = x[rows]
-    d2 = (q * q).sum(1, keepdim=True) + (x * x).sum(1)[None, :] - 2.0 * (q @ x.T)
-    cand = d2.topk(4 * k, dim=1, largest=False).indices
+    best_v = best_i = None
+    for c0 in range(0, x.shape[0], 1_000_000):
+        xs = x[c0:c0 + 1_000_000]
+        d2 = (q * q).sum(1, keepdim=True) + (xs * xs).sum(1)[None, :] - 2.0 * (q @ xs.T)
+        tk = d2.topk(min(4 * k, xs.shape[0]), dim=1, largest=False)
+        best_v = tk.values if best_v is None else torch.cat([best_v, tk.values], 1)
+        best_i = tk.indices + c0 if best_i is None else torch.cat([best_i, tk.indices + c0], 1)
+    cand = torch.gather(best_i, 1, best_v.argsort(dim=1)[:, :4 * k])
     qq = q.double()[:, None, :]
     dd = ((qq - x[cand].double()) ** 2).sum(-1)
     order = dd.argsort(dim=1)[:, :k]
