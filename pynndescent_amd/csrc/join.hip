@@ -569,6 +569,317 @@ static int launch_join16_ks(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     return launch_join16_t<DC, 4>(ctx, v_begin, v_end);
 }
 
+// ------------------------------------------------------------------------------------------------
+// max_candidates 17..64 (k = 30, the reference's default, lands here with mcp = 32): the same wave-per-vertex,
+// operands-from-global design as k_local_join16, generalised to NA = mcp/16 tile rows of new candidates against
+// NB = 2 NA tiles of [new | old].  The neighbour lists are not staged (64-128 rows x k ids would cost the occupancy):
+// the membership test of a queued pair reads the target's list straight from global memory (L2) when the queue is
+// drained; the queue holds 512 entries and is drained whenever half full.
+#ifndef NND_JW_WAVES
+#define NND_JW_WAVES 3
+#endif
+#ifndef NND_JW_DCW
+#define NND_JW_DCW 32
+#endif
+template <int MCP, int DC>
+__global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_join_w(const float *__restrict__ xp, int dp,
+                                                                       const float *__restrict__ nrm, int metric,
+                                                                       const int32_t *__restrict__ cand,
+                                                                       const int32_t *__restrict__ order, int64_t v_begin,
+                                                                       int64_t v_end, int k, int ks,
+                                                                       const uint32_t *__restrict__ knn_e,
+                                                                       const float *__restrict__ th, uint64_t *__restrict__ pbuf,
+                                                                       uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed,
+                                                                       long long *__restrict__ counters) {
+    constexpr int NA = MCP / 16, NB = 2 * NA, RV = 2 * MCP;
+    constexpr int NT = DC / 16;                       // 16-byte chunks per lane, row and K block
+    constexpr int RPL = RV / 64;                      // candidate slots per lane (1 or 2)
+    constexpr int QCAP = 512;
+    constexpr int WAVE_BYTES = QCAP * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + 8;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
+    unsigned char *mine = smem + (size_t)w * ((WAVE_BYTES + 15) & ~15);
+    uint2 *queue = (uint2 *)mine;                       // QCAP
+    int32_t *cidbuf = (int32_t *)(queue + QCAP);        // 2 * RV
+    int32_t *nnewbuf = cidbuf + 2 * RV;                 // 2
+    int32_t *cid = nnewbuf + 2;                         // RV
+    float *cnrm = (float *)(cid + RV);                  // RV
+    float *cth = cnrm + RV;                             // RV
+    uint32_t *cslot = (uint32_t *)(cth + RV);           // RV
+    uint32_t *cflag = cslot + RV;                       // RV
+    const int kq = ks >> 2;
+    const int r16 = lane & 15, gq = lane >> 4;
+    int64_t n_v = v_end - v_begin;
+    int64_t g, stride;
+    if ((gridDim.x & 7) == 0) {  // one contiguous eighth of the visiting order per XCD (see k_local_join16)
+        const int64_t per = (((n_v + 7) >> 3) + 3) & ~(int64_t)3;
+        const int64_t g0 = (int64_t)(blockIdx.x & 7) * per;
+        n_v = n_v < g0 + per ? n_v : g0 + per;
+        g = g0 + (int64_t)(blockIdx.x >> 3) * 4 + w;
+        stride = (int64_t)(gridDim.x >> 3) * 4;
+    } else {
+        g = (int64_t)blockIdx.x * 4 + w;
+        stride = (int64_t)gridDim.x * 4;
+    }
+
+    // candidate ids of vertex g: slot lane + 64*u of [new(MCP) | old(MCP)]
+    auto load_cand = [&](int64_t g, int (&c)[RPL]) __attribute__((always_inline)) {
+        const bool ok = g < n_v;
+        const int64_t v = ok ? (order ? (int64_t)order[v_begin + g] : v_begin + g) : 0;
+#pragma unroll
+        for (int u = 0; u < RPL; u++) {
+            const int cc = cand[v * RV + lane + 64 * u];
+            c[u] = ok ? cc : -1;
+        }
+    };
+    auto store_cand = [&](int buf, const int (&c)[RPL]) __attribute__((always_inline)) {
+        int nn = 0, no = 0;
+#pragma unroll
+        for (int u = 0; u < RPL; u++) {
+            const unsigned long long m = __ballot(c[u] >= 0);
+            cidbuf[buf * RV + lane + 64 * u] = c[u];
+            if (RPL == 1) {  // RV == 64: lanes [0,32) new, [32,64) old
+                nn += __popcll(m & 0xFFFFFFFFull);
+                no += __popcll(m >> 32);
+            } else {  // RV == 128: u == 0 new, u == 1 old
+                if (u == 0) nn += __popcll(m); else no += __popcll(m);
+            }
+        }
+        if (lane == 0) nnewbuf[buf] = nn | (no << 8);
+    };
+    f32x4 rt[NB][NT];  // this lane's chunks of its row in every tile (one K block)
+    float nx_nrm[RPL], nx_th[RPL];
+    int nx_id[RPL];
+    auto tile_live = [&](int t, int nn, int no) __attribute__((always_inline)) -> bool {
+        return t < NA ? 16 * t < nn : 16 * (t - NA) < no;
+    };
+    // rows of K block [c0, c0 + cw) of the vertex whose ids are in cb[]; empty slots read row 0 (cache hit, masked later)
+    auto load_rows = [&](const int32_t *cb, int c0, int cw, int nn, int no) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NB; t++) {
+            if (!tile_live(t, nn, no)) continue;
+            const int id = cb[16 * t + r16];
+            const float *pr = xp + (int64_t)(id >= 0 ? id : 0) * dp + c0 + 4 * gq;
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+                if (16 * j < cw) rt[t][j] = *(const f32x4 *)(pr + 16 * j);
+        }
+    };
+    auto issue_gather = [&](int buf) __attribute__((always_inline)) {
+        const int32_t *cb = cidbuf + buf * RV;
+        const int cnt = nnewbuf[buf], nn = cnt & 255, no = cnt >> 8;
+        if (nn == 0) return;  // wave-uniform: no new candidate, no join (utils.py:611-613)
+        load_rows(cb, 0, dp < DC ? dp : DC, nn, no);
+#pragma unroll
+        for (int u = 0; u < RPL; u++) {
+            nx_id[u] = cb[lane + 64 * u];
+            const int64_t ide = nx_id[u] >= 0 ? nx_id[u] : 0;
+            nx_nrm[u] = nrm[ide];
+            nx_th[u] = th[ide];
+        }
+    };
+    auto land_gather = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < RPL; u++) {
+            const int r = lane + 64 * u;
+            cid[r] = nx_id[u];
+            cnrm[r] = nx_nrm[u];
+            cth[r] = nx_th[u];
+            cslot[r] = nnd_hash2(slot_seed, (uint32_t)nx_id[u]) & (uint32_t)(pcap - 1);
+            cflag[r] = 0;
+        }
+    };
+    // is `id` among the neighbour ids of vertex `row` (global memory; the list sits in L2 more often than not)
+    auto list_has = [&](int row, uint32_t id) __attribute__((always_inline)) -> bool {
+        const u32x4 *kl = (const u32x4 *)(knn_e + (int64_t)row * ks);
+        bool present = false;
+        for (int c = 0; c < kq; c += 4) {
+            u32x4 wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) wv[j] = kl[c + j < kq ? c + j : c];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32x4 m = wv[j] & NND_IDX_MASK;
+                present |= (c + j < kq) && ((m.x == id) | (m.y == id) | (m.z == id) | (m.w == id));
+            }
+        }
+        return present;
+    };
+    int tot_pairs = 0, tot_prop = 0, tot_rows = 0, tot_act = 0;
+    int qn = 0;
+    auto drain = [&]() __attribute__((always_inline)) {
+        nnd_wave_lds_sync();
+        for (int base = 0; base < qn; base += 64) {
+            const int t = base + lane;
+            if (t < qn) {
+                const uint2 en = queue[t];
+                const int a = en.x & 63, b = (en.x >> 6) & 127;
+                const float d = __uint_as_float(en.y);
+                const int pid = cid[a], qid = cid[b];
+                if ((en.x & (1u << 13)) && !list_has(pid, (uint32_t)qid)) {  // p <- q
+                    atomicMin((unsigned long long *)&pbuf[(int64_t)pid * pcap + cslot[b]],
+                              (unsigned long long)nnd_make_key(d, (uint32_t)qid));
+                    cflag[a] = 1;
+                    tot_prop++;
+                }
+                if ((en.x & (1u << 14)) && !list_has(qid, (uint32_t)pid)) {  // q <- p
+                    atomicMin((unsigned long long *)&pbuf[(int64_t)qid * pcap + cslot[a]],
+                              (unsigned long long)nnd_make_key(d, (uint32_t)pid));
+                    cflag[b] = 1;
+                    tot_prop++;
+                }
+            }
+        }
+        nnd_wave_lds_sync();
+        qn = 0;
+    };
+
+    {
+        int c0[RPL], c1[RPL];
+        load_cand(g, c0);
+        load_cand(g + stride, c1);
+        store_cand(0, c0);
+        store_cand(1, c1);
+    }
+    nnd_wave_lds_sync();
+    issue_gather(0);
+
+    for (int it = 0; g < n_v; g += stride, it++) {
+        const int cur = it & 1;
+        const int my_cnt = nnewbuf[cur], nn = my_cnt & 255, no = my_cnt >> 8;
+        int c2[RPL];
+        load_cand(g + 2 * stride, c2);
+        f32x4 acc[NA][NB];
+#pragma unroll
+        for (int a = 0; a < NA; a++)
+#pragma unroll
+            for (int b = 0; b < NB; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nn > 0) {
+            land_gather();
+            nnd_wave_lds_sync();
+            for (int c0 = 0; c0 < dp; c0 += DC) {
+                const int cw = (dp - c0) < DC ? (dp - c0) : DC;
+                if (c0 > 0) load_rows(cid, c0, cw, nn, no);  // later K blocks are fetched in turn
+#pragma unroll
+                for (int a = 0; a < NA; a++) {
+                    if (!tile_live(a, nn, no)) continue;
+#pragma unroll
+                    for (int b = a; b < NB; b++) {  // new x new from the diagonal tile up, then new x old
+                        if (!tile_live(b, nn, no)) continue;
+#pragma unroll
+                        for (int j = 0; j < NT; j++) {
+                            if (16 * j >= cw) continue;
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(rt[a][j].x, rt[b][j].x, acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(rt[a][j].y, rt[b][j].y, acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(rt[a][j].z, rt[b][j].z, acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(rt[a][j].w, rt[b][j].w, acc[a][b], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // the row registers are free: the gather of this wave's next vertex flies during the epilogue
+        if (g + stride < n_v) issue_gather(cur ^ 1);
+        if (nn > 0) {
+#pragma unroll
+            for (int a = 0; a < NA; a++) {
+                if (!tile_live(a, nn, no)) continue;
+                int pid4[4];
+                float pn4[4], pth4[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    pid4[r] = cid[16 * a + 4 * gq + r];
+                    pn4[r] = cnrm[16 * a + 4 * gq + r];
+                    pth4[r] = cth[16 * a + 4 * gq + r];
+                }
+#pragma unroll
+                for (int b = a; b < NB; b++) {
+                    if (!tile_live(b, nn, no)) continue;
+                    const int jj = 16 * b + r16;  // index inside [new | old]
+                    const int qid = cid[jj];
+                    const float qn_ = cnrm[jj], qth = cth[jj];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = 16 * a + 4 * gq + r;  // index inside new
+                        const int pid = pid4[r];
+                        const bool valid = pid >= 0 && qid >= 0 && (jj >= MCP || jj >= i);
+                        tot_pairs += valid ? 1 : 0;
+                        const bool self = (pid == qid);
+                        const float d = self ? 0.0f : nnd_gram_to_dist(metric, acc[a][b][r], pn4[r], qn_);
+                        const bool need_p = valid && d < pth4[r], need_q = valid && !self && d < qth;
+                        const unsigned long long pm = __ballot(need_p | need_q);
+                        if (pm) {  // wave-uniform
+                            if (need_p | need_q) {
+                                const int off = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                                queue[off] = make_uint2((uint32_t)i | ((uint32_t)jj << 6) | (need_p ? (1u << 13) : 0u) | (need_q ? (1u << 14) : 0u),
+                                                        __float_as_uint(d));
+                            }
+                            qn += __popcll(pm);
+                        }
+                    }
+                    if (qn > QCAP - 256) drain();  // room for one more tile (4 x 64 entries)
+                }
+            }
+            if (qn > 0) drain();
+            nnd_wave_lds_sync();
+#pragma unroll
+            for (int u = 0; u < RPL; u++) {
+                const int r = lane + 64 * u;
+                if (cflag[r]) pdirty[cid[r]] = 1;
+                tot_rows += cid[r] >= 0;
+            }
+            if (lane == 0) tot_act += 1;
+        }
+        nnd_wave_lds_sync();
+        store_cand(cur, c2);
+    }
+    tot_pairs = nnd_wave_sum_i32(tot_pairs);
+    tot_prop = nnd_wave_sum_i32(tot_prop);
+    tot_rows = nnd_wave_sum_i32(tot_rows);
+    tot_act = nnd_wave_sum_i32(tot_act);
+    __syncthreads();
+    int *red = (int *)smem;  // every wave is done with its region
+    if (lane == 0) {
+        red[w * 4 + 0] = tot_pairs; red[w * 4 + 1] = tot_prop; red[w * 4 + 2] = tot_rows; red[w * 4 + 3] = tot_act;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const long long sum = (long long)red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
+        const int which = tid == 0 ? CNT_PAIRS : (tid == 1 ? CNT_PROPOSALS : (tid == 2 ? CNT_ROWS : CNT_ACTIVE));
+        nnd_count(counters, which, sum);
+    }
+}
+
+template <int MCP, int DC>
+static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
+    constexpr int RV = 2 * MCP;
+    constexpr int WAVE_BYTES = 512 * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + 8;
+    size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
+    auto kern = k_local_join_w<MCP, DC>;
+    static int wg_per_cu = 0, n_cu = 0;
+    if (wg_per_cu == 0) {
+        NND_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipDeviceProp_t prop;
+        NND_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->p.device));
+        n_cu = prop.multiProcessorCount;
+        int occ = 0;
+        NND_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, 256, smem));
+        wg_per_cu = occ < 1 ? 1 : occ;
+    }
+    int64_t nv = v_end - v_begin;
+    int64_t groups = (nv + 3) / 4;
+    int64_t resident = (int64_t)n_cu * wg_per_cu;
+    unsigned grid = (unsigned)(groups < resident ? groups : resident);
+    if (grid > 8) grid &= ~7u;
+    uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
+                       nnd_vertex_order(ctx), v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty,
+                       ctx->pcap, slot_seed, ctx->counters);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <int MCP, int DC, int KS16>
 static int launch_join_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     constexpr int VPW = 64 / MCP;
@@ -614,7 +925,7 @@ int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
 #define NND_J16_DCW 64
 #endif
         case 16: return wide ? launch_join16_ks<NND_J16_DCW>(ctx, v_begin, v_end) : launch_join16_ks<32>(ctx, v_begin, v_end);
-        case 32: return wide ? launch_join_ks<32, 128>(ctx, v_begin, v_end) : launch_join_ks<32, 32>(ctx, v_begin, v_end);
+        case 32: return wide ? launch_join_w<32, NND_JW_DCW>(ctx, v_begin, v_end) : launch_join_w<32, 32>(ctx, v_begin, v_end);
         case 64: return wide ? launch_join_ks<64, 128>(ctx, v_begin, v_end) : launch_join_ks<64, 32>(ctx, v_begin, v_end);
     }
     ctx->set_error("unsupported padded max_candidates %d", ctx->mcp);

@@ -290,6 +290,8 @@ int nnd_launch_leaf_init(nnd_ctx *ctx) {
             hipLaunchKernelGGL((k_leaf_join<6, 4, 128>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 128)
             hipLaunchKernelGGL((k_leaf_join<8, 4, 64>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 160)  // k = 30 (leaf_size 150): 10 x 10 tiles instead of 16 x 16
+            hipLaunchKernelGGL((k_leaf_join<10, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
         else
             hipLaunchKernelGGL((k_leaf_join<16, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
 #undef LEAF_ARGS

@@ -19,6 +19,8 @@ CONFIGS = {
     "c3": (1_200_000, 100, 24, 2, "cosine", 15, 12, False),
     "c4_one_gpu": (10_000_000, 128, 16, 3, "euclidean", 15, 12, True),
     "c5": (290_000, 256, 32, 4, "cosine", 15, 11, False),
+    "k30": (1_000_000, 128, 16, 1, "euclidean", 30, 8, True),
+    "k60": (500_000, 128, 16, 1, "euclidean", 60, 8, True),
     "s1m": (1_000_000, 128, 16, 3, "euclidean", 15, 12, True),
     "s2m": (2_000_000, 128, 16, 3, "euclidean", 15, 12, True),
     "s4m": (4_000_000, 128, 16, 3, "euclidean", 15, 12, True),
