@@ -8,28 +8,27 @@
 // target's list (utils.py:484-492).  Measured on the reference: ~half of the evaluated pairs pass
 // the max() filter but only 1-5 % of pushes succeed, almost all failures being "already present".
 //
-// MI355X design
-//   * a workgroup of 4 waves joins 64/MCP vertices (MCP = max_candidates padded to 16/32/64):
-//     128 candidate rows are gathered per workgroup -- [new | old] per vertex -- into swizzled LDS
-//     with 16-byte-per-lane coalesced loads of whole 128-byte lines; this gather is the HBM term
-//     that bounds the kernel (C_i * row bytes).  Workgroups are persistent and
-//     software-pipelined: while the MFMA block and the proposal epilogue of group i run, the gather
-//     of group i+1 (rows, neighbour lists, norms, thresholds: all loads issued back to back) is in
-//     flight in registers and the candidate ids of group i+2 are being fetched;
-//   * the new x (new U old) distance block is a Gram contraction on the f32 MFMA pipe
-//     (16x16x4, one A tile row per wave, tiles below the diagonal of new x new skipped);
-//   * each endpoint is tested on its OWN threshold (d < th_p for p, d < th_q for q) and against the
-//     target's current neighbour ids, which are gathered next to the vectors (k*4 bytes per
-//     candidate): a proposal leaves the workgroup only if the push would succeed on the snapshot;
+// MI355X design (one kernel family, k_local_join16 for max_candidates <= 16 and k_local_join_w<32|64> above that)
+//   * ONE WAVE PER VERTEX, no workgroup barrier, no LDS row tile: a wave computes its vertex's whole
+//     [new] x [new | old] block, nothing is shared between waves, so every lane loads its MFMA operands straight
+//     from global memory in MFMA layout (lane (r16, g) holds 16-byte chunks 4t+g of candidate row r16 of a tile);
+//     the gather of candidate rows is the HBM term that prices the kernel (C_i * row bytes);
+//   * the new x (new U old) distance block is a Gram contraction on the f32 MFMA pipe (16x16x4; tiles below the
+//     diagonal of new x new skipped; only filled slots are fetched);
+//   * software pipeline per wave: right after the last MFMA has consumed the operand registers, the gather of the
+//     wave's next vertex is issued into them and flies during the epilogue; candidate ids are prefetched two
+//     vertices ahead;
+//   * epilogue: each endpoint is tested on its OWN threshold (d < th_p for p, d < th_q for q); survivors go to a
+//     wave-private LDS queue that is drained on full waves: membership test against the target's current
+//     neighbour ids (a proposal leaves the wave only if the push would succeed on the snapshot), then
 //   * surviving proposals go to a per-target bank of PCAP hashed slots with a 64-bit atomicMin on
 //     (dist_bits << 32 | source): order independent (deterministic), duplicate proposals of the
-//     same source collapse into one slot, and a slot collision keeps the nearer source.
+//     same source collapse into one slot, and a slot collision keeps the nearer source;
+//   * vertices are visited in the first tree's leaf order, one contiguous eighth per XCD.
 #include "common.h"
 #include "gram.h"
 #include "state.h"
 
-#define JOIN_ROWS 128        // candidate rows per workgroup
-#define NND_JOIN_MAX_KS 64    // k-list row stride bound (k <= 64)
 
 // is `id` among the neighbour ids of LDS row kl?  All KS16*4 16-byte reads are issued before the first compare.
 template <int KS16>
@@ -41,226 +40,6 @@ __device__ __forceinline__ bool klist_has(const uint32_t *kl, uint32_t id) {
 #pragma unroll
     for (int c = 0; c < KS16 * 4; c++) present |= (w[c].x == id) | (w[c].y == id) | (w[c].z == id) | (w[c].w == id);
     return present;
-}
-
-template <int MCP, int DC, int KS16>
-__global__ __launch_bounds__(256, 2) void k_local_join(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
-                                                    int metric, const int32_t *__restrict__ cand, int64_t v_begin,
-                                                    int64_t v_end, int64_t n_groups, int k, int ks,
-                                                    const uint32_t *__restrict__ knn_e, const float *__restrict__ th,
-                                                    uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
-                                                    uint32_t slot_seed, long long *__restrict__ counters) {
-    constexpr int NA = MCP / 16;      // A tile rows per vertex == waves per vertex
-    constexpr int NB = 2 * MCP / 16;  // B tiles per vertex: [new | old]
-    constexpr int RV = 2 * MCP;       // candidate rows per vertex
-    constexpr int VPW = 64 / MCP;     // vertices per group
-    constexpr int ROWS = JOIN_ROWS;   // VPW * RV
-    constexpr int NCH = DC / 4;       // 16-byte chunks per staged row
-    constexpr int NLD = ROWS * NCH / 256;  // row chunks per thread
-    constexpr int KQ = KS16 * 4;              // uint4 chunks per staged neighbour-list row (ks <= 16 * KS16)
-    constexpr int KQMAX = ROWS * KQ / 256;    // of which per thread
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *Xs = (float *)smem;                        // ROWS * DC floats
-    int32_t *cidbuf = (int32_t *)(Xs + ROWS * DC);    // 2 * ROWS: candidate ids of the current and the next group
-    int32_t *nnewbuf = cidbuf + 2 * ROWS;             // 2 * 4: new-candidate count per vertex slot
-    int32_t *cid = nnewbuf + 8;                       // ROWS: ids of the group being joined (-1: empty / inactive vertex)
-    float *cnrm = (float *)(cid + ROWS);              // ROWS
-    float *cth = cnrm + ROWS;                         // ROWS
-    uint32_t *klist = (uint32_t *)(cth + ROWS);       // ROWS * kls neighbour ids of every candidate
-    constexpr int kls = KS16 * 16 + 4;                // padded row stride: conflict-free 16-byte reads across rows
-    const int kq = ks >> 2;                           // uint4 chunks per neighbour-list row
-
-    const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
-    const int64_t stride = gridDim.x;
-    const int cw0 = dp < DC ? dp : DC;
-    const int nch0 = cw0 >> 2;
-
-    // candidate ids of group g for row tid (tid < ROWS)
-    // (loads are unconditional with clamped addresses: a "default, then conditional load" pattern makes the
-    //  compiler drain the whole memory queue (s_waitcnt vmcnt(0)) before it may overwrite the default)
-    auto load_cand = [&](int64_t g) __attribute__((always_inline)) -> int {
-        const int row = tid < ROWS ? tid : 0;
-        const int slot = row / RV, within = row - slot * RV;
-        const int64_t v = v_begin + g * VPW + slot;
-        const bool ok = tid < ROWS && g < n_groups && v < v_end;
-        const int c = cand[ok ? v * RV + within : 0];
-        return ok ? c : -1;
-    };
-    // publish them (and the per-vertex count of new candidates: lists are filled from the front, sample.hip)
-    auto store_cand = [&](int buf, int c) __attribute__((always_inline)) {
-        if (tid < ROWS) {
-            const int slot = tid / RV, within = tid - slot * RV;
-            cidbuf[buf * ROWS + tid] = c;
-            const unsigned long long m = __ballot(c >= 0 && within < MCP);
-            if (RV >= 64) {
-                if (within == 0) nnewbuf[buf * 4 + slot] = __popcll(m);
-            } else {
-                if (within == 0) nnewbuf[buf * 4 + slot] = __popcll(lane < 32 ? (m & 0xFFFFFFFFull) : (m >> 32));
-            }
-        }
-    };
-
-    // registers that carry the NEXT group's gather across the current group's MFMA + epilogue
-    f32x4 rowv[NLD];  // native vector types: these arrays must stay in registers
-    u32x4 klv[KQMAX];
-    float nx_nrm = 0.0f, nx_th = 0.0f;
-    int nx_id = -1;
-    auto issue_gather = [&](int buf) __attribute__((always_inline)) {  // every global load of a group's gather, issued back to back
-        const int32_t *cb = cidbuf + buf * ROWS;
-        const int32_t *nb = nnewbuf + buf * 4;
-#pragma clang loop unroll(full)
-        for (int i = 0; i < NLD; i++) {
-            const int idx = tid + i * 256;
-            int r, ch;
-            if (cw0 == DC) { r = idx / NCH; ch = idx % NCH; } else { r = idx / nch0; ch = idx - r * nch0; }
-            const int rr = r < ROWS ? r : 0;
-            const int id = nb[rr / RV] > 0 ? cb[rr] : -1;
-            rowv[i] = *(const f32x4 *)(xp + (int64_t)(id >= 0 ? id : 0) * dp + 4 * ch);  // empty slot: row 0 (an L2 hit), masked later
-        }
-        {
-            const int row = tid < ROWS ? tid : 0;
-            nx_id = (tid < ROWS && nb[row / RV] > 0) ? cb[row] : -1;
-            const int64_t ide = nx_id >= 0 ? nx_id : 0;
-            nx_nrm = nrm[ide];
-            nx_th = th[ide];  // compact per-row worst distance (L2 resident), not a 128-byte line per candidate
-        }
-#pragma clang loop unroll(full)
-        for (int i = 0; i < KQMAX; i++) {
-            const int idx = tid + i * 256;  // covers every (row, chunk < KQ) exactly once
-            const int r = idx / KQ, c = idx % KQ;
-            const int id = nb[r / RV] > 0 ? cb[r] : -1;
-            const bool ok = c < kq && id >= 0;
-            klv[i] = *(const u32x4 *)(knn_e + (ok ? (int64_t)id * ks + 4 * c : 0));  // raw; masked when it lands
-        }
-    };
-    auto land_gather = [&](int buf) __attribute__((always_inline)) {  // registers -> LDS
-        const int32_t *cb = cidbuf + buf * ROWS;
-        const int32_t *nb = nnewbuf + buf * 4;
-#pragma clang loop unroll(full)
-        for (int i = 0; i < NLD; i++) {
-            const int idx = tid + i * 256;
-            int r, ch;
-            if (cw0 == DC) { r = idx / NCH; ch = idx % NCH; } else { r = idx / nch0; ch = idx - r * nch0; }
-            if (r < ROWS) *(f32x4 *)&Xs[nnd_swz<DC>(r, ch)] = rowv[i];
-        }
-        if (tid < ROWS) {
-            cid[tid] = nx_id;
-            cnrm[tid] = nx_nrm;
-            cth[tid] = nx_th;
-        }
-#pragma clang loop unroll(full)
-        for (int i = 0; i < KQMAX; i++) {
-            const int idx = tid + i * 256;
-            const int r = idx / KQ, c = idx % KQ;
-            const bool ok = c < kq && nb[r / RV] > 0 && cb[r] >= 0;  // padding beyond k is EMPTY already
-            const u32x4 empty = {NND_IDX_MASK, NND_IDX_MASK, NND_IDX_MASK, NND_IDX_MASK};
-            *(u32x4 *)(klist + r * kls + 4 * c) = ok ? (klv[i] & NND_IDX_MASK) : empty;
-        }
-    };
-
-    // ---- prologue: ids of the first two groups, gather of the first ----
-    int64_t g = blockIdx.x;
-    store_cand(0, load_cand(g));
-    store_cand(1, load_cand(g + stride));
-    __syncthreads();
-    issue_gather(0);
-
-    int tot_pairs = 0, tot_prop = 0, tot_rows = 0, tot_act = 0;  // per-thread partial statistics
-    const int slot = w / NA, ar = w % NA;
-    const int base = slot * RV;
-
-    for (int it = 0; g < n_groups; g += stride, it++) {
-        const int cur = it & 1;
-        int act = 0;
-#pragma unroll
-        for (int s2 = 0; s2 < VPW; s2++) act += nnewbuf[cur * 4 + s2] > 0;
-        const int my_new = nnewbuf[cur * 4 + slot];
-        // 1. land this group's gather (issued one iteration ago) in LDS
-        if (act) land_gather(cur);
-        __syncthreads();
-        // 2./3. keep the memory system busy: rows one group ahead, ids two groups ahead (issued last, so
-        // that nothing has to wait for it before the end of the iteration: loads return in order)
-        if (g + stride < n_groups) issue_gather(cur ^ 1);
-        const int c2 = load_cand(g + 2 * stride);
-        // 4. this group's distance block and proposals
-        if (act) {
-            const int nb_new = (my_new + 15) >> 4;
-            const bool wave_on = ar < nb_new;  // this wave's A tile row holds at least one new candidate
-            f32x4 acc[NB];
-#pragma unroll
-            for (int J = 0; J < NB; J++) acc[J] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int c0 = 0; c0 < dp; c0 += DC) {
-                const int cw = (dp - c0) < DC ? (dp - c0) : DC;
-                if (c0 > 0) {  // rows wider than one LDS chunk: the remaining chunks are staged synchronously
-                    __syncthreads();
-                    nnd_stage_rows<DC>(xp, dp, cid, ROWS, c0, cw, Xs, tid, 256);
-                    __syncthreads();
-                }
-                if (wave_on)
-                    nnd_gram_chunk<DC, NB>(Xs, base + ar * 16, base, cw, acc,
-                                           [ar](int J) { return J >= NA || J >= ar; });  // new x new: diagonal and above
-            }
-            if (wave_on) {
-                const int r16 = lane & 15, gq = lane >> 4;
-#pragma unroll
-                for (int J = 0; J < NB; J++) {
-                    if (J < NA && J < ar) continue;
-                    const int jj = J * 16 + r16;  // index inside [new | old]
-                    const int qrow = base + jj;
-                    const int qid = cid[qrow];
-                    const float qn = cnrm[qrow], qth = cth[qrow];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int i = ar * 16 + 4 * gq + r;  // index inside new
-                        const int prow = base + i;
-                        const int pid = cid[prow];
-                        const bool valid = pid >= 0 && qid >= 0 && (jj >= MCP || jj >= i);
-                        if (!valid) continue;
-                        tot_pairs++;
-                        const bool self = (pid == qid);
-                        const float d = self ? 0.0f : nnd_gram_to_dist(metric, acc[J][r], cnrm[prow], qn);
-                        const bool need_p = d < cth[prow], need_q = !self && d < qth;
-                        if (!(need_p | need_q)) continue;
-                        // both neighbour lists are fetched together (one LDS round trip)
-                        const bool in_p = klist_has<KS16>(klist + prow * kls, (uint32_t)qid);
-                        const bool in_q = klist_has<KS16>(klist + qrow * kls, (uint32_t)pid);
-                        if (need_p && !in_p) {  // p <- q
-                            const uint32_t sl = nnd_hash2(slot_seed, (uint32_t)qid) & (uint32_t)(pcap - 1);
-                            atomicMin((unsigned long long *)&pbuf[(int64_t)pid * pcap + sl],
-                                      (unsigned long long)nnd_make_key(d, (uint32_t)qid));
-                            pdirty[pid] = 1;
-                            tot_prop++;
-                        }
-                        if (need_q && !in_q) {  // q <- p
-                            const uint32_t sl = nnd_hash2(slot_seed, (uint32_t)pid) & (uint32_t)(pcap - 1);
-                            atomicMin((unsigned long long *)&pbuf[(int64_t)qid * pcap + sl],
-                                      (unsigned long long)nnd_make_key(d, (uint32_t)pid));
-                            pdirty[qid] = 1;
-                            tot_prop++;
-                        }
-                    }
-                }
-            }
-            if (tid < ROWS) tot_rows += cid[tid] >= 0;
-            if (tid == 0) tot_act += act;
-        }
-        // 5. the id buffer of this group is free: publish the ids fetched in step 2
-        __syncthreads();
-        store_cand(cur, c2);
-    }
-
-    // ---- statistics: one atomic per workgroup per counter (striped) ----
-    __syncthreads();
-    int *red = (int *)Xs;
-    red[tid * 4 + 0] = tot_pairs; red[tid * 4 + 1] = tot_prop; red[tid * 4 + 2] = tot_rows; red[tid * 4 + 3] = tot_act;
-    __syncthreads();
-    if (tid < 4) {
-        long long sum = 0;
-        for (int t = 0; t < 256; t++) sum += red[t * 4 + tid];
-        const int which = tid == 0 ? CNT_PAIRS : (tid == 1 ? CNT_PROPOSALS : (tid == 2 ? CNT_ROWS : CNT_ACTIVE));
-        nnd_count(counters, which, sum);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -880,43 +659,6 @@ static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     return 0;
 }
 
-template <int MCP, int DC, int KS16>
-static int launch_join_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
-    constexpr int VPW = 64 / MCP;
-    size_t smem = sizeof(float) * JOIN_ROWS * DC + sizeof(int32_t) * (2 * JOIN_ROWS + 8 + JOIN_ROWS) +
-                  sizeof(float) * 2 * JOIN_ROWS + sizeof(uint32_t) * JOIN_ROWS * (size_t)(KS16 * 16 + 4);
-    auto kern = k_local_join<MCP, DC, KS16>;
-    static size_t configured = 0;
-    static int wg_per_cu = 0, n_cu = 0;
-    if (smem > configured || wg_per_cu == 0) {
-        NND_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        configured = smem;
-        hipDeviceProp_t prop;
-        NND_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->p.device));
-        n_cu = prop.multiProcessorCount;
-        int occ = 0;
-        NND_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, 256, smem));
-        wg_per_cu = occ < 1 ? 1 : occ;
-    }
-    int64_t nv = v_end - v_begin;
-    int64_t n_groups = (nv + VPW - 1) / VPW;
-    int64_t resident = (int64_t)n_cu * wg_per_cu;
-    unsigned grid = (unsigned)(n_groups < resident ? n_groups : resident);
-    uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
-                       v_begin, v_end, n_groups, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty, ctx->pcap,
-                       slot_seed, ctx->counters);
-    NND_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-template <int MCP, int DC>
-static int launch_join_ks(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
-    if (ctx->ks <= 16) return launch_join_t<MCP, DC, 1>(ctx, v_begin, v_end);
-    if (ctx->ks <= 32) return launch_join_t<MCP, DC, 2>(ctx, v_begin, v_end);
-    return launch_join_t<MCP, DC, 4>(ctx, v_begin, v_end);
-}
-
 int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     if (v_end <= v_begin) return 0;
     const bool wide = ctx->dp >= 128;
@@ -926,7 +668,7 @@ int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
 #endif
         case 16: return wide ? launch_join16_ks<NND_J16_DCW>(ctx, v_begin, v_end) : launch_join16_ks<32>(ctx, v_begin, v_end);
         case 32: return wide ? launch_join_w<32, NND_JW_DCW>(ctx, v_begin, v_end) : launch_join_w<32, 32>(ctx, v_begin, v_end);
-        case 64: return wide ? launch_join_ks<64, 128>(ctx, v_begin, v_end) : launch_join_ks<64, 32>(ctx, v_begin, v_end);
+        case 64: return launch_join_w<64, 32>(ctx, v_begin, v_end);
     }
     ctx->set_error("unsupported padded max_candidates %d", ctx->mcp);
     return 1;

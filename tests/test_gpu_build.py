@@ -276,3 +276,14 @@ def test_update_errors_and_plain_refresh():
     assert O.recall(ti, idx) > 0.97
     index.update(xs_fresh=x[:50] + 0.01)
     assert index.neighbor_graph[0].shape == (650, 8)
+
+
+@pytest.mark.parametrize("k,mc", [(40, None), (64, None), (20, 50)])
+def test_wide_candidate_lists_against_oracle(k, mc):
+    """max_candidates 33..64 (k_local_join_w<64,...>): recall parity with the CPU oracle on the same inputs."""
+    x = clustered(6000, 24, 8, 30, seed=9)
+    idx, _ = NNDescent(x, "euclidean", n_neighbors=k, max_candidates=mc, random_state=7)._neighbor_graph
+    oidx, _ = O.build_index(x, "euclidean", n_neighbors=k, max_candidates=mc, random_state=7, n_threads=8, kind="fast")
+    _parity(x, "euclidean", k, idx, oidx, k_true=min(k, 20))
+    for row in idx[::97]:
+        assert len(set(row.tolist())) == len(row)
