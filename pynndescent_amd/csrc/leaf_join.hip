@@ -27,6 +27,9 @@ struct leaf_cfg {
     // NT <= 6: the whole leaf x leaf distance block lives in LDS and its rows are dealt round-robin to ALL waves
     // (balanced merges); larger leaves: each wave keeps only the 16 rows of the tile row it is working on.
     static constexpr bool FULLD = NT <= 6;
+    // FULLD: the leaf x leaf block is symmetric -- only the tile pairs I <= J are computed (dealt round-robin to the
+    // waves) and every off-diagonal tile is written twice, once transposed
+    static constexpr int TPW = (NT * (NT + 1) / 2 + NW - 1) / NW;
     static constexpr int DB_FLOATS = FULLD ? MP * DSTRIDE : NW * 16 * DSTRIDE;
     static constexpr bool PREFETCH = FULLD;                  // k-list prefetch buffers sit next to the distance block
     static constexpr int PRE_FLOATS = PREFETCH ? MP * 16 * 2 : 0;  // budgeted for k <= 16; larger k uses what Xs leaves free
@@ -69,11 +72,26 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
     float *Xs = big;
     uint32_t pe[NKL];
     float pd[NKL];
-    f32x4 acc[C::TR][NT];
+    f32x4 acc[C::TR][NT];   // !FULLD: tile row I = w + tr*NW against every J
+    f32x4 acct[C::TPW];     // FULLD: tile pairs t = w, w + NW, ... of the upper triangle
+    int tI[C::TPW], tJ[C::TPW];
+    bool tOn[C::TPW];
 #pragma unroll
     for (int tr = 0; tr < C::TR; tr++)
 #pragma unroll
         for (int J = 0; J < NT; J++) acc[tr][J] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < C::TPW; q++) {
+        acct[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int t = w + q * NW, I = 0;
+        while (I < nt && t >= nt - I) {  // wave-uniform: row-major walk of the upper triangle
+            t -= nt - I;
+            I++;
+        }
+        tOn[q] = I < nt;  // idle slots recompute tile (0, 0) and drop the result: no conditional register arrays
+        tI[q] = I < nt ? I : 0;
+        tJ[q] = I < nt ? I + t : 0;
+    }
 
     for (int c0 = 0; c0 < dp; c0 += DC) {
         const int cw = (dp - c0) < DC ? (dp - c0) : DC;
@@ -116,10 +134,31 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
             if (c0 == 0 && tid < C::MP) nrs[tid] = my_nrm;
         }
         __syncthreads();
+        if constexpr (C::FULLD) {
+            const int lr = lane & 15, lg = lane >> 4;
+            for (int t = 0; t < (cw >> 4); t++) {
+                const int c = 4 * t + lg;
+                float4 a[C::TPW], b[C::TPW];
 #pragma unroll
-        for (int tr = 0; tr < C::TR; tr++) {
-            const int I = w + tr * NW;
-            if (I < nt) nnd_gram_chunk<DC, NT>(Xs, I * 16, 0, cw, acc[tr], [nt](int J) { return J < nt; });
+                for (int q = 0; q < C::TPW; q++) {
+                    a[q] = *(const float4 *)&Xs[nnd_swz<DC>(tI[q] * 16 + lr, c)];
+                    b[q] = *(const float4 *)&Xs[nnd_swz<DC>(tJ[q] * 16 + lr, c)];
+                }
+#pragma unroll
+                for (int q = 0; q < C::TPW; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b[q].x, acct[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < C::TPW; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, b[q].y, acct[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < C::TPW; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, b[q].z, acct[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < C::TPW; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, b[q].w, acct[q], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int tr = 0; tr < C::TR; tr++) {
+                const int I = w + tr * NW;
+                if (I < nt) nnd_gram_chunk<DC, NT>(Xs, I * 16, 0, cw, acc[tr], [nt](int J) { return J < nt; });
+            }
         }
     }
     __syncthreads();  // Xs is overwritten by the distance blocks below
@@ -130,20 +169,17 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
     if constexpr (C::FULLD) {
         float *Dm = big;  // MP x DSTRIDE; Xs is dead (barrier at the end of the K loop)
 #pragma unroll
-        for (int tr = 0; tr < C::TR; tr++) {
-            const int I = w + tr * NW;
-            if (I >= nt) continue;
+        for (int q = 0; q < C::TPW; q++) {
+            if (!tOn[q]) continue;
+            const int I = tI[q], J = tJ[q];
+            const int j = J * 16 + r16;
+            const float nj = nrs[j];
 #pragma unroll
-            for (int J = 0; J < NT; J++) {
-                if (J < nt) {
-                    const int j = J * 16 + r16;
-                    const float nj = nrs[j];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int il = I * 16 + 4 * g + r;
-                        Dm[il * C::DSTRIDE + j] = nnd_gram_to_dist(metric, acc[tr][J][r], nrs[il], nj);
-                    }
-                }
+            for (int r = 0; r < 4; r++) {
+                const int il = I * 16 + 4 * g + r;
+                const float dv = nnd_gram_to_dist(metric, acct[q][r], nrs[il], nj);
+                Dm[il * C::DSTRIDE + j] = dv;
+                if (I != J) Dm[j * C::DSTRIDE + il] = dv;  // the mirrored tile
             }
         }
         // the k-lists fetched with the rows (this workgroup owns them for this tree) land next to the distance block
@@ -283,11 +319,11 @@ int nnd_launch_leaf_init(nnd_ctx *ctx) {
 #define LEAF_ARGS ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, perm, d_ws, d_wl, tb[t], tb[t + 1], ctx->k, ctx->ks, \
                   ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters
         if (maxlen <= 64)
-            hipLaunchKernelGGL((k_leaf_join<4, 4, 128>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+            hipLaunchKernelGGL((k_leaf_join<4, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 80)  // the default leaf_size (<= 75 points): 36 KB of LDS, 4 workgroups per CU
             hipLaunchKernelGGL((k_leaf_join<5, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 96)
-            hipLaunchKernelGGL((k_leaf_join<6, 4, 128>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+            hipLaunchKernelGGL((k_leaf_join<6, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 128)
             hipLaunchKernelGGL((k_leaf_join<8, 4, 64>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 160)  // k = 30 (leaf_size 150): 10 x 10 tiles instead of 16 x 16
