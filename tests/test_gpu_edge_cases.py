@@ -1,0 +1,40 @@
+"""Degenerate shapes through the drop-in class on the GPU: tiny n, n < k (the reference pads with (-1, inf) and
+warns, pynndescent_.py:1262-1267), d = 1, k = 64, leaf_size = 2, one iteration, delta = 0."""
+import warnings
+
+import numpy as np
+import pytest
+
+from pynndescent_amd import NNDescent
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,d,k,kw", [
+    (5, 3, 10, {}), (1, 3, 2, {}), (2, 1, 1, {}), (50, 1, 5, {}), (100, 2, 64, {}),
+    (70, 7, 3, {"n_trees": 1, "leaf_size": 2}), (300, 5, 15, {"metric": "cosine"}),
+    (64, 33, 15, {"max_candidates": 3}), (1000, 130, 15, {"n_iters": 1}), (200, 16, 5, {"delta": 0.0, "n_iters": 3}),
+])
+def test_degenerate_shapes(n, d, k, kw):
+    x = np.random.RandomState(n + d + k).standard_normal((n, d)).astype(np.float32)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        idx, dist = NNDescent(x, n_neighbors=k, random_state=1, **kw).neighbor_graph
+    assert idx.shape == dist.shape == (n, k)
+    filled = idx >= 0
+    # a row holds min(k, n) entries when the build can reach every point (tiny sets always can)
+    if n <= k:
+        assert np.all(filled.sum(1) == n)
+        assert any("Failed to correctly find n_neighbors" in str(m.message) for m in w)
+    else:
+        assert filled.all()
+    assert np.all(np.isinf(dist[~filled]))
+    big = np.where(filled, dist, np.inf)
+    assert np.all(big[:, 1:] >= big[:, :-1])
+    for row, f in zip(idx, filled):
+        ids = row[f]
+        assert len(set(ids.tolist())) == len(ids)
+    # the self pair comes from the local join (utils.py:619): a point that is nobody's new candidate (tiny
+    # max_candidates) may miss it, exactly as in the reference
+    if "max_candidates" not in kw and kw.get("metric") != "cosine":
+        assert np.all(idx[:, 0] == np.arange(n))
