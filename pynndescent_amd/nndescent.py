@@ -263,10 +263,88 @@ class NNDescent:
             self.prune_degree_multiplier, self.diversify_prob, self.diversify_method, device=self.device)
         return self._search_graph
 
+    # attributes of the reference class that prepare() / query() / update() read (pynndescent_.py:1014-1113)
+    _HANDOVER = (
+        "n_trees", "angular_trees", "n_trees_after_update", "n_neighbors", "metric", "metric_kwds", "bit_metric",
+        "leaf_size", "prune_degree_multiplier", "diversify_prob", "diversify_method", "degree_prune_aggressiveness",
+        "n_search_trees", "search_tree_leaf_size", "max_search_tree_depth", "max_rptree_depth", "max_candidates",
+        "quantization", "low_memory", "n_iters", "delta", "dim", "n_jobs", "compressed", "parallel_batch_queries",
+        "verbose", "_input_dtype", "_raw_data", "tree_init", "_dist_args", "random_state", "_angular_trees",
+        "_bit_trees", "_is_sparse", "rng_state", "search_rng_state", "_rp_forest",
+    )
+
+    def to_reference(self):
+        """Hand the GPU-built index to ``pynndescent.NNDescent`` (must be importable) WITHOUT rebuilding: the returned
+        object carries this index's data, graph and parameters, so the reference's own ``prepare()`` (hub search tree,
+        pruned + reordered search graph) and ``query()`` run on it unchanged.  The reference only null-checks
+        ``_rp_forest`` before building its hub tree from the graph (pynndescent_.py:1353-1437)."""
+        import pynndescent
+
+        ref = object.__new__(pynndescent.NNDescent)
+        for name in self._HANDOVER:
+            setattr(ref, name, getattr(self, name))
+        ref._neighbor_graph = (self._neighbor_graph[0].copy(), self._neighbor_graph[1].copy())
+        ref._distance_correction = None
+        ref._set_distance_func()  # pynndescent_.py:1271-1298: numba distance, correction, proxy flags
+        return ref
+
+    @classmethod
+    def from_graph(cls, data, indices, distances, metric="euclidean", random_state=None, **kwargs):
+        """An index object around an existing k-NN graph (``distances`` in the alternative space, rows ascending), no
+        build: the starting point for ``update()`` / ``build_search_graph()`` / ``to_reference()``."""
+        self = object.__new__(cls)
+        data = check_array(data, dtype=np.float32, order="C")
+        n = data.shape[0]
+        n_trees = kwargs.pop("n_trees", None)
+        n_iters = kwargs.pop("n_iters", None)
+        if n_trees is None:
+            n_trees = max(3, min(12, int(round(2.0 * np.log10(n)))))
+        if n_iters is None:
+            n_iters = max(5, int(round(np.log2(n))))
+        defaults = dict(
+            angular_trees=False, metric_kwds=None, bit_metric=False, leaf_size=None, prune_degree_multiplier=1.5,
+            diversify_prob=1.0, diversify_method="standard", degree_prune_aggressiveness=1.0, n_search_trees=1,
+            search_tree_leaf_size=None, max_search_tree_depth=None, max_rptree_depth=200, max_candidates=None,
+            quantization=None, low_memory=True, delta=0.001, n_jobs=None, compressed=False,
+            parallel_batch_queries=False, verbose=False, device=0,
+        )
+        unknown = set(kwargs) - set(defaults)
+        if unknown:
+            raise TypeError("unexpected arguments: %s" % sorted(unknown))
+        defaults.update(kwargs)
+        for name, value in defaults.items():
+            setattr(self, name, value)
+        if metric not in _METRIC_CODES:
+            raise ValueError("Metric is neither callable, " + "nor a recognised string")
+        indices = np.ascontiguousarray(indices, np.int32)
+        distances = np.ascontiguousarray(distances, np.float32)
+        if indices.shape != distances.shape or indices.shape[0] != n:
+            raise ValueError("Init graph size does not match dataset size!")
+        self.metric, self.n_neighbors = metric, indices.shape[1]
+        self.n_trees, self.n_iters = n_trees, n_iters
+        self.n_trees_after_update = max(2, int(np.round(n_trees / 3)))
+        self.dim = data.shape[1]
+        self._input_dtype, self._raw_data = np.float32, data
+        self.tree_init = True
+        self._dist_args = tuple((self.metric_kwds or {}).values())
+        self.random_state = random_state
+        rs = check_random_state(random_state)
+        self._distance_correction = _DISTANCE_CORRECTIONS[metric]
+        self._distance_func = None
+        self._angular_trees = metric in _ANGULAR_METRICS
+        self._bit_trees = self._is_sparse = False
+        self.rng_state = rs.randint(INT32_MIN, INT32_MAX, 3).astype(np.int64)
+        self.search_rng_state = rs.randint(INT32_MIN, INT32_MAX, 3).astype(np.int64)
+        for _ in range(10):
+            tau_rand_int(self.search_rng_state)
+        self._rp_forest = _DeviceForestSentinel(n_trees, 0, 0)
+        self._neighbor_graph = (indices, distances)
+        return self
+
     def _out_of_scope(self, what):
         raise NotImplementedError(
             "%s is out of scope for pynndescent_amd (build path only; SURVEY.md section 8f). "
-            "Hand this index's neighbor_graph to the reference as init_graph, or use pynndescent.NNDescent." % what
+            "Use index.to_reference() to continue with pynndescent.NNDescent on this graph without rebuilding." % what
         )
 
     def prepare(self):
