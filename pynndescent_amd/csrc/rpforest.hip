@@ -109,10 +109,14 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
 // margin = h . x + off for one point, computed by the 4 lanes of a quad (lane `sub` takes the 16-byte chunks
 // sub, sub+4, ... of the row, i.e. 64 contiguous bytes per 4-chunk step).
 // Screening pass: row AND hyperplane are read from their bf16 copies (half the bytes) and multiplied with the packed
-// v_dot2_f32_bf16 (two products per instruction, no conversions).  Round-to-nearest bf16 moves each operand by at
-// most 2^-9 relative, so |margin_bf16 - margin_f32| <= ~2^-8 |h||x|; if the screened margin is further from zero than
-// twice that bound its SIGN is already the f32 sign and the f32 row is never touched.  The (rare) points inside the
-// band are recomputed from the f32 row and the f32 hyperplane, so the split is exactly the f32 split.
+// v_dot2_f32_bf16 (two products per instruction, no conversions).  bf16 carries 8 significant bits: round-to-nearest
+// moves each operand by at most 2^-8 relative, each product by at most (2 * 2^-8 + 2^-16), so
+//     |margin_bf16 - margin_f32| <= (2 * 2^-8 + 2^-16) * sum|h_i x_i|  <=  RP_BAND * |h| |x|      (Cauchy-Schwarz)
+// with RP_BAND also covering the f32 accumulation-order difference (<= d * 2^-24 relative).  If the screened margin is
+// further from zero than that, its SIGN is already the f32 sign and the f32 row is never touched.  The points inside
+// the band (a few percent at the top of a tree, more in small dense nodes) are recomputed from the f32 row and the
+// f32 hyperplane, so the split is exactly the f32 split.
+#define RP_BAND 0.00786f
 typedef __attribute__((ext_vector_type(2))) __bf16 rp_bf16x2;
 __device__ __forceinline__ float rp_dot8(uint4 q, uint4 p, float acc) {
     acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2, q.x), __builtin_bit_cast(rp_bf16x2, p.x), acc, false);
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, co
             if (c + 4 * j < (dp >> 3)) acc = rp_dot8(q[j], p[j], acc);
     }
     const float m = rp_quad_sum(acc) + off;
-    const float band = 0.0078125f * hnorm * (metric == 0 ? sqrtf(xn) : xn) + 1e-30f;  // 2 * 2^-8 |h||x|
+    const float band = RP_BAND * hnorm * (metric == 0 ? sqrtf(xn) : xn) + 1e-30f;
     const uint8_t sd = rp_side(m, band, xp + pt * dp, h, off, dp, sub, seed, (uint32_t)g, depth);
     if (sub == 0) side[g] = sd;
 }
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ 
             const float *h = hyper + (int64_t)sg[u] * hs;
             const float off = h[dp], hnorm = h[dp + 1];
             const float m = rp_quad_sum(acc[u]) + off;
-            const float band = 0.0078125f * hnorm * xnorm + 1e-30f;
+            const float band = RP_BAND * hnorm * xnorm + 1e-30f;
             const int64_t slot = (int64_t)(t0 + u) * n + i;
             const uint8_t sd = rp_side(m, band, xp + i * dp, h, off, dp, sub, seed, (uint32_t)slot, depth);
             if (sub == 0) side_pt[slot] = sd;
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
                 const int i = i0 + u * 64 + grp;
                 if (i >= l) continue;  // whole quad
                 const float m = rp_quad_sum(acc[u]) + off;
-                const float band = 0.0078125f * hnorm * (metric == 0 ? sqrtf(xn[u]) : xn[u]) + 1e-30f;
+                const float band = RP_BAND * hnorm * (metric == 0 ? sqrtf(xn[u]) : xn[u]) + 1e-30f;
                 const uint8_t side = rp_side(m, band, xp + pt[u] * dp, h, off, dp, sub, seed, gpos + (uint32_t)i, dep);
                 if (sub == 0) sd[i] = side;
             }
