@@ -13,23 +13,41 @@
 #include "merge.h"
 #include "state.h"
 
+// One wave per TWO consecutive rows: the slots and k-lists of both rows are fetched before the first merge starts, so a
+// wave pays one exposed memory latency for two rows (the kernel is latency bound: a million short waves).
 __global__ __launch_bounds__(256) void k_merge(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
                                                int64_t lo, int64_t n, int k, int ks, uint32_t *__restrict__ knn_e,
                                                float *__restrict__ knn_d, float *__restrict__ th,
                                                long long *__restrict__ counters) {
     __shared__ int wacc[4];
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;  // [lo, n): the rows this handle owns
+    const int64_t v0 = lo + ((int64_t)blockIdx.x * 4 + w) * 2;  // [lo, n): the rows this handle owns
     int acc = 0;
-    if (v < n && pdirty[v]) {
-        uint64_t *slots = pbuf + v * pcap;
-        acc = nnd_merge_row<1>(v, k, ks, knn_e, knn_d, th, pcap, [&](int c, uint32_t &id, float &dc) {
-            uint64_t key = slots[c];
-            id = nnd_key_idx(key);
-            dc = nnd_key_dist(key);
-            return key != NND_EMPTY_KEY;
-        });
-        for (int s = lane; s < pcap; s += 64) slots[s] = NND_EMPTY_KEY;
+    bool on[2];
+    uint64_t key[2];
+    uint32_t e[2];
+    float d[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int64_t v = v0 + u;
+        on[u] = v < n && pdirty[v < n ? v : lo];
+        const int64_t vv = on[u] ? v : lo;
+        key[u] = lane < pcap ? pbuf[vv * pcap + lane] : NND_EMPTY_KEY;  // pcap <= 64: one slot per lane
+        e[u] = lane < k ? knn_e[vv * ks + lane] : NND_EMPTY_E;
+        d[u] = lane < k ? knn_d[vv * ks + lane] : INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (!on[u]) continue;  // wave-uniform
+        const int64_t v = v0 + u;
+        const uint64_t mykey = key[u];
+        acc += nnd_merge_row_regs<1>(knn_e + v * ks, knn_d + v * ks, th + v, e[u], d[u], k, pcap,
+                                     [&](int c, uint32_t &id, float &dc) {
+                                         id = nnd_key_idx(mykey);
+                                         dc = nnd_key_dist(mykey);
+                                         return mykey != NND_EMPTY_KEY;
+                                     });
+        if (lane < pcap && mykey != NND_EMPTY_KEY) pbuf[v * pcap + lane] = NND_EMPTY_KEY;
         if (lane == 0) pdirty[v] = 0;
     }
     if (lane == 0) wacc[w] = acc;
@@ -38,7 +56,8 @@ __global__ __launch_bounds__(256) void k_merge(uint64_t *__restrict__ pbuf, uint
 }
 
 int nnd_launch_merge(nnd_ctx *ctx) {
-    hipLaunchKernelGGL(k_merge, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream, ctx->pbuf,
+    if (ctx->pcap > 64) { ctx->set_error("k_merge expects at most 64 proposal slots per row"); return 1; }
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 7) / 8)), dim3(256), 0, ctx->stream, ctx->pbuf,
                        ctx->pdirty, ctx->pcap, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
