@@ -243,17 +243,28 @@ __global__ __launch_bounds__(NW * 64) void k_leaf_join(const float *__restrict__
                 }
             }
             nnd_wave_lds_sync();
+            // rolling prefetch: the k-list row of point il+1 is in flight while point il is merged
+            const int lk = lane < k ? lane : 0;
+            uint32_t e_nx = knn_e[(int64_t)ids[I * 16] * ks + lk];
+            float d_nx = knn_d[(int64_t)ids[I * 16] * ks + lk];
             for (int il = 0; il < 16; il++) {
                 const int i = I * 16 + il;
                 if (i >= m) break;
                 const float *Drow = Dw + il * C::DSTRIDE;
                 const int64_t v = ids[i];
-                accepted += nnd_merge_row<(C::MP + 63) / 64>(v, k, ks, knn_e, knn_d, th, m,
-                                                            [&](int c, uint32_t &id, float &dc) {
-                                                                id = (uint32_t)ids[c];
-                                                                dc = Drow[c];
-                                                                return c != i;  // pynndescent_.py:97: p != q
-                                                            });
+                const uint32_t e0 = lane < k ? e_nx : NND_EMPTY_E;
+                const float d0 = lane < k ? d_nx : INFINITY;
+                if (il + 1 < 16 && i + 1 < m) {
+                    const int64_t vn = ids[i + 1];
+                    e_nx = knn_e[vn * ks + lk];
+                    d_nx = knn_d[vn * ks + lk];
+                }
+                accepted += nnd_merge_row_regs<(C::MP + 63) / 64>(knn_e + v * ks, knn_d + v * ks, th + v, e0, d0, k, m,
+                                                                 [&](int c, uint32_t &id, float &dc) {
+                                                                     id = (uint32_t)ids[c];
+                                                                     dc = Drow[c];
+                                                                     return c != i;  // pynndescent_.py:97: p != q
+                                                                 });
             }
             nnd_wave_lds_sync();
         }
