@@ -69,7 +69,7 @@ struct nnd_handle_s {
     int64_t P = 0;
     int32_t *perm[2] = {nullptr, nullptr};    // point id per position (ping-pong)
     int32_t *pos_seg[2] = {nullptr, nullptr}; // active segment index per position or -1
-    int32_t *inv = nullptr;                   // (P) position of point i in tree t (top, point-major levels)
+    int32_t *inv = nullptr;                   // (P) seg_pt: segment of point i in tree t, point-major [tree][point], -1 once final (top levels)
     uint8_t *side = nullptr;                  // (P) 0 left / 1 right
     uint8_t *side_pt = nullptr;               // (P) the same, point-major [tree][point] (written by the fused margin pass)
     uint8_t *leaf_flag = nullptr;             // (P) 1 at the first position of every final leaf
