@@ -44,7 +44,7 @@ static void free_all(nnd_ctx *ctx) {
     F(ctx->pdirty); F(ctx->active);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
-    F(ctx->hyper); F(ctx->hyper_h); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->counters);
+    F(ctx->hyper); F(ctx->hyper_h); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->wl_start); F(ctx->wl_len); F(ctx->colsum_partial); F(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

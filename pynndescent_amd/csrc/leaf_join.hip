@@ -289,38 +289,47 @@ static constexpr int LEAF_MAX = 256;
 int nnd_launch_leaf_init(nnd_ctx *ctx) {
     if (!ctx->forest_built || ctx->n_leaves == 0) return 0;
     const int T = ctx->p.n_trees;
-    // host copies of the leaf table (small) -> per-tree work lists
-    std::vector<int32_t> hs(ctx->n_leaves), hl(ctx->n_leaves);
-    NND_HIP_CHECK(hipMemcpyAsync(hs.data(), ctx->leaf_start, sizeof(int32_t) * ctx->n_leaves, hipMemcpyDeviceToHost, ctx->stream));
-    NND_HIP_CHECK(hipMemcpyAsync(hl.data(), ctx->leaf_len, sizeof(int32_t) * ctx->n_leaves, hipMemcpyDeviceToHost, ctx->stream));
-    NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    std::vector<int32_t> ws, wl;
-    std::vector<int64_t> tb(T + 1, 0);
-    ws.reserve(ctx->n_leaves);
-    wl.reserve(ctx->n_leaves);
-    int maxlen = 0;
-    for (int t = 0; t < T; t++) {
-        tb[t] = (int64_t)ws.size();
-        for (int64_t i = ctx->tree_leaf_begin[t]; i < ctx->tree_leaf_begin[t + 1]; i++) {
-            int32_t a = hs[i], len = hl[i];
-            while (len > 0) {
-                int32_t piece = len > LEAF_MAX ? LEAF_MAX : len;
-                ws.push_back(a);
-                wl.push_back(piece);
-                if (piece > maxlen) maxlen = piece;
-                a += piece;
-                len -= piece;
+    // Work list = the leaf table itself (device resident, per-tree offsets known from the forest build) unless some
+    // leaf is longer than LEAF_MAX: only then are the pieces listed on the host and uploaded.
+    const int32_t *d_ws = ctx->leaf_start, *d_wl = ctx->leaf_len;
+    std::vector<int64_t> tb(ctx->tree_leaf_begin.begin(), ctx->tree_leaf_begin.end());
+    int maxlen = ctx->max_leaf;
+    if (ctx->max_leaf > LEAF_MAX) {
+        const std::vector<int32_t> &hs = ctx->h_leaf_start, &hl = ctx->h_leaf_len;
+        std::vector<int32_t> ws, wl;
+        ws.reserve(ctx->n_leaves);
+        wl.reserve(ctx->n_leaves);
+        maxlen = 0;
+        for (int t = 0; t < T; t++) {
+            tb[t] = (int64_t)ws.size();
+            for (int64_t i = ctx->tree_leaf_begin[t]; i < ctx->tree_leaf_begin[t + 1]; i++) {
+                int32_t a = hs[i], len = hl[i];
+                while (len > 0) {
+                    int32_t piece = len > LEAF_MAX ? LEAF_MAX : len;
+                    ws.push_back(a);
+                    wl.push_back(piece);
+                    if (piece > maxlen) maxlen = piece;
+                    a += piece;
+                    len -= piece;
+                }
             }
         }
+        tb[T] = (int64_t)ws.size();
+        const int64_t nw = (int64_t)ws.size();
+        if (nw == 0) return 0;
+        if (nw > ctx->wl_cap) {
+            if (ctx->wl_start) { NND_HIP_CHECK(hipFree(ctx->wl_start)); ctx->wl_start = nullptr; }
+            if (ctx->wl_len) { NND_HIP_CHECK(hipFree(ctx->wl_len)); ctx->wl_len = nullptr; }
+            ctx->wl_cap = nw + nw / 4;
+            NND_HIP_CHECK(hipMalloc((void **)&ctx->wl_start, sizeof(int32_t) * (size_t)ctx->wl_cap));
+            NND_HIP_CHECK(hipMalloc((void **)&ctx->wl_len, sizeof(int32_t) * (size_t)ctx->wl_cap));
+        }
+        NND_HIP_CHECK(hipMemcpyAsync(ctx->wl_start, ws.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, ctx->stream));
+        NND_HIP_CHECK(hipMemcpyAsync(ctx->wl_len, wl.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, ctx->stream));
+        NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // ws / wl are about to go out of scope
+        d_ws = ctx->wl_start;
+        d_wl = ctx->wl_len;
     }
-    tb[T] = (int64_t)ws.size();
-    int64_t nw = (int64_t)ws.size();
-    if (nw == 0) return 0;
-    int32_t *d_ws = nullptr, *d_wl = nullptr;
-    NND_HIP_CHECK(hipMalloc((void **)&d_ws, sizeof(int32_t) * nw));
-    NND_HIP_CHECK(hipMalloc((void **)&d_wl, sizeof(int32_t) * nw));
-    NND_HIP_CHECK(hipMemcpyAsync(d_ws, ws.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, ctx->stream));
-    NND_HIP_CHECK(hipMemcpyAsync(d_wl, wl.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice, ctx->stream));
     if (nnd_zero_counters(ctx)) return 1;
     const int32_t *perm = ctx->perm[ctx->cur];
     for (int t = 0; t < T; t++) {
@@ -347,7 +356,5 @@ int nnd_launch_leaf_init(nnd_ctx *ctx) {
     if (nnd_read_counters(ctx)) return 1;
     ctx->stats.leaf_pairs = ctx->h_counters[CNT_PAIRS];
     ctx->stats.leaf_rows = ctx->h_counters[CNT_ROWS];
-    NND_HIP_CHECK(hipFree(d_ws));
-    NND_HIP_CHECK(hipFree(d_wl));
     return 0;
 }

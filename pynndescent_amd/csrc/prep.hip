@@ -81,14 +81,17 @@ int nnd_launch_prep(nnd_ctx *ctx) {
     if (ctx->p.metric == 0) {
         int rows_per_block = 256;
         int nblocks = (int)((n + rows_per_block - 1) / rows_per_block);
-        double *partial = nullptr;
-        NND_HIP_CHECK(hipMalloc((void **)&partial, sizeof(double) * (size_t)nblocks * d));
+        const size_t need = (size_t)nblocks * d;
+        if (need > ctx->colsum_cap) {  // grow-only scratch: no hipMalloc / hipFree (both synchronise) per build
+            if (ctx->colsum_partial) { NND_HIP_CHECK(hipFree(ctx->colsum_partial)); ctx->colsum_partial = nullptr; }
+            NND_HIP_CHECK(hipMalloc((void **)&ctx->colsum_partial, sizeof(double) * need));
+            ctx->colsum_cap = need;
+        }
+        double *partial = ctx->colsum_partial;
         hipLaunchKernelGGL(k_colsum_partial, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->x_orig, n, d,
                            rows_per_block, partial);
         hipLaunchKernelGGL(k_colsum_final, dim3(dp), dim3(256), 0, ctx->stream, partial, nblocks, d, dp,
                            n, ctx->mean);
-        NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        NND_HIP_CHECK(hipFree(partial));
     } else {
         NND_HIP_CHECK(hipMemsetAsync(ctx->mean, 0, sizeof(float) * dp, ctx->stream));
     }

@@ -789,16 +789,21 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     NND_HIP_CHECK(hipMemcpyAsync(&nl, scan_total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->n_leaves = nl;
-    if (ctx->leaf_start) { NND_HIP_CHECK(hipFree(ctx->leaf_start)); ctx->leaf_start = nullptr; }
-    if (ctx->leaf_len) { NND_HIP_CHECK(hipFree(ctx->leaf_len)); ctx->leaf_len = nullptr; }
-    NND_HIP_CHECK(hipMalloc((void **)&ctx->leaf_start, sizeof(int32_t) * (size_t)(nl + 1)));
-    NND_HIP_CHECK(hipMalloc((void **)&ctx->leaf_len, sizeof(int32_t) * (size_t)(nl + 1)));
+    if (nl + 1 > ctx->leaf_cap) {  // grow-only: repeated builds on one handle do not pay hipFree / hipMalloc (both synchronise)
+        if (ctx->leaf_start) { NND_HIP_CHECK(hipFree(ctx->leaf_start)); ctx->leaf_start = nullptr; }
+        if (ctx->leaf_len) { NND_HIP_CHECK(hipFree(ctx->leaf_len)); ctx->leaf_len = nullptr; }
+        ctx->leaf_cap = (int64_t)(nl + 1) + (nl + 1) / 4;
+        NND_HIP_CHECK(hipMalloc((void **)&ctx->leaf_start, sizeof(int32_t) * (size_t)ctx->leaf_cap));
+        NND_HIP_CHECK(hipMalloc((void **)&ctx->leaf_len, sizeof(int32_t) * (size_t)ctx->leaf_cap));
+    }
     hipLaunchKernelGGL(k_leaf_starts, dim3(gridP), dim3(256), 0, ctx->stream, ctx->leaf_flag, ctx->scan_out, P,
                        ctx->leaf_start);
     hipLaunchKernelGGL(k_leaf_lens, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream, ctx->leaf_start,
                        (int64_t)nl, n, P, ctx->leaf_len);
     NND_HIP_CHECK(hipGetLastError());
-    std::vector<int32_t> hs_start(nl), hs_len(nl);
+    std::vector<int32_t> &hs_start = ctx->h_leaf_start, &hs_len = ctx->h_leaf_len;  // kept: the leaf seeding reuses them
+    hs_start.resize(nl);
+    hs_len.resize(nl);
     NND_HIP_CHECK(hipMemcpyAsync(hs_start.data(), ctx->leaf_start, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ctx->stream));
     NND_HIP_CHECK(hipMemcpyAsync(hs_len.data(), ctx->leaf_len, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ctx->stream));
     NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -81,7 +81,13 @@ struct nnd_handle_s {
     uint16_t *hyper_h = nullptr;              // (max_segs, dp) bf16 copy of the normals (screening pass)
     int64_t max_segs = 0;
     int cur = 0; // which ping-pong half holds the finished permutation
-    int32_t *leaf_start = nullptr, *leaf_len = nullptr; // (n_leaves) after the forest is done
+    int32_t *leaf_start = nullptr, *leaf_len = nullptr; // (n_leaves) after the forest is done; grow-only buffers
+    double *colsum_partial = nullptr;         // prep scratch (column sums per row block), grow-only
+    size_t colsum_cap = 0;
+    int64_t leaf_cap = 0;                     // allocated entries of leaf_start / leaf_len
+    std::vector<int32_t> h_leaf_start, h_leaf_len;  // host copies (per-tree work lists, leaf array shape)
+    int32_t *wl_start = nullptr, *wl_len = nullptr; // leaf-seeding work list when leaves had to be cut (grow-only)
+    int64_t wl_cap = 0;
     int64_t n_leaves = 0;
     int32_t max_leaf = 0;
     std::vector<int64_t> tree_leaf_begin; // per tree: first leaf index (host)
