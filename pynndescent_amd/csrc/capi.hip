@@ -44,9 +44,11 @@ static void free_all(nnd_ctx *ctx) {
     F(ctx->pdirty); F(ctx->active);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
-    F(ctx->hyper); F(ctx->hyper_h); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->wl_start); F(ctx->wl_len); F(ctx->colsum_partial); F(ctx->counters);
+    F(ctx->hyper); F(ctx->hyper_h); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->wl_start); F(ctx->wl_len); F(ctx->colsum_partial); F(ctx->counters_sum);
+    if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; } F(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_spin) (void)hipEventDestroy(ctx->ev_spin);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 }
 
@@ -90,6 +92,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->set_error("hipStreamCreate failed"); rc = 1; break; }
         (void)hipEventCreate(&ctx->ev0);
         (void)hipEventCreate(&ctx->ev1);
+        (void)hipEventCreateWithFlags(&ctx->ev_spin, hipEventDisableTiming);
         const size_t n = (size_t)ctx->n;
         if ((rc = dalloc(ctx, &ctx->xp, n * ctx->dp))) break;
         if ((rc = dalloc(ctx, &ctx->nrm, n))) break;
@@ -104,6 +107,8 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
         if ((rc = dalloc(ctx, &ctx->pdirty, n))) break;
         if ((rc = dalloc(ctx, &ctx->active, n))) break;
         if ((rc = dalloc(ctx, &ctx->counters, (size_t)CNT_COUNT * NND_CNT_STRIPES))) break;
+        if ((rc = dalloc(ctx, &ctx->counters_sum, (size_t)CNT_COUNT))) break;
+        if (hipHostMalloc((void **)&ctx->h_pin, sizeof(long long) * 64, hipHostMallocDefault) != hipSuccess) { ctx->set_error("hipHostMalloc failed"); rc = 1; break; }
         if (hipMemset(ctx->pdirty, 0, n) != hipSuccess) { ctx->set_error("hipMemset failed"); rc = 1; break; }
         if (p->n_trees > 0) {
             ctx->P = (int64_t)p->n_trees * ctx->n;

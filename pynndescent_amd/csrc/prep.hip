@@ -129,15 +129,27 @@ int nnd_zero_counters(nnd_ctx *ctx) {
     NND_HIP_CHECK(hipMemsetAsync(ctx->counters, 0, sizeof(long long) * CNT_COUNT * NND_CNT_STRIPES, ctx->stream));
     return 0;
 }
-int nnd_read_counters(nnd_ctx *ctx) {
-    static thread_local std::vector<long long> host(CNT_COUNT * NND_CNT_STRIPES);
-    NND_HIP_CHECK(hipMemcpyAsync(host.data(), ctx->counters, sizeof(long long) * CNT_COUNT * NND_CNT_STRIPES,
-                                 hipMemcpyDeviceToHost, ctx->stream));
-    NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+// stripes -> one value per counter, on the device (the host then reads CNT_COUNT words, not CNT_COUNT * 512)
+__global__ __launch_bounds__(256) void k_counters_reduce(const long long *__restrict__ counters, long long *__restrict__ out) {
+    __shared__ long long red[256];
     for (int c = 0; c < CNT_COUNT; c++) {
         long long s = 0;
-        for (int i = 0; i < NND_CNT_STRIPES; i++) s += host[(size_t)i * CNT_COUNT + c];
-        ctx->h_counters[c] = s;
+        for (int i = threadIdx.x; i < NND_CNT_STRIPES; i += 256) s += counters[(size_t)i * CNT_COUNT + c];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[c] = red[0];
+        __syncthreads();
     }
+}
+int nnd_read_counters(nnd_ctx *ctx) {
+    hipLaunchKernelGGL(k_counters_reduce, dim3(1), dim3(256), 0, ctx->stream, ctx->counters, ctx->counters_sum);
+    NND_HIP_CHECK(hipGetLastError());
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin, ctx->counters_sum, sizeof(long long) * CNT_COUNT, hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(nnd_sync_spin(ctx));
+    for (int c = 0; c < CNT_COUNT; c++) ctx->h_counters[c] = ctx->h_pin[c];
     return 0;
 }

@@ -749,11 +749,11 @@ int nnd_launch_forest(nnd_ctx *ctx) {
                            ctx->pos_seg[1 - cur], inv_live ? ctx->inv : (int32_t *)nullptr);
         NND_HIP_CHECK(hipGetLastError());
         // one small read-back per level: the number of segments that stay in the level-synchronous passes
-        long long next[2] = {0, 0};  // CNT_ACTIVE_SEGS, CNT_LEAVES are adjacent
+        long long *next = ctx->h_pin + 32;  // CNT_ACTIVE_SEGS, CNT_LEAVES are adjacent; pinned words
         static_assert(CNT_LEAVES == CNT_ACTIVE_SEGS + 1, "counter layout");
         NND_HIP_CHECK(hipMemcpyAsync(next, ctx->counters + CNT_ACTIVE_SEGS, 2 * sizeof(long long), hipMemcpyDeviceToHost,
                                      ctx->stream));
-        NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        NND_HIP_CHECK(nnd_sync_spin(ctx));
         S = next[0];
         active_pos = next[1];
         cur = 1 - cur;

@@ -34,6 +34,7 @@ struct nnd_handle_s {
     char err[512] = {0};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_spin = nullptr;  // nnd_sync_spin: busy-polled completion of small read-backs (lower wake-up latency)
 
     // geometry
     int64_t n = 0;
@@ -96,6 +97,8 @@ struct nnd_handle_s {
 
     long long *counters = nullptr;      // device NND_CNT_STRIPES x CNT_COUNT (stripe 0 doubles as scratch for single-block kernels)
     long long h_counters[CNT_COUNT] = {0};
+    long long *counters_sum = nullptr;        // (CNT_COUNT) device: stripes summed by k_counters_reduce
+    long long *h_pin = nullptr;               // pinned host words for the small latency-critical read-backs
 
     void set_error(const char *fmt, ...) {
         va_list ap;
@@ -139,4 +142,15 @@ int nnd_zero_counters(nnd_ctx *ctx);
 static inline const int32_t *nnd_vertex_order(const nnd_ctx *ctx) {
     if (!ctx->forest_built || ctx->p.n_trees <= 0 || ctx->own_lo != 0 || ctx->own_hi != ctx->n) return nullptr;
     return ctx->perm[ctx->cur];
+}
+
+// Wait for everything queued on the handle's stream by polling an event: the per-level read-backs of the forest build
+// are latency critical (the GPU idles until the host has the segment count), and a blocking wait wakes up late.
+static inline hipError_t nnd_sync_spin(nnd_ctx *ctx) {
+    if (!ctx->ev_spin) return hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipEventRecord(ctx->ev_spin, ctx->stream);
+    if (e != hipSuccess) return e;
+    while ((e = hipEventQuery(ctx->ev_spin)) == hipErrorNotReady) {
+    }
+    return e;
 }
