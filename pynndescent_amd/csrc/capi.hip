@@ -232,7 +232,7 @@ extern "C" int32_t nnd_get_leaf_array(nnd_handle_t ctx, int32_t *out_host) {
     API_HIP(hipMalloc((void **)&d, sizeof(int32_t) * (total ? total : 1)));
     if (nnd_launch_leaf_array(ctx, d)) { (void)hipFree(d); return 1; }
     API_HIP(hipMemcpyAsync(out_host, d, sizeof(int32_t) * total, hipMemcpyDeviceToHost, ctx->stream));
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     API_HIP(hipFree(d));
     return 0;
 }
@@ -389,7 +389,7 @@ extern "C" int32_t nnd_finalize_host(nnd_handle_t ctx, int32_t *out_idx, float *
     if (!rc) {
         API_HIP(hipMemcpyAsync(out_idx, di, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
         API_HIP(hipMemcpyAsync(out_dist, dd, sizeof(float) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(hipStreamSynchronize(ctx->stream));
+        API_HIP(nnd_sync_spin(ctx));
     }
     (void)hipFree(di);
     (void)hipFree(dd);
@@ -471,7 +471,7 @@ extern "C" int32_t nnd_get_stats(nnd_handle_t ctx, nnd_stats *out) {
 
 extern "C" int32_t nnd_synchronize(nnd_handle_t ctx) {
     ENTER(ctx);
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 
@@ -483,7 +483,7 @@ extern "C" int32_t nnd_get_graph(nnd_handle_t ctx, int32_t *idx, float *dist, ui
     std::vector<float> hd(cnt);
     API_HIP(hipMemcpyAsync(he.data(), ctx->knn_e, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
     API_HIP(hipMemcpyAsync(hd.data(), ctx->knn_d, sizeof(float) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     for (int64_t v = 0; v < ctx->n; v++)
         for (int j = 0; j < ctx->k; j++) {
             uint32_t e = he[v * ctx->ks + j];
@@ -500,7 +500,7 @@ extern "C" int32_t nnd_get_candidates(nnd_handle_t ctx, int32_t *new_idx, int32_
     size_t cnt = (size_t)ctx->n * 2 * ctx->mcp;
     std::vector<int32_t> hc(cnt);
     API_HIP(hipMemcpyAsync(hc.data(), ctx->cand, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     for (int64_t v = 0; v < ctx->n; v++)
         for (int j = 0; j < ctx->mc; j++) {
             if (new_idx) new_idx[v * ctx->mc + j] = hc[v * 2 * ctx->mcp + j];
@@ -523,7 +523,7 @@ extern "C" int32_t nnd_pairwise_gram(nnd_handle_t ctx, const int32_t *rows_a, in
     int rc = nnd_launch_pairwise(ctx, da, na, db, nb, dout);
     if (!rc) {
         API_HIP(hipMemcpyAsync(out, dout, sizeof(float) * (size_t)na * nb, hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(hipStreamSynchronize(ctx->stream));
+        API_HIP(nnd_sync_spin(ctx));
     }
     (void)hipFree(da);
     (void)hipFree(db);
@@ -547,7 +547,7 @@ extern "C" int32_t nnd_export_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t h
     API_HIP(hipMemcpyAsync(e_dst_dev, ctx->knn_e + lo * ctx->ks, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
     if (d_dst_dev)
         API_HIP(hipMemcpyAsync(d_dst_dev, ctx->knn_d + lo * ctx->ks, sizeof(float) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_import_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, const uint32_t *e_src_dev, const float *d_src_dev) {
@@ -559,27 +559,27 @@ extern "C" int32_t nnd_import_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t h
         API_HIP(hipMemcpyAsync(ctx->knn_d + lo * ctx->ks, d_src_dev, sizeof(float) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
         if (nnd_launch_refresh_th(ctx, lo, hi)) return 1;
     }
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 // per-row worst distances (thresholds): 4 bytes per row instead of the 4*ks-byte distance rows
 extern "C" int32_t nnd_export_thresholds(nnd_handle_t ctx, int64_t lo, int64_t hi, float *th_dst_dev) {
     ENTER(ctx);
     API_HIP(hipMemcpyAsync(th_dst_dev, ctx->th + lo, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_import_thresholds(nnd_handle_t ctx, int64_t lo, int64_t hi, const float *th_src_dev) {
     ENTER(ctx);
     API_HIP(hipMemcpyAsync(ctx->th + lo, th_src_dev, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_merge_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, const uint32_t *e_src_dev, const float *d_src_dev) {
     if (ctx) ctx->all_new = false;  // imported rows may carry cleared flags
     ENTER(ctx);
     if (nnd_launch_merge_graph_rows(ctx, lo, hi, e_src_dev, d_src_dev)) return 1;
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_descent_sample(nnd_handle_t ctx) {
@@ -602,19 +602,19 @@ extern "C" int32_t nnd_descent_join(nnd_handle_t ctx) {
 extern "C" int32_t nnd_proposal_counts(nnd_handle_t ctx, int32_t *cnt_dev) {
     ENTER(ctx);
     if (nnd_launch_proposal_counts(ctx, cnt_dev)) return 1;
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_export_proposals(nnd_handle_t ctx, const int64_t *offsets_dev, uint64_t *keys_out_dev, int32_t *targets_out_dev) {
     ENTER(ctx);
     if (nnd_launch_export_proposals(ctx, offsets_dev, keys_out_dev, targets_out_dev)) return 1;
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_import_proposals(nnd_handle_t ctx, const uint64_t *keys_dev, const int32_t *targets_dev, int64_t count) {
     ENTER(ctx);
     if (nnd_launch_import_proposals(ctx, keys_dev, targets_dev, count)) return 1;
-    API_HIP(hipStreamSynchronize(ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_descent_merge(nnd_handle_t ctx, int64_t *c_local) {
@@ -655,7 +655,7 @@ extern "C" int32_t nnd_diversify_host(nnd_handle_t ctx, int32_t *idx /* (n,k) in
     if (!rc) {
         API_HIP(hipMemcpyAsync(idx, di, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
         API_HIP(hipMemcpyAsync(dist, dd, sizeof(float) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(hipStreamSynchronize(ctx->stream));
+        API_HIP(nnd_sync_spin(ctx));
     }
     (void)hipFree(di);
     (void)hipFree(dd);
@@ -682,7 +682,7 @@ extern "C" int32_t nnd_diversify_csr_host(nnd_handle_t ctx, const int32_t *indpt
     if (!rc) {
         API_HIP(hipMemcpyAsync(data, dd, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
         API_HIP(hipMemcpyAsync(&too_long, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(hipStreamSynchronize(ctx->stream));
+        API_HIP(nnd_sync_spin(ctx));
     }
     (void)hipFree(dp); (void)hipFree(di); (void)hipFree(dd); (void)hipFree(flag);
     if (!rc && too_long) {
@@ -704,7 +704,7 @@ extern "C" int32_t nnd_degree_prune_host(nnd_handle_t ctx, const int32_t *indptr
     int rc = nnd_launch_degree_prune(ctx, dp, dd, max_degree);
     if (!rc) {
         API_HIP(hipMemcpyAsync(data, dd, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(hipStreamSynchronize(ctx->stream));
+        API_HIP(nnd_sync_spin(ctx));
     }
     (void)hipFree(dp); (void)hipFree(dd);
     return rc;

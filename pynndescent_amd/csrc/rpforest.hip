@@ -760,9 +760,9 @@ int nnd_launch_forest(nnd_ctx *ctx) {
         depth++;
     }
     {  // subtrees that fit in LDS: one workgroup each, no more global passes
-        long long nfin = 0;
-        NND_HIP_CHECK(hipMemcpyAsync(&nfin, ctx->counters + CNT_SCRATCH + 1, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-        NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 34, ctx->counters + CNT_SCRATCH + 1, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        NND_HIP_CHECK(nnd_sync_spin(ctx));
+        const long long nfin = ctx->h_pin[34];
         if (nfin > ctx->max_segs) {
             ctx->set_error("rp-forest: %lld finisher segments exceed the allocation of %lld", nfin, (long long)ctx->max_segs);
             return 1;
@@ -785,9 +785,9 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     ctx->stats.tree_levels = depth;
     // leaf tables
     if (run_scan(ctx, 1, nullptr, ctx->leaf_flag, scan_total)) return 1;
-    int32_t nl = 0;
-    NND_HIP_CHECK(hipMemcpyAsync(&nl, scan_total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 35, scan_total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(nnd_sync_spin(ctx));
+    const int32_t nl = *(const int32_t *)(ctx->h_pin + 35);
     ctx->n_leaves = nl;
     if (nl + 1 > ctx->leaf_cap) {  // grow-only: repeated builds on one handle do not pay hipFree / hipMalloc (both synchronise)
         if (ctx->leaf_start) { NND_HIP_CHECK(hipFree(ctx->leaf_start)); ctx->leaf_start = nullptr; }
