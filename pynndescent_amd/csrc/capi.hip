@@ -45,7 +45,9 @@ static void free_all(nnd_ctx *ctx) {
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
     F(ctx->hyper); F(ctx->hyper_h); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->wl_start); F(ctx->wl_len); F(ctx->colsum_partial); F(ctx->counters_sum);
-    if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; } F(ctx->counters);
+    if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; }
+    if (ctx->h_tree_begin) { (void)hipHostFree(ctx->h_tree_begin); ctx->h_tree_begin = nullptr; }
+    F(ctx->tree_begin_dev); F(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_spin) (void)hipEventDestroy(ctx->ev_spin);
@@ -132,6 +134,8 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
             if ((rc = dalloc(ctx, &ctx->seg_child, 5 * S))) break;  // child ids (2S) + finisher work list (3S)
             if ((rc = dalloc(ctx, &ctx->hyper, S * (size_t)(ctx->dp + 4)))) break;
             if ((rc = dalloc(ctx, &ctx->hyper_h, S * (size_t)ctx->dp))) break;
+            if ((rc = dalloc(ctx, &ctx->tree_begin_dev, (size_t)p->n_trees + 1))) break;
+            if (hipHostMalloc((void **)&ctx->h_tree_begin, sizeof(long long) * ((size_t)p->n_trees + 1), hipHostMallocDefault) != hipSuccess) { ctx->set_error("hipHostMalloc failed"); rc = 1; break; }
         }
     } while (0);
     if (rc) {

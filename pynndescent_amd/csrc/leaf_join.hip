@@ -295,6 +295,7 @@ int nnd_launch_leaf_init(nnd_ctx *ctx) {
     std::vector<int64_t> tb(ctx->tree_leaf_begin.begin(), ctx->tree_leaf_begin.end());
     int maxlen = ctx->max_leaf;
     if (ctx->max_leaf > LEAF_MAX) {
+        if (nnd_fetch_leaf_tables(ctx)) return 1;
         const std::vector<int32_t> &hs = ctx->h_leaf_start, &hl = ctx->h_leaf_len;
         std::vector<int32_t> ws, wl;
         ws.reserve(ctx->n_leaves);

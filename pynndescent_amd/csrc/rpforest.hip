@@ -639,14 +639,28 @@ __global__ void k_leaf_starts(const uint8_t *__restrict__ leaf_flag, const int32
     if (g < P && leaf_flag[g]) leaf_start[scan[g]] = (int32_t)g;
 }
 __global__ void k_leaf_lens(const int32_t *__restrict__ leaf_start, int64_t n_leaves, int64_t n, int64_t P,
-                            int32_t *__restrict__ leaf_len) {
+                            int32_t *__restrict__ leaf_len, int32_t *__restrict__ max_len) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_leaves) return;
-    int64_t a = leaf_start[i];
-    int64_t e = i + 1 < n_leaves ? leaf_start[i + 1] : P;
-    int64_t tree_end = (a / n + 1) * n;  // leaves never cross a tree boundary
-    if (e > tree_end) e = tree_end;
-    leaf_len[i] = (int32_t)(e - a);
+    int len = 0;
+    if (i < n_leaves) {
+        int64_t a = leaf_start[i];
+        int64_t e = i + 1 < n_leaves ? leaf_start[i + 1] : P;
+        int64_t tree_end = (a / n + 1) * n;  // leaves never cross a tree boundary
+        if (e > tree_end) e = tree_end;
+        len = (int)(e - a);
+        leaf_len[i] = len;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(len, o, 64);
+        len = other > len ? other : len;
+    }
+    if (nnd_lane() == 0 && len > 0) atomicMax(max_len, len);  // one atomic per wave
+}
+// first leaf index of every tree = the exclusive leaf-flag scan at the tree's first position
+__global__ void k_tree_leaf_begin(const int32_t *__restrict__ scan, int n_trees, int64_t n, long long *__restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_trees) out[t] = scan[(int64_t)t * n];
 }
 __global__ void k_fill_leaf_array(const int32_t *__restrict__ perm, const int32_t *__restrict__ leaf_start,
                                   const int32_t *__restrict__ leaf_len, int64_t n_leaves, int max_leaf,
@@ -798,26 +812,41 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     }
     hipLaunchKernelGGL(k_leaf_starts, dim3(gridP), dim3(256), 0, ctx->stream, ctx->leaf_flag, ctx->scan_out, P,
                        ctx->leaf_start);
+    // leaf lengths, the longest leaf and the per-tree leaf offsets stay on the device; the host reads T + 1 words
+    // (the full tables are fetched lazily, only when a leaf has to be cut or the caller asks for the leaf array)
+    int32_t *max_len_dev = (int32_t *)(ctx->counters + CNT_SCRATCH + 2);
+    NND_HIP_CHECK(hipMemsetAsync(max_len_dev, 0, sizeof(long long), ctx->stream));
     hipLaunchKernelGGL(k_leaf_lens, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream, ctx->leaf_start,
-                       (int64_t)nl, n, P, ctx->leaf_len);
+                       (int64_t)nl, n, P, ctx->leaf_len, max_len_dev);
+    hipLaunchKernelGGL(k_tree_leaf_begin, dim3((T + 63) / 64), dim3(64), 0, ctx->stream, ctx->scan_out, T, n, ctx->tree_begin_dev);
     NND_HIP_CHECK(hipGetLastError());
-    std::vector<int32_t> &hs_start = ctx->h_leaf_start, &hs_len = ctx->h_leaf_len;  // kept: the leaf seeding reuses them
-    hs_start.resize(nl);
-    hs_len.resize(nl);
-    NND_HIP_CHECK(hipMemcpyAsync(hs_start.data(), ctx->leaf_start, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ctx->stream));
-    NND_HIP_CHECK(hipMemcpyAsync(hs_len.data(), ctx->leaf_len, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ctx->stream));
-    NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_tree_begin, ctx->tree_begin_dev, sizeof(long long) * T, hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 36, max_len_dev, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(nnd_sync_spin(ctx));
+    ctx->h_leaf_valid = false;
     int32_t mx = leaf_size;  // rp_trees.py:2548
+    const int32_t longest = *(const int32_t *)(ctx->h_pin + 36);
+    if (longest > mx) mx = longest;
     ctx->tree_leaf_begin.assign(T + 1, nl);
-    int t_next = 0;
-    for (int64_t i = 0; i < nl; i++) {
-        if (hs_len[i] > mx) mx = hs_len[i];
-        int t = (int)(hs_start[i] / n);
-        while (t_next <= t) ctx->tree_leaf_begin[t_next++] = i;
-    }
+    for (int t = 0; t < T; t++) ctx->tree_leaf_begin[t] = ctx->h_tree_begin[t];
     ctx->max_leaf = mx;
     ctx->stats.n_leaves = nl;
     ctx->forest_built = true;
+    return 0;
+}
+
+// host copies of the leaf table, fetched on demand (work-list cutting for over-long leaves)
+int nnd_fetch_leaf_tables(nnd_ctx *ctx) {
+    if (ctx->h_leaf_valid) return 0;
+    const int64_t nl = ctx->n_leaves;
+    ctx->h_leaf_start.resize(nl);
+    ctx->h_leaf_len.resize(nl);
+    if (nl > 0) {
+        NND_HIP_CHECK(hipMemcpyAsync(ctx->h_leaf_start.data(), ctx->leaf_start, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ctx->stream));
+        NND_HIP_CHECK(hipMemcpyAsync(ctx->h_leaf_len.data(), ctx->leaf_len, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ctx->stream));
+        NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->h_leaf_valid = true;
     return 0;
 }
 

@@ -86,7 +86,10 @@ struct nnd_handle_s {
     double *colsum_partial = nullptr;         // prep scratch (column sums per row block), grow-only
     size_t colsum_cap = 0;
     int64_t leaf_cap = 0;                     // allocated entries of leaf_start / leaf_len
-    std::vector<int32_t> h_leaf_start, h_leaf_len;  // host copies (per-tree work lists, leaf array shape)
+    std::vector<int32_t> h_leaf_start, h_leaf_len;  // host copies, fetched lazily (nnd_fetch_leaf_tables)
+    bool h_leaf_valid = false;
+    long long *tree_begin_dev = nullptr;      // (n_trees) first leaf index of every tree
+    long long *h_tree_begin = nullptr;        // pinned host copy
     int32_t *wl_start = nullptr, *wl_len = nullptr; // leaf-seeding work list when leaves had to be cut (grow-only)
     int64_t wl_cap = 0;
     int64_t n_leaves = 0;
@@ -114,6 +117,7 @@ int nnd_launch_prep(nnd_ctx *ctx);
 int nnd_launch_reset_graph(nnd_ctx *ctx);
 int nnd_launch_forest(nnd_ctx *ctx);
 int nnd_launch_leaf_array(nnd_ctx *ctx, int32_t *out_dev /* (n_leaves,max_leaf) */);
+int nnd_fetch_leaf_tables(nnd_ctx *ctx);
 int nnd_launch_leaf_init(nnd_ctx *ctx);
 int nnd_launch_random_init(nnd_ctx *ctx);
 int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float *dist_dev, int width);
