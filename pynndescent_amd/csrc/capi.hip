@@ -51,6 +51,8 @@ static void free_all(nnd_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_spin) (void)hipEventDestroy(ctx->ev_spin);
+    for (hipEvent_t e : ctx->tev) if (e) (void)hipEventDestroy(e);
+    ctx->tev.clear();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 }
 
@@ -161,20 +163,41 @@ extern "C" int32_t nnd_destroy(nnd_handle_t ctx) {
     if (!ctx) { gerr("null handle"); return 1; }             \
     API_HIP(hipSetDevice(ctx->p.device));
 
-static float elapsed_ms(nnd_ctx *ctx) {
-    float ms = 0.f;
-    (void)hipEventRecord(ctx->ev1, ctx->stream);
-    (void)hipEventSynchronize(ctx->ev1);
-    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-    return ms;
+// Stage timers are DEFERRED: begin/end events are recorded on the stream and read back in one go (t_flush) where the
+// host waits anyway, so timing a stage never drains the GPU pipeline between stages.
+static int t_begin(nnd_ctx *ctx) {
+    const int idx = ctx->tev_used;
+    while ((int)ctx->tev.size() < idx + 2) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        ctx->tev.push_back(e);
+    }
+    (void)hipEventRecord(ctx->tev[idx], ctx->stream);
+    ctx->tev_used += 2;
+    return idx;
 }
-static void tick(nnd_ctx *ctx) { (void)hipEventRecord(ctx->ev0, ctx->stream); }
+static void t_end(nnd_ctx *ctx, int idx, float *dst, bool add) {
+    (void)hipEventRecord(ctx->tev[idx + 1], ctx->stream);
+    ctx->tlog.push_back({idx, dst, add});
+}
+static void t_flush(nnd_ctx *ctx) {
+    if (ctx->tlog.empty()) { ctx->tev_used = 0; return; }
+    (void)nnd_sync_spin(ctx);
+    for (const nnd_tlog &t : ctx->tlog) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ctx->tev[t.ev], ctx->tev[t.ev + 1]);
+        if (t.add) *t.dst += ms; else *t.dst = ms;
+    }
+    ctx->tlog.clear();
+    ctx->tev_used = 0;
+}
 
 static int after_data(nnd_ctx *ctx) {
-    tick(ctx);
+    const int t_ = t_begin(ctx);
     if (nnd_launch_prep(ctx)) return 1;
     if (nnd_launch_reset_graph(ctx)) return 1;
-    ctx->stats.ms_prep = elapsed_ms(ctx);
+    t_end(ctx, t_, &ctx->stats.ms_prep, false);
+    t_flush(ctx);
     return 0;
 }
 
@@ -207,9 +230,10 @@ static int need_data(nnd_ctx *ctx) {
 extern "C" int32_t nnd_make_forest(nnd_handle_t ctx) {
     ENTER(ctx);
     if (need_data(ctx)) return 1;
-    tick(ctx);
+    const int t_ = t_begin(ctx);
     if (nnd_launch_forest(ctx)) return 1;
-    ctx->stats.ms_forest = elapsed_ms(ctx);
+    t_end(ctx, t_, &ctx->stats.ms_forest, false);
+    t_flush(ctx);
     return 0;
 }
 
@@ -249,18 +273,20 @@ extern "C" int32_t nnd_reset_graph(nnd_handle_t ctx) {
 extern "C" int32_t nnd_init_from_leaves(nnd_handle_t ctx) {
     ENTER(ctx);
     if (need_data(ctx)) return 1;
-    tick(ctx);
+    const int t_ = t_begin(ctx);
     if (nnd_launch_leaf_init(ctx)) return 1;
-    ctx->stats.ms_leaf_init = elapsed_ms(ctx);
+    t_end(ctx, t_, &ctx->stats.ms_leaf_init, false);
+    t_flush(ctx);
     return 0;
 }
 
 extern "C" int32_t nnd_init_random(nnd_handle_t ctx) {
     ENTER(ctx);
     if (need_data(ctx)) return 1;
-    tick(ctx);
+    const int t_ = t_begin(ctx);
     if (nnd_launch_random_init(ctx)) return 1;
-    ctx->stats.ms_random_init = elapsed_ms(ctx);
+    t_end(ctx, t_, &ctx->stats.ms_random_init, false);
+    t_flush(ctx);
     return 0;
 }
 
@@ -304,28 +330,30 @@ extern "C" int32_t nnd_sample_candidates(nnd_handle_t ctx) {
 // one iteration of nn_descent_internal (pynndescent_.py:296-320)
 static int descent_iter(nnd_ctx *ctx, int64_t *c_out, bool timed) {
     const int it = ctx->iter;
-    float ms;
-    if (timed) tick(ctx);
-    if (nnd_launch_sample(ctx)) return 1;
-    if (timed) { ms = elapsed_ms(ctx); if (it < 64) ctx->stats.ms_sample[it] = ms; }
+    static float sink;  // timer target for iterations beyond the 64 that the stats block records
+    {
+        const int t_ = timed ? t_begin(ctx) : -1;
+        if (nnd_launch_sample(ctx)) return 1;
+        if (timed) t_end(ctx, t_, it < 64 ? &ctx->stats.ms_sample[it] : &sink, false);
+    }
     if (nnd_zero_counters(ctx)) return 1;
     // The reference joins vertices in blocks of 16384 and applies updates between blocks
     // (pynndescent_.py:239-261) so thresholds tighten inside an iteration; join_blocks sub-steps do the same.
     const int nb = ctx->p.join_blocks;
-    float ms_join = 0.f, ms_merge = 0.f;
+    if (it < 64) ctx->stats.ms_join[it] = ctx->stats.ms_merge[it] = 0.f;
     for (int b = 0; b < nb; b++) {
         const int64_t span = ctx->own_hi - ctx->own_lo;
         int64_t v0 = ctx->own_lo + span * b / nb, v1 = ctx->own_lo + span * (b + 1) / nb;
-        if (timed) tick(ctx);
+        const int tj = timed ? t_begin(ctx) : -1;
         if (nnd_launch_join(ctx, v0, v1)) return 1;
-        if (timed) { ms_join += elapsed_ms(ctx); tick(ctx); }
+        if (timed) t_end(ctx, tj, it < 64 ? &ctx->stats.ms_join[it] : &sink, true);
+        const int tm = timed ? t_begin(ctx) : -1;
         if (nnd_launch_merge(ctx)) return 1;
-        if (timed) ms_merge += elapsed_ms(ctx);
+        if (timed) t_end(ctx, tm, it < 64 ? &ctx->stats.ms_merge[it] : &sink, true);
     }
-    if (nnd_read_counters(ctx)) return 1;
+    if (nnd_read_counters(ctx)) return 1;  // the host needs c here anyway: the timers are read at no extra wait
+    t_flush(ctx);
     if (it < 64) {
-        ctx->stats.ms_join[it] = ms_join;
-        ctx->stats.ms_merge[it] = ms_merge;
         ctx->stats.join_pairs[it] = ctx->h_counters[CNT_PAIRS];
         ctx->stats.join_rows[it] = ctx->h_counters[CNT_ROWS];
         ctx->stats.join_active[it] = ctx->h_counters[CNT_ACTIVE];
@@ -375,9 +403,10 @@ extern "C" int32_t nnd_descent(nnd_handle_t ctx) {
 extern "C" int32_t nnd_finalize_device(nnd_handle_t ctx, int32_t *out_idx_dev, float *out_dist_dev) {
     ENTER(ctx);
     if (need_data(ctx)) return 1;
-    tick(ctx);
+    const int t_ = t_begin(ctx);
     if (nnd_launch_finalize(ctx, out_idx_dev, out_dist_dev)) return 1;
-    ctx->stats.ms_finalize = elapsed_ms(ctx);
+    t_end(ctx, t_, &ctx->stats.ms_finalize, false);
+    t_flush(ctx);
     return 0;
 }
 
@@ -406,20 +435,21 @@ extern "C" int32_t nnd_build_device(nnd_handle_t ctx, int32_t *out_idx_dev, floa
     if (need_data(ctx)) return 1;
     if (nnd_launch_reset_graph(ctx)) return 1;
     if (ctx->p.n_trees > 0) {
-        tick(ctx);
+        const int tf = t_begin(ctx);
         if (nnd_launch_forest(ctx)) return 1;
-        ctx->stats.ms_forest = elapsed_ms(ctx);
-        tick(ctx);
+        t_end(ctx, tf, &ctx->stats.ms_forest, false);
+        const int tl = t_begin(ctx);
         if (nnd_launch_leaf_init(ctx)) return 1;
-        ctx->stats.ms_leaf_init = elapsed_ms(ctx);
+        t_end(ctx, tl, &ctx->stats.ms_leaf_init, false);
     }
-    tick(ctx);
+    const int tr = t_begin(ctx);
     if (nnd_launch_random_init(ctx)) return 1;
-    ctx->stats.ms_random_init = elapsed_ms(ctx);
+    t_end(ctx, tr, &ctx->stats.ms_random_init, false);
     if (descent_loop(ctx, true)) return 1;
-    tick(ctx);
+    const int t_ = t_begin(ctx);
     if (nnd_launch_finalize(ctx, out_idx_dev, out_dist_dev)) return 1;
-    ctx->stats.ms_finalize = elapsed_ms(ctx);
+    t_end(ctx, t_, &ctx->stats.ms_finalize, false);
+    t_flush(ctx);
     return 0;
 }
 
@@ -588,19 +618,19 @@ extern "C" int32_t nnd_merge_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi
 }
 extern "C" int32_t nnd_descent_sample(nnd_handle_t ctx) {
     ENTER(ctx);
-    tick(ctx);
+    static float sink;
+    const int t_ = t_begin(ctx);
     if (nnd_launch_sample(ctx)) return 1;
-    float ms = elapsed_ms(ctx);
-    if (ctx->iter < 64) ctx->stats.ms_sample[ctx->iter] = ms;
+    t_end(ctx, t_, ctx->iter < 64 ? &ctx->stats.ms_sample[ctx->iter] : &sink, false);
     return 0;
 }
 extern "C" int32_t nnd_descent_join(nnd_handle_t ctx) {
     ENTER(ctx);
     if (nnd_zero_counters(ctx)) return 1;
-    tick(ctx);
+    static float sink;
+    const int t_ = t_begin(ctx);
     if (nnd_launch_join(ctx, ctx->own_lo, ctx->own_hi)) return 1;
-    float ms = elapsed_ms(ctx);
-    if (ctx->iter < 64) ctx->stats.ms_join[ctx->iter] = ms;
+    t_end(ctx, t_, ctx->iter < 64 ? &ctx->stats.ms_join[ctx->iter] : &sink, false);
     return 0;
 }
 extern "C" int32_t nnd_proposal_counts(nnd_handle_t ctx, int32_t *cnt_dev) {
@@ -624,12 +654,13 @@ extern "C" int32_t nnd_import_proposals(nnd_handle_t ctx, const uint64_t *keys_d
 extern "C" int32_t nnd_descent_merge(nnd_handle_t ctx, int64_t *c_local) {
     ENTER(ctx);
     const int it = ctx->iter;
-    tick(ctx);
+    static float sink;
+    const int t_ = t_begin(ctx);
     if (nnd_launch_merge(ctx)) return 1;
-    float ms = elapsed_ms(ctx);
+    t_end(ctx, t_, it < 64 ? &ctx->stats.ms_merge[it] : &sink, false);
     if (nnd_read_counters(ctx)) return 1;
+    t_flush(ctx);
     if (it < 64) {
-        ctx->stats.ms_merge[it] = ms;
         ctx->stats.join_pairs[it] = ctx->h_counters[CNT_PAIRS];
         ctx->stats.join_rows[it] = ctx->h_counters[CNT_ROWS];
         ctx->stats.join_active[it] = ctx->h_counters[CNT_ACTIVE];

@@ -28,12 +28,17 @@ enum {
 // would serialise a million-wave launch.  nnd_read_counters sums the stripes.
 #define NND_CNT_STRIPES 512
 
+struct nnd_tlog { int ev; float *dst; bool add; };  // a pending stage timer: events ev, ev+1 -> *dst
+
 struct nnd_handle_s {
     nnd_params p{};
     nnd_stats stats{};
     char err[512] = {0};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> tev;   // event pool of the deferred stage timers (capi.hip t_begin / t_end / t_flush)
+    int tev_used = 0;
+    std::vector<nnd_tlog> tlog;
     hipEvent_t ev_spin = nullptr;  // nnd_sync_spin: busy-polled completion of small read-backs (lower wake-up latency)
 
     // geometry
