@@ -26,7 +26,11 @@ __device__ __forceinline__ uint64_t nnd_readlane_u64(uint64_t v, int src_lane) {
 
 // All 64 lanes of the wave call this with the same arguments.
 // cand(c, id, d) -> bool : candidate c of [0, ncand), ncand <= 64 * NCHUNK (ids unique inside the batch).
-// Returns the number of accepted candidates (same value on every lane).
+// Returns (same value on every lane) the number of candidates that beat the row's worst distance as it was when the
+// merge started and were not in the row yet -- the pushes that succeed on the snapshot.  This is what feeds the stop
+// rule c <= delta*k*n: the reference counts every successful push of its SEQUENTIAL apply (utils.py:717-729), also
+// those evicted later in the same pass, so the net number of new entries would under-count and stop descents that
+// converge slowly one or two iterations before the reference does.
 // Core: lane j < k already holds list entry j in (e, d) (lanes >= k hold EMPTY / +inf; filled entries are packed
 // at the front of the row).
 //
@@ -96,6 +100,7 @@ __device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, 
         for (int ch = 0; ch < NCHUNK; ch++) nv += __popcll(cmask[ch]);
         if (nv == 0) return 0;
     }
+    const int pushed = nv;
 
     uint64_t ckey[NCHUNK];
 #pragma unroll
@@ -164,17 +169,15 @@ __device__ __forceinline__ int nnd_merge_row_regs(uint32_t *__restrict__ row_e, 
         row_d[lane + shift] = d;
         if (lane + shift == k - 1) *th_slot = d;  // new worst distance of the row
     }
-    int accepted = 0;
 #pragma unroll
     for (int ch = 0; ch < NCHUNK; ch++) {
         if (ckey[ch] != NND_EMPTY_KEY && rank[ch] < k) {
             row_e[rank[ch]] = nnd_key_idx(ckey[ch]) | NND_NEW_BIT;
             row_d[rank[ch]] = nnd_key_dist(ckey[ch]);
             if (rank[ch] == k - 1) *th_slot = nnd_key_dist(ckey[ch]);
-            accepted++;
         }
     }
-    return nnd_wave_sum_i32(accepted);
+    return pushed;
 }
 
 // Loader wrapper: fetches row v of the k-lists from global memory, then merges.

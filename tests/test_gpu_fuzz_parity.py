@@ -1,0 +1,15 @@
+"""Randomised parity sweep (tools/fuzz_parity.py): GPU build vs the oracle's NN-descent on the GPU's own leaf array over
+random (n, d, k, metric, n_trees, leaf_size, max_candidates) -- 12 configurations per run, recall within 0.03."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def test_random_configurations():
+    import fuzz_parity
+
+    assert fuzz_parity.main(12, 7) == 0
