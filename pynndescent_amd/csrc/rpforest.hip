@@ -399,6 +399,7 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
     __syncthreads();
     int run = part[threadIdx.x], runf = partf[threadIdx.x];
     long long active_pos = 0;
+    int max_stay = 0;
     for (int s = s0; s < s1; s++) {
         int a = seg_start[s], len = seg_len[s], nl = nleft[s];
         if (nl < 0) nl = -nl - 1;
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
                     next_len[run] = lens[c];
                     seg_child[2 * s + c] = run++;
                     active_pos += lens[c];
+                    if (lens[c] > max_stay) max_stay = lens[c];
                 } else {
                     fin_start[runf] = starts[c];
                     fin_len[runf] = lens[c];
@@ -426,6 +428,7 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
         }
     }
     if (active_pos) atomicAdd((unsigned long long *)&counters[CNT_LEAVES], (unsigned long long)active_pos);  // positions still in the passes
+    if (max_stay) atomicMax((unsigned long long *)&counters[CNT_SCRATCH + 3], (unsigned long long)max_stay);  // longest of them
 }
 
 // stable partition (rp_trees.py:405-418): lefts keep their order at the front, rights behind them
@@ -472,31 +475,45 @@ __global__ void k_scatter(const int32_t *__restrict__ perm, const int32_t *__res
 #define NND_FIN_MAX 2048
 #endif
 static constexpr int FIN_MAX = NND_FIN_MAX;     // points per finisher segment
+#ifndef NND_BIG_MAX
+#define NND_BIG_MAX 8192
+#endif
+static constexpr int BIG_MAX = NND_BIG_MAX;     // longest segment the global-memory finisher variant takes (one workgroup each)
 static constexpr int FIN_STACK = 512;    // sub-segments pending (depth budget is 200: a DFS needs <= depth+1 entries)
 
+// BIG = true: the same node loop for the FEW segments between FIN_MAX and BIG_MAX points that are left when the
+// level-synchronous passes stop paying (most positions already handed over): member ids, partition scratch and side
+// bits live in global memory (perm itself, the other perm buffer, side[]), and a node that has shrunk to <= FIN_MAX
+// points is appended to the LDS finisher's work list instead of being split here.
+template <bool BIG>
 __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
                                                          const float *__restrict__ nrm, int metric, int dp,
                                                          int32_t *__restrict__ perm,
                                                          const int32_t *__restrict__ seg_start,
                                                          const int32_t *__restrict__ seg_len,
-                                                         const int32_t *__restrict__ seg_depth, int n_segs, int angular,
-                                                         uint32_t seed, int max_depth, int leaf_size,
-                                                         uint8_t *__restrict__ leaf_flag) {
+                                                         const int32_t *__restrict__ seg_depth, int depth0, int n_segs,
+                                                         int angular, uint32_t seed, int max_depth, int leaf_size,
+                                                         uint8_t *__restrict__ leaf_flag, int32_t *__restrict__ tmp_g,
+                                                         uint8_t *__restrict__ side_g, int fin_max,
+                                                         int32_t *__restrict__ fin_start, int32_t *__restrict__ fin_len,
+                                                         int32_t *__restrict__ fin_depth, long long *__restrict__ fin_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
-    int32_t *ids = (int32_t *)fsm;                 // FIN_MAX
-    int32_t *tmp = ids + FIN_MAX;                  // FIN_MAX (partition scratch)
-    uint8_t *sd = (uint8_t *)(tmp + FIN_MAX);      // FIN_MAX side bits
-    float *h = (float *)(sd + FIN_MAX);            // dp + 4 hyperplane + offset
+    const int s = blockIdx.x;
+    if (s >= n_segs) return;
+    const int a = seg_start[s], len = seg_len[s];
+    constexpr int NLDS = BIG ? 0 : FIN_MAX;
+    int32_t *ids = BIG ? perm + a : (int32_t *)fsm;               // member ids of the segment
+    int32_t *tmp = BIG ? tmp_g + a : (int32_t *)fsm + NLDS;       // partition scratch
+    uint8_t *sd = BIG ? side_g + a : (uint8_t *)((int32_t *)fsm + 2 * NLDS);  // side bits
+    float *h = (float *)(fsm + (size_t)NLDS * 9);  // dp + 4 hyperplane + offset
     uint16_t *hb = (uint16_t *)(h + dp + 4);       // dp: bf16 copy of the normal (dp is a multiple of 32)
     int32_t *stk = (int32_t *)(hb + dp);           // FIN_STACK * 3: (start, len, depth)
     int32_t *wsum = stk + FIN_STACK * 3;           // 8: per-wave partial sums / scalars
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
-    const int s = blockIdx.x;
-    if (s >= n_segs) return;
-    const int a = seg_start[s], len = seg_len[s];
-    for (int i = tid; i < len; i += 256) ids[i] = perm[a + i];
+    if (!BIG)
+        for (int i = tid; i < len; i += 256) ids[i] = perm[a + i];
     if (tid == 0) {
-        stk[0] = 0; stk[1] = len; stk[2] = seg_depth[s];
+        stk[0] = 0; stk[1] = len; stk[2] = seg_depth ? seg_depth[s] : depth0;
         wsum[7] = 1;  // stack size
     }
     __syncthreads();
@@ -508,6 +525,16 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
         if (tid == 0) wsum[7] = sp - 1;
         if (!(l > leaf_size && (max_depth - dep) > 0)) {  // rp_trees.py:2188: this node is a leaf
             if (tid == 0 && l > 0) leaf_flag[a + ss] = 1;
+            __syncthreads();
+            continue;
+        }
+        if (BIG && l <= fin_max) {  // small enough for the LDS finisher: hand it over
+            if (tid == 0) {
+                const int idx = (int)atomicAdd((unsigned long long *)fin_count, 1ull);
+                fin_start[idx] = a + ss;
+                fin_len[idx] = l;
+                fin_depth[idx] = dep;
+            }
             __syncthreads();
             continue;
         }
@@ -629,7 +656,8 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
         }
         __syncthreads();
     }
-    for (int i = tid; i < len; i += 256) perm[a + i] = ids[i];
+    if (!BIG)
+        for (int i = tid; i < len; i += 256) perm[a + i] = ids[i];
 }
 
 // ------------------------------------------------------------ leaf tables --
@@ -715,6 +743,7 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     const int fin_max = FIN_MAX;
     const size_t fin_smem = sizeof(int32_t) * 2 * FIN_MAX + FIN_MAX + sizeof(float) * (dp + 4) + sizeof(uint16_t) * dp +
                             sizeof(int32_t) * (FIN_STACK * 3 + 8);
+    const size_t fin_smem_big = sizeof(float) * (dp + 4) + sizeof(uint16_t) * dp + sizeof(int32_t) * (FIN_STACK * 3 + 8);
     int32_t *fin_start = ctx->seg_child + 2 * ctx->max_segs;  // finisher work list lives behind seg_child
     int32_t *fin_len = fin_start + ctx->max_segs;
     int32_t *fin_depth = fin_len + ctx->max_segs;
@@ -755,6 +784,7 @@ int nnd_launch_forest(nnd_ctx *ctx) {
                            ctx->seg_len[cur], (int)S, ctx->scan_out, scan_total, P, ctx->seg_nleft);
         int child_can_split = (max_depth - (depth + 1)) > 0 ? 1 : 0;
         NND_HIP_CHECK(hipMemsetAsync(ctx->counters + CNT_LEAVES, 0, sizeof(long long), ctx->stream));
+        NND_HIP_CHECK(hipMemsetAsync(ctx->counters + CNT_SCRATCH + 3, 0, sizeof(long long), ctx->stream));
         hipLaunchKernelGGL(k_children, dim3(1), dim3(256), 0, ctx->stream, ctx->seg_start[cur], ctx->seg_len[cur],
                            ctx->seg_nleft, (int)S, leaf_size, child_can_split, fin_max, depth + 1, ctx->seg_start[1 - cur],
                            ctx->seg_len[1 - cur], ctx->seg_child, ctx->leaf_flag, fin_start, fin_len, fin_depth, ctx->counters);
@@ -763,15 +793,28 @@ int nnd_launch_forest(nnd_ctx *ctx) {
                            ctx->pos_seg[1 - cur], inv_live ? ctx->inv : (int32_t *)nullptr);
         NND_HIP_CHECK(hipGetLastError());
         // one small read-back per level: the number of segments that stay in the level-synchronous passes
-        long long *next = ctx->h_pin + 32;  // CNT_ACTIVE_SEGS, CNT_LEAVES are adjacent; pinned words
-        static_assert(CNT_LEAVES == CNT_ACTIVE_SEGS + 1, "counter layout");
-        NND_HIP_CHECK(hipMemcpyAsync(next, ctx->counters + CNT_ACTIVE_SEGS, 2 * sizeof(long long), hipMemcpyDeviceToHost,
+        long long *next = ctx->h_pin + 32;  // CNT_ACTIVE_SEGS, CNT_LEAVES, CNT_SCRATCH.. are adjacent; pinned words
+        static_assert(CNT_LEAVES == CNT_ACTIVE_SEGS + 1 && CNT_SCRATCH == CNT_LEAVES + 1, "counter layout");
+        NND_HIP_CHECK(hipMemcpyAsync(next, ctx->counters + CNT_ACTIVE_SEGS, 6 * sizeof(long long), hipMemcpyDeviceToHost,
                                      ctx->stream));
         NND_HIP_CHECK(nnd_sync_spin(ctx));
         S = next[0];
         active_pos = next[1];
+        const long long max_stay = next[5];  // CNT_SCRATCH + 3
         cur = 1 - cur;
         depth++;
+        // Tail of the level loop: once most positions have been handed over, a level-synchronous pass still costs P
+        // positions per kernel for a few hundred segments.  If what is left fits the global-memory variant of the
+        // finisher (every segment <= BIG_MAX), one launch finishes the tail: its nodes are split in place until they fit
+        // the LDS finisher, whose work list they join.
+        if (S > 0 && (active_pos * 2 < 3 * n) && max_stay <= BIG_MAX) {
+            hipLaunchKernelGGL(k_finish_subtrees<true>, dim3((unsigned)S), dim3(256), fin_smem_big, ctx->stream, ctx->xp, ctx->xh,
+                               ctx->nrm, ctx->p.metric, dp, ctx->perm[cur], ctx->seg_start[cur], ctx->seg_len[cur],
+                               (const int32_t *)nullptr, depth, (int)S, angular, ctx->tree_seed, max_depth, leaf_size, ctx->leaf_flag,
+                               ctx->perm[1 - cur], ctx->side, fin_max, fin_start, fin_len, fin_depth, ctx->counters + CNT_SCRATCH + 1);
+            NND_HIP_CHECK(hipGetLastError());
+            S = 0;
+        }
     }
     {  // subtrees that fit in LDS: one workgroup each, no more global passes
         NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 34, ctx->counters + CNT_SCRATCH + 1, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -784,13 +827,14 @@ int nnd_launch_forest(nnd_ctx *ctx) {
         if (nfin > 0) {
             static bool configured = false;
             if (!configured) {
-                NND_HIP_CHECK(hipFuncSetAttribute((const void *)k_finish_subtrees, hipFuncAttributeMaxDynamicSharedMemorySize,
+                NND_HIP_CHECK(hipFuncSetAttribute((const void *)k_finish_subtrees<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   (int)fin_smem));
                 configured = true;
             }
-            hipLaunchKernelGGL(k_finish_subtrees, dim3((unsigned)nfin), dim3(256), fin_smem, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
-                               ctx->p.metric, dp, ctx->perm[cur], fin_start, fin_len, fin_depth, (int)nfin, angular, ctx->tree_seed, max_depth,
-                               leaf_size, ctx->leaf_flag);
+            hipLaunchKernelGGL(k_finish_subtrees<false>, dim3((unsigned)nfin), dim3(256), fin_smem, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
+                               ctx->p.metric, dp, ctx->perm[cur], fin_start, fin_len, fin_depth, 0, (int)nfin, angular, ctx->tree_seed,
+                               max_depth, leaf_size, ctx->leaf_flag, (int32_t *)nullptr, (uint8_t *)nullptr, fin_max, fin_start, fin_len,
+                               fin_depth, ctx->counters + CNT_SCRATCH + 1);
             NND_HIP_CHECK(hipGetLastError());
         }
         ctx->stats.n_leaves = nfin;  // overwritten below; kept for debugging
