@@ -38,7 +38,7 @@ struct leaf_cfg {
 };
 
 template <int NT, int NW, int DC>
-__global__ __launch_bounds__(NW * 64, (NT == 5 && NW == 8) ? 8 : 1) void k_leaf_join(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
+__global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_join(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
                                                        int metric, const int32_t *__restrict__ perm,
                                                        const int32_t *__restrict__ wl_start,
                                                        const int32_t *__restrict__ wl_len, int64_t leaf0,
