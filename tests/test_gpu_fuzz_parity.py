@@ -13,3 +13,11 @@ def test_random_configurations():
     import fuzz_parity
 
     assert fuzz_parity.main(12, 7) == 0
+
+
+def test_structural_stress():
+    """tools/fuzz_structural.py: 60 random configurations (duplicates, d up to 513, k up to 64, leaf sizes 2..300,
+    0..16 trees, 1..64 candidates): shapes, ascending rows, unique ids, finite distances, no exception."""
+    import fuzz_structural
+
+    assert fuzz_structural.main(60, 11) == 0

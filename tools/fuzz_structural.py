@@ -1,0 +1,77 @@
+"""GPU-only stress: many random configurations (shapes, k, trees, leaf sizes, candidate counts, metrics), structural
+invariants of the result; the share of rows whose k-th distance is exact is printed for information.  usage: fuzz_structural.py [N] [seed]"""
+import os
+import sys
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from pynndescent_amd import NNDescent
+
+
+def main(count, seed):
+    rs = np.random.RandomState(seed)
+    bad = 0
+    for t in range(count):
+        n = int(rs.choice([65, 257, 1000, 4097, 20000, 70000]))
+        d = int(rs.choice([1, 2, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 255, 256, 300, 513]))
+        k = int(min(rs.choice([1, 2, 3, 7, 15, 16, 17, 31, 32, 33, 50, 64]), n - 1))
+        metric = str(rs.choice(["euclidean", "cosine"]))
+        n_trees = rs.choice([None, 0, 1, 2, 5, 16])
+        n_trees = None if n_trees is None else int(n_trees)
+        leaf = rs.choice([None, None, 2, 17, 64, 65, 96, 129, 200, 300])
+        leaf = None if leaf is None else int(leaf)
+        mc = rs.choice([None, None, 1, 2, 16, 17, 33, 64])
+        mc = None if mc is None else int(mc)
+        kind = rs.randint(4)
+        if kind == 0:
+            x = rs.standard_normal((n, d)).astype(np.float32)
+        elif kind == 1:
+            x = (rs.standard_normal((n, min(d, 4))) @ rs.standard_normal((min(d, 4), d))).astype(np.float32)
+        elif kind == 2:
+            x = np.repeat(rs.standard_normal((max(n // 7, 1), d)), 7, axis=0)[:n].astype(np.float32)  # exact duplicates
+            if x.shape[0] < n:
+                x = np.vstack([x, rs.standard_normal((n - x.shape[0], d)).astype(np.float32)])
+        else:
+            x = rs.uniform(0, 1000, (n, d)).astype(np.float32)
+        cfg = dict(n=n, d=d, k=k, metric=metric, n_trees=n_trees, leaf_size=leaf, max_candidates=mc, data=kind)
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                idx, dist = NNDescent(x, metric, n_neighbors=k, n_trees=n_trees, leaf_size=leaf, max_candidates=mc,
+                                      random_state=int(rs.randint(1 << 30))).neighbor_graph
+            filled = idx >= 0
+            ok = idx.shape == (n, k) and bool(np.all(np.isfinite(dist[filled])))
+            big = np.where(filled, dist, np.inf)
+            ok &= bool(np.all(big[:, 1:] >= big[:, :-1] - 1e-12))
+            ok &= bool(idx.max() < n)
+            for r, f in zip(idx[:: max(1, n // 200)], filled[:: max(1, n // 200)]):
+                ok &= len(set(r[f].tolist())) == int(f.sum())
+            xt = torch.from_numpy(x).cuda()
+            rows = torch.arange(0, n, max(1, n // 300), device="cuda")
+            if metric == "euclidean":
+                dd = torch.cdist(xt[rows].double(), xt.double())
+            else:
+                xn = torch.nn.functional.normalize(xt.double(), dim=1)
+                dd = 1.0 - xn[rows] @ xn.T
+            kt = min(k, 5)
+            truth = dd.topk(kt, dim=1, largest=False).values[:, -1].cpu().numpy()  # exact k-th distance
+            got = dist[rows.cpu().numpy(), kt - 1]
+            # duplicates / ties make id recall meaningless: compare the kt-th DISTANCE instead
+            hit = np.mean(got <= truth * (1 + 1e-4) + 1e-6)
+            # iid high-dimensional data is legitimately hard for NN-descent (SURVEY: recall 0.49 at 64-d Gaussian): the hit
+            # rate is informational; parity with the reference algorithm is what tools/fuzz_parity.py checks
+            print("%s kth-dist hit %.3f filled %.3f %s" % ("ok  " if ok else "FAIL", hit, filled.mean(), cfg))
+            bad += 0 if ok else 1
+        except Exception as e:  # noqa: BLE001
+            print("EXC ", type(e).__name__, str(e)[:150], cfg)
+            bad += 1
+        sys.stdout.flush()
+    print("failures:", bad, "of", count)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)
