@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
     const int nfwd[2] = {cnt[0], cnt[1]};
     // reverse offers: when both classes' slot banks fit one wave (2 * rcap <= 64) they are fetched and screened together
     if (2 * rcap <= 64) {
-        const int c = lane >= rcap ? 1 : 0, s = lane - c * rcap;
+        const int c = lane >= rcap ? 1 : 0;
         uint64_t *slots = rbuf + v * 2 * rcap;  // [class 0 | class 1] are adjacent
         uint64_t rk = NND_EMPTY_KEY;
         if (lane < 2 * rcap) {
@@ -103,7 +103,6 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
             const int nf = c ? nfwd[1] : nfwd[0];
             for (int j = 0; j < nf; j++) ok &= ((uint32_t)sc.key[c][j] != src);
         }
-        (void)s;
 #pragma unroll
         for (int cc = 0; cc < 2; cc++) {
             const bool mine = ok && c == cc;
