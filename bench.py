@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--k", type=int, default=15)
     ap.add_argument("--n-trees", type=int, default=8)
     ap.add_argument("--join-blocks", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--cpu-sample", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
