@@ -79,7 +79,7 @@ int nnd_launch_prep(nnd_ctx *ctx) {
     int64_t n = ctx->n;
     int d = ctx->d, dp = ctx->dp;
     if (ctx->p.metric == 0) {
-        int rows_per_block = 256;
+        int rows_per_block = 128;
         int nblocks = (int)((n + rows_per_block - 1) / rows_per_block);
         const size_t need = (size_t)nblocks * d;
         if (need > ctx->colsum_cap) {  // grow-only scratch: no hipMalloc / hipFree (both synchronise) per build
@@ -88,7 +88,9 @@ int nnd_launch_prep(nnd_ctx *ctx) {
             ctx->colsum_cap = need;
         }
         double *partial = ctx->colsum_partial;
-        hipLaunchKernelGGL(k_colsum_partial, dim3(nblocks), dim3(256), 0, ctx->stream, ctx->x_orig, n, d,
+        int bt = ((d + 63) / 64) * 64;  // one thread per column: no idle half-blocks at d = 128
+        if (bt > 256) bt = 256;
+        hipLaunchKernelGGL(k_colsum_partial, dim3(nblocks), dim3(bt), 0, ctx->stream, ctx->x_orig, n, d,
                            rows_per_block, partial);
         hipLaunchKernelGGL(k_colsum_final, dim3(dp), dim3(256), 0, ctx->stream, partial, nblocks, d, dp,
                            n, ctx->mean);
