@@ -61,3 +61,27 @@ def test_constructor_mirrors_reference_signature():
         assert kw in names
     sig = inspect.signature(NNDescent.__init__).parameters
     assert sig["n_neighbors"].default == 30 and sig["delta"].default == 0.001 and sig["max_rptree_depth"].default == 200
+
+
+def test_from_graph_validates_and_mirrors_reference_attributes():
+    """NNDescent.from_graph needs no GPU: it wraps an existing graph; shapes / metric are validated like the ctor's
+    init_graph branch (pynndescent_.py:1229, 1292) and the attributes the reference's prepare()/query() read exist."""
+    import numpy as np
+    import pytest
+
+    from pynndescent_amd import NNDescent
+
+    x = np.random.RandomState(0).standard_normal((50, 4)).astype(np.float32)
+    idx = np.tile(np.arange(5, dtype=np.int32), (50, 1))
+    dist = np.zeros((50, 5), np.float32)
+    index = NNDescent.from_graph(x, idx, dist, metric="cosine", random_state=3, leaf_size=20)
+    assert index.n_neighbors == 5 and index._angular_trees and index.leaf_size == 20
+    assert index.rng_state.shape == (3,) and index.search_rng_state.shape == (3,)
+    for name in NNDescent._HANDOVER:
+        assert hasattr(index, name), name
+    with pytest.raises(ValueError, match="Init graph size does not match"):
+        NNDescent.from_graph(x, idx[:10], dist[:10])
+    with pytest.raises(ValueError, match="Metric is neither callable"):
+        NNDescent.from_graph(x, idx, dist, metric="no-such-metric")
+    with pytest.raises(TypeError):
+        NNDescent.from_graph(x, idx, dist, not_a_parameter=1)
