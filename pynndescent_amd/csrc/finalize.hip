@@ -18,7 +18,10 @@ __device__ __forceinline__ double fin_group16_sum_f64(double v) {
 // One wave per row.  The 64 lanes work as 4 groups of 16: group g takes neighbours g, 4+g, 8+g, ... so four distances
 // are accumulated side by side and up to 16 neighbour rows are in flight per wave (the gather is latency bound when
 // the rows are fetched one after another).
-__global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, int d, int metric, int64_t lo, int64_t n, int k, int ks,
+// METRIC is a template parameter: the euclidean instance does not carry the cosine accumulators (146 -> far fewer
+// registers, i.e. more waves per SIMD for what is a gather-latency-bound kernel).
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, int d, int64_t lo, int64_t n, int k, int ks,
                                                   const uint32_t *__restrict__ knn_e, const int32_t *__restrict__ order,
                                                   int32_t *__restrict__ out_idx, float *__restrict__ out_dist) {
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
@@ -33,6 +36,7 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, i
     const float *xv = x + v * d;
     const int grp = lane >> 4, l16 = lane & 15;
     const bool vec = (d & 3) == 0;  // rows 16-byte aligned
+    constexpr int metric = METRIC;
     float mine = INFINITY;
     const int nsteps = (k + 3) >> 2;
     for (int s0 = 0; s0 < nsteps; s0 += 4) {
@@ -118,8 +122,12 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, i
 int nnd_launch_finalize(nnd_ctx *ctx, int32_t *out_idx_dev, float *out_dist_dev) {
     unsigned grid = (unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4);
     grid = (grid + 7u) & ~7u;  // whole multiples of the XCD count
-    hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, ctx->stream, ctx->x_orig, ctx->d, ctx->p.metric, ctx->own_lo,
-                       ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, nnd_vertex_order(ctx), out_idx_dev, out_dist_dev);
+    if (ctx->p.metric == 0)
+        hipLaunchKernelGGL(k_finalize<0>, dim3(grid), dim3(256), 0, ctx->stream, ctx->x_orig, ctx->d, ctx->own_lo, ctx->own_hi,
+                           ctx->k, ctx->ks, ctx->knn_e, nnd_vertex_order(ctx), out_idx_dev, out_dist_dev);
+    else
+        hipLaunchKernelGGL(k_finalize<1>, dim3(grid), dim3(256), 0, ctx->stream, ctx->x_orig, ctx->d, ctx->own_lo, ctx->own_hi,
+                           ctx->k, ctx->ks, ctx->knn_e, nnd_vertex_order(ctx), out_idx_dev, out_dist_dev);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
