@@ -21,7 +21,7 @@ __device__ __forceinline__ double fin_group16_sum_f64(double v) {
 // METRIC is a template parameter: the euclidean instance does not carry the cosine accumulators (146 -> far fewer
 // registers, i.e. more waves per SIMD for what is a gather-latency-bound kernel).
 template <int METRIC>
-__global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ x, int d, int64_t lo, int64_t n, int k, int ks,
+__global__ __launch_bounds__(256, METRIC == 0 ? 6 : 4) void k_finalize(const float *__restrict__ x, int d, int64_t lo, int64_t n, int k, int ks,
                                                   const uint32_t *__restrict__ knn_e, const int32_t *__restrict__ order,
                                                   int32_t *__restrict__ out_idx, float *__restrict__ out_dist) {
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
