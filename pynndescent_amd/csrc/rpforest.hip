@@ -259,15 +259,29 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_reduce(int mode, const int3
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int s = 0;
     if (mode == 2) {
-        int64_t tb = base < P ? (base / n) * n : 0;
+        // three rounds of independent loads (segment ids, point ids, sides) instead of a dependent chain per item
+        const int64_t tb0 = base < P ? (base / n) * n : 0;
+        int sg[SCAN_ITEMS], pt[SCAN_ITEMS];
+        uint8_t sd[SCAN_ITEMS];
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            const int64_t g = base + i < P ? base + i : P - 1;
+            sg[i] = pos_seg[g];
+            pt[i] = perm[g];
+        }
 #pragma unroll
         for (int i = 0; i < SCAN_ITEMS; i++) {
             const int64_t g = base + i;
-            if (g < P && pos_seg[g] >= 0) {
-                if (g >= tb + n) tb += n;
-                const uint8_t sd = side_pt[tb + perm[g]];
-                bytes[g] = sd;
-                s += sd == 0;
+            int64_t tb = tb0;
+            while (g >= tb + n && tb + n < P) tb += n;  // a run of SCAN_ITEMS positions rarely crosses a tree boundary
+            sd[i] = side_pt[tb + pt[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            const int64_t g = base + i;
+            if (g < P && sg[i] >= 0) {
+                bytes[g] = sd[i];
+                s += sd[i] == 0;
             }
         }
     } else {
