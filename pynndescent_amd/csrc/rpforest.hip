@@ -245,7 +245,11 @@ __global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ 
 // exclusive scan over flag(g) = (pos_seg[g] >= 0 && side[g] == 0)  [mode 0]  or  leaf_flag[g] [mode 1]
 __device__ __forceinline__ int scan_flag(int mode, const int32_t *pos_seg, const uint8_t *bytes, int64_t g, int64_t P) {
     if (g >= P) return 0;
-    if (mode == 0) return (pos_seg[g] >= 0 && bytes[g] == 0) ? 1 : 0;
+    if (mode == 0) {  // both loads are issued (no short circuit): the unrolled callers then have 2 * SCAN_ITEMS loads in flight
+        const int sg = pos_seg[g];
+        const uint8_t b = bytes[g];
+        return (sg >= 0) & (b == 0);
+    }
     return bytes[g] ? 1 : 0;
 }
 
