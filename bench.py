@@ -8,15 +8,26 @@ is already resident in HBM, with the neighbour graph left resident in HBM.  Work
 BASELINE.json configs[1] -- "SIFT-1M (1e6 x 128 float32) euclidean k=15, RP-tree init n_trees=8" --
 on the seeded SIFT-like stand-in of SURVEY.md section 8d (no dataset files / network here).
 
+N > 1: one rank per GPU over RCCL (`backend="nccl"`).  The driver launches the ranks with
+torch.distributed.run; when WORLD_SIZE is not set (plain `python bench.py --gpus N`) this script re-executes
+itself under torch.distributed.run with N ranks and fails loudly if fewer than N devices are visible.
+N = 2, 4: weak scaling, 1 M points per GPU, one global index.  N = 8 (no --points-per-gpu): BASELINE configs[3],
+ONE 10 M x 128 set row-sharded over the 8 GPUs (1.25 M rows per rank), "scaling": "strong".
+
 Rank 0 prints ONE JSON line (contract in the task statement) carrying, besides the metric:
-  roofline     : dominant kernel's algorithmic HBM bytes / its HIP-event duration vs 8 TB/s
-  cpu_baseline : the CPU oracle (restatement of the reference algorithm, oracle/) timed on this
-                 box's host cores on a bounded sample of the same workload
-  recall_at_10 : recall vs exact brute force on a sample of points (reference-test convention)
+  roofline             : dominant kernel's algorithmic HBM bytes / its HIP-event duration vs 8 TB/s, plus
+                         roofline.mfma: MFMA flops issued (counted by the kernels) vs the f32 matrix peak
+  cpu_baseline         : the CPU oracle (restatement of the reference algorithm, oracle/) timed on this
+                         box's host cores on the same 1 M points
+  value_host_inclusive : the same build through nnd_build (host buffers in, host buffers out: H2D + build + D2H)
+  workload_hard        : a second, slow-converging input (latent dimension 48) so tuning is not judged on one workload
+  recall_at_10         : recall vs exact brute force on a sample of points (reference-test convention)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,7 +39,9 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402  (device memory, streams, torch.distributed: plumbing only)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # same guide: f32-input MFMA (v_mfma_f32_16x16x4_f32) = the f32 vector rate
+MFMA_FLOP = 2048.0        # one v_mfma_f32_16x16x4_f32: 16 * 16 * 4 multiply-adds
 
 
 def sift_like(n, d, seed, device, latent=16, n_clusters=1024, noise=0.3, sample_seed=None):
@@ -76,27 +89,73 @@ def recall_at(true_idx, approx_idx, k_true=10, cols=None):
     return hits / float(t.shape[0] * k_true)
 
 
-def cpu_baseline(O, xs, k, n_trees):
-    """The CPU oracle (restatement of the reference algorithm) on this box's host cores.  The reference's
-    parallel scheme makes every thread scan all edges (utils.py:266-273), so more threads is not always
-    faster: a short probe picks the thread count, then the bounded sample is timed once."""
+def cpu_baseline(O, xs, k, n_trees, true_rows=None, true_idx=None):
+    """The CPU oracle (restatement of the reference algorithm) on this box's host cores, on the SAME points as the
+    GPU build.  The reference's parallel scheme makes every thread scan all edges (utils.py:266-273), so more threads
+    is not always faster: the thread count is picked by a probe on the first 200 k points, then the whole set is
+    timed once."""
     cores = os.cpu_count() or 1
     O.build()
-    probe = xs[: min(30000, xs.shape[0])]
+    probe = xs[: min(200_000, xs.shape[0])]
     best_t, best = None, None
-    for t in sorted({min(cores, c) for c in (8, 16, 32, 64, 128)}):
+    for t in sorted({min(cores, c) for c in (32, 64, 128)}):
         t1 = time.perf_counter()
         O.build_index(probe, "euclidean", n_neighbors=k, n_trees=n_trees, random_state=1234, n_threads=t, kind="fast")
         dt = time.perf_counter() - t1
         if best is None or dt < best:
             best_t, best = t, dt
     t1 = time.perf_counter()
-    O.build_index(xs, "euclidean", n_neighbors=k, n_trees=n_trees, random_state=1234, n_threads=best_t, kind="fast")
+    oidx, _ = O.build_index(xs, "euclidean", n_neighbors=k, n_trees=n_trees, random_state=1234, n_threads=best_t, kind="fast")
     dt = time.perf_counter() - t1
+    rec = None
+    if true_rows is not None:
+        rec = round(float(O.recall(true_idx, oidx[true_rows])), 4)
     return {"value": round(xs.shape[0] / dt, 1), "unit": "points/s", "cores": best_t, "host_cores": cores, "kind": "port",
-            "sample": "first %d points of the same synthetic set, same k/n_trees/defaults; CPU restatement of the "
+            "seconds": round(dt, 2), "recall_at_10": rec,
+            "sample": "all %d points of the same synthetic set, same k/n_trees/defaults; CPU restatement of the "
                       "reference algorithm (numba unavailable), gcc -O3 -ffast-math + OpenMP, %d threads "
-                      "(fastest of a probe over 8..128)" % (xs.shape[0], best_t)}
+                      "(fastest of a probe over 32/64/128 on the first %d points)" % (xs.shape[0], best_t, probe.shape[0])}
+
+
+def host_inclusive(_capi, x_host, k, n_trees, leaf_size, n_iters, rng_state, tree_state, device, reps=2):
+    """n / wall(build -> neighbor_graph arrays on the host): ONE nnd_build call per repetition --
+    the entry point INTEGRATION.md binds -- incl. handle creation, H2D of the points and D2H of the graph."""
+    import ctypes as C
+
+    lib = _capi.load_library()
+    n, d = x_host.shape
+    p = _capi.NNDParams()
+    p.n, p.dim, p.metric, p.n_neighbors, p.n_trees, p.leaf_size = n, d, 0, k, n_trees, leaf_size
+    p.max_depth, p.max_candidates, p.n_iters, p.delta, p.device, p.join_blocks = 200, min(60, k), n_iters, 0.001, device, 1
+    for i in range(3):
+        p.rng_state[i], p.tree_rng[i] = int(rng_state[i]), int(tree_state[i])
+    idx = np.empty((n, k), np.int32)
+    dist = np.empty((n, k), np.float32)
+    err = C.create_string_buffer(512)
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        rc = lib.nnd_build(C.byref(p), x_host.ctypes.data_as(C.c_void_p), None, None, 0, idx.ctypes.data_as(C.c_void_p),
+                           dist.ctypes.data_as(C.c_void_p), None, err, 512)
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError(err.value.decode())
+        best = dt if best is None else min(best, dt)
+    return {"value": round(n / best, 1), "unit": "points/s", "ms": round(best * 1e3, 2),
+            "what": "nnd_build: hipMalloc of the state + H2D %d MB (pageable numpy) + build + D2H %d MB, best of %d"
+                    % (x_host.nbytes >> 20, (idx.nbytes + dist.nbytes) >> 20, reps)}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def builder_dp(d):
+    return (d + 31) // 32 * 32
 
 
 def main():
@@ -104,37 +163,63 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--points-per-gpu", dest="n", type=int, default=1_000_000)
+    ap.add_argument("--points-per-gpu", dest="n", type=int, default=None)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=15)
-    ap.add_argument("--n-trees", type=int, default=8)
+    ap.add_argument("--n-trees", type=int, default=None)
     ap.add_argument("--join-blocks", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=500_000)
+    ap.add_argument("--latent", type=int, default=16, help="latent dimension of the synthetic mixture (48 = the hard workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_host_inclusive and workload_hard")
     args = ap.parse_args()
+
+    share_gpu = os.environ.get("PYNND_BENCH_SHARE_GPU") == "1"  # debug: all ranks on GPU 0 over gloo
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become N ranks, one per GPU (torch.distributed.run, RCCL)
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not share_gpu:
+            sys.exit("bench.py: --gpus %d requested but only %d HIP device(s) are visible" % (args.gpus, ndev))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # PYNND_BENCH_SHARE_GPU=1 (debug only): all ranks on GPU 0 over gloo, to exercise the multi-process
-        # path on a one-GPU box; the real run is one rank per GPU over nccl (= RCCL)
-        if os.environ.get("PYNND_BENCH_SHARE_GPU") == "1":
+        if share_gpu:
             local_rank = 0
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            if torch.cuda.device_count() <= local_rank:
+                sys.exit("bench.py: rank %d has no HIP device %d (visible: %d)" % (rank, local_rank, torch.cuda.device_count()))
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
     from pynndescent_amd import _capi, sharded
 
-    n, d, k = args.n, args.dim, args.k
-    n_total = n * world
-    x = sift_like(n, d, seed=1, device=device, sample_seed=100 + rank)
+    d, k = args.dim, args.k
+    strong = world == 8 and args.n is None  # BASELINE configs[3]: one 10 M x 128 set over 8 GPUs
+    if strong:
+        n_total = 10_000_000
+        lo, hi = sharded.shard_ranges(n_total, world)[rank]
+        n = hi - lo
+        shard_sizes = [b - a for a, b in sharded.shard_ranges(n_total, world)]
+    else:
+        n = 1_000_000 if args.n is None else args.n
+        n_total = n * world
+        shard_sizes = [n] * world
+    n_trees = args.n_trees
+    if n_trees is None:  # configs[1] names 8 trees; configs[3] names none -> the reference default (pynndescent_.py:1009-1010)
+        n_trees = max(3, min(12, int(round(2.0 * np.log10(n_total))))) if strong else 8
+    x = sift_like(n, d, seed=1, device=device, sample_seed=100 + rank, latent=args.latent)
     torch.cuda.synchronize()
     n_iters = max(5, int(round(np.log2(n_total))))  # pynndescent_.py:1011-1012
     leaf_size = max(60, min(256, 5 * k))              # rp_trees.py:2845-2846
@@ -142,12 +227,12 @@ def main():
     rs = np.random.RandomState(1234)
     rng_state = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
     _ = rs.randint(lim.min + 1, lim.max - 1, 3)
-    tree_states = rs.randint(lim.min + 1, lim.max - 1, size=(args.n_trees, 3)).astype(np.int64)
+    tree_states = rs.randint(lim.min + 1, lim.max - 1, size=(n_trees, 3)).astype(np.int64)
 
     if world == 1:
         out_idx = torch.empty((n, k), dtype=torch.int32, device=device)
         out_dist = torch.empty((n, k), dtype=torch.float32, device=device)
-        builder = _capi.Builder(n, d, _capi.NND_METRIC_SQEUCLIDEAN, k, args.n_trees, leaf_size, 200, min(60, k), n_iters,
+        builder = _capi.Builder(n, d, _capi.NND_METRIC_SQEUCLIDEAN, k, n_trees, leaf_size, 200, min(60, k), n_iters,
                                 0.001, rng_state, tree_states[0], device=local_rank, join_blocks=args.join_blocks)
         sb = None
 
@@ -157,7 +242,7 @@ def main():
             return builder.stats(), None
     else:
         comm = sharded.TorchDistComm()
-        sb = sharded.ShardedBuilder(comm, [n] * world, d, "euclidean", k, args.n_trees, seed=1234, device_index=local_rank)
+        sb = sharded.ShardedBuilder(comm, shard_sizes, d, "euclidean", k, n_trees, seed=1234, device_index=local_rank)
         builder = sb.b
         out_idx, out_dist = sb.out_idx, sb.out_dist
 
@@ -178,6 +263,7 @@ def main():
     stage = {"forest": 0.0, "leaf_init": 0.0, "join": 0.0, "sample": 0.0, "merge": 0.0, "finalize": 0.0, "prep": 0.0,
              "random_init": 0.0}
     join_bytes = join_ms = leaf_bytes = 0.0
+    join_mfma = leaf_mfma = join_pairs = leaf_pairs = 0.0
     n_join_launches = 0
     last = info = None
     for _ in range(args.steps):
@@ -192,6 +278,10 @@ def main():
         join_ms += sum(st["ms_join"])
         join_bytes += sum(st["join_rows"]) * 4.0 * builder_dp(d)
         leaf_bytes += st["leaf_rows"] * 4.0 * builder_dp(d)
+        join_mfma += sum(st["join_mfma"])
+        leaf_mfma += st["leaf_mfma"]
+        join_pairs += sum(st["join_pairs"])
+        leaf_pairs += st["leaf_pairs"]
         n_join_launches += st["n_iters_run"] * args.join_blocks
     barrier()
     elapsed = time.perf_counter() - t0
@@ -209,7 +299,8 @@ def main():
         x_all = x
     if rank == 0:
         rsmp = np.random.RandomState(0)
-        rows = torch.from_numpy(rsmp.choice(n, size=min(2000, n), replace=False)).to(device)  # rank 0 owns rows [0, n)
+        rows_np = rsmp.choice(n, size=min(2000, n), replace=False)
+        rows = torch.from_numpy(rows_np).to(device)  # rank 0 owns rows [0, n)
         true_idx = exact_knn_sample(x_all, rows, 10)
         rec_all = recall_at(true_idx, out_idx[rows], 10)
         rec_strict = recall_at(true_idx, out_idx[rows], 10, cols=10)
@@ -222,8 +313,7 @@ def main():
         #   k_leaf_join  : sum of leaf sizes * dp*4 bytes per launch
         #   rp forest    : n * dp*4 * levels (each row once per level, all trees fused) + 8 B/position/level
         steps = float(args.steps)
-        # the two single-kernel stages; every kernel of the forest stage (k_margin_fused, k_finish_subtrees, scans,
-        # k_scatter) is smaller than either, so the dominant KERNEL is one of these two
+        local_trees = max(1, n_trees // world)
         dominant = max(("join", "leaf_init"), key=lambda sname: stage[sname])
         join_gbs = join_bytes / (join_ms * 1e-3) / 1e9 if join_ms > 0 else 0.0
         leaf_gbs = leaf_bytes / (stage["leaf_init"] * 1e-3) / 1e9 if stage["leaf_init"] > 0 else 0.0
@@ -233,35 +323,81 @@ def main():
             achieved, kernel = leaf_gbs, "k_leaf_join"
         n_here = builder.n
         tree_bytes = steps * (n_here * 4.0 * builder_dp(d) * last["tree_levels"] +
-                              n_here * 8.0 * last["tree_levels"] * max(1, args.n_trees // world))
+                              n_here * 8.0 * last["tree_levels"] * local_trees)
         forest_gbs = tree_bytes / (stage["forest"] * 1e-3) / 1e9 if stage["forest"] > 0 else 0.0
-        # HBM traffic per launch from the committed PMC passes (tools/pmc_traffic.py; separate --pmc runs, gfx950
-        # FETCH_SIZE correction applied); null if no profile of this kernel has been committed
+        # HBM traffic per launch from the committed PMC passes (tools/pmc_traffic.py; separate --pmc runs, FETCH_SIZE
+        # corrected by the factor calibrated for this access pattern); null if no profile of this kernel is committed
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            key = {"join": "k_local_join", "leaf_init": "k_leaf_join"}[dominant]
-            for name, rec in tj.items():
-                if isinstance(rec, dict) and key in name:
-                    traffic = rec["traffic_bytes_per_launch"]
+        for tname in ("r02_traffic.json", "r01_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if traffic is None and os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                key = {"join": "k_local_join", "leaf_init": "k_leaf_join"}[dominant]
+                for name, rec in tj.items():
+                    if isinstance(rec, dict) and key in name:
+                        traffic = rec["traffic_bytes_per_launch"]
+
+        # MFMA side (north_star: "MFMA utilisation reported against gfx950 peak"): instructions are counted by the
+        # kernels themselves (v_mfma_f32_16x16x4_f32, 2048 flop each); algorithmic = 2*dp flop per evaluated pair
+        def mfma_rec(instr, ms, pairs):
+            issued = instr * MFMA_FLOP / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            alg = pairs * 2.0 * builder_dp(d) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"issued_tflops": round(issued, 2), "frac_of_f32_mfma_peak": round(issued / MFMA_F32_PEAK_TF, 4),
+                    "algorithmic_tflops": round(alg, 2), "tile_efficiency": round(alg / issued, 3) if issued > 0 else None,
+                    "mfma_instructions_per_build": round(instr / steps)}
+
+        mfma = {"peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "instruction": "v_mfma_f32_16x16x4_f32",
+                "k_local_join": mfma_rec(join_mfma, join_ms, join_pairs),
+                "k_leaf_join": mfma_rec(leaf_mfma, stage["leaf_init"], leaf_pairs)}
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "k_local_join": {"achieved": round(join_gbs, 2), "frac": round(join_gbs / HBM_PEAK_GBS, 5),
                                      "avg_launch_ms": round(join_ms / max(n_join_launches, 1), 4),
                                      "bytes_per_launch": round(join_bytes / max(n_join_launches, 1))},
                     "k_leaf_join": {"achieved": round(leaf_gbs, 2), "frac": round(leaf_gbs / HBM_PEAK_GBS, 5),
-                                    "avg_launch_ms": round(stage["leaf_init"] / steps / max(args.n_trees // world, 1), 4),
-                                    "bytes_per_launch": round(leaf_bytes / steps / max(args.n_trees // world, 1))},
+                                    "avg_launch_ms": round(stage["leaf_init"] / steps / local_trees, 4),
+                                    "bytes_per_launch": round(leaf_bytes / steps / local_trees)},
                     "rp_forest_stage": {"achieved": round(forest_gbs, 2), "frac": round(forest_gbs / HBM_PEAK_GBS, 5),
-                                        "ms": round(stage["forest"] / steps, 3)}}
+                                        "ms": round(stage["forest"] / steps, 3)},
+                    "mfma": mfma}
 
-        cpu = None
+        cpu = host_incl = hard = None
+        if world == 1 and not args.no_extras:
+            host_incl = host_inclusive(_capi, x.cpu().numpy(), k, n_trees, leaf_size, n_iters, rng_state, tree_states[0],
+                                       local_rank)
+            if args.latent == 16:  # second perf line: same generator, latent dimension 48 (converges slowly)
+                xh = sift_like(n, d, seed=1, device=device, sample_seed=100, latent=48)
+                torch.cuda.synchronize()
+                builder.set_data_device(xh.data_ptr(), keepalive=xh)
+                builder.build_device(out_idx.data_ptr(), out_dist.data_ptr())  # warm-up
+                builder.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    builder.set_data_device(xh.data_ptr(), keepalive=xh)
+                    builder.build_device(out_idx.data_ptr(), out_dist.data_ptr())
+                builder.synchronize()
+                dt = (time.perf_counter() - t1) / 2
+                sth = builder.stats()
+                rows_h = rows[:1000]
+                th = exact_knn_sample(xh, rows_h, 10)
+                hard = {"workload": "same generator, latent dimension 48: %dx%d euclidean k=%d n_trees=%d" % (n, d, k, n_trees),
+                        "value": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 3), "iters": sth["n_iters_run"],
+                        "recall_at_10": round(recall_at(th, out_idx[rows_h], 10), 4),
+                        "stage_ms": {"forest": round(sth["ms_forest"], 3), "leaf_init": round(sth["ms_leaf_init"], 3),
+                                     "join": round(sum(sth["ms_join"]), 3), "sample": round(sum(sth["ms_sample"]), 3),
+                                     "merge": round(sum(sth["ms_merge"]), 3), "finalize": round(sth["ms_finalize"], 3)}}
+                del xh
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O  # test infrastructure: the cpu_baseline leg only
 
-            cpu = cpu_baseline(O, x[: min(args.cpu_sample, n)].cpu().numpy(), k, args.n_trees)
+            cpu = cpu_baseline(O, x.cpu().numpy(), k, n_trees, rows_np, true_idx.cpu().numpy())
 
+        if strong:
+            workload = ("BASELINE configs[3] stand-in: ONE SIFT-like %dx%d float32 euclidean k=%d set (n_trees=%d) row-sharded "
+                        "over %d GPUs, %d rows per rank" % (n_total, d, k, n_trees, world, n))
+        else:
+            workload = ("SIFT-like %dx%d float32 euclidean k=%d n_trees=%d (BASELINE configs[1] stand-in, SURVEY 8d C2'%s); "
+                        "%d points per GPU" % (n_total, d, k, n_trees, "" if args.latent == 16 else ", latent %d" % args.latent, n))
         result = {
             "metric": "index build: points indexed/sec (recall@10 vs brute force reported alongside)",
             "value": round(value, 1),
@@ -271,16 +407,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "SIFT-like %dx%d float32 euclidean k=%d n_trees=%d (BASELINE configs[1] stand-in, "
-                                   "SURVEY 8d C2'); %d points per GPU" % (n_total, d, k, args.n_trees, n),
+            "config": {"workload": workload,
                        "parallelism": "1 GPU" if world == 1 else
                        "rows sharded over %d GPUs (one global index of %d points): point set all-gathered once, forest split "
-                       "by tree, per iteration k-list all-gather + proposal all-to-all-v + count all-reduce over RCCL"
-                       % (world, n_total),
+                       "by tree, per iteration reverse-offer all-to-all-v + threshold all-gather + proposal all-to-all-v + "
+                       "count all-reduce over RCCL" % (world, n_total),
                        "join_blocks": args.join_blocks},
             "recall_at_10": round(rec_all, 4),
             "recall_at_10_strict_first10": round(rec_strict, 4),
@@ -295,6 +430,8 @@ def main():
                        "updates": last["updates"]},
             "exchanged_records_rank0": None if info is None else info["exchanged_records"],
             "roofline": roofline,
+            "value_host_inclusive": host_incl,
+            "workload_hard": hard,
             "cpu_baseline": cpu,
         }
         print(json.dumps(result))
@@ -306,10 +443,6 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
-
-
-def builder_dp(d):
-    return (d + 31) // 32 * 32
 
 
 if __name__ == "__main__":

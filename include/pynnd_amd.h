@@ -41,7 +41,7 @@ extern "C" {
 #define NND_METRIC_SQEUCLIDEAN 0 /* reference distances.py:63  squared_euclidean  */
 #define NND_METRIC_ALT_COSINE 1  /* reference distances.py:583 alternative_cosine */
 
-#define NND_ABI_VERSION 1
+#define NND_ABI_VERSION 2
 
 typedef struct nnd_handle_s *nnd_handle_t;
 
@@ -80,6 +80,8 @@ typedef struct nnd_stats {
     int64_t updates[64];         /* c: accepted k-list insertions, per iteration */
     float ms_prep, ms_forest, ms_leaf_init, ms_random_init, ms_descent, ms_finalize;
     float ms_sample[64], ms_join[64], ms_merge[64];
+    int64_t join_mfma[64];       /* v_mfma_f32_16x16x4_f32 instructions issued by the join (2048 flop each), per iteration */
+    int64_t leaf_mfma;           /* the same for the leaf-seeding kernel, whole stage */
 } nnd_stats;
 
 int32_t nnd_abi_version(void);
@@ -183,12 +185,25 @@ int32_t nnd_import_proposals(nnd_handle_t h, const uint64_t *keys, const int32_t
 int32_t nnd_descent_merge(nnd_handle_t h, int64_t *c_local);
 
 /* ---- search-graph pruning pass (BASELINE config 5; reference NNDescent._init_search_graph, pynndescent_.py:1451-1611) ----
- * Standard diversify method at diversify_prob = 1.  Host arrays in / out: like the reference, the conversions
- * between these kernels (COO->CSR, transpose, maximum, binarise) are scipy calls on the host. */
-/* diversify (pynndescent_.py:369-403): (n,k) rows ascending in alt space; pruned slots -> (-1, +inf) */
-int32_t nnd_diversify_host(nnd_handle_t h, int32_t *idx, float *dist);
-/* diversify_csr (pynndescent_.py:549-588) on CSR rows of <= 64 entries; pruned entries get weight 0 */
-int32_t nnd_diversify_csr_host(nnd_handle_t h, const int32_t *indptr, const int32_t *indices, float *data, int64_t nnz);
+ * Host arrays in / out: like the reference, the conversions between these kernels (COO->CSR, transpose, maximum,
+ * binarise) are scipy calls on the host. */
+typedef struct nnd_prune_opts {
+    float prune_probability; /* diversify_prob: an eligible edge is pruned with this probability (pynndescent_.py:388, 582) */
+    int32_t degree_aware;    /* 0: diversify / diversify_csr; 1: diversify_degree_aware / diversify_csr_degree_aware */
+    int32_t max_degree;      /* degree-aware: the degree above which the threshold is relaxed (pynndescent_.py:1478, 1567) */
+    float aggressiveness;    /* degree-aware: degree_prune_aggressiveness */
+    float alpha;             /* degree-aware forward pass only (pynndescent_.py:435, 528) */
+    uint32_t seed;           /* coin hash seed (the reference draws from NNDescent.rng_state) */
+    int32_t reserved[2];
+} nnd_prune_opts;
+/* diversify (pynndescent_.py:369-403) / diversify_degree_aware (433-546): (n,k) rows ascending in alt space; pruned
+ * slots -> (-1, +inf).  opts NULL = the reference defaults (standard method, probability 1).  degree: host int32 (n)
+ * undirected degrees (compute_degrees, pynndescent_.py:406-418), required when opts->degree_aware. */
+int32_t nnd_diversify_host(nnd_handle_t h, int32_t *idx, float *dist, const nnd_prune_opts *opts, const int32_t *degree);
+/* diversify_csr (pynndescent_.py:549-588) / diversify_csr_degree_aware (625-726) on CSR rows of <= 64 entries; pruned
+ * entries get weight 0.  degree: host int32 (n) (compute_degrees_csr, pynndescent_.py:591-622) when degree_aware. */
+int32_t nnd_diversify_csr_host(nnd_handle_t h, const int32_t *indptr, const int32_t *indices, float *data, int64_t nnz,
+                               const nnd_prune_opts *opts, const int32_t *degree);
 /* degree_prune_internal (pynndescent_.py:728-738): rows longer than max_degree keep entries <= sorted(row)[max_degree] */
 int32_t nnd_degree_prune_host(nnd_handle_t h, const int32_t *indptr, float *data, int64_t nnz, int32_t max_degree);
 

@@ -113,6 +113,12 @@ def load(kind="strict"):
     lib.orc_diversify.argtypes = [_i32p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_int]
     lib.orc_diversify_csr.argtypes = [_i32p, _i32p, _f32p, C.c_int64, _f32p, C.c_int, C.c_int]
     lib.orc_degree_prune.argtypes = [_i32p, _f32p, C.c_int64, C.c_int]
+    lib.orc_diversify_p.argtypes = [_i32p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_int, _i64p, C.c_float]
+    lib.orc_diversify_degree_aware.argtypes = [_i32p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, C.c_int, C.c_int,
+                                               C.c_float, C.c_float]
+    lib.orc_diversify_csr_p.argtypes = [_i32p, _i32p, _f32p, C.c_int64, _f32p, C.c_int, C.c_int, _i64p, C.c_float]
+    lib.orc_diversify_csr_degree_aware.argtypes = [_i32p, _i32p, _f32p, C.c_int64, _f32p, C.c_int, C.c_int, _i64p, C.c_int,
+                                                   C.c_float, C.c_float]
     _LIBS[kind] = lib
     return lib
 
@@ -315,32 +321,56 @@ def diversify(indices, distances, data, metric, lib=None):
 
 
 def search_graph(data, indices, distances, metric, n_neighbors, pruning_degree_multiplier=1.5, lib=None,
-                 return_stages=False):
+                 return_stages=False, diversify_prob=1.0, diversify_method="standard", degree_prune_aggressiveness=1.0,
+                 rng_state=None):
     """The pruning pass of ``NNDescent._init_search_graph`` (pynndescent_.py:1451-1611) on an (indices,
     alt-space distances) neighbour graph: forward diversify -> CSR -> reverse diversify -> union by maximum ->
     no diagonal -> degree prune to round(multiplier * k) -> binarise.  Vertex reordering by the search tree
-    (pynndescent_.py:1629-1651) is NOT applied.  Returns a scipy CSR uint8 matrix."""
+    (pynndescent_.py:1629-1651) is NOT applied.  Returns a scipy CSR uint8 matrix.
+
+    ``diversify_method`` 'standard' | 'degree_aware', ``diversify_prob`` and ``degree_prune_aggressiveness`` as in the
+    reference constructor; ``rng_state`` (int64[3], advanced in place) feeds the coins when ``diversify_prob < 1``."""
     import scipy.sparse as sp
 
     lib = lib or load()
     x = np.ascontiguousarray(data, np.float32)
     n = x.shape[0]
-    rows, dd = diversify(indices, distances, x, metric, lib)
+    aware = diversify_method == "degree_aware"
+    st = np.array([1, 2, 3], np.int64) if rng_state is None else rng_state
+    if aware:  # pynndescent_.py:1476-1498 (diversify_prob is handed to `alpha`)
+        rows = np.ascontiguousarray(indices, np.int32).copy()
+        dd = np.ascontiguousarray(distances, np.float32).copy()
+        lib.orc_diversify_degree_aware(rows, dd, n, rows.shape[1], x, x.shape[1], METRICS[metric],
+                                       max(1, int(pruning_degree_multiplier * n_neighbors)),
+                                       float(degree_prune_aggressiveness), float(diversify_prob))
+    elif diversify_prob < 1.0:
+        rows = np.ascontiguousarray(indices, np.int32).copy()
+        dd = np.ascontiguousarray(distances, np.float32).copy()
+        lib.orc_diversify_p(rows, dd, n, rows.shape[1], x, x.shape[1], METRICS[metric], st, float(diversify_prob))
+    else:
+        rows, dd = diversify(indices, distances, x, metric, lib)
     dd = dd.copy()
-    dd[dd == 0.0] = FLOAT32_EPS  # pynndescent_.py:1517
-    # COO -> CSR as scipy builds it (pynndescent_.py:1520-1527): entries stay in row order, i.e. ascending
+    dd[dd == 0.0] = FLOAT32_EPS  # pynndescent_.py:1525
+    # COO -> CSR as scipy builds it (pynndescent_.py:1527-1537): entries stay in row order, i.e. ascending
     # distance, -1 slots dropped; the forward graph is NOT index-sorted at this point
     keep = rows >= 0
     indptr = np.concatenate([[0], np.cumsum(keep.sum(1))]).astype(np.int32)
-    fwd = sp.csr_array((dd[keep].astype(np.float32), rows[keep].astype(np.int32), indptr), shape=(n, n))
-    # "Reverse graph" (pynndescent_.py:1541-1577): scipy's transpose of a CSR matrix is a CSC matrix over the SAME
-    # (indptr, indices, data) arrays, so what the reference hands to diversify_csr are the forward rows again;
-    # the pruned weights are then read as the transposed matrix.
-    rdata = np.ascontiguousarray(fwd.data, np.float32).copy()
-    lib.orc_diversify_csr(np.ascontiguousarray(fwd.indptr, np.int32), np.ascontiguousarray(fwd.indices, np.int32),
-                          rdata, n, x, x.shape[1], METRICS[metric])
-    rev = sp.csr_array((rdata, fwd.indices.copy(), fwd.indptr.copy()), shape=(n, n)).transpose().tocsr()
-    rev.eliminate_zeros()
+    f_indices = np.ascontiguousarray(rows[keep], np.int32)
+    # "Reverse graph" (pynndescent_.py:1549-1588): scipy's transpose of a CSR matrix is a CSC matrix over the SAME
+    # (indptr, indices, data) arrays, so what the reference hands to diversify_csr are the forward rows again; and
+    # because the arrays are shared, reverse_graph.eliminate_zeros() (in place) removes the pruned edges from the
+    # FORWARD matrix too.  The union below is therefore max(F', F'^T) of the doubly pruned F'.
+    rdata = np.ascontiguousarray(dd[keep], np.float32).copy()
+    if aware:
+        lib.orc_diversify_csr_degree_aware(indptr, f_indices, rdata, n, x, x.shape[1], METRICS[metric], st,
+                                           int(n_neighbors), float(degree_prune_aggressiveness), float(diversify_prob))
+    elif diversify_prob < 1.0:
+        lib.orc_diversify_csr_p(indptr, f_indices, rdata, n, x, x.shape[1], METRICS[metric], st, float(diversify_prob))
+    else:
+        lib.orc_diversify_csr(indptr, f_indices, rdata, n, x, x.shape[1], METRICS[metric])
+    fwd = sp.csr_array((rdata, f_indices, indptr), shape=(n, n))
+    fwd.eliminate_zeros()
+    rev = fwd.transpose().tocsr()
     rev.sort_indices()
     fwd.sort_indices()
     u = fwd.maximum(rev).tocsr()

@@ -56,6 +56,8 @@ class NNDStats(C.Structure):
         ("ms_sample", C.c_float * 64),
         ("ms_join", C.c_float * 64),
         ("ms_merge", C.c_float * 64),
+        ("join_mfma", C.c_int64 * 64),
+        ("leaf_mfma", C.c_int64),
     ]
 
     def as_dict(self):
@@ -63,15 +65,27 @@ class NNDStats(C.Structure):
         m = min(it, 64)
         out = {
             "n_iters_run": it, "n_leaves": int(self.n_leaves), "tree_levels": int(self.tree_levels),
-            "leaf_pairs": int(self.leaf_pairs), "leaf_rows": int(self.leaf_rows),
+            "leaf_pairs": int(self.leaf_pairs), "leaf_rows": int(self.leaf_rows), "leaf_mfma": int(self.leaf_mfma),
         }
-        for name in ("join_pairs", "join_rows", "join_active", "proposals", "updates"):
+        for name in ("join_pairs", "join_rows", "join_active", "proposals", "updates", "join_mfma"):
             out[name] = [int(v) for v in getattr(self, name)[:m]]
         for name in ("ms_prep", "ms_forest", "ms_leaf_init", "ms_random_init", "ms_descent", "ms_finalize"):
             out[name] = float(getattr(self, name))
         for name in ("ms_sample", "ms_join", "ms_merge"):
             out[name] = [float(v) for v in getattr(self, name)[:m]]
         return out
+
+
+class NNDPruneOpts(C.Structure):
+    _fields_ = [
+        ("prune_probability", C.c_float),
+        ("degree_aware", C.c_int32),
+        ("max_degree", C.c_int32),
+        ("aggressiveness", C.c_float),
+        ("alpha", C.c_float),
+        ("seed", C.c_uint32),
+        ("reserved", C.c_int32 * 2),
+    ]
 
 
 # every symbol include/pynnd_amd.h declares: (name, restype, argtypes)
@@ -118,8 +132,9 @@ _SIGNATURES = [
     ("nnd_export_proposals", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nnd_import_proposals", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
     ("nnd_descent_merge", C.c_int32, [_H, C.POINTER(C.c_int64)]),
-    ("nnd_diversify_host", C.c_int32, [_H, C.c_void_p, C.c_void_p]),
-    ("nnd_diversify_csr_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    ("nnd_diversify_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.POINTER(NNDPruneOpts), C.c_void_p]),
+    ("nnd_diversify_csr_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(NNDPruneOpts),
+                                           C.c_void_p]),
     ("nnd_degree_prune_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
@@ -325,19 +340,32 @@ class Builder:
         return c.value
 
     # -- search-graph pruning pass (numpy arrays in / out, like the reference's numba kernels)
-    def diversify(self, idx, dist):
+    @staticmethod
+    def _prune_opts(prune_probability=1.0, degree_aware=False, max_degree=1, aggressiveness=1.0, alpha=1.0, seed=0):
+        o = NNDPruneOpts()
+        o.prune_probability, o.degree_aware, o.max_degree = float(prune_probability), int(bool(degree_aware)), int(max_degree)
+        o.aggressiveness, o.alpha, o.seed = float(aggressiveness), float(alpha), int(seed) & 0xFFFFFFFF
+        return o
+
+    def diversify(self, idx, dist, degree=None, **opts):
+        """diversify / diversify_degree_aware; opts: prune_probability, degree_aware, max_degree, aggressiveness, alpha, seed."""
         idx = np.ascontiguousarray(idx, np.int32).copy()
         dist = np.ascontiguousarray(dist, np.float32).copy()
         assert idx.shape == (self.n, self.k) and dist.shape == idx.shape
-        self._check(self.lib.nnd_diversify_host(self._h, _ptr(idx), _ptr(dist)))
+        o = self._prune_opts(**opts)
+        degree = None if degree is None else np.ascontiguousarray(degree, np.int32)
+        self._check(self.lib.nnd_diversify_host(self._h, _ptr(idx), _ptr(dist), C.byref(o), _ptr(degree)))
         return idx, dist
 
-    def diversify_csr(self, indptr, indices, data):
+    def diversify_csr(self, indptr, indices, data, degree=None, **opts):
         indptr = np.ascontiguousarray(indptr, np.int32)
         indices = np.ascontiguousarray(indices, np.int32)
         data = np.ascontiguousarray(data, np.float32).copy()
         assert indptr.shape[0] == self.n + 1
-        self._check(self.lib.nnd_diversify_csr_host(self._h, _ptr(indptr), _ptr(indices), _ptr(data), data.shape[0]))
+        o = self._prune_opts(**opts)
+        degree = None if degree is None else np.ascontiguousarray(degree, np.int32)
+        self._check(self.lib.nnd_diversify_csr_host(self._h, _ptr(indptr), _ptr(indices), _ptr(data), data.shape[0],
+                                                    C.byref(o), _ptr(degree)))
         return data
 
     def degree_prune(self, indptr, data, max_degree):

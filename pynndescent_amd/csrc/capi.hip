@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "common.h"
 #include "state.h"
@@ -35,6 +36,26 @@ static int dalloc(nnd_ctx *ctx, T **p, size_t count) {
     return 0;
 }
 
+// Temporary device buffers of one API call: released on every return path.
+struct nnd_scratch {
+    std::vector<void *> ptrs;
+    ~nnd_scratch() {
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    T *get(nnd_ctx *ctx, size_t count) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, sizeof(T) * (count ? count : 1));
+        if (e != hipSuccess) {
+            ctx->set_error("hipMalloc of %zu scratch bytes failed: %s", sizeof(T) * count, hipGetErrorString(e));
+            return nullptr;
+        }
+        ptrs.push_back(p);
+        return (T *)p;
+    }
+};
+
 static void free_all(nnd_ctx *ctx) {
     auto F = [](void *p) {
         if (p) (void)hipFree(p);
@@ -65,6 +86,10 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
     if (p->max_candidates < 1 || p->max_candidates > 64) { gerr("nnd_create: max_candidates must be in 1..64 (got %d)", p->max_candidates); return 1; }
     if (p->n_trees < 0 || p->leaf_size < 1) { gerr("nnd_create: bad n_trees/leaf_size"); return 1; }
     if (p->n >= (int64_t)0x7FFFFFF0) { gerr("nnd_create: n too large for int32 ids"); return 1; }
+    if (p->n_trees > 0 && (int64_t)p->n_trees * p->n >= (int64_t)0x7FFFFFF0) {
+        gerr("nnd_create: n_trees * n = %lld exceeds the forest's int32 position space (2^31)", (long long)((int64_t)p->n_trees * p->n));
+        return 1;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { gerr("nnd_create: no HIP device visible (this library has no CPU path)"); return 1; }
     if (p->device < 0 || p->device >= ndev) { gerr("nnd_create: device %d out of range (%d visible)", p->device, ndev); return 1; }
@@ -84,7 +109,9 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
     ctx->ks = (p->n_neighbors + 15) & ~15;
     ctx->mc = p->max_candidates;
     ctx->mcp = p->max_candidates <= 16 ? 16 : (p->max_candidates <= 32 ? 32 : 64);
-    ctx->rcap = 32;
+    // reverse-offer slots per (vertex, class): at least max_candidates rounded up to a power of two, so that a vertex
+    // can fill its list from reverse offers alone, as the reference's max_candidates-deep heaps can (utils.py:277-306)
+    ctx->rcap = p->max_candidates <= 32 ? 32 : 64;
     ctx->pcap = 64;  // one candidate per lane in k_merge (merge.h NCHUNK = 1)
     if (ctx->p.join_blocks < 1) ctx->p.join_blocks = 1;
     ctx->seed = nnd_mix32((uint32_t)p->rng_state[0] ^ nnd_mix32((uint32_t)p->rng_state[1] + 0x9E3779B9u) ^
@@ -94,9 +121,8 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
     int rc = 0;
     do {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { ctx->set_error("hipStreamCreate failed"); rc = 1; break; }
-        (void)hipEventCreate(&ctx->ev0);
-        (void)hipEventCreate(&ctx->ev1);
-        (void)hipEventCreateWithFlags(&ctx->ev_spin, hipEventDisableTiming);
+        if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_spin, hipEventDisableTiming) != hipSuccess) { ctx->set_error("hipEventCreate failed"); rc = 1; break; }
         const size_t n = (size_t)ctx->n;
         if ((rc = dalloc(ctx, &ctx->xp, n * ctx->dp))) break;
         if ((rc = dalloc(ctx, &ctx->nrm, n))) break;
@@ -169,7 +195,7 @@ static int t_begin(nnd_ctx *ctx) {
     const int idx = ctx->tev_used;
     while ((int)ctx->tev.size() < idx + 2) {
         hipEvent_t e = nullptr;
-        (void)hipEventCreate(&e);
+        if (hipEventCreate(&e) != hipSuccess) return -1;  // callers skip the timer
         ctx->tev.push_back(e);
     }
     (void)hipEventRecord(ctx->tev[idx], ctx->stream);
@@ -177,6 +203,7 @@ static int t_begin(nnd_ctx *ctx) {
     return idx;
 }
 static void t_end(nnd_ctx *ctx, int idx, float *dst, bool add) {
+    if (idx < 0) return;
     (void)hipEventRecord(ctx->tev[idx + 1], ctx->stream);
     ctx->tlog.push_back({idx, dst, add});
 }
@@ -256,12 +283,12 @@ extern "C" int32_t nnd_get_leaf_array(nnd_handle_t ctx, int32_t *out_host) {
         return 0;
     }
     size_t total = (size_t)ctx->n_leaves * ctx->max_leaf;
-    int32_t *d = nullptr;
-    API_HIP(hipMalloc((void **)&d, sizeof(int32_t) * (total ? total : 1)));
-    if (nnd_launch_leaf_array(ctx, d)) { (void)hipFree(d); return 1; }
+    nnd_scratch tmp;
+    int32_t *d = tmp.get<int32_t>(ctx, total);
+    if (!d) return 1;
+    if (nnd_launch_leaf_array(ctx, d)) return 1;
     API_HIP(hipMemcpyAsync(out_host, d, sizeof(int32_t) * total, hipMemcpyDeviceToHost, ctx->stream));
     API_HIP(nnd_sync_spin(ctx));
-    API_HIP(hipFree(d));
     return 0;
 }
 
@@ -295,18 +322,14 @@ extern "C" int32_t nnd_init_from_graph(nnd_handle_t ctx, const int32_t *init_idx
     if (need_data(ctx)) return 1;
     if (!init_idx || width < 1) { ctx->set_error("nnd_init_from_graph: bad arguments"); return 1; }
     size_t cnt = (size_t)ctx->n * width;
-    int32_t *di = nullptr;
-    float *dd = nullptr;
-    API_HIP(hipMalloc((void **)&di, sizeof(int32_t) * cnt));
+    nnd_scratch tmp;
+    int32_t *di = tmp.get<int32_t>(ctx, cnt);
+    float *dd = init_dist ? tmp.get<float>(ctx, cnt) : nullptr;
+    if (!di || (init_dist && !dd)) return 1;
     API_HIP(hipMemcpyAsync(di, init_idx, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, ctx->stream));
-    if (init_dist) {
-        API_HIP(hipMalloc((void **)&dd, sizeof(float) * cnt));
-        API_HIP(hipMemcpyAsync(dd, init_dist, sizeof(float) * cnt, hipMemcpyHostToDevice, ctx->stream));
-    }
+    if (init_dist) API_HIP(hipMemcpyAsync(dd, init_dist, sizeof(float) * cnt, hipMemcpyHostToDevice, ctx->stream));
     int rc = nnd_launch_init_from_graph(ctx, di, dd, width);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(di);
-    if (dd) (void)hipFree(dd);
+    (void)hipStreamSynchronize(ctx->stream);  // the scratch buffers are released on return
     return rc;
 }
 
@@ -359,6 +382,7 @@ static int descent_iter(nnd_ctx *ctx, int64_t *c_out, bool timed) {
         ctx->stats.join_active[it] = ctx->h_counters[CNT_ACTIVE];
         ctx->stats.proposals[it] = ctx->h_counters[CNT_PROPOSALS];
         ctx->stats.updates[it] = ctx->h_counters[CNT_ACCEPT];
+        ctx->stats.join_mfma[it] = ctx->h_counters[CNT_MFMA];
     }
     *c_out = ctx->h_counters[CNT_ACCEPT];
     ctx->iter++;
@@ -414,19 +438,15 @@ extern "C" int32_t nnd_finalize_host(nnd_handle_t ctx, int32_t *out_idx, float *
     ENTER(ctx);
     if (need_data(ctx)) return 1;
     size_t cnt = (size_t)(ctx->own_hi - ctx->own_lo) * ctx->k;  // owned rows only
-    int32_t *di = nullptr;
-    float *dd = nullptr;
-    API_HIP(hipMalloc((void **)&di, sizeof(int32_t) * cnt));
-    API_HIP(hipMalloc((void **)&dd, sizeof(float) * cnt));
-    int rc = nnd_finalize_device(ctx, di, dd);
-    if (!rc) {
-        API_HIP(hipMemcpyAsync(out_idx, di, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(hipMemcpyAsync(out_dist, dd, sizeof(float) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(nnd_sync_spin(ctx));
-    }
-    (void)hipFree(di);
-    (void)hipFree(dd);
-    return rc;
+    nnd_scratch tmp;
+    int32_t *di = tmp.get<int32_t>(ctx, cnt);
+    float *dd = tmp.get<float>(ctx, cnt);
+    if (!di || !dd) return 1;
+    if (nnd_finalize_device(ctx, di, dd)) return 1;
+    API_HIP(hipMemcpyAsync(out_idx, di, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(hipMemcpyAsync(out_dist, dd, sizeof(float) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
+    return 0;
 }
 
 // nn_descent (pynndescent_.py:323-366) on a resident point set: EMPTY_GRAPH branch
@@ -547,22 +567,16 @@ extern "C" int32_t nnd_pairwise_gram(nnd_handle_t ctx, const int32_t *rows_a, in
                                      int32_t nb, float *out) {
     ENTER(ctx);
     if (need_data(ctx)) return 1;
-    int32_t *da = nullptr, *db = nullptr;
-    float *dout = nullptr;
-    API_HIP(hipMalloc((void **)&da, sizeof(int32_t) * na));
-    API_HIP(hipMalloc((void **)&db, sizeof(int32_t) * nb));
-    API_HIP(hipMalloc((void **)&dout, sizeof(float) * (size_t)na * nb));
+    nnd_scratch tmp;
+    int32_t *da = tmp.get<int32_t>(ctx, (size_t)na), *db = tmp.get<int32_t>(ctx, (size_t)nb);
+    float *dout = tmp.get<float>(ctx, (size_t)na * nb);
+    if (!da || !db || !dout) return 1;
     API_HIP(hipMemcpyAsync(da, rows_a, sizeof(int32_t) * na, hipMemcpyHostToDevice, ctx->stream));
     API_HIP(hipMemcpyAsync(db, rows_b, sizeof(int32_t) * nb, hipMemcpyHostToDevice, ctx->stream));
-    int rc = nnd_launch_pairwise(ctx, da, na, db, nb, dout);
-    if (!rc) {
-        API_HIP(hipMemcpyAsync(out, dout, sizeof(float) * (size_t)na * nb, hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(nnd_sync_spin(ctx));
-    }
-    (void)hipFree(da);
-    (void)hipFree(db);
-    (void)hipFree(dout);
-    return rc;
+    if (nnd_launch_pairwise(ctx, da, na, db, nb, dout)) return 1;
+    API_HIP(hipMemcpyAsync(out, dout, sizeof(float) * (size_t)na * nb, hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
+    return 0;
 }
 
 // ---- row-sharded multi-GPU build; host orchestration: pynndescent_amd/sharded.py ----
@@ -666,6 +680,7 @@ extern "C" int32_t nnd_descent_merge(nnd_handle_t ctx, int64_t *c_local) {
         ctx->stats.join_active[it] = ctx->h_counters[CNT_ACTIVE];
         ctx->stats.proposals[it] = ctx->h_counters[CNT_PROPOSALS];
         ctx->stats.updates[it] = ctx->h_counters[CNT_ACCEPT];
+        ctx->stats.join_mfma[it] = ctx->h_counters[CNT_MFMA];
     }
     if (c_local) *c_local = ctx->h_counters[CNT_ACCEPT];
     ctx->iter++;
@@ -676,71 +691,77 @@ extern "C" int32_t nnd_descent_merge(nnd_handle_t ctx, int64_t *c_local) {
 // ---- search-graph pruning pass (BASELINE config 5); host glue: pynndescent_amd/search_graph.py ----
 // Host-buffer entry points: the graph of this stage is handed over and taken back as numpy arrays by the
 // reference as well (its glue between the numba kernels is scipy on the host, pynndescent_.py:1509-1611).
-extern "C" int32_t nnd_diversify_host(nnd_handle_t ctx, int32_t *idx /* (n,k) in/out */, float *dist /* (n,k) in/out */) {
+static nnd_prune_opts prune_defaults(const nnd_prune_opts *o) {
+    nnd_prune_opts d{};
+    d.prune_probability = 1.0f;
+    d.alpha = 1.0f;
+    d.max_degree = 1;
+    return o ? *o : d;
+}
+
+extern "C" int32_t nnd_diversify_host(nnd_handle_t ctx, int32_t *idx /* (n,k) in/out */, float *dist /* (n,k) in/out */,
+                                      const nnd_prune_opts *opts, const int32_t *degree /* (n), degree-aware only */) {
     ENTER(ctx);
     if (need_data(ctx)) return 1;
+    const nnd_prune_opts o = prune_defaults(opts);
+    if (o.degree_aware && (!degree || o.max_degree < 1)) { ctx->set_error("nnd_diversify_host: the degree-aware method needs degrees and max_degree >= 1"); return 1; }
     size_t cnt = (size_t)ctx->n * ctx->k;
-    int32_t *di = nullptr;
-    float *dd = nullptr;
-    API_HIP(hipMalloc((void **)&di, sizeof(int32_t) * cnt));
-    API_HIP(hipMalloc((void **)&dd, sizeof(float) * cnt));
+    nnd_scratch tmp;
+    int32_t *di = tmp.get<int32_t>(ctx, cnt);
+    float *dd = tmp.get<float>(ctx, cnt);
+    int32_t *dg = o.degree_aware ? tmp.get<int32_t>(ctx, (size_t)ctx->n) : nullptr;
+    if (!di || !dd || (o.degree_aware && !dg)) return 1;
     API_HIP(hipMemcpyAsync(di, idx, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, ctx->stream));
     API_HIP(hipMemcpyAsync(dd, dist, sizeof(float) * cnt, hipMemcpyHostToDevice, ctx->stream));
-    int rc = nnd_launch_diversify_rows(ctx, di, dd);
-    if (!rc) {
-        API_HIP(hipMemcpyAsync(idx, di, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(hipMemcpyAsync(dist, dd, sizeof(float) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(nnd_sync_spin(ctx));
-    }
-    (void)hipFree(di);
-    (void)hipFree(dd);
-    return rc;
+    if (dg) API_HIP(hipMemcpyAsync(dg, degree, sizeof(int32_t) * (size_t)ctx->n, hipMemcpyHostToDevice, ctx->stream));
+    if (nnd_launch_diversify_rows(ctx, di, dd, &o, dg)) return 1;
+    API_HIP(hipMemcpyAsync(idx, di, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(hipMemcpyAsync(dist, dd, sizeof(float) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
+    return 0;
 }
 
 extern "C" int32_t nnd_diversify_csr_host(nnd_handle_t ctx, const int32_t *indptr /* n+1 */, const int32_t *indices,
-                                          float *data /* nnz in/out */, int64_t nnz) {
+                                          float *data /* nnz in/out */, int64_t nnz, const nnd_prune_opts *opts,
+                                          const int32_t *degree /* (n), degree-aware only */) {
     ENTER(ctx);
     if (need_data(ctx)) return 1;
-    int32_t *dp = nullptr, *di = nullptr;
-    float *dd = nullptr;
-    int *flag = nullptr;
-    API_HIP(hipMalloc((void **)&dp, sizeof(int32_t) * (size_t)(ctx->n + 1)));
-    API_HIP(hipMalloc((void **)&di, sizeof(int32_t) * (size_t)(nnz ? nnz : 1)));
-    API_HIP(hipMalloc((void **)&dd, sizeof(float) * (size_t)(nnz ? nnz : 1)));
-    API_HIP(hipMalloc((void **)&flag, sizeof(int)));
+    const nnd_prune_opts o = prune_defaults(opts);
+    if (o.degree_aware && !degree) { ctx->set_error("nnd_diversify_csr_host: the degree-aware method needs degrees"); return 1; }
+    nnd_scratch tmp;
+    int32_t *dp = tmp.get<int32_t>(ctx, (size_t)(ctx->n + 1)), *di = tmp.get<int32_t>(ctx, (size_t)nnz);
+    float *dd = tmp.get<float>(ctx, (size_t)nnz);
+    int *flag = tmp.get<int>(ctx, 1);
+    int32_t *dg = o.degree_aware ? tmp.get<int32_t>(ctx, (size_t)ctx->n) : nullptr;
+    if (!dp || !di || !dd || !flag || (o.degree_aware && !dg)) return 1;
     API_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
     API_HIP(hipMemcpyAsync(dp, indptr, sizeof(int32_t) * (size_t)(ctx->n + 1), hipMemcpyHostToDevice, ctx->stream));
     API_HIP(hipMemcpyAsync(di, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
     API_HIP(hipMemcpyAsync(dd, data, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
-    int rc = nnd_launch_diversify_csr(ctx, dp, di, dd, flag);
+    if (dg) API_HIP(hipMemcpyAsync(dg, degree, sizeof(int32_t) * (size_t)ctx->n, hipMemcpyHostToDevice, ctx->stream));
+    if (nnd_launch_diversify_csr(ctx, dp, di, dd, flag, &o, dg)) return 1;
     int too_long = 0;
-    if (!rc) {
-        API_HIP(hipMemcpyAsync(data, dd, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(hipMemcpyAsync(&too_long, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(nnd_sync_spin(ctx));
-    }
-    (void)hipFree(dp); (void)hipFree(di); (void)hipFree(dd); (void)hipFree(flag);
-    if (!rc && too_long) {
+    API_HIP(hipMemcpyAsync(data, dd, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(hipMemcpyAsync(&too_long, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
+    if (too_long) {
         ctx->set_error("nnd_diversify_csr_host: %d rows are longer than 64 entries (rows of a diversified k-NN graph have <= k <= 64)", too_long);
         return 1;
     }
-    return rc;
+    return 0;
 }
 
 extern "C" int32_t nnd_degree_prune_host(nnd_handle_t ctx, const int32_t *indptr /* n+1 */, float *data /* nnz in/out */,
                                          int64_t nnz, int32_t max_degree) {
     ENTER(ctx);
-    int32_t *dp = nullptr;
-    float *dd = nullptr;
-    API_HIP(hipMalloc((void **)&dp, sizeof(int32_t) * (size_t)(ctx->n + 1)));
-    API_HIP(hipMalloc((void **)&dd, sizeof(float) * (size_t)(nnz ? nnz : 1)));
+    nnd_scratch tmp;
+    int32_t *dp = tmp.get<int32_t>(ctx, (size_t)(ctx->n + 1));
+    float *dd = tmp.get<float>(ctx, (size_t)nnz);
+    if (!dp || !dd) return 1;
     API_HIP(hipMemcpyAsync(dp, indptr, sizeof(int32_t) * (size_t)(ctx->n + 1), hipMemcpyHostToDevice, ctx->stream));
     API_HIP(hipMemcpyAsync(dd, data, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
-    int rc = nnd_launch_degree_prune(ctx, dp, dd, max_degree);
-    if (!rc) {
-        API_HIP(hipMemcpyAsync(data, dd, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
-        API_HIP(nnd_sync_spin(ctx));
-    }
-    (void)hipFree(dp); (void)hipFree(dd);
-    return rc;
+    if (nnd_launch_degree_prune(ctx, dp, dd, max_degree)) return 1;
+    API_HIP(hipMemcpyAsync(data, dd, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+    API_HIP(nnd_sync_spin(ctx));
+    return 0;
 }

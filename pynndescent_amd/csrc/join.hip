@@ -69,15 +69,17 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
     constexpr int RPK = 64 / KQ;              // rows per neighbour-list load
     constexpr int kls = KS16 * 16 + 4;        // padded neighbour-list row stride (words)
     constexpr int QCAP = 8 * 64;              // pair queue: 8 (tile, row) combinations x 64 lanes
-    constexpr int WAVE_BYTES = QCAP * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;
+    constexpr int WAVE_BYTES = QCAP * 8 + 2 * RV * 4 + 4 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;
+    // klist rows are read / written as 16-byte vectors: everything in front of them is a multiple of 16 bytes
+    static_assert((QCAP * 8 + 2 * RV * 4 + 4 * 4 + 5 * RV * 4) % 16 == 0 && (kls * 4) % 16 == 0, "klist must be 16-byte aligned");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
     unsigned char *mine = smem + (size_t)w * ((WAVE_BYTES + 15) & ~15);
     uint2 *queue = (uint2 *)mine;                       // QCAP
     int32_t *cidbuf = (int32_t *)(queue + QCAP);        // 2 * RV
-    int32_t *nnewbuf = cidbuf + 2 * RV;                 // 2
-    int32_t *cid = nnewbuf + 2;                         // RV
+    int32_t *nnewbuf = cidbuf + 2 * RV;                 // 2 used, padded to 4 (16 bytes)
+    int32_t *cid = nnewbuf + 4;                         // RV
     float *cnrm = (float *)(cid + RV);                  // RV
     float *cth = cnrm + RV;                             // RV
     uint32_t *cslot = (uint32_t *)(cth + RV);           // RV: proposal slot of each candidate id (hashed once per vertex)
@@ -182,11 +184,12 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
     nnd_wave_lds_sync();
     issue_gather(0);
 
-    int tot_pairs = 0, tot_prop = 0, tot_rows = 0, tot_act = 0;
+    int tot_pairs = 0, tot_prop = 0, tot_rows = 0, tot_act = 0, tot_tiles = 0;
     for (int it = 0; g < n_v; g += stride, it++) {
         const int cur = it & 1;
         const int my_cnt = nnewbuf[cur], my_new = my_cnt & 255;
         const bool has_old = (my_cnt >> 8) > 0;
+        if (my_new > 0) tot_tiles += has_old ? 2 : 1;  // 16x16 Gram tiles of this vertex (wave-uniform)
         const int c2 = load_cand(g + 2 * stride);
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         if (my_new > 0) {
@@ -302,12 +305,14 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
     __syncthreads();
     int *red = (int *)smem;  // every wave is done with its region
     if (lane == 0) {
-        red[w * 4 + 0] = tot_pairs; red[w * 4 + 1] = tot_prop; red[w * 4 + 2] = tot_rows; red[w * 4 + 3] = tot_act;
+        red[w * 5 + 0] = tot_pairs; red[w * 5 + 1] = tot_prop; red[w * 5 + 2] = tot_rows; red[w * 5 + 3] = tot_act;
+        red[w * 5 + 4] = tot_tiles;
     }
     __syncthreads();
-    if (tid < 4) {
-        const long long sum = (long long)red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
-        const int which = tid == 0 ? CNT_PAIRS : (tid == 1 ? CNT_PROPOSALS : (tid == 2 ? CNT_ROWS : CNT_ACTIVE));
+    if (tid < 5) {
+        long long sum = (long long)red[tid] + red[5 + tid] + red[10 + tid] + red[15 + tid];
+        if (tid == 4) sum *= (dp >> 2);  // tiles -> v_mfma_f32_16x16x4 instructions (4 k-values each)
+        const int which = tid == 0 ? CNT_PAIRS : (tid == 1 ? CNT_PROPOSALS : (tid == 2 ? CNT_ROWS : (tid == 3 ? CNT_ACTIVE : CNT_MFMA)));
         nnd_count(counters, which, sum);
     }
 }
@@ -315,10 +320,12 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
 template <int DC, int KS16>
 static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     constexpr int RV = 32, kls = KS16 * 16 + 4;
-    constexpr int WAVE_BYTES = 8 * 64 * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;
+    constexpr int WAVE_BYTES = 8 * 64 * 8 + 2 * RV * 4 + 4 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;  // = the kernel's
     size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
     auto kern = k_local_join16<DC, KS16>;
-    static int wg_per_cu = 0, n_cu = 0;
+    // function attributes and occupancy are per DEVICE: cached per device ordinal, not per process
+    static int wg_per_cu_dev[64] = {0}, n_cu_dev[64] = {0};
+    int &wg_per_cu = wg_per_cu_dev[ctx->p.device & 63], &n_cu = n_cu_dev[ctx->p.device & 63];
     if (wg_per_cu == 0) {
         NND_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipDeviceProp_t prop;
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
         }
         return present;
     };
-    int tot_pairs = 0, tot_prop = 0, tot_rows = 0, tot_act = 0;
+    int tot_pairs = 0, tot_prop = 0, tot_rows = 0, tot_act = 0, tot_tiles = 0;
     int qn = 0;
     auto drain = [&]() __attribute__((always_inline)) {
         nnd_wave_lds_sync();
@@ -546,6 +553,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
 #pragma unroll
                     for (int b = a; b < NB; b++) {  // new x new from the diagonal tile up, then new x old
                         if (!tile_live(b, nn, no)) continue;
+                        if (c0 == 0) tot_tiles++;  // wave-uniform
 #pragma unroll
                         for (int j = 0; j < NT; j++) {
                             if (16 * j >= cw) continue;
@@ -620,12 +628,14 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
     __syncthreads();
     int *red = (int *)smem;  // every wave is done with its region
     if (lane == 0) {
-        red[w * 4 + 0] = tot_pairs; red[w * 4 + 1] = tot_prop; red[w * 4 + 2] = tot_rows; red[w * 4 + 3] = tot_act;
+        red[w * 5 + 0] = tot_pairs; red[w * 5 + 1] = tot_prop; red[w * 5 + 2] = tot_rows; red[w * 5 + 3] = tot_act;
+        red[w * 5 + 4] = tot_tiles;
     }
     __syncthreads();
-    if (tid < 4) {
-        const long long sum = (long long)red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
-        const int which = tid == 0 ? CNT_PAIRS : (tid == 1 ? CNT_PROPOSALS : (tid == 2 ? CNT_ROWS : CNT_ACTIVE));
+    if (tid < 5) {
+        long long sum = (long long)red[tid] + red[5 + tid] + red[10 + tid] + red[15 + tid];
+        if (tid == 4) sum *= (dp >> 2);  // tiles -> v_mfma_f32_16x16x4 instructions
+        const int which = tid == 0 ? CNT_PAIRS : (tid == 1 ? CNT_PROPOSALS : (tid == 2 ? CNT_ROWS : (tid == 3 ? CNT_ACTIVE : CNT_MFMA)));
         nnd_count(counters, which, sum);
     }
 }
@@ -636,7 +646,9 @@ static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     constexpr int WAVE_BYTES = 512 * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + 8;
     size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
     auto kern = k_local_join_w<MCP, DC>;
-    static int wg_per_cu = 0, n_cu = 0;
+    // function attributes and occupancy are per DEVICE: cached per device ordinal, not per process
+    static int wg_per_cu_dev[64] = {0}, n_cu_dev[64] = {0};
+    int &wg_per_cu = wg_per_cu_dev[ctx->p.device & 63], &n_cu = n_cu_dev[ctx->p.device & 63];
     if (wg_per_cu == 0) {
         NND_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipDeviceProp_t prop;

@@ -279,6 +279,8 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_
         nnd_count(counters, CNT_ACCEPT, a);
         nnd_count(counters, CNT_PAIRS, (long long)m * (m - 1) / 2);
         nnd_count(counters, CNT_ROWS, m);
+        // MFMA instructions: tiles computed (upper triangle when the whole block lives in LDS) x dp / 4 k-steps
+        nnd_count(counters, CNT_MFMA, (long long)(C::FULLD ? nt * (nt + 1) / 2 : nt * nt) * (dp >> 2));
     }
 }
 
@@ -357,5 +359,6 @@ int nnd_launch_leaf_init(nnd_ctx *ctx) {
     if (nnd_read_counters(ctx)) return 1;
     ctx->stats.leaf_pairs = ctx->h_counters[CNT_PAIRS];
     ctx->stats.leaf_rows = ctx->h_counters[CNT_ROWS];
+    ctx->stats.leaf_mfma = ctx->h_counters[CNT_MFMA];
     return 0;
 }

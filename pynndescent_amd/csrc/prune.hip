@@ -1,9 +1,14 @@
 // prune.hip -- search-graph pruning pass (BASELINE config 5: "+ graph diversification/prune pass").
 //
-// Replaces, for the standard diversify method at diversify_prob = 1 (the defaults):
-//   diversify             reference pynndescent_.py:369-403   -> k_diversify_rows
-//   diversify_csr         reference pynndescent_.py:549-588   -> k_diversify_csr
-//   degree_prune_internal reference pynndescent_.py:728-738   -> k_degree_prune
+// Replaces
+//   diversify                   reference pynndescent_.py:369-403   -> k_diversify_rows<false>
+//   diversify_degree_aware      reference pynndescent_.py:433-546   -> k_diversify_rows<true>
+//   diversify_csr               reference pynndescent_.py:549-588   -> k_diversify_csr<false>
+//   diversify_csr_degree_aware  reference pynndescent_.py:625-726   -> k_diversify_csr<true>
+//   degree_prune_internal       reference pynndescent_.py:728-738   -> k_degree_prune
+// prune_probability < 1 (diversify_prob): the reference draws tau_rand(rng_state) from ONE state shared by all
+// prange threads (a data race: its coin sequence depends on the thread schedule); here the coin of a test is the
+// counter hash of (seed, row, entry, compared entry) -- statistically the same Bernoulli(prune_probability).
 // The COO/CSR conversions, the transpose, the element-wise maximum and the binarisation between them are
 // scipy calls in the reference (pynndescent_.py:1509-1611) and stay host glue (pynndescent_amd/search_graph.py).
 //
@@ -31,20 +36,42 @@ __device__ __forceinline__ float prune_pair_dist(const float *__restrict__ xp, i
     return nnd_gram_to_dist(1, s, nrm[a], nrm[b]);
 }
 
-// pynndescent_.py:369-403.  rows: (n,k) ascending; pruned slots become (-1, +inf); kept entries stay in order.
+// u in [0,1): the coin of one pruning test (reference: tau_rand(rng_state) < prune_probability)
+__device__ __forceinline__ bool prune_coin(uint32_t seed, uint32_t row, uint32_t a, uint32_t b, float prob) {
+    if (prob >= 1.0f) return true;
+    const uint32_t h = nnd_hash3(seed, row, a * 64u + b);
+    return (float)(h >> 8) * (1.0f / 16777216.0f) < prob;
+}
+
+// pynndescent_.py:369-403 (AWARE = false) / 433-546 (AWARE = true).  rows: (n,k) ascending; pruned slots become
+// (-1, +inf); kept entries stay in order.  AWARE: an entry u whose undirected degree exceeds max_degree is pruned
+// against d(i,u) * threshold_factor * alpha (pynndescent_.py:506-531); there is no coin in that variant (the
+// reference call site hands diversify_prob to `alpha`, pynndescent_.py:1486-1497 -- the host passes it the same way).
+template <bool AWARE>
 __global__ __launch_bounds__(256) void k_diversify_rows(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
                                                         int metric, int64_t n, int k, int32_t *__restrict__ idx,
-                                                        float *__restrict__ dist) {
+                                                        float *__restrict__ dist, float prob, uint32_t seed,
+                                                        const int32_t *__restrict__ degree, int max_degree,
+                                                        float base_rate, float alpha) {
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + w;
     if (i >= n) return;
     const int32_t my_idx = lane < k ? idx[i * k + lane] : -1;
     const float my_d = lane < k ? dist[i * k + lane] : INFINITY;
+    float my_fac = 1.0f;
+    if (AWARE && my_idx >= 0) {  // pynndescent_.py:506-521
+        const float ratio = (float)degree[my_idx] / (float)max_degree;
+        if (ratio > 1.0f) {
+            const float excess = fminf(ratio - 1.0f, 2.0f);
+            my_fac = fmaxf(0.8f, fminf(1.2f, 1.0f + base_rate * excess));
+        }
+    }
     unsigned long long kept = 1ull;  // position 0 is always kept (pynndescent_.py:374-375)
     for (int j = 1; j < k; j++) {
         const int32_t idj = __builtin_amdgcn_readlane(my_idx, j);
         if (idj < 0) break;  // pynndescent_.py:377-378
         const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_d), j));
+        const float lim = AWARE ? dj * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_fac), j)) * alpha : dj;
         bool flag = true;
         unsigned long long m = kept;
         while (m) {
@@ -54,7 +81,7 @@ __global__ __launch_bounds__(256) void k_diversify_rows(const float *__restrict_
             if (dc > PRUNE_EPS) {
                 const int32_t idc = __builtin_amdgcn_readlane(my_idx, c);
                 const float d = prune_pair_dist(xp, dp, nrm, metric, idj, idc);
-                if (d < dj) {  // pynndescent_.py:386-389 (prune_probability = 1)
+                if (d < lim && (AWARE || prune_coin(seed, (uint32_t)i, (uint32_t)j, (uint32_t)c, prob))) {  // pynndescent_.py:386-389
                     flag = false;
                     break;
                 }
@@ -75,14 +102,20 @@ __global__ __launch_bounds__(256) void k_diversify_rows(const float *__restrict_
     }
 }
 
-// pynndescent_.py:549-588 on CSR rows of length <= 64 (rows of a diversified k-NN graph have <= k entries).
-// Entries are walked in ascending weight order (ties by position); NOTE the reference takes the comparison POINT
-// from storage position `k` (`current_indices[k]`, line 577) while it takes weight and retained-flag from the
-// weight order (`l = order[k]`); that is reproduced here.  Pruned entries get weight 0.
+// pynndescent_.py:549-588 (AWARE = false) / 625-726 (AWARE = true) on CSR rows of length <= 64 (rows of a diversified
+// k-NN graph have <= k entries).  Entries are walked in ascending weight order (ties by position).
+// AWARE = false: NOTE the reference takes the comparison POINT from storage position `k` (`current_indices[k]`,
+// line 577) while it takes weight and retained-flag from the weight order (`l = order[k]`); that is reproduced here.
+// AWARE = true (pynndescent_.py:682-719): the walk starts at the first entry, skips weight-0 entries, compares with
+// the point at order[k], has no FLOAT32_EPS guard, and prunes when d * threshold_factor(degree of entry j) < w_j.
+// Pruned entries get weight 0.
+template <bool AWARE>
 __global__ __launch_bounds__(256) void k_diversify_csr(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
                                                        int metric, int64_t n_rows, const int32_t *__restrict__ indptr,
                                                        const int32_t *__restrict__ indices, float *__restrict__ data,
-                                                       int *__restrict__ too_long) {
+                                                       int *__restrict__ too_long, float prob, uint32_t seed,
+                                                       const int32_t *__restrict__ degree, int max_degree,
+                                                       float aggressiveness) {
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + w;
     if (i >= n_rows) return;
@@ -94,6 +127,12 @@ __global__ __launch_bounds__(256) void k_diversify_csr(const float *__restrict__
     }
     const int32_t my_idx = lane < len ? indices[a + lane] : -1;
     const float my_w = lane < len ? data[a + lane] : INFINITY;
+    float my_fac = 1.0f;
+    if (AWARE && my_idx >= 0) {  // pynndescent_.py:700-709
+        const int tgt = (int64_t)my_idx < n_rows ? degree[my_idx] : 0;
+        const float ratio = (float)tgt / (float)(max_degree > 1 ? max_degree : 1);
+        my_fac = fmaxf(1.0f + 0.04f * aggressiveness * fminf(ratio - 1.0f, 2.0f), 1.0f);
+    }
     // rank of this entry in ascending weight order, ties by position (np.argsort order up to ties)
     int rank = 0;
     for (int t = 0; t < len; t++) {
@@ -101,18 +140,25 @@ __global__ __launch_bounds__(256) void k_diversify_csr(const float *__restrict__
         rank += (wt < my_w || (wt == my_w && t < lane)) ? 1 : 0;
     }
     unsigned long long retained = len == 64 ? ~0ull : ((1ull << len) - 1ull);  // bit per storage position
-    for (int idx = 1; idx < len; idx++) {
+    for (int idx = AWARE ? 0 : 1; idx < len; idx++) {
         const int j = __builtin_ctzll(__ballot(lane < len && rank == idx));  // order[idx]
         const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j));
+        if (AWARE && wj == 0.0f) continue;  // pynndescent_.py:685-686
         const int32_t idj = __builtin_amdgcn_readlane(my_idx, j);
+        const float fj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_fac), j));
         for (int kk = 0; kk < idx; kk++) {
             const int l = __builtin_ctzll(__ballot(lane < len && rank == kk));  // order[kk]
             if ((retained >> l) & 1ull) {
                 const float wl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), l));
-                if (wl > PRUNE_EPS) {
-                    const int32_t idk = __builtin_amdgcn_readlane(my_idx, kk);  // storage position kk (reference quirk)
-                    const float d = prune_pair_dist(xp, dp, nrm, metric, idj, idk);
-                    if (d < wj) {
+                if (AWARE || wl > PRUNE_EPS) {
+                    // AWARE: the point at order[kk]; standard: storage position kk (reference quirk)
+                    const int32_t idk = __builtin_amdgcn_readlane(my_idx, AWARE ? l : kk);
+                    // AWARE has no EPS guard: the row's own vertex (weight EPS) is a comparison point and d(x_i, x_j) is
+                    // compared with the stored d(i, j) = wj, the same quantity -- bitwise equal in the reference (same
+                    // function, same operands), so never pruned at factor >= 1.  Use the stored value, not a
+                    // recomputation that may differ by an ulp.
+                    const float d = (AWARE && wl <= PRUNE_EPS) ? wj : prune_pair_dist(xp, dp, nrm, metric, idj, idk);
+                    if ((AWARE ? d * fj : d) < wj && prune_coin(seed, (uint32_t)i, (uint32_t)j, (uint32_t)kk, prob)) {
                         retained &= ~(1ull << j);
                         break;
                     }
@@ -153,16 +199,30 @@ __global__ __launch_bounds__(256) void k_degree_prune(int64_t n_rows, const int3
         if (data[a + e] > cut) data[a + e] = 0.0f;
 }
 
-int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev) {
-    hipLaunchKernelGGL(k_diversify_rows, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm,
-                       ctx->p.metric, ctx->n, ctx->k, idx_dev, dist_dev);
+int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev, const nnd_prune_opts *o, const int32_t *degree_dev) {
+    const dim3 grid((unsigned)((ctx->n + 3) / 4));
+    if (o->degree_aware) {
+        const float base_rate = 0.04f * fmaxf(0.0f, o->aggressiveness);  // pynndescent_.py:487-488
+        hipLaunchKernelGGL(k_diversify_rows<true>, grid, dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric,
+                           ctx->n, ctx->k, idx_dev, dist_dev, 1.0f, o->seed, degree_dev, o->max_degree, base_rate, o->alpha);
+    } else {
+        hipLaunchKernelGGL(k_diversify_rows<false>, grid, dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric,
+                           ctx->n, ctx->k, idx_dev, dist_dev, o->prune_probability, o->seed, (const int32_t *)nullptr, 1, 0.0f, 1.0f);
+    }
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int nnd_launch_diversify_csr(nnd_ctx *ctx, const int32_t *indptr_dev, const int32_t *indices_dev, float *data_dev,
-                             int *too_long_dev) {
-    hipLaunchKernelGGL(k_diversify_csr, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm,
-                       ctx->p.metric, ctx->n, indptr_dev, indices_dev, data_dev, too_long_dev);
+                             int *too_long_dev, const nnd_prune_opts *o, const int32_t *degree_dev) {
+    const dim3 grid((unsigned)((ctx->n + 3) / 4));
+    if (o->degree_aware)
+        hipLaunchKernelGGL(k_diversify_csr<true>, grid, dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric,
+                           ctx->n, indptr_dev, indices_dev, data_dev, too_long_dev, o->prune_probability, o->seed ^ 0x51ED270Bu,
+                           degree_dev, o->max_degree, o->aggressiveness);
+    else
+        hipLaunchKernelGGL(k_diversify_csr<false>, grid, dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric,
+                           ctx->n, indptr_dev, indices_dev, data_dev, too_long_dev, o->prune_probability, o->seed ^ 0x51ED270Bu,
+                           (const int32_t *)nullptr, 1, 0.0f);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

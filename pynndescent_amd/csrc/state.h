@@ -20,7 +20,8 @@ enum {
     CNT_DEGENERATE,   // rp-forest: segments whose split left one side empty
     CNT_ACTIVE_SEGS,  // rp-forest: splittable segments for the next level
     CNT_LEAVES,
-    CNT_SCRATCH,
+    CNT_SCRATCH,      // + 1 .. + 3: forest scratch words
+    CNT_MFMA = 12,    // v_mfma_f32_16x16x4_f32 instructions issued (2048 flop each) by the join / leaf kernels
     CNT_COUNT = 16
 };
 // Hot kernels add to one of NND_CNT_STRIPES copies of the counter block (stripe = workgroup id), one
@@ -138,9 +139,10 @@ int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_
 int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
 int nnd_launch_refresh_th(nnd_ctx *ctx, int64_t lo, int64_t hi);
 int nnd_launch_clear_new_flags(nnd_ctx *ctx);
-int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev);
+int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev, const nnd_prune_opts *opts,
+                              const int32_t *degree_dev);
 int nnd_launch_diversify_csr(nnd_ctx *ctx, const int32_t *indptr_dev, const int32_t *indices_dev, float *data_dev,
-                             int *too_long_dev);
+                             int *too_long_dev, const nnd_prune_opts *opts, const int32_t *degree_dev);
 int nnd_launch_degree_prune(nnd_ctx *ctx, const int32_t *indptr_dev, float *data_dev, int max_degree);
 int nnd_read_counters(nnd_ctx *ctx);  // device -> ctx->h_counters (synchronises the stream)
 int nnd_zero_counters(nnd_ctx *ctx);

@@ -7,9 +7,11 @@ construction, same errors and warnings.  The dense euclidean / cosine branch
 the GPU through the C ABI of ``include/pynnd_amd.h``.  Nothing here computes neighbours on the CPU:
 if the HIP library or a gfx950 device is missing, construction raises.
 
-Out of scope (SURVEY.md section 8 "next"): ``prepare`` / ``query`` / ``update``, sparse input, and
-metrics other than euclidean / l2 / cosine.  Those raise ``NotImplementedError`` naming the
-reference entry point to use instead.
+Also on the GPU: ``update`` (warm start, pynndescent_.py:2381-2553), ``build_search_graph`` (the pruning
+pass of ``_init_search_graph``, all diversify methods), ``prepare`` (hub search tree + reordering) and
+``query``.  Out of scope: sparse input, metrics other than euclidean / l2 / cosine, ``n_neighbors`` or
+``max_candidates`` above 64.  Those raise ``NotImplementedError`` naming the reference entry point to use
+instead; ``pynndescent_amd.make_index`` hands such inputs to ``pynndescent.NNDescent`` when it is importable.
 """
 import time
 from warnings import warn
@@ -150,6 +152,7 @@ class NNDescent:
         except ImportError:  # pragma: no cover
             pass
 
+        _check_supported_sizes(n_neighbors, max_candidates, init_graph)
         data = check_array(data, dtype=np.float32, order="C")  # pynndescent_.py:1054
         self._input_dtype = np.float32
         self._raw_data = data
@@ -260,7 +263,9 @@ class NNDescent:
 
         self._search_graph = build_search_graph(
             self._raw_data, self._neighbor_graph[0], self._neighbor_graph[1], self.metric, self.n_neighbors,
-            self.prune_degree_multiplier, self.diversify_prob, self.diversify_method, device=self.device)
+            self.prune_degree_multiplier, self.diversify_prob, self.diversify_method,
+            degree_prune_aggressiveness=self.degree_prune_aggressiveness,
+            seed=int(self.rng_state[0]) & 0xFFFFFFFF, device=self.device)
         return self._search_graph
 
     # attributes of the reference class that prepare() / query() / update() read (pynndescent_.py:1014-1113)
@@ -308,6 +313,8 @@ class NNDescent:
             quantization=None, low_memory=True, delta=0.001, n_jobs=None, compressed=False,
             parallel_batch_queries=False, verbose=False, device=0,
         )
+        if "pruning_degree_multiplier" in kwargs:  # the constructor's name for prune_degree_multiplier
+            kwargs["prune_degree_multiplier"] = kwargs.pop("pruning_degree_multiplier")
         unknown = set(kwargs) - set(defaults)
         if unknown:
             raise TypeError("unexpected arguments: %s" % sorted(unknown))
@@ -320,6 +327,7 @@ class NNDescent:
         distances = np.ascontiguousarray(distances, np.float32)
         if indices.shape != distances.shape or indices.shape[0] != n:
             raise ValueError("Init graph size does not match dataset size!")
+        _check_supported_sizes(indices.shape[1], self.max_candidates, None)
         self.metric, self.n_neighbors = metric, indices.shape[1]
         self.n_trees, self.n_iters = n_trees, n_iters
         self.n_trees_after_update = max(2, int(np.round(n_trees / 3)))
@@ -444,6 +452,34 @@ class NNDescent:
         if hasattr(self, "_search_graph"):  # pynndescent_.py:2538-2553: the derived structures are rebuilt
             del self._search_graph
             self.build_search_graph()
+
+
+def _check_supported_sizes(n_neighbors, max_candidates, init_graph):
+    """The GPU k-lists / candidate lists hold at most 64 entries (one wave); the reference has no such bound
+    (pynndescent_.py:976-982), so the limit is reported up front and by name."""
+    if int(n_neighbors) > 64 or (max_candidates is not None and int(max_candidates) > 64):
+        raise NotImplementedError(
+            "pynndescent_amd supports n_neighbors <= 64 and max_candidates <= 64 (got n_neighbors=%s, max_candidates=%s); "
+            "use pynndescent.NNDescent (or pynndescent_amd.make_index) for wider graphs" % (n_neighbors, max_candidates))
+    if init_graph is not None and np.ndim(init_graph) == 2 and np.shape(init_graph)[1] > 64:
+        raise NotImplementedError("pynndescent_amd supports init_graph with at most 64 columns (got %d); use "
+                                  "pynndescent.NNDescent" % np.shape(init_graph)[1])
+
+
+def make_index(data, *args, **kwargs):
+    """``NNDescent(data, ...)`` on the GPU when the input is in scope (dense data, euclidean / l2 / cosine, k <= 64);
+    otherwise -- and only then -- the reference ``pynndescent.NNDescent`` on the CPU when that package is importable
+    (SURVEY.md section 8b), with a warning.  A missing HIP library or GPU is never papered over: that still raises."""
+    device = kwargs.pop("device", 0)
+    try:
+        return NNDescent(data, *args, device=device, **kwargs)
+    except NotImplementedError as exc:
+        try:
+            import pynndescent
+        except ImportError:
+            raise exc
+        warn("pynndescent_amd: %s -- building with pynndescent.NNDescent on the CPU instead" % exc)
+        return pynndescent.NNDescent(data, *args, **kwargs)
 
 
 # string metrics the reference recognises (distances.py:2103-2168 named_distances keys) -- used only to

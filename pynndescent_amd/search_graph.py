@@ -1,12 +1,21 @@
 """Search-graph pruning pass on the GPU (BASELINE config 5: "+ graph diversification/prune pass").
 
-Mirrors the pruning part of ``NNDescent._init_search_graph`` (reference pynndescent_.py:1451-1611) for the
-standard diversify method at ``diversify_prob = 1``: forward ``diversify`` (369-403) -> COO -> CSR ->
-"reverse" ``diversify_csr`` (549-588) -> union by element-wise maximum -> drop the diagonal ->
-``degree_prune`` to ``round(pruning_degree_multiplier * n_neighbors)`` (728-760) -> binarise.
-The three numba kernels run as HIP kernels (csrc/prune.hip); the conversions between them are the same scipy
-calls the reference makes.  The later steps of ``_init_search_graph`` -- hub search tree, reordering of data and
-graph by tree leaf order (1629-1651) -- belong to the query path and are out of scope.
+Mirrors the pruning part of ``NNDescent._init_search_graph`` (reference pynndescent_.py:1451-1611):
+forward ``diversify`` (369-403) or ``diversify_degree_aware`` (433-546) -> COO -> CSR -> "reverse"
+``diversify_csr`` (549-588) or ``diversify_csr_degree_aware`` (625-726) -> union by element-wise maximum -> drop
+the diagonal -> ``degree_prune`` to ``round(pruning_degree_multiplier * n_neighbors)`` (728-760) -> binarise.
+The numba kernels run as HIP kernels (csrc/prune.hip); the conversions between them are the same scipy calls the
+reference makes.  Two things the reference does BY ACCIDENT are reproduced, because parity is with what it computes:
+
+* scipy's ``transpose()`` of a CSR matrix is a CSC matrix over the SAME ``indptr`` / ``indices`` / ``data`` arrays,
+  so the "reverse" pass walks the forward rows again;
+* and because the arrays are shared, zeroing weights in the "reverse" matrix and calling its ``eliminate_zeros()``
+  (which compacts in place) prunes the FORWARD matrix as well: the union is ``max(F', F'^T)`` of the doubly pruned
+  ``F'``, not ``max(F, F'^T)`` (pynndescent_.py:1541-1599; verified with scipy 1.15.3).  With ``diversify_prob = 1``
+  the second pass finds nothing new on rows the first pass already diversified; with ``diversify_prob < 1`` it
+  re-tests the edges the first pass's coins spared.
+
+The hub search tree and the reordering by its leaf order (1629-1651) are in ``pynndescent_amd/search_tree.py``.
 """
 import numpy as np
 import scipy.sparse as sp
@@ -16,13 +25,34 @@ from . import _capi
 FLOAT32_EPS = np.finfo(np.float32).eps  # pynndescent_.py:65
 
 
+def compute_degrees(indices):
+    """pynndescent_.py:406-418: undirected degree of every vertex of an (n,k) neighbour array."""
+    idx = np.asarray(indices)
+    n = idx.shape[0]
+    valid = idx >= 0
+    deg = valid.sum(1).astype(np.int64)
+    deg += np.bincount(idx[valid].ravel(), minlength=n)[:n]
+    return deg.astype(np.int32)
+
+
+def compute_degrees_csr(indptr, indices):
+    """pynndescent_.py:591-622."""
+    n = indptr.shape[0] - 1
+    deg = np.diff(indptr).astype(np.int64)
+    ind = np.asarray(indices[: indptr[-1]])
+    deg += np.bincount(ind[(ind >= 0) & (ind < n)], minlength=n)[:n]
+    return deg.astype(np.int32)
+
+
 def build_search_graph(data, indices, distances, metric="euclidean", n_neighbors=None, pruning_degree_multiplier=1.5,
-                       diversify_prob=1.0, diversify_method="standard", device=0, return_stages=False):
+                       diversify_prob=1.0, diversify_method="standard", degree_prune_aggressiveness=1.0, seed=0,
+                       device=0, return_stages=False):
     """(indices int32 (n,k), alt-space distances float32 (n,k)) -> scipy CSR uint8 search graph (unordered).
 
     ``indices``/``distances`` are ``NNDescent._neighbor_graph`` (rows ascending, squared-L2 / log2-cosine)."""
-    if diversify_method != "standard" or diversify_prob != 1.0:
-        raise NotImplementedError("only the reference defaults diversify_method='standard', diversify_prob=1.0 run on the GPU")
+    if diversify_method not in ("standard", "degree_aware"):
+        raise ValueError("diversify_method must be 'standard' or 'degree_aware'")
+    aware = diversify_method == "degree_aware"
     x = np.ascontiguousarray(data, dtype=np.float32)
     n, d = x.shape
     k = indices.shape[1]
@@ -31,18 +61,30 @@ def build_search_graph(data, indices, distances, metric="euclidean", n_neighbors
     b = _capi.Builder(n, d, code, k, 0, 60, 200, min(60, k), 1, 0.001, [1, 2, 3], [4, 5, 6], device=device)
     try:
         b.set_data_host(x)
-        rows, dd = b.diversify(indices, distances)  # pynndescent_.py:1502-1511
         nnz_pre = int((np.asarray(indices) >= 0).sum())
-        dd[dd == 0.0] = FLOAT32_EPS  # preserve distance-0 points (pynndescent_.py:1517)
-        # COO -> CSR (1520-1527): entries stay in row order (ascending distance), -1 slots dropped
+        if aware:  # pynndescent_.py:1476-1498: max_degree = int(multiplier * k); diversify_prob lands in `alpha`
+            rows, dd = b.diversify(indices, distances, degree=compute_degrees(indices), degree_aware=True,
+                                   max_degree=max(1, int(pruning_degree_multiplier * n_neighbors)),
+                                   aggressiveness=degree_prune_aggressiveness, alpha=diversify_prob, seed=seed)
+        else:      # pynndescent_.py:1499-1518
+            rows, dd = b.diversify(indices, distances, prune_probability=diversify_prob, seed=seed)
+        dd[dd == 0.0] = FLOAT32_EPS  # preserve distance-0 points (pynndescent_.py:1525)
+        # COO -> CSR (1527-1537): entries stay in row order (ascending distance), -1 slots dropped
         keep = rows >= 0
         indptr = np.concatenate([[0], np.cumsum(keep.sum(1))]).astype(np.int32)
-        fwd = sp.csr_array((dd[keep].astype(np.float32), rows[keep].astype(np.int32), indptr), shape=(n, n))
-        # "Reverse graph" (1541-1577): scipy's transpose of a CSR matrix is a CSC view of the SAME arrays, so
-        # diversify_csr sees the forward rows; the surviving weights are then read as the transposed matrix.
-        rdata = b.diversify_csr(fwd.indptr, fwd.indices, fwd.data)
-        rev = sp.csr_array((rdata, fwd.indices.copy(), fwd.indptr.copy()), shape=(n, n)).transpose().tocsr()
-        rev.eliminate_zeros()
+        f_indices, f_data = rows[keep].astype(np.int32), dd[keep].astype(np.float32)
+        forward_nnz = int(f_data.shape[0])
+        # "Reverse graph" (1549-1587): the forward rows again (shared arrays, see the module docstring)
+        if aware:  # max_degree = n_neighbors (1567)
+            rdata = b.diversify_csr(indptr, f_indices, f_data, degree=compute_degrees_csr(indptr, f_indices),
+                                    degree_aware=True, max_degree=n_neighbors, aggressiveness=degree_prune_aggressiveness,
+                                    prune_probability=diversify_prob, seed=seed)
+        else:
+            rdata = b.diversify_csr(indptr, f_indices, f_data, prune_probability=diversify_prob, seed=seed)
+        # reverse_graph.eliminate_zeros() (1588) compacts the shared arrays: the forward matrix loses the edges too
+        fwd = sp.csr_array((rdata, f_indices, indptr), shape=(n, n))
+        fwd.eliminate_zeros()
+        rev = fwd.transpose().tocsr()
         rev.sort_indices()
         fwd.sort_indices()
         union = fwd.maximum(rev).tocsr()  # 1599
@@ -58,6 +100,6 @@ def build_search_graph(data, indices, distances, metric="euclidean", n_neighbors
     finally:
         b.close()
     if return_stages:
-        return graph, {"forward_rows": rows, "forward_dist": dd, "nnz_pre_diversify": nnz_pre, "forward_nnz": int(fwd.nnz),
+        return graph, {"forward_rows": rows, "forward_dist": dd, "nnz_pre_diversify": nnz_pre, "forward_nnz": forward_nnz,
                        "reverse_nnz": int(rev.nnz), "union_nnz": nnz_pre_prune, "final_nnz": int(graph.nnz)}
     return graph

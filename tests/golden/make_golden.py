@@ -399,6 +399,71 @@ def gen_search_graph(ref):
     save("search_graph", **out)
 
 
+def gen_search_graph_modes(ref):
+    """The non-default pruning modes of NNDescent._init_search_graph (pynndescent_.py:1451-1611) with the reference's own
+    functions and scipy glue, INCLUDING its array aliasing (reverse_graph = self._search_graph.transpose() shares the
+    forward matrix's arrays, so the reverse pass prunes the forward matrix too): diversify_prob = 0.5 (standard method;
+    coins drawn serially from rng_state) and diversify_method = 'degree_aware' (aggressiveness 2.0)."""
+    import numba
+    import scipy.sparse as sp
+    from pynndescent import distances as D
+    from pynndescent import pynndescent_ as P
+
+    numba.set_num_threads(1)
+    out = {}
+    for tag, metric, seed, method, prob, aggr in (("prob_euclidean", "euclidean", 51, "standard", 0.5, 1.0),
+                                                  ("prob_cosine", "cosine", 52, "standard", 0.5, 1.0),
+                                                  ("aware_euclidean", "euclidean", 53, "degree_aware", 1.0, 2.0),
+                                                  ("aware_cosine", "cosine", 54, "degree_aware", 1.0, 2.0)):
+        x = clustered(1200, 12, 5, 15, seed=seed)
+        index = ref.NNDescent(x, metric=metric, n_neighbors=15, random_state=np.random.RandomState(7))
+        idx, dst = index._neighbor_graph
+        dist = D.fast_distance_alternatives[metric]["dist"]
+        rng = np.asarray(index.rng_state, np.int64).copy()
+        rng_before = rng.copy()
+        k = 15
+        if method == "degree_aware":
+            rows, dd = P.diversify_degree_aware(idx.copy(), dst.copy(), x, dist, int(1.5 * k), aggr, prob)
+        else:
+            rows, dd = P.diversify(idx.copy(), dst.copy(), x, dist, rng, prob)
+        fwd_rows = rows.copy()
+        n = x.shape[0]
+        g = sp.coo_array((n, n), dtype=np.float32)
+        dd[dd == 0.0] = P.FLOAT32_EPS
+        g.row = np.repeat(np.arange(n, dtype=np.int32), rows.shape[1])
+        g.col = rows.ravel()
+        g.data = dd.ravel()
+        g = g.tocsr()
+        g.data[g.indices == -1] = 0.0
+        g.eliminate_zeros()
+        fwd_nnz = int(g.nnz)
+        rev = g.transpose()
+        if method == "degree_aware":
+            P.diversify_csr_degree_aware(rev.indptr, rev.indices, rev.data, x, dist, rng, k, aggr, prob)
+        else:
+            P.diversify_csr(rev.indptr, rev.indices, rev.data, x, dist, rng, prob)
+        rev.eliminate_zeros()
+        rev_nnz = int(rev.nnz)
+        rev = rev.tocsr()
+        rev.sort_indices()
+        g = g.tocsr()
+        g.sort_indices()
+        u = g.maximum(rev).tocsr()
+        u.setdiag(0.0)
+        u.eliminate_zeros()
+        pre_prune = u.nnz
+        u = P.degree_prune(u, int(np.round(1.5 * k)))
+        u.eliminate_zeros()
+        u = (u != 0).astype(np.uint8).tocsr()
+        u.sort_indices()
+        print(tag, "fwd nnz", fwd_nnz, "after reverse pass", rev_nnz, "forward matrix nnz now", int(g.nnz), "final", int(u.nnz))
+        out.update({tag + "_gen": np.array([1200, 12, 5, 15, seed]), tag + "_idx": idx, tag + "_dist": dst,
+                    tag + "_rng": rng_before, tag + "_fwd_rows": fwd_rows, tag + "_fwd_nnz": np.int64(fwd_nnz),
+                    tag + "_rev_nnz": np.int64(rev_nnz), tag + "_pre_prune_nnz": np.int64(pre_prune),
+                    tag + "_indptr": u.indptr.astype(np.int32), tag + "_indices": u.indices.astype(np.int32)})
+    save("search_graph_modes", **out)
+
+
 def gen_update(ref):
     """NNDescent.update (pynndescent_.py:2381-2553): fresh rows appended + some rows replaced, warm start from the
     old graph (flag 0) + a smaller forest, no random init."""
@@ -435,6 +500,7 @@ GENERATORS = {
     "build_c1": gen_build_c1,
     "reference_testdata": gen_reference_testdata,
     "search_graph": gen_search_graph,
+    "search_graph_modes": gen_search_graph_modes,
     "update": gen_update,
 }
 

@@ -1,0 +1,91 @@
+"""The drop-in boundary as a reference maintainer would use it: INTEGRATION.md section 2's ctypes stub, executed
+verbatim (host buffers through ``nnd_build``), and bench.py's multi-process launch path."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util_data import clustered
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _integration_stub():
+    """The python code block of INTEGRATION.md section 2, with the library name resolved to the in-tree build."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2."):text.index("## 3.")]
+    code = re.search(r"```python\n(.*?)```", sec, re.DOTALL).group(1)
+    lib = os.path.join(ROOT, "pynndescent_amd", "libpynnd_amd.so")
+    assert 'C.CDLL("libpynnd_amd.so")' in code
+    code = code.replace('C.CDLL("libpynnd_amd.so")', "C.CDLL(%r)" % lib)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#2", "exec"), ns)
+    return ns["_gpu_nn_descent"]
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_integration_md_stub_verbatim(metric):
+    """nnd_build -- the ONE function the stub binds -- with numpy buffers in and out, against the CPU oracle."""
+    gpu_nn_descent = _integration_stub()
+    x = clustered(20000, 48, 10, 64, seed=3)
+    k, n_trees, seed = 15, 8, 11
+    rng_state, _, tree_states = O.draw_rng_states(seed, n_trees)
+    idx, dist = gpu_nn_descent(x, k, rng_state, tree_states, min(60, k), metric, O.default_n_iters(x.shape[0]), 0.001,
+                               n_trees, O.default_leaf_size(k), 200)
+    assert idx.shape == dist.shape == (20000, k) and idx.dtype == np.int32 and dist.dtype == np.float32
+    assert (idx >= 0).all() and np.all(np.diff(dist, axis=1) >= 0)
+    assert np.mean(idx[:, 0] == np.arange(20000)) > 0.999
+    oidx, _ = O.build_index(x, metric, n_neighbors=k, n_trees=n_trees, random_state=seed, n_threads=16, kind="fast")
+    ti, _ = O.brute_force_knn(x, 10, metric)
+    r_gpu, r_cpu = O.recall(ti, idx), O.recall(ti, oidx)
+    print("INTEGRATION.md stub (%s): recall@10 gpu %.4f oracle %.4f" % (metric, r_gpu, r_cpu))
+    assert abs(r_gpu - r_cpu) <= 0.005
+    # alt-space distances, exact for the returned ids
+    xi = x.astype(np.float64)
+    if metric == "euclidean":
+        np.testing.assert_allclose(dist, ((xi[:, None, :] - xi[idx]) ** 2).sum(-1), rtol=1e-5, atol=1e-6)
+
+
+def test_integration_md_stub_init_graph_and_error():
+    gpu_nn_descent = _integration_stub()
+    x = clustered(3000, 16, 5, 20, seed=5)
+    ti, _ = O.brute_force_knn(x, 10, "euclidean")
+    rs = np.random.RandomState(0)
+    noisy = np.where(rs.uniform(size=ti.shape) < 0.5, rs.randint(0, 3000, ti.shape), ti).astype(np.int32)
+    rng_state, _, tree_states = O.draw_rng_states(1, 1)
+    idx, _ = gpu_nn_descent(x, 10, rng_state, tree_states, 10, "euclidean", 12, 0.001, 4, 60, 200, init_graph=noisy)
+    assert O.recall(ti, idx) > 0.95
+    with pytest.raises(RuntimeError, match="n_neighbors"):  # no silent fallback: the library's message surfaces
+        gpu_nn_descent(x, 100, rng_state, tree_states, 60, "euclidean", 12, 0.001, 4, 60, 200)
+
+
+def test_bench_two_processes_sharing_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: the script must re-execute itself as 2 ranks (here both on GPU 0
+    over gloo -- PYNND_BENCH_SHARE_GPU=1 -- since the test box has one GPU) and report n_gpus = 2."""
+    env = dict(os.environ, PYNND_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--points-per-gpu", "60000",
+                          "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["recall_at_10"] >= 0.95
+    assert sum(rec["exchanged_records_rank0"]) > 0
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PYNND_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "--gpus 64 requested" in (out.stderr + out.stdout)

@@ -129,7 +129,7 @@ def test_init_from_graph():
     b.close()
 
 
-@pytest.mark.parametrize("k,mc", [(15, 15), (30, 30), (10, 6)])
+@pytest.mark.parametrize("k,mc", [(15, 15), (30, 30), (10, 6), (60, 60), (20, 40)])
 def test_sample_candidates(k, mc):
     """Structural contract of new_build_candidates (utils.py:221-320)."""
     x = clustered(3000, 16, 5, 20, seed=11)

@@ -187,6 +187,36 @@ def test_search_graph_pruning_pass(golden_dir, metric):
     assert np.diff(sg.indptr).max() <= int(np.round(1.5 * 15)) + 1
 
 
+@pytest.mark.parametrize("tag,metric,method,prob,aggr", [("prob_euclidean", "euclidean", "standard", 0.5, 1.0),
+                                                        ("prob_cosine", "cosine", "standard", 0.5, 1.0),
+                                                        ("aware_euclidean", "euclidean", "degree_aware", 1.0, 2.0),
+                                                        ("aware_cosine", "cosine", "degree_aware", 1.0, 2.0)])
+def test_search_graph_non_default_modes(golden_dir, tag, metric, method, prob, aggr):
+    """diversify_prob < 1 and diversify_method='degree_aware' (pynndescent_.py:386-389, 433-546, 625-726) incl. the
+    reference's array aliasing (the reverse pass prunes the forward matrix too, pynndescent_.py:1549-1599): oracle vs
+    the reference's own run.  The coins are drawn serially from rng_state on both sides: euclidean is bit-exact."""
+    g = _g(golden_dir, "search_graph_modes")
+    n, d, latent, ncl, seed = (int(v) for v in g[tag + "_gen"])
+    x = clustered(n, d, latent, ncl, seed)
+    sg, st = O.search_graph(x, g[tag + "_idx"], g[tag + "_dist"], metric, 15, return_stages=True, diversify_prob=prob,
+                            diversify_method=method, degree_prune_aggressiveness=aggr, rng_state=g[tag + "_rng"].copy())
+    ref_indptr, ref_indices = g[tag + "_indptr"], g[tag + "_indices"]
+    if metric == "euclidean":
+        np.testing.assert_array_equal(st["forward_rows"], g[tag + "_fwd_rows"])
+        assert st["reverse_nnz"] == int(g[tag + "_rev_nnz"]) and st["union_nnz"] == int(g[tag + "_pre_prune_nnz"])
+        np.testing.assert_array_equal(sg.indptr, ref_indptr)
+        np.testing.assert_array_equal(sg.indices, ref_indices)
+    else:
+        a = set(zip(np.repeat(np.arange(n), np.diff(sg.indptr)).tolist(), sg.indices.tolist()))
+        b = set(zip(np.repeat(np.arange(n), np.diff(ref_indptr)).tolist(), ref_indices.tolist()))
+        # one flipped distance comparison shifts every later coin of the serial stream: only the rate is comparable
+        tol = 0.01 if prob >= 1.0 else 0.6
+        assert len(a ^ b) <= tol * len(b), (len(a ^ b), len(b))
+        assert abs(st["reverse_nnz"] - int(g[tag + "_rev_nnz"])) <= 0.03 * int(g[tag + "_rev_nnz"])
+    if prob < 1.0:  # the aliasing is visible: the reverse pass removed edges the forward pass's coins had spared
+        assert int(g[tag + "_rev_nnz"]) < int(g[tag + "_fwd_nnz"])
+
+
 @pytest.mark.parametrize("metric", ["euclidean", "cosine"])
 def test_update_matches_reference(golden_dir, metric):
     """NNDescent.update (pynndescent_.py:2381-2553): warm start from the old graph (flag 0) + a smaller forest."""

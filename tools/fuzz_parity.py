@@ -55,7 +55,7 @@ def main(count, seed):
             # one tree or a few hundred points: the random fill (different RNG on the two sides) decides how many escape
             # routes a stuck graph gets; recall then moves by several percent from run to run on BOTH sides
             tol = 0.08 if (n_trees == 1 or n < 1000) else 0.03
-            ok = rg >= ro - tol
+            ok = abs(rg - ro) <= tol
             filled = idx >= 0
             big = np.where(filled, dist, np.inf)
             ok &= bool(np.all(big[:, 1:] >= big[:, :-1]))
