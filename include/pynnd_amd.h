@@ -82,6 +82,7 @@ typedef struct nnd_stats {
     float ms_sample[64], ms_join[64], ms_merge[64];
     int64_t join_mfma[64];       /* v_mfma_f32_16x16x4_f32 instructions issued by the join (2048 flop each), per iteration */
     int64_t leaf_mfma;           /* the same for the leaf-seeding kernel, whole stage */
+    int64_t n_cells;             /* rp forest: cells of the routing pass (0 = whole-set level-synchronous build) */
 } nnd_stats;
 
 int32_t nnd_abi_version(void);

@@ -58,6 +58,7 @@ class NNDStats(C.Structure):
         ("ms_merge", C.c_float * 64),
         ("join_mfma", C.c_int64 * 64),
         ("leaf_mfma", C.c_int64),
+        ("n_cells", C.c_int64),
     ]
 
     def as_dict(self):
@@ -65,7 +66,7 @@ class NNDStats(C.Structure):
         m = min(it, 64)
         out = {
             "n_iters_run": it, "n_leaves": int(self.n_leaves), "tree_levels": int(self.tree_levels),
-            "leaf_pairs": int(self.leaf_pairs), "leaf_rows": int(self.leaf_rows), "leaf_mfma": int(self.leaf_mfma),
+            "leaf_pairs": int(self.leaf_pairs), "leaf_rows": int(self.leaf_rows), "leaf_mfma": int(self.leaf_mfma), "n_cells": int(self.n_cells),
         }
         for name in ("join_pairs", "join_rows", "join_active", "proposals", "updates", "join_mfma"):
             out[name] = [int(v) for v in getattr(self, name)[:m]]

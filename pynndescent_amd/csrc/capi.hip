@@ -1,5 +1,6 @@
 // capi.hip -- extern "C" boundary (include/pynnd_amd.h): handle lifetime, HBM allocation, and
 // the orchestration that mirrors nn_descent / nn_descent_internal (reference pynndescent_.py:266-366).
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -65,6 +66,8 @@ static void free_all(nnd_ctx *ctx) {
     F(ctx->pdirty); F(ctx->active);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
+    F(ctx->xs); F(ctx->xsh); F(ctx->nrms); F(ctx->node_hf); F(ctx->node_hh); F(ctx->node_child); F(ctx->node_pack); F(ctx->s_leaf_depth);
+    F(ctx->cell_count); F(ctx->cell_start); F(ctx->cell_depth); F(ctx->small_list);
     F(ctx->hyper); F(ctx->hyper_h); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->wl_start); F(ctx->wl_len); F(ctx->colsum_partial); F(ctx->counters_sum);
     if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; }
     if (ctx->h_tree_begin) { (void)hipHostFree(ctx->h_tree_begin); ctx->h_tree_begin = nullptr; }
@@ -144,6 +147,37 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
             ctx->P = (int64_t)p->n_trees * ctx->n;
             const size_t P = (size_t)ctx->P;
             ctx->max_segs = ctx->P / (p->leaf_size + 1) + p->n_trees + 8;
+            // Routing pass (rpforest.hip): the top of the trees is built from every 8th point when the set is large
+            // enough for that sample to resolve cells of a few hundred points, and rows fit the route kernel's registers.
+            // NND_FOREST_WHOLE=1 forces the whole-set level-synchronous build (A/B measurements).
+            const char *whole = getenv("NND_FOREST_WHOLE");
+            if (p->n >= 131072 && ctx->dp <= 256 && !(whole && whole[0] == '1')) {
+                const char *ss = getenv("NND_SAMPLE_STRIDE");
+                ctx->s_stride = ss ? atoi(ss) : 8;
+                if (ctx->s_stride < 2) ctx->s_stride = 2;
+                ctx->s_m = p->n / ctx->s_stride;
+                const char *cl = getenv("NND_CELL_LEAF");
+                const char *es = getenv("NND_EARLY_STOP");
+                ctx->early_stop = es ? atoi(es) : 8;
+                ctx->cell_leaf = cl ? atoi(cl) : 48;  // x stride: cells of <= ~450 points, ~215 on average (one wave per cell)
+                if (ctx->cell_leaf < 8) ctx->cell_leaf = 8;
+                const int64_t Ps = (int64_t)p->n_trees * ctx->s_m;
+                ctx->node_cap = Ps / (ctx->cell_leaf / 4 > 1 ? ctx->cell_leaf / 4 : 1) + 4 * p->n_trees + 64;
+                ctx->cell_cap = ctx->node_cap + p->n_trees;
+                ctx->max_segs += ctx->cell_cap;
+                if ((rc = dalloc(ctx, &ctx->xs, (size_t)ctx->s_m * ctx->dp))) break;
+                if ((rc = dalloc(ctx, &ctx->xsh, (size_t)ctx->s_m * ctx->dp))) break;
+                if ((rc = dalloc(ctx, &ctx->nrms, (size_t)ctx->s_m))) break;
+                if ((rc = dalloc(ctx, &ctx->node_hf, (size_t)ctx->node_cap * (ctx->dp + 4)))) break;
+                if ((rc = dalloc(ctx, &ctx->node_hh, (size_t)ctx->node_cap * ctx->dp))) break;
+                if ((rc = dalloc(ctx, &ctx->node_child, (size_t)ctx->node_cap * 2))) break;
+                if ((rc = dalloc(ctx, &ctx->node_pack, (size_t)ctx->node_cap * (2 * ctx->dp + 16)))) break;
+                if ((rc = dalloc(ctx, &ctx->s_leaf_depth, (size_t)Ps))) break;
+                if ((rc = dalloc(ctx, &ctx->cell_count, (size_t)ctx->cell_cap))) break;
+                if ((rc = dalloc(ctx, &ctx->cell_start, (size_t)ctx->cell_cap))) break;
+                if ((rc = dalloc(ctx, &ctx->cell_depth, (size_t)ctx->cell_cap))) break;
+                if ((rc = dalloc(ctx, &ctx->small_list, (size_t)ctx->cell_cap * 3))) break;
+            }
             const size_t S = (size_t)ctx->max_segs;
             for (int i = 0; i < 2 && !rc; i++) {
                 if ((rc = dalloc(ctx, &ctx->perm[i], P))) break;

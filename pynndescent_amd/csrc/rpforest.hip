@@ -384,10 +384,19 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
                                                   int32_t *__restrict__ next_start, int32_t *__restrict__ next_len,
                                                   int32_t *__restrict__ seg_child, uint8_t *__restrict__ leaf_flag,
                                                   int32_t *__restrict__ fin_start, int32_t *__restrict__ fin_len,
-                                                  int32_t *__restrict__ fin_depth, long long *__restrict__ counters) {
+                                                  int32_t *__restrict__ fin_depth, long long *__restrict__ counters,
+                                                  int32_t *__restrict__ node_child, int node_base, int next_base,
+                                                  int32_t *__restrict__ leaf_depth) {
+    // node_child != nullptr (sample forest, see nnd_launch_forest): the tree itself is recorded -- node (node_base + s)
+    // gets its two children: >= 0 the child's node id (next_base + its index in the next level), <= -2 a final
+    // leaf ("cell") encoded as -2 - first position; leaf_depth[first position] = its depth.
     // a child that splits again either stays in the level-synchronous passes (len > fin_max) or is handed to
     // k_finish_subtrees (len <= fin_max: its whole subtree fits in one workgroup's LDS)
     __shared__ int part[256], partf[256];
+    if (threadIdx.x == 0) {  // this launch's accumulators (single workgroup: ordered by the barrier below)
+        atomicExch((unsigned long long *)&counters[CNT_LEAVES], 0ull);  // atomics: ordered with the atomicAdd / atomicMax below at L2
+        atomicExch((unsigned long long *)&counters[CNT_SCRATCH + 3], 0ull);
+    }
     int chunk = (n_segs + 255) / 256;
     int s0 = threadIdx.x * chunk, s1 = s0 + chunk < n_segs ? s0 + chunk : n_segs;
     int cnt = 0, cntf = 0;
@@ -429,6 +438,7 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
                 if (lens[c] > fin_max) {
                     next_start[run] = starts[c];
                     next_len[run] = lens[c];
+                    if (node_child) node_child[2 * (node_base + s) + c] = next_base + run;
                     seg_child[2 * s + c] = run++;
                     active_pos += lens[c];
                     if (lens[c] > max_stay) max_stay = lens[c];
@@ -442,6 +452,10 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
             } else {
                 seg_child[2 * s + c] = -1;
                 if (lens[c] > 0) leaf_flag[starts[c]] = 1;  // rp_trees.py:2229-2232
+                if (node_child) {
+                    node_child[2 * (node_base + s) + c] = -2 - starts[c];
+                    if (lens[c] > 0) leaf_depth[starts[c]] = child_depth;
+                }
             }
         }
     }
@@ -484,11 +498,18 @@ __global__ void k_scatter(const int32_t *__restrict__ perm, const int32_t *__res
 }
 
 // ------------------------------------------------------------ subtree finisher --
-// Once every splittable segment fits in LDS (<= FIN_MAX points) the level-synchronous passes stop and one
-// workgroup per segment finishes its whole subtree on its own: explicit stack of sub-segments, hyperplane and
-// member ids in LDS, margins by 16-lane groups, stable partition by a block-wide scan.  No global
-// synchronisation, no per-level launches; deep unbalanced branches only cost their own workgroup.
-// Same split rule, same hashes (position- and depth-keyed) as the level-synchronous kernels above.
+// Once a segment fits in LDS (<= FIN_MAX points) no global pass touches it again: one workgroup finishes its whole
+// subtree on its own: explicit stack of sub-segments, hyperplane and member ids in LDS, margins by quads, stable
+// partition by a block-wide scan.  No global synchronisation, no per-level launches; deep unbalanced branches only
+// cost their own workgroup.
+//
+// Everything random here is keyed by POINT ID (and tree, depth), never by position, and every final leaf is written
+// in ascending id order: the result does not depend on the order in which the members of the segment arrive.  That is
+// what lets the routing pass (k_route below) place points into their cells with one atomicAdd each instead of a
+// stable sort, and still leaves the forest bit-reproducible for a seed.
+//   pivots      : the two members with the smallest hash(tree, id, depth) -- a uniformly random pair (rp_trees.py:351-356)
+//   |margin|<eps: coin = hash bit of (tree, id, depth)                                  (rp_trees.py:380-385)
+//   one-sided   : every member re-assigned by its hash bit -- the reference's rule       (rp_trees.py:393-403)
 #ifndef NND_FIN_MAX
 #define NND_FIN_MAX 2048
 #endif
@@ -496,16 +517,33 @@ static constexpr int FIN_MAX = NND_FIN_MAX;     // points per finisher segment
 #ifndef NND_BIG_MAX
 #define NND_BIG_MAX 8192
 #endif
-static constexpr int BIG_MAX = NND_BIG_MAX;     // longest segment the global-memory finisher variant takes (one workgroup each)
-static constexpr int FIN_STACK = 512;    // sub-segments pending (depth budget is 200: a DFS needs <= depth+1 entries)
+static constexpr int BIG_MAX = NND_BIG_MAX;     // whole-set passes: longest segment handed to the global-memory variant early
+static constexpr int FIN_STACK = 40;            // sub-segments pending: <= log2(2^31) + 1 because the smaller child is split first
+static constexpr int FIN_SMALL = 512;           // cells of <= FIN_SMALL points: one wave per cell
+static constexpr int FIN_WS = 40;               // int32 scratch words behind the stack
 
-// BIG = true: the same node loop for the FEW segments between FIN_MAX and BIG_MAX points that are left when the
-// level-synchronous passes stop paying (most positions already handed over): member ids, partition scratch and side
-// bits live in global memory (perm itself, the other perm buffer, side[]), and a node that has shrunk to <= FIN_MAX
-// points is appended to the LDS finisher's work list instead of being split here.
-template <bool BIG>
-__global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
-                                                         const float *__restrict__ nrm, int metric, int dp,
+__device__ __forceinline__ void rp_top2_push(uint64_t &a, uint64_t &b, uint64_t k) {
+    if (k < a) {
+        b = a;
+        a = k;
+    } else if (k < b) {
+        b = k;
+    }
+}
+__device__ __forceinline__ uint64_t rp_shfl_xor_u64(uint64_t v, int o) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// BIG = true: the same node loop for segments of any length: member ids, partition scratch and side bits live in
+// global memory (perm itself, the other perm buffer, side[]), and a node that has shrunk to <= fin_max points is
+// appended to the LDS finisher's work list instead of being split here.
+// NTHR threads per workgroup, CAP = most points of a segment whose ids live in LDS.  Small cells run with ONE WAVE per
+// cell (NTHR = 64, CAP = 512: ~6 KB of LDS, the barriers are single-wave): a node of a hundred points is a chain of
+// dependent latencies (pivot rows, member rows), so what pays is many independent cells per CU, not many lanes per cell.
+template <bool BIG, int NTHR, int CAP>
+__global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
+                                                         const float *__restrict__ nrm, int metric, int dp, int64_t n,
                                                          int32_t *__restrict__ perm,
                                                          const int32_t *__restrict__ seg_start,
                                                          const int32_t *__restrict__ seg_len,
@@ -519,17 +557,21 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
     const int s = blockIdx.x;
     if (s >= n_segs) return;
     const int a = seg_start[s], len = seg_len[s];
-    constexpr int NLDS = BIG ? 0 : FIN_MAX;
+    if (len <= 0) return;
+    constexpr int NLDS = BIG ? 0 : CAP;
+    constexpr int NW = NTHR / 64;
     int32_t *ids = BIG ? perm + a : (int32_t *)fsm;               // member ids of the segment
     int32_t *tmp = BIG ? tmp_g + a : (int32_t *)fsm + NLDS;       // partition scratch
     uint8_t *sd = BIG ? side_g + a : (uint8_t *)((int32_t *)fsm + 2 * NLDS);  // side bits
     float *h = (float *)(fsm + (size_t)NLDS * 9);  // dp + 4 hyperplane + offset
     uint16_t *hb = (uint16_t *)(h + dp + 4);       // dp: bf16 copy of the normal (dp is a multiple of 32)
     int32_t *stk = (int32_t *)(hb + dp);           // FIN_STACK * 3: (start, len, depth)
-    int32_t *wsum = stk + FIN_STACK * 3;           // 8: per-wave partial sums / scalars
+    int32_t *wsum = stk + FIN_STACK * 3;           // FIN_WS: per-wave partial sums / scalars (FIN_STACK entries: see the push below)
+    uint64_t *wkeys = (uint64_t *)(wsum + 8);      // 8 keys (16 words): per-wave top-2 of the pivot draw
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
+    const uint32_t seedt = seed ^ ((uint32_t)((int64_t)a / n) * 0x9E3779B9u);  // per tree
     if (!BIG)
-        for (int i = tid; i < len; i += 256) ids[i] = perm[a + i];
+        for (int i = tid; i < len; i += NTHR) ids[i] = perm[a + i];
     if (tid == 0) {
         stk[0] = 0; stk[1] = len; stk[2] = seg_depth ? seg_depth[s] : depth0;
         wsum[7] = 1;  // stack size
@@ -543,6 +585,16 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
         if (tid == 0) wsum[7] = sp - 1;
         if (!(l > leaf_size && (max_depth - dep) > 0)) {  // rp_trees.py:2188: this node is a leaf
             if (tid == 0 && l > 0) leaf_flag[a + ss] = 1;
+            if (l > 1) {  // canonical order: ascending ids (rank by counting; leaves are small)
+                for (int i = tid; i < l; i += NTHR) {
+                    const int32_t id = ids[ss + i];
+                    int r = 0;
+                    for (int j = 0; j < l; j++) r += ids[ss + j] < id ? 1 : 0;
+                    tmp[r] = id;
+                }
+                __syncthreads();
+                for (int i = tid; i < l; i += NTHR) ids[ss + i] = tmp[i];
+            }
             __syncthreads();
             continue;
         }
@@ -556,15 +608,31 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
             __syncthreads();
             continue;
         }
-        // two random members -> hyperplane (rp_trees.py:350-367 / 87-118); hashes keyed like k_hyperplane
-        const uint32_t gpos = (uint32_t)(a + ss);
-        uint32_t li = nnd_hash3(seed, gpos, (uint32_t)(2 * dep)) % (uint32_t)l;
-        uint32_t ri = nnd_hash3(seed, gpos, (uint32_t)(2 * dep + 1)) % (uint32_t)l;
-        if (ri == li) ri = (ri + 1) % (uint32_t)l;
-        const float *xl = xp + (int64_t)ids[ss + li] * dp;
-        const float *xr = xp + (int64_t)ids[ss + ri] * dp;
+        // two random members -> hyperplane (rp_trees.py:350-367 / 87-118): the two smallest hash(tree, id, depth)
+        uint64_t k1 = ~0ull, k2 = ~0ull;
+        for (int i = tid; i < l; i += NTHR) {
+            const uint32_t id = (uint32_t)ids[ss + i];
+            rp_top2_push(k1, k2, ((uint64_t)nnd_hash3(seedt, id, (uint32_t)(2 * dep)) << 32) | id);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t o1 = rp_shfl_xor_u64(k1, o), o2 = rp_shfl_xor_u64(k2, o);
+            rp_top2_push(k1, k2, o1);
+            rp_top2_push(k1, k2, o2);
+        }
+        if (lane == 0) {
+            wkeys[2 * w] = k1;
+            wkeys[2 * w + 1] = k2;
+        }
+        __syncthreads();
+        k1 = k2 = ~0ull;
+#pragma unroll
+        for (int q = 0; q < 2 * NW; q++) rp_top2_push(k1, k2, wkeys[q]);
+        const int64_t idl = (int64_t)(uint32_t)k1, idr = (int64_t)(uint32_t)k2;
+        const float *xl = xp + idl * dp;
+        const float *xr = xp + idr * dp;
         float part = 0.0f, psq = 0.0f;
-        for (int j = tid; j < dp; j += 256) {
+        for (int j = tid; j < dp; j += NTHR) {
             const float lv = xl[j], rv = xr[j];
             const float v = lv - rv;
             h[j] = v;
@@ -577,16 +645,20 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
             ((float *)wsum)[w] = part;
         }
         __syncthreads();
-        const float tot = ((float *)wsum)[0] + ((float *)wsum)[1] + ((float *)wsum)[2] + ((float *)wsum)[3];
+        float tot = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NW; q++) tot += ((float *)wsum)[q];
         __syncthreads();
         if (lane == 0) ((float *)wsum)[w] = psq;
         __syncthreads();
-        const float totsq = ((float *)wsum)[0] + ((float *)wsum)[1] + ((float *)wsum)[2] + ((float *)wsum)[3];
+        float totsq = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NW; q++) totsq += ((float *)wsum)[q];
         __syncthreads();
         if (angular) {  // normalise in place (rp_trees.py:113-118); offset 0
             const float nh = sqrtf(tot);
             const float inv = nh < RP_EPS ? 1.0f : 1.0f / nh;
-            for (int j = tid; j < dp; j += 256) h[j] *= inv;
+            for (int j = tid; j < dp; j += NTHR) h[j] *= inv;
             if (tid == 0) { h[dp] = 0.0f; h[dp + 1] = nh * inv; }
         } else if (tid == 0) {
             h[dp] = -0.5f * tot;
@@ -595,18 +667,19 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
         __syncthreads();
         // margins: one quad per member (bf16-screened like k_margin), two members per quad and step so that 8 row
         // fetches are in flight per lane; the bf16 hyperplane comes from LDS
-        for (int j = tid; j < dp; j += 256) hb[j] = nnd_f32_to_bf16(h[j]);
+        for (int j = tid; j < dp; j += NTHR) hb[j] = nnd_f32_to_bf16(h[j]);
         __syncthreads();
         const int sub = tid & 3, grp = tid >> 2;
         const int nch = dp >> 3;
         const float off = h[dp], hnorm = h[dp + 1];
         const uint4 *h8 = (const uint4 *)hb;
-        for (int i0 = 0; i0 < l; i0 += 128) {
+        constexpr int GQ = NTHR / 4;  // quads per workgroup
+        for (int i0 = 0; i0 < l; i0 += 2 * GQ) {
             int64_t pt[2];
             float acc[2], xn[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int i = i0 + u * 64 + grp;
+                const int i = i0 + u * GQ + grp;
                 pt[u] = ids[ss + (i < l ? i : 0)];
                 acc[u] = 0.0f;
             }
@@ -628,54 +701,68 @@ __global__ __launch_bounds__(256) void k_finish_subtrees(const float *__restrict
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int i = i0 + u * 64 + grp;
+                const int i = i0 + u * GQ + grp;
                 if (i >= l) continue;  // whole quad
                 const float m = rp_quad_sum(acc[u]) + off;
                 const float band = RP_BAND * hnorm * (metric == 0 ? sqrtf(xn[u]) : xn[u]) + 1e-30f;
-                const uint8_t side = rp_side(m, band, xp + pt[u] * dp, h, off, dp, sub, seed, gpos + (uint32_t)i, dep);
+                const uint8_t side = rp_side(m, band, xp + pt[u] * dp, h, off, dp, sub, seedt, (uint32_t)pt[u], dep);
                 if (sub == 0) sd[i] = side;
             }
         }
         __syncthreads();
-        // stable partition: block-wide exclusive scan of "left" over l <= FIN_MAX members (16 per thread)
-        const int per = (l + 255) / 256;
-        const int b0 = tid * per, b1 = b0 + per < l ? b0 + per : l;
-        int cntl = 0;
-        for (int i = b0; i < b1; i++) cntl += sd[i] == 0;
-        int incl = cntl;
+        // stable partition: block-wide exclusive scan of "left" over the l members (l / 256 per thread).  A one-sided
+        // split (rp_trees.py:393-403) re-draws every member's side from its hash bit first (and, should those agree
+        // too, sends the first pivot left on its own), then scans again.
+        const int per = (l + NTHR - 1) / NTHR;
+        const int b0 = tid * per < l ? tid * per : l, b1 = b0 + per < l ? b0 + per : l;
+        int cntl, incl, nl, woff;
+        for (int attempt = 0;; attempt++) {
+            cntl = 0;
+            for (int i = b0; i < b1; i++) cntl += sd[i] == 0;
+            incl = cntl;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) wsum[w] = incl;
+            __syncthreads();
+            woff = 0;
+            for (int i = 0; i < w; i++) woff += wsum[i];
+            nl = 0;
+#pragma unroll
+            for (int q = 0; q < NW; q++) nl += wsum[q];
+            if (nl != 0 && nl != l) break;  // block-uniform
+            __syncthreads();                // everyone has read wsum
+            for (int i = b0; i < b1; i++) {
+                const uint32_t id = (uint32_t)ids[ss + i];
+                sd[i] = attempt == 0 ? (uint8_t)(nnd_hash3(seedt ^ 0x5bd1e995u, id, (uint32_t)(2 * dep + 1)) & 1u)
+                                     : (uint8_t)((int64_t)id == idl ? 0 : 1);
+            }
+            __syncthreads();
         }
-        if (lane == 63) wsum[w] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int i = 0; i < w; i++) woff += wsum[i];
-        int nl = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        const bool one_sided = (nl == 0 || nl == l);  // rp_trees.py:393-403 -> even split by offset parity
-        if (one_sided) nl = (l + 1) / 2;
         int run = woff + incl - cntl;
         for (int i = b0; i < b1; i++) {
             int dest;
-            if (one_sided) dest = (i & 1) ? nl + (i >> 1) : (i >> 1);
-            else if (sd[i] == 0) dest = run++;
+            if (sd[i] == 0) dest = run++;
             else dest = nl + (i - run);
             tmp[dest] = ids[ss + i];
         }
         __syncthreads();
-        for (int i = tid; i < l; i += 256) ids[ss + i] = tmp[i];
-        if (tid == 0) {  // right child first so that the left one is processed next (order is immaterial)
+        for (int i = tid; i < l; i += NTHR) ids[ss + i] = tmp[i];
+        if (tid == 0) {  // the LARGER child is pushed first, the smaller one is processed next: the pending stack never
+                         // holds more than log2(len) + 1 entries (the order in which nodes are split is immaterial)
             int top = wsum[7];
-            stk[top * 3] = ss + nl; stk[top * 3 + 1] = l - nl; stk[top * 3 + 2] = dep + 1;
+            const bool left_big = nl >= l - nl;
+            stk[top * 3] = left_big ? ss : ss + nl; stk[top * 3 + 1] = left_big ? nl : l - nl; stk[top * 3 + 2] = dep + 1;
             top++;
-            stk[top * 3] = ss; stk[top * 3 + 1] = nl; stk[top * 3 + 2] = dep + 1;
+            stk[top * 3] = left_big ? ss + nl : ss; stk[top * 3 + 1] = left_big ? l - nl : nl; stk[top * 3 + 2] = dep + 1;
             wsum[7] = top + 1;
         }
         __syncthreads();
     }
     if (!BIG)
-        for (int i = tid; i < len; i += 256) perm[a + i] = ids[i];
+        for (int i = tid; i < len; i += NTHR) perm[a + i] = ids[i];
 }
 
 // ------------------------------------------------------------ leaf tables --
@@ -718,13 +805,221 @@ __global__ void k_fill_leaf_array(const int32_t *__restrict__ perm, const int32_
     out[t] = j < leaf_len[i] ? perm[leaf_start[i] + j] : -1;
 }
 
+// ------------------------------------------------------------ routing pass --
+// Large point sets do not run the level-synchronous passes over all P = n_trees * n positions.  The TOP of every tree is
+// built from a SAMPLE (every SAMPLE_STRIDE-th point, jittered): the level-synchronous machinery above runs on the
+// compact copy of the sample rows -- 1/8 of the positions -- and records the tree (hyperplanes, children) down to nodes
+// of <= cell_leaf sample members ("cells": a few hundred points each).  A node's two pivots are uniformly random
+// members of the sample inside the node, i.e. uniformly random members of the node (rp_trees.py:351-356); the top
+// nodes all hold far more than leaf_size points, so the reference's stop rule (rp_trees.py:2188) never fires there.
+// Then ONE pass routes every point through the recorded trees (k_route): the f32 row stays in registers for all
+// trees and levels, only hyperplanes are fetched (bf16 screen from L2, exact f32 recheck inside the error band, same
+// coin flips for |margin| < eps), the point's cell is counted with one atomicAdd whose return value is its slot in
+// the cell, and k_place writes the permutation.  Cells are finished by k_finish_subtrees, which is order independent.
+__global__ void k_gather_sample(const float *__restrict__ xp, const uint16_t *__restrict__ xh, const float *__restrict__ nrm,
+                                int dp, int64_t m, int64_t stride, uint32_t seed, float *__restrict__ xs,
+                                uint16_t *__restrict__ xsh, float *__restrict__ nrms) {
+    const int sub = threadIdx.x & 15;
+    const int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    if (j >= m) return;
+    const int64_t i = j * stride + (int64_t)(nnd_hash2(seed ^ 0x7F4A7C15u, (uint32_t)j) % (uint32_t)stride);
+    for (int c = sub; c < (dp >> 2); c += 16) ((float4 *)(xs + j * dp))[c] = ((const float4 *)(xp + i * dp))[c];
+    for (int c = sub; c < (dp >> 3); c += 16) ((uint4 *)(xsh + j * dp))[c] = ((const uint4 *)(xh + i * dp))[c];
+    if (sub == 0) nrms[j] = nrm[i];
+}
+
+__device__ __forceinline__ uint32_t rp_pack_bf16(float a, float b) {
+    return (uint32_t)nnd_f32_to_bf16(a) | ((uint32_t)nnd_f32_to_bf16(b) << 16);
+}
+__device__ __forceinline__ float rp_dot4f(float4 a, float4 b, float acc) {
+    return acc + a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+// Recorded nodes are packed for the walk: [dp bf16 hyperplane | f32 offset | f32 |h| | child 0 | child 1], one record of
+// 2 * dp + 16 bytes per node (a walk step touches ONE contiguous record instead of three tables).
+__global__ void k_pack_nodes(const uint16_t *__restrict__ node_hh, const float *__restrict__ node_hf, int hs,
+                             const int32_t *__restrict__ node_child, int dp, int64_t n_nodes, unsigned char *__restrict__ pack) {
+    const int sub = threadIdx.x & 15;
+    const int64_t v = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    if (v >= n_nodes) return;
+    const int rec = 2 * dp + 16;
+    uint4 *dst = (uint4 *)(pack + v * rec);
+    const uint4 *src = (const uint4 *)(node_hh + v * dp);
+    for (int c = sub; c < (dp >> 3); c += 16) dst[c] = src[c];
+    if (sub == 0) {
+        const float *h = node_hf + v * hs;
+        dst[dp >> 3] = make_uint4(__float_as_uint(h[dp]), __float_as_uint(h[dp + 1]), (uint32_t)node_child[2 * v],
+                                  (uint32_t)node_child[2 * v + 1]);
+    }
+}
+
+// One quad per point; lane `sub` of the quad holds the 8-float chunks sub, sub+4, ... of the row (NC = dp / 32 of them)
+// as f32 (exact recheck) and as packed bf16 (screening operand of v_dot2_f32_bf16).  TB trees walk down in lock step
+// from their roots, so step d of every walk is at depth d: the records of the first l_top levels (node ids
+// [0, n_top), the level-synchronous build numbers nodes level by level) are served from an LDS copy, deeper ones from
+// L2.  Persistent workgroups (the LDS copy is loaded once per workgroup).
+template <int NC, int TB>
+__global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, const float *__restrict__ nrm, int metric, int dp,
+                                               int64_t n, int n_trees, const unsigned char *__restrict__ node_pack,
+                                               const float *__restrict__ node_hf, int hs,
+                                               const int32_t *__restrict__ leafscan, uint32_t seed,
+                                               int32_t *__restrict__ cell_count, int32_t *__restrict__ cell_of,
+                                               int32_t *__restrict__ rank_of, int n_top, int l_top) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char top_tab[];
+    const int rec = 2 * dp + 16;
+    {
+        const uint4 *src = (const uint4 *)node_pack;
+        uint4 *dst = (uint4 *)top_tab;
+        const int total = n_top * (rec >> 4);
+        for (int q = threadIdx.x; q < total; q += blockDim.x) dst[q] = src[q];
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 3;
+    const int qpb = blockDim.x >> 2;
+    for (int64_t i0 = (int64_t)blockIdx.x * qpb; i0 < n; i0 += (int64_t)gridDim.x * qpb) {
+        const int64_t i = i0 + (threadIdx.x >> 2);
+        if (i >= n) continue;  // whole quad; no workgroup barrier below
+        float4 xa[NC], xb[NC];
+        uint4 xq[NC];
+        {
+            const float4 *row = (const float4 *)(xp + i * dp);
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                const int c = sub + 4 * q;
+                xa[q] = row[2 * c];
+                xb[q] = row[2 * c + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < NC; q++)
+                xq[q] = make_uint4(rp_pack_bf16(xa[q].x, xa[q].y), rp_pack_bf16(xa[q].z, xa[q].w), rp_pack_bf16(xb[q].x, xb[q].y),
+                                   rp_pack_bf16(xb[q].z, xb[q].w));
+        }
+        const float xn = nrm[i];
+        const float xnorm = metric == 0 ? sqrtf(xn) : xn;
+        for (int t0 = 0; t0 < n_trees; t0 += TB) {
+            int node[TB];  // >= 0: current node (the root of tree t is node t); -1: this walk is over
+#pragma unroll
+            for (int u = 0; u < TB; u++) node[u] = t0 + u < n_trees ? t0 + u : -1;
+            for (int depth = 0;; depth++) {
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < TB; u++) any |= node[u] >= 0;
+                if (!__ballot(any)) break;  // wave-uniform
+                uint4 p[TB][NC], meta[TB];
+                if (depth < l_top) {  // every live walk is at depth `depth`: its node id is < n_top
+#pragma unroll
+                    for (int u = 0; u < TB; u++) {
+                        const uint4 *r8 = (const uint4 *)(top_tab + (size_t)(node[u] >= 0 ? node[u] : 0) * rec);
+#pragma unroll
+                        for (int q = 0; q < NC; q++) p[u][q] = r8[sub + 4 * q];
+                        meta[u] = r8[dp >> 3];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < TB; u++) {
+                        const uint4 *r8 = (const uint4 *)(node_pack + (int64_t)(node[u] >= 0 ? node[u] : 0) * rec);
+#pragma unroll
+                        for (int q = 0; q < NC; q++) p[u][q] = r8[sub + 4 * q];
+                        meta[u] = r8[dp >> 3];
+                    }
+                }
+                float acc[TB];
+#pragma unroll
+                for (int u = 0; u < TB; u++) {
+                    acc[u] = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < NC; q++) acc[u] = rp_dot8(xq[q], p[u][q], acc[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < TB; u++) {
+                    if (node[u] < 0) continue;  // whole quad
+                    const float off = __uint_as_float(meta[u].x), hnorm = __uint_as_float(meta[u].y);
+                    float m = rp_quad_sum(acc[u]) + off;
+                    const float band = RP_BAND * hnorm * xnorm + 1e-30f;
+                    if (!(fabsf(m) > band)) {  // inside the bf16 error band: the exact f32 margin decides (quad-uniform)
+                        const float4 *h4 = (const float4 *)(node_hf + (int64_t)node[u] * hs);
+                        float e = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < NC; q++) {
+                            const int c = sub + 4 * q;
+                            e = rp_dot4f(xa[q], h4[2 * c], e);
+                            e = rp_dot4f(xb[q], h4[2 * c + 1], e);
+                        }
+                        m = rp_quad_sum(e) + off;
+                    }
+                    const int64_t slot = (int64_t)(t0 + u) * n + i;
+                    int side;
+                    if (fabsf(m) < RP_EPS) side = (int)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)slot, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
+                    else side = m > 0.0f ? 0 : 1;                                                                             // rp_trees.py:386-391
+                    const int nxt = (int)(side ? meta[u].w : meta[u].z);
+                    if (nxt <= -2) {  // reached a cell: first sample position -2 - nxt -> cell index
+                        if (sub == 0) {
+                            const int cell = leafscan[-2 - nxt];
+                            cell_of[slot] = cell;
+                            rank_of[slot] = atomicAdd(&cell_count[cell], 1);
+                        }
+                        node[u] = -1;
+                    } else {
+                        node[u] = nxt;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// cell -> depth of its node in the recorded tree (sample positions with a leaf mark start a cell)
+__global__ void k_cell_depths(const uint8_t *__restrict__ leaf_flag, const int32_t *__restrict__ leafscan,
+                              const int32_t *__restrict__ leaf_depth, int64_t ps, int32_t *__restrict__ cell_depth) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < ps && leaf_flag[g]) cell_depth[leafscan[g]] = leaf_depth[g];
+}
+
+// cells -> work lists: <= fin_small points: one wave per cell; <= fin_max: one workgroup per cell (ids in LDS); longer:
+// the global-memory variant.  Cells that are final leaves already go through a finisher too (it writes them in
+// canonical id order).  One atomic per wave and class; the order of the lists is immaterial.
+__global__ void k_cell_lists(const int32_t *__restrict__ cell_count, const int32_t *__restrict__ cell_start,
+                             const int32_t *__restrict__ cell_depth, int n_cells, int fin_small, int fin_max,
+                             int32_t *__restrict__ small_list, int32_t *__restrict__ fin_start, int32_t *__restrict__ fin_len,
+                             int32_t *__restrict__ fin_depth, int32_t *__restrict__ big_start, int32_t *__restrict__ big_len,
+                             int32_t *__restrict__ big_depth, int64_t list_stride,
+                             long long *__restrict__ counts /* [0] fin, [1] big, [2] small */) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int len = c < n_cells ? cell_count[c] : 0;
+    const int cls = len <= 0 ? -1 : (len <= fin_small ? 2 : (len <= fin_max ? 0 : 1));
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const unsigned long long m = __ballot(cls == k);
+        if (!m) continue;  // wave-uniform
+        long long base = 0;
+        if (nnd_lane() == __builtin_ctzll(m)) base = (long long)atomicAdd((unsigned long long *)&counts[k], (unsigned long long)__popcll(m));
+        base = ((long long)__shfl((int)(base >> 32), __builtin_ctzll(m), 64) << 32) | (unsigned)__shfl((int)base, __builtin_ctzll(m), 64);
+        if (cls == k) {
+            const int64_t idx = base + nnd_prefix_popc(m);
+            int32_t *st = k == 2 ? small_list : (k == 0 ? fin_start : big_start);
+            int32_t *ln = k == 2 ? small_list + list_stride : (k == 0 ? fin_len : big_len);
+            int32_t *dp_ = k == 2 ? small_list + 2 * list_stride : (k == 0 ? fin_depth : big_depth);
+            st[idx] = cell_start[c];
+            ln[idx] = len;
+            dp_[idx] = cell_depth[c];
+        }
+    }
+}
+
+__global__ void k_place(const int32_t *__restrict__ cell_of, const int32_t *__restrict__ rank_of,
+                        const int32_t *__restrict__ cell_start, int64_t n, int32_t *__restrict__ perm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t slot = (int64_t)blockIdx.y * n + i;
+    perm[cell_start[cell_of[slot]] + rank_of[slot]] = (int32_t)i;
+}
+
 // -------------------------------------------------------------- host side --
-static int run_scan(nnd_ctx *ctx, int mode, const int32_t *pos_seg, uint8_t *bytes, int32_t *total_dev,
+static int run_scan(nnd_ctx *ctx, int mode, const int32_t *pos_seg, uint8_t *bytes, int32_t *total_dev, int64_t P, int64_t n,
                     const int32_t *perm = nullptr) {
-    int64_t P = ctx->P;
     int nb = (int)((P + SCAN_TILE - 1) / SCAN_TILE);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, mode, pos_seg, bytes, P, ctx->scan_blk, perm,
-                       ctx->side_pt, ctx->n);
+                       ctx->side_pt, n);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->scan_blk, nb, total_dev);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, mode == 2 ? 0 : mode, pos_seg, bytes, P,
                        ctx->scan_blk, ctx->scan_out);
@@ -732,20 +1027,71 @@ static int run_scan(nnd_ctx *ctx, int mode, const int32_t *pos_seg, uint8_t *byt
     return 0;
 }
 
-int nnd_launch_forest(nnd_ctx *ctx) {
-    const int64_t n = ctx->n, P = ctx->P;
-    const int T = ctx->p.n_trees, dp = ctx->dp, leaf_size = ctx->p.leaf_size, max_depth = ctx->p.max_depth;
-    const int angular = ctx->p.metric == NND_METRIC_ALT_COSINE;
-    const int hs = dp + 4;
-    ctx->forest_built = false;
-    ctx->n_leaves = 0;
-    ctx->max_leaf = leaf_size;
-    ctx->tree_leaf_begin.clear();
-    if (T <= 0) return 0;
-    if (P >= (int64_t)0x7FFFFFF0) {
-        ctx->set_error("n_trees * n = %lld exceeds the int32 position space", (long long)P);
+static size_t fin_smem_bytes(int dp, int cap /* 0: ids in global memory */) {
+    const size_t tail = sizeof(float) * (dp + 4) + sizeof(uint16_t) * dp + sizeof(int32_t) * (FIN_STACK * 3 + FIN_WS);
+    return (size_t)cap * 9 + tail;
+}
+
+// What the level-synchronous passes run on: the whole point set (small n), or the compact sample (recording the tree).
+struct forest_view {
+    const float *xp;
+    const uint16_t *xh;
+    const float *nrm;
+    int64_t n, P;     // points per tree, n_trees * n
+    int leaf_size;    // split while len > leaf_size (rp_trees.py:2188)
+    int fin_max;      // children of <= fin_max points leave the passes for k_finish_subtrees (0: never)
+    bool record;      // keep hyperplanes and children of every node (routing pass)
+    int cur = 0, depth = 0;
+    int64_t n_nodes = 0;
+    std::vector<int64_t> level_base;  // recording: first node id of every level (+ the total at the end)
+};
+
+// big list (global-memory variant; its nodes join the workgroup list as they shrink) -> workgroup list -> small list
+static int launch_finishers(nnd_ctx *ctx, int32_t *perm, int32_t *other, const int32_t *big_start, const int32_t *big_len,
+                            const int32_t *big_depth, int depth0, long long n_big, long long n_small = 0) {
+    const int dp = ctx->dp, angular = ctx->p.metric == NND_METRIC_ALT_COSINE;
+    int32_t *fin_start = ctx->seg_child + 2 * ctx->max_segs;  // finisher work list lives behind seg_child
+    int32_t *fin_len = fin_start + ctx->max_segs;
+    int32_t *fin_depth = fin_len + ctx->max_segs;
+    long long *fin_count = ctx->counters + CNT_SCRATCH + 1;
+#define FIN_ARGS(st, ln, dpth, d0, cnt) ctx->xp, ctx->xh, ctx->nrm, ctx->p.metric, dp, ctx->n, perm, st, ln, dpth, d0, (int)(cnt), angular, \
+                 ctx->tree_seed, ctx->p.max_depth, ctx->p.leaf_size, ctx->leaf_flag
+    if (n_small > 0) {  // one wave per cell
+        const int32_t *sl = ctx->small_list;
+        hipLaunchKernelGGL((k_finish_subtrees<false, 64, FIN_SMALL>), dim3((unsigned)n_small), dim3(64), fin_smem_bytes(dp, FIN_SMALL),
+                           ctx->stream, FIN_ARGS(sl, sl + ctx->cell_cap, sl + 2 * ctx->cell_cap, 0, n_small), (int32_t *)nullptr,
+                           (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, fin_count);
+        NND_HIP_CHECK(hipGetLastError());
+    }
+    if (n_big > 0) {
+        hipLaunchKernelGGL((k_finish_subtrees<true, 256, 0>), dim3((unsigned)n_big), dim3(256), fin_smem_bytes(dp, 0), ctx->stream,
+                           FIN_ARGS(big_start, big_len, big_depth, depth0, n_big), other, ctx->side, FIN_MAX, fin_start, fin_len,
+                           fin_depth, fin_count);
+        NND_HIP_CHECK(hipGetLastError());
+    }
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 34, fin_count, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(nnd_sync_spin(ctx));
+    const long long nfin = ctx->h_pin[34];
+    if (nfin > ctx->max_segs) {
+        ctx->set_error("rp-forest: %lld finisher segments exceed the allocation of %lld", nfin, (long long)ctx->max_segs);
         return 1;
     }
+    if (nfin > 0) {
+        hipLaunchKernelGGL((k_finish_subtrees<false, 256, FIN_MAX>), dim3((unsigned)nfin), dim3(256), fin_smem_bytes(dp, FIN_MAX),
+                           ctx->stream, FIN_ARGS(fin_start, fin_len, fin_depth, 0, nfin), (int32_t *)nullptr, (uint8_t *)nullptr,
+                           FIN_MAX, fin_start, fin_len, fin_depth, fin_count);
+        NND_HIP_CHECK(hipGetLastError());
+    }
+#undef FIN_ARGS
+    return 0;
+}
+
+// The level-synchronous passes on `v`.  Returns 0, 1 (error) or 2 (recording ran out of node slots: caller falls back).
+static int forest_levels(nnd_ctx *ctx, forest_view &v) {
+    const int64_t n = v.n, P = v.P;
+    const int T = ctx->p.n_trees, dp = ctx->dp, leaf_size = v.leaf_size, max_depth = ctx->p.max_depth;
+    const int angular = ctx->p.metric == NND_METRIC_ALT_COSINE;
+    const int hs = dp + 4;
     int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);  // device scratch word(s)
     int splittable = (n > leaf_size && max_depth > 0) ? 1 : 0;
     int cur = 0;
@@ -758,20 +1104,18 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     int depth = 0;
     bool inv_live = true;  // inv[] is maintained while the point-major margin kernel is in use
     long long active_pos = P;
-    const int fin_max = FIN_MAX;
-    const size_t fin_smem = sizeof(int32_t) * 2 * FIN_MAX + FIN_MAX + sizeof(float) * (dp + 4) + sizeof(uint16_t) * dp +
-                            sizeof(int32_t) * (FIN_STACK * 3 + 8);
-    const size_t fin_smem_big = sizeof(float) * (dp + 4) + sizeof(uint16_t) * dp + sizeof(int32_t) * (FIN_STACK * 3 + 8);
+    const int fin_max = v.fin_max;
     int32_t *fin_start = ctx->seg_child + 2 * ctx->max_segs;  // finisher work list lives behind seg_child
     int32_t *fin_len = fin_start + ctx->max_segs;
     int32_t *fin_depth = fin_len + ctx->max_segs;
+    int64_t node_base = 0;
     NND_HIP_CHECK(hipMemsetAsync(ctx->counters + CNT_SCRATCH + 1, 0, sizeof(long long), ctx->stream));
-    if (S > 0 && n <= fin_max) {  // small point sets: the roots go straight to the finisher
-        std::vector<int32_t> hs(T), hl(T), hd(T, 0);
-        for (int t = 0; t < T; t++) { hs[t] = (int32_t)(t * n); hl[t] = (int32_t)n; }
-        NND_HIP_CHECK(hipMemcpyAsync(fin_start, hs.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
-        NND_HIP_CHECK(hipMemcpyAsync(fin_len, hl.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
-        NND_HIP_CHECK(hipMemcpyAsync(fin_depth, hd.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
+    if (!v.record && S > 0 && n <= fin_max) {  // small point sets: the roots go straight to the finisher
+        std::vector<int32_t> h_s(T), h_l(T), h_d(T, 0);
+        for (int t = 0; t < T; t++) { h_s[t] = (int32_t)(t * n); h_l[t] = (int32_t)n; }
+        NND_HIP_CHECK(hipMemcpyAsync(fin_start, h_s.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
+        NND_HIP_CHECK(hipMemcpyAsync(fin_len, h_l.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
+        NND_HIP_CHECK(hipMemcpyAsync(fin_depth, h_d.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, ctx->stream));
         long long cntf = T;
         NND_HIP_CHECK(hipMemcpyAsync(ctx->counters + CNT_SCRATCH + 1, &cntf, sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
         NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -782,30 +1126,38 @@ int nnd_launch_forest(nnd_ctx *ctx) {
             ctx->set_error("rp-forest: %lld segments exceed the allocation of %lld", (long long)S, (long long)ctx->max_segs);
             return 1;
         }
-        hipLaunchKernelGGL(k_hyperplane, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, dp,
+        if (v.record && node_base + S > ctx->node_cap) return 2;
+        if (v.record) v.level_base.push_back(node_base);
+        // recording: this level's hyperplanes are written straight into the node tables at [node_base, node_base + S)
+        float *hyper = v.record ? ctx->node_hf + node_base * hs : ctx->hyper;
+        uint16_t *hyper_h = v.record ? ctx->node_hh + node_base * dp : ctx->hyper_h;
+        hipLaunchKernelGGL(k_hyperplane, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, ctx->stream, v.xp, dp,
                            ctx->perm[cur], ctx->seg_start[cur], ctx->seg_len[cur], (int)S, angular, ctx->tree_seed, depth,
-                           ctx->hyper, hs, ctx->hyper_h);
+                           hyper, hs, hyper_h);
         // point-major pass: hyperplane table fits in L2 AND enough positions are still active to amortise
         // streaming every row once (it costs n rows regardless of how many positions are active)
         const bool fused = inv_live && (S * (int64_t)dp * 2 <= (int64_t)6 << 20) && (active_pos * 2 >= 3 * n);
         if (fused) {
-            hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
-                               ctx->p.metric, dp, n, T, ctx->inv, ctx->hyper, hs, ctx->hyper_h, ctx->tree_seed, depth, ctx->side_pt);
+            hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, v.xp, v.xh, v.nrm,
+                               ctx->p.metric, dp, n, T, ctx->inv, hyper, hs, hyper_h, ctx->tree_seed, depth, ctx->side_pt);
         } else {
             inv_live = false;
-            hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
-                               ctx->p.metric, dp, ctx->perm[cur], ctx->pos_seg[cur], P, ctx->hyper, hs, ctx->hyper_h, ctx->tree_seed, depth,
+            hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, ctx->stream, v.xp, v.xh, v.nrm,
+                               ctx->p.metric, dp, ctx->perm[cur], ctx->pos_seg[cur], P, hyper, hs, hyper_h, ctx->tree_seed, depth,
                                ctx->side);
         }
-        if (run_scan(ctx, fused ? 2 : 0, ctx->pos_seg[cur], ctx->side, scan_total, ctx->perm[cur])) return 1;
+        if (run_scan(ctx, fused ? 2 : 0, ctx->pos_seg[cur], ctx->side, scan_total, P, n, ctx->perm[cur])) return 1;
         hipLaunchKernelGGL(k_seg_count, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, ctx->seg_start[cur],
                            ctx->seg_len[cur], (int)S, ctx->scan_out, scan_total, P, ctx->seg_nleft);
         int child_can_split = (max_depth - (depth + 1)) > 0 ? 1 : 0;
-        NND_HIP_CHECK(hipMemsetAsync(ctx->counters + CNT_LEAVES, 0, sizeof(long long), ctx->stream));
-        NND_HIP_CHECK(hipMemsetAsync(ctx->counters + CNT_SCRATCH + 3, 0, sizeof(long long), ctx->stream));
+        // Recording: once only a few sample positions are still in splittable nodes the recorded tree stops: the
+        // children of this level all become cells, however long (a straggler level costs a full pass over the sample
+        // for a handful of nodes; an over-long cell just goes to a workgroup finisher instead of a single wave).
+        if (v.record && active_pos * ctx->early_stop < P) child_can_split = 0;
         hipLaunchKernelGGL(k_children, dim3(1), dim3(256), 0, ctx->stream, ctx->seg_start[cur], ctx->seg_len[cur],
                            ctx->seg_nleft, (int)S, leaf_size, child_can_split, fin_max, depth + 1, ctx->seg_start[1 - cur],
-                           ctx->seg_len[1 - cur], ctx->seg_child, ctx->leaf_flag, fin_start, fin_len, fin_depth, ctx->counters);
+                           ctx->seg_len[1 - cur], ctx->seg_child, ctx->leaf_flag, fin_start, fin_len, fin_depth, ctx->counters,
+                           v.record ? ctx->node_child : (int32_t *)nullptr, (int)node_base, (int)(node_base + S), ctx->s_leaf_depth);
         hipLaunchKernelGGL(k_scatter, dim3(gridP), dim3(256), 0, ctx->stream, ctx->perm[cur], ctx->pos_seg[cur], ctx->side,
                            ctx->scan_out, ctx->seg_start[cur], ctx->seg_nleft, ctx->seg_child, P, n, ctx->perm[1 - cur],
                            ctx->pos_seg[1 - cur], inv_live ? ctx->inv : (int32_t *)nullptr);
@@ -816,51 +1168,141 @@ int nnd_launch_forest(nnd_ctx *ctx) {
         NND_HIP_CHECK(hipMemcpyAsync(next, ctx->counters + CNT_ACTIVE_SEGS, 6 * sizeof(long long), hipMemcpyDeviceToHost,
                                      ctx->stream));
         NND_HIP_CHECK(nnd_sync_spin(ctx));
+        node_base += S;
         S = next[0];
         active_pos = next[1];
-        const long long max_stay = next[5];  // CNT_SCRATCH + 3
         cur = 1 - cur;
         depth++;
-        // Tail of the level loop: once most positions have been handed over, a level-synchronous pass still costs P
-        // positions per kernel for a few hundred segments.  If what is left fits the global-memory variant of the
-        // finisher (every segment <= BIG_MAX), one launch finishes the tail: its nodes are split in place until they fit
-        // the LDS finisher, whose work list they join.
-        if (S > 0 && (active_pos * 2 < 3 * n) && max_stay <= BIG_MAX) {
-            hipLaunchKernelGGL(k_finish_subtrees<true>, dim3((unsigned)S), dim3(256), fin_smem_big, ctx->stream, ctx->xp, ctx->xh,
-                               ctx->nrm, ctx->p.metric, dp, ctx->perm[cur], ctx->seg_start[cur], ctx->seg_len[cur],
-                               (const int32_t *)nullptr, depth, (int)S, angular, ctx->tree_seed, max_depth, leaf_size, ctx->leaf_flag,
-                               ctx->perm[1 - cur], ctx->side, fin_max, fin_start, fin_len, fin_depth, ctx->counters + CNT_SCRATCH + 1);
-            NND_HIP_CHECK(hipGetLastError());
-            S = 0;
+        // Tail of the level loop (whole-set mode): once most positions have been handed over, a level-synchronous pass
+        // still costs P positions per kernel for a few hundred segments: the global-memory variant of the finisher
+        // takes them (its nodes are split in place until they fit the LDS finisher, whose work list they join).
+        if (!v.record && S > 0 && (active_pos * 2 < 3 * n) && next[5] <= BIG_MAX) {  // next[5] = CNT_SCRATCH + 3: longest stayer
+            if (launch_finishers(ctx, ctx->perm[cur], ctx->perm[1 - cur], ctx->seg_start[cur], ctx->seg_len[cur], nullptr, depth, S)) return 1;
+            v.cur = cur;
+            v.depth = depth;
+            v.n_nodes = node_base;
+            return 0;  // both finishers have been launched
         }
     }
-    {  // subtrees that fit in LDS: one workgroup each, no more global passes
-        NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 34, ctx->counters + CNT_SCRATCH + 1, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-        NND_HIP_CHECK(nnd_sync_spin(ctx));
-        const long long nfin = ctx->h_pin[34];
-        if (nfin > ctx->max_segs) {
-            ctx->set_error("rp-forest: %lld finisher segments exceed the allocation of %lld", nfin, (long long)ctx->max_segs);
-            return 1;
-        }
-        if (nfin > 0) {
-            static bool configured = false;
-            if (!configured) {
-                NND_HIP_CHECK(hipFuncSetAttribute((const void *)k_finish_subtrees<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)fin_smem));
-                configured = true;
-            }
-            hipLaunchKernelGGL(k_finish_subtrees<false>, dim3((unsigned)nfin), dim3(256), fin_smem, ctx->stream, ctx->xp, ctx->xh, ctx->nrm,
-                               ctx->p.metric, dp, ctx->perm[cur], fin_start, fin_len, fin_depth, 0, (int)nfin, angular, ctx->tree_seed,
-                               max_depth, leaf_size, ctx->leaf_flag, (int32_t *)nullptr, (uint8_t *)nullptr, fin_max, fin_start, fin_len,
-                               fin_depth, ctx->counters + CNT_SCRATCH + 1);
-            NND_HIP_CHECK(hipGetLastError());
-        }
-        ctx->stats.n_leaves = nfin;  // overwritten below; kept for debugging
+    v.cur = cur;
+    v.depth = depth;
+    v.n_nodes = node_base;
+    if (v.record) v.level_base.push_back(node_base);
+    if (!v.record && launch_finishers(ctx, ctx->perm[cur], ctx->perm[1 - cur], nullptr, nullptr, nullptr, 0, 0)) return 1;
+    return 0;
+}
+
+template <int NC, int TB>
+static int launch_route(nnd_ctx *ctx, const int32_t *leafscan, int n_top, int l_top) {
+    auto kern = k_route<NC, TB>;
+    const size_t smem = (size_t)n_top * (2 * ctx->dp + 16);
+    static int n_cu_dev[64] = {0};
+    int &n_cu = n_cu_dev[ctx->p.device & 63];
+    if (n_cu == 0) {
+        NND_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        hipDeviceProp_t prop;
+        NND_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->p.device));
+        n_cu = prop.multiProcessorCount;
     }
-    ctx->cur = cur;
-    ctx->stats.tree_levels = depth;
+    int64_t blocks = (ctx->n + 127) / 128;
+    if (blocks > 2 * (int64_t)n_cu) blocks = 2 * (int64_t)n_cu;  // persistent: two 512-thread workgroups per CU
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), smem, ctx->stream, ctx->xp, ctx->nrm, ctx->p.metric, ctx->dp, ctx->n,
+                       ctx->p.n_trees, ctx->node_pack, ctx->node_hf, ctx->dp + 4, leafscan, ctx->tree_seed, ctx->cell_count,
+                       ctx->pos_seg[0], ctx->pos_seg[1], n_top, l_top);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// sample forest -> routing pass -> cells -> finishers.  Returns 0, 1, or 2 (fall back to the whole-set passes).
+static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
+    const int64_t n = ctx->n, P = ctx->P, M = ctx->s_m, Ps = (int64_t)ctx->p.n_trees * M;
+    const int T = ctx->p.n_trees, dp = ctx->dp;
+    int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
+    hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm, dp,
+                       M, ctx->s_stride, ctx->tree_seed, ctx->xs, ctx->xsh, ctx->nrms);
+    forest_view v{ctx->xs, ctx->xsh, ctx->nrms, M, Ps, ctx->cell_leaf, 0, true};
+    int rc = forest_levels(ctx, v);
+    if (rc) return rc;
+    // cells = leaves of the recorded trees, numbered in position order (tree-major)
+    if (run_scan(ctx, 1, nullptr, ctx->leaf_flag, scan_total, Ps, M)) return 1;
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 35, scan_total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(nnd_sync_spin(ctx));
+    const int32_t n_cells = *(const int32_t *)(ctx->h_pin + 35);
+    if (n_cells > ctx->cell_cap || n_cells + P / (ctx->p.leaf_size + 1) > ctx->max_segs) return 2;
+    hipLaunchKernelGGL(k_cell_depths, dim3((unsigned)((Ps + 255) / 256)), dim3(256), 0, ctx->stream, ctx->leaf_flag, ctx->scan_out,
+                       ctx->s_leaf_depth, Ps, ctx->cell_depth);
+    NND_HIP_CHECK(hipMemsetAsync(ctx->cell_count, 0, sizeof(int32_t) * (size_t)n_cells, ctx->stream));
+    hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)((v.n_nodes + 15) / 16)), dim3(256), 0, ctx->stream, ctx->node_hh, ctx->node_hf,
+                       dp + 4, ctx->node_child, dp, v.n_nodes, ctx->node_pack);
+    // levels whose records fit the route kernel's LDS copy (<= 72 KB: two workgroups per CU)
+    int l_top = 0;
+    while (l_top + 1 < (int)v.level_base.size() && v.level_base[l_top + 1] * (2 * dp + 16) <= 72 * 1024) l_top++;
+    const int n_top = (int)v.level_base[l_top];
+    int rrc = 2;
+    switch (dp / 32) {  // NC = 8-float chunks per lane; trees per batch sized for <= 128 VGPRs
+        case 1: rrc = launch_route<1, 4>(ctx, ctx->scan_out, n_top, l_top); break;
+        case 2: rrc = launch_route<2, 4>(ctx, ctx->scan_out, n_top, l_top); break;
+        case 3: rrc = launch_route<3, 2>(ctx, ctx->scan_out, n_top, l_top); break;
+        case 4: rrc = launch_route<4, 2>(ctx, ctx->scan_out, n_top, l_top); break;
+        case 5: rrc = launch_route<5, 1>(ctx, ctx->scan_out, n_top, l_top); break;
+        case 6: rrc = launch_route<6, 1>(ctx, ctx->scan_out, n_top, l_top); break;
+        case 7: rrc = launch_route<7, 1>(ctx, ctx->scan_out, n_top, l_top); break;
+        case 8: rrc = launch_route<8, 1>(ctx, ctx->scan_out, n_top, l_top); break;
+        default: break;  // wider rows: whole-set passes (nnd_create does not enable routing for them)
+    }
+    if (rrc) return rrc;
+    // cell_start = exclusive scan of the counts (k_scan_blocks scans in place: copy first)
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->cell_start, ctx->cell_count, sizeof(int32_t) * (size_t)n_cells, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->cell_start, (int)n_cells, scan_total);
+    NND_HIP_CHECK(hipMemsetAsync(ctx->leaf_flag, 0, (size_t)P, ctx->stream));
+    long long *counts = ctx->counters + CNT_SCRATCH + 1;  // [0] workgroup list (what launch_finishers reads), [1] big, [2] small
+    NND_HIP_CHECK(hipMemsetAsync(counts, 0, 3 * sizeof(long long), ctx->stream));
+    int32_t *fin_start = ctx->seg_child + 2 * ctx->max_segs, *fin_len = fin_start + ctx->max_segs, *fin_depth = fin_len + ctx->max_segs;
+    int32_t *big_start = ctx->seg_start[0], *big_len = ctx->seg_len[0], *big_depth = ctx->seg_nleft;
+    hipLaunchKernelGGL(k_cell_lists, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->cell_count, ctx->cell_start,
+                       ctx->cell_depth, (int)n_cells, FIN_SMALL, FIN_MAX, ctx->small_list, fin_start, fin_len, fin_depth, big_start,
+                       big_len, big_depth, ctx->cell_cap, counts);
+    hipLaunchKernelGGL(k_place, dim3((unsigned)((n + 255) / 256), (unsigned)T), dim3(256), 0, ctx->stream, ctx->pos_seg[0], ctx->pos_seg[1],
+                       ctx->cell_start, n, ctx->perm[0]);
+    NND_HIP_CHECK(hipGetLastError());
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 36, counts + 1, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(nnd_sync_spin(ctx));
+    const long long n_big = ctx->h_pin[36], n_small = ctx->h_pin[37];
+    if (n_big > ctx->max_segs) return 2;
+    if (launch_finishers(ctx, ctx->perm[0], ctx->perm[1], big_start, big_len, big_depth, 0, n_big, n_small)) return 1;
+    *levels_out = v.depth;
+    ctx->cur = 0;
+    ctx->stats.n_cells = n_cells;
+    return 0;
+}
+
+int nnd_launch_forest(nnd_ctx *ctx) {
+    const int64_t n = ctx->n, P = ctx->P;
+    const int T = ctx->p.n_trees, leaf_size = ctx->p.leaf_size;
+    ctx->forest_built = false;
+    ctx->n_leaves = 0;
+    ctx->max_leaf = leaf_size;
+    ctx->tree_leaf_begin.clear();
+    ctx->stats.n_cells = 0;
+    if (T <= 0) return 0;
+    if (P >= (int64_t)0x7FFFFFF0) {
+        ctx->set_error("n_trees * n = %lld exceeds the int32 position space", (long long)P);
+        return 1;
+    }
+    int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);  // device scratch word(s)
+    unsigned gridP = (unsigned)((P + 255) / 256);
+    int levels = 0, rc = 2;
+    if (ctx->s_m > 0) rc = forest_by_routing(ctx, &levels);
+    if (rc == 1) return 1;
+    if (rc == 2) {  // small point set, very wide rows, or the recorded tree outgrew its tables: whole-set passes
+        forest_view v{ctx->xp, ctx->xh, ctx->nrm, n, P, leaf_size, FIN_MAX, false};
+        if (forest_levels(ctx, v)) return 1;
+        ctx->cur = v.cur;
+        levels = v.depth;
+    }
+    ctx->stats.tree_levels = levels;
     // leaf tables
-    if (run_scan(ctx, 1, nullptr, ctx->leaf_flag, scan_total)) return 1;
+    if (run_scan(ctx, 1, nullptr, ctx->leaf_flag, scan_total, P, n)) return 1;
     NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 35, scan_total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     NND_HIP_CHECK(nnd_sync_spin(ctx));
     const int32_t nl = *(const int32_t *)(ctx->h_pin + 35);

@@ -88,6 +88,21 @@ struct nnd_handle_s {
     uint16_t *hyper_h = nullptr;              // (max_segs, dp) bf16 copy of the normals (screening pass)
     int64_t max_segs = 0;
     int cur = 0; // which ping-pong half holds the finished permutation
+    // routing pass (rpforest.hip forest_by_routing): sample, recorded top of the trees, cells
+    int64_t s_m = 0, s_stride = 0;            // sample size per tree (0: routing disabled), sampling stride
+    int cell_leaf = 0;                        // recorded trees stop at nodes of <= cell_leaf sample members
+    int early_stop = 8;                       // ... or when fewer than 1 / early_stop of the sample positions are still splittable
+    float *xs = nullptr;                      // (s_m, dp) compact copy of the sample rows
+    uint16_t *xsh = nullptr;                  // (s_m, dp) bf16
+    float *nrms = nullptr;                    // (s_m)
+    int64_t node_cap = 0, cell_cap = 0;
+    float *node_hf = nullptr;                 // (node_cap, dp + 4) f32 hyperplane + offset + |h|
+    uint16_t *node_hh = nullptr;              // (node_cap, dp) bf16 hyperplane
+    int32_t *node_child = nullptr;            // (node_cap, 2) child node id, or -2 - first sample position of a cell
+    unsigned char *node_pack = nullptr;       // (node_cap, 2 * dp + 16) packed records read by k_route
+    int32_t *s_leaf_depth = nullptr;          // (n_trees * s_m) depth of the cell that starts at a sample position
+    int32_t *cell_count = nullptr, *cell_start = nullptr, *cell_depth = nullptr;  // (cell_cap)
+    int32_t *small_list = nullptr;            // (3, cell_cap) start / len / depth of the cells finished one wave per cell
     int32_t *leaf_start = nullptr, *leaf_len = nullptr; // (n_leaves) after the forest is done; grow-only buffers
     double *colsum_partial = nullptr;         // prep scratch (column sums per row block), grow-only
     size_t colsum_cap = 0;

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # load torch's HIP runtime BEFORE libpynnd_amd.so initialises its own: one runtime per process (GPU tests)
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

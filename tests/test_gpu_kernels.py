@@ -203,3 +203,57 @@ def test_descent_iterations_keep_invariants_and_improve(metric, k):
     fidx, fdist = b.finalize()
     assert np.mean(fidx[:, 0] == np.arange(x.shape[0])) > 0.999 and np.all(fdist[fidx[:, 0] == np.arange(x.shape[0]), 0] == 0)
     b.close()
+
+
+@pytest.mark.parametrize("metric,n,d,k,T", [("euclidean", 200_000, 32, 15, 4), ("cosine", 150_000, 48, 10, 3)])
+def test_forest_routing_pass(metric, n, d, k, T):
+    """n >= 131072: the top of the trees is built from a sample and every point is ROUTED to its cell (rpforest.hip
+    k_route) instead of taking part in level-synchronous passes.  Same contract as the whole-set build: every tree
+    holds every point exactly once, leaves <= leaf_size, reference-like leaf statistics, bit-reproducible."""
+    x = clustered(n, d, 8, 200, seed=n % 1000)
+    b = make_builder(x, metric, k=k, n_trees=T)
+    b.make_forest()
+    st = b.stats()
+    assert st["n_cells"] > 0, "routing pass did not run"
+    la = b.leaf_array()
+    ls = O.default_leaf_size(k)
+    assert la.shape[1] == ls
+    ids = la[la >= 0]
+    assert ids.shape[0] == T * n
+    assert np.all(np.bincount(ids, minlength=n) == T)
+    lens = (la >= 0).sum(1)
+    assert lens.max() <= ls and lens.min() >= 1
+    assert np.all((la >= 0) == (np.arange(ls)[None, :] < lens[:, None]))
+    # leaves are written in ascending id order (canonical: independent of the order in which points reached their cell)
+    for row, m in zip(la[::97], lens[::97]):
+        assert np.all(np.diff(row[:m]) > 0)
+    _, _, ts = O.draw_rng_states(1, T)
+    ola = O.make_leaf_array(x, T, ls, ts, metric == "cosine")
+    ofill = (ola >= 0).sum(1).mean()
+    assert abs(lens.mean() - ofill) <= 0.15 * ofill, (lens.mean(), ofill)
+    # locality: fraction of true 5-NN of a sample of points that share a leaf with their point, vs the oracle's forest
+    rows = np.random.RandomState(3).choice(n, 2000, replace=False)
+    ti, _ = O.brute_force_knn(x, 6, metric, rows=rows)
+
+    def colocated(arr):
+        want = {int(p): set(ti[j, 1:].tolist()) for j, p in enumerate(rows)}
+        hit = 0
+        for row in arr:
+            members = row[row >= 0]
+            s = None
+            for p in members:
+                w = want.get(int(p))
+                if w is not None:
+                    if s is None:
+                        s = set(members.tolist())
+                    hit += len(w & s)
+        return hit / (len(rows) * 5 * T)
+
+    cg, co = colocated(la), colocated(ola)
+    print("routing forest: leaves %d (oracle %d) mean fill %.1f (oracle %.1f) colocation %.4f (oracle %.4f) cells %d levels %d"
+          % (la.shape[0], ola.shape[0], lens.mean(), ofill, cg, co, st["n_cells"], st["tree_levels"]))
+    assert abs(cg - co) <= 0.04, (cg, co)
+    b.make_forest()
+    la2 = b.leaf_array()
+    assert np.array_equal(la, la2), "forest not reproducible for a seed"
+    b.close()
