@@ -185,6 +185,24 @@ int32_t nnd_export_proposals(nnd_handle_t h, const int64_t *offsets /* exclusive
 int32_t nnd_import_proposals(nnd_handle_t h, const uint64_t *keys, const int32_t *targets, int64_t count);
 int32_t nnd_descent_merge(nnd_handle_t h, int64_t *c_local);
 
+/* Sharded build, exchange X2 of SURVEY.md section 8e: every rank scans only its OWN rows; a reverse offer or a proposal
+ * whose target is owned by another rank becomes a record in that owner's region and is applied there (the cross-process
+ * form of the ownership tests utils.py:266-273 and utils.py:721-731).  These entry points are stream-ordered (no host
+ * wait): with nnd_set_stream the handle runs on the caller's stream, so RCCL collectives issued by the caller between
+ * them need no synchronisation. */
+int32_t nnd_set_stream(nnd_handle_t h, void *hip_stream /* NULL: the handle's own stream again */);
+int32_t nnd_set_shard_bounds(nnd_handle_t h, const int64_t *bounds_host /* n_ranks + 1 */, int32_t n_ranks, int32_t rank);
+/* new_build_candidates (utils.py:221-320) in two halves around the offer all-to-all-v.  Regions: records of destination
+ * d at [d * cap, d * cap + counts[d]); record = (target | class << 31, priority << 32 | source). */
+int32_t nnd_sample_begin(nnd_handle_t h, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, int64_t *counts_dev);
+int32_t nnd_sample_finish(nnd_handle_t h, const int32_t *targets_dev, const uint64_t *keys_dev, int64_t count);
+/* apply_graph_update_array's ownership split (utils.py:721-731): proposals for vertices owned elsewhere, same region
+ * layout, record = (target, dist_bits << 32 | source); target -1 = hole, skipped by the importer */
+int32_t nnd_proposal_export(nnd_handle_t h, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, int64_t *counts_dev);
+int32_t nnd_import_proposals_async(nnd_handle_t h, const uint64_t *keys_dev, const int32_t *targets_dev, int64_t count);
+int32_t nnd_export_thresholds_async(nnd_handle_t h, int64_t lo, int64_t hi, float *th_dst_dev);
+int32_t nnd_import_thresholds_async(nnd_handle_t h, int64_t lo, int64_t hi, const float *th_src_dev);
+
 /* ---- search-graph pruning pass (BASELINE config 5; reference NNDescent._init_search_graph, pynndescent_.py:1451-1611) ----
  * Host arrays in / out: like the reference, the conversions between these kernels (COO->CSR, transpose, maximum,
  * binarise) are scipy calls on the host. */

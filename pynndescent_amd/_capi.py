@@ -133,6 +133,14 @@ _SIGNATURES = [
     ("nnd_export_proposals", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nnd_import_proposals", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
     ("nnd_descent_merge", C.c_int32, [_H, C.POINTER(C.c_int64)]),
+    ("nnd_set_stream", C.c_int32, [_H, C.c_void_p]),
+    ("nnd_set_shard_bounds", C.c_int32, [_H, C.c_void_p, C.c_int32, C.c_int32]),
+    ("nnd_sample_begin", C.c_int32, [_H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nnd_sample_finish", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
+    ("nnd_proposal_export", C.c_int32, [_H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nnd_import_proposals_async", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
+    ("nnd_export_thresholds_async", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p]),
+    ("nnd_import_thresholds_async", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p]),
     ("nnd_diversify_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.POINTER(NNDPruneOpts), C.c_void_p]),
     ("nnd_diversify_csr_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(NNDPruneOpts),
                                            C.c_void_p]),
@@ -298,6 +306,34 @@ class Builder:
     def set_owned_range(self, lo, hi):
         self._check(self.lib.nnd_set_owned_range(self._h, int(lo), int(hi)))
         self.own = (int(lo), int(hi))
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.nnd_set_stream(self._h, C.c_void_p(int(stream_ptr)) if stream_ptr else None))
+
+    def set_shard_bounds(self, bounds, rank):
+        b = np.ascontiguousarray(bounds, np.int64)
+        self._check(self.lib.nnd_set_shard_bounds(self._h, _ptr(b), b.shape[0] - 1, int(rank)))
+        self.own = (int(b[rank]), int(b[rank + 1]))
+
+    def sample_begin(self, cap, targets_ptr, keys_ptr, counts_ptr):
+        self._check(self.lib.nnd_sample_begin(self._h, int(cap), C.c_void_p(int(targets_ptr)), C.c_void_p(int(keys_ptr)),
+                                              C.c_void_p(int(counts_ptr))))
+
+    def sample_finish(self, targets_ptr, keys_ptr, count):
+        self._check(self.lib.nnd_sample_finish(self._h, C.c_void_p(int(targets_ptr)), C.c_void_p(int(keys_ptr)), int(count)))
+
+    def proposal_export(self, cap, targets_ptr, keys_ptr, counts_ptr):
+        self._check(self.lib.nnd_proposal_export(self._h, int(cap), C.c_void_p(int(targets_ptr)), C.c_void_p(int(keys_ptr)),
+                                                 C.c_void_p(int(counts_ptr))))
+
+    def import_proposals_async(self, keys_ptr, targets_ptr, count):
+        self._check(self.lib.nnd_import_proposals_async(self._h, C.c_void_p(int(keys_ptr)), C.c_void_p(int(targets_ptr)), int(count)))
+
+    def export_thresholds_async(self, lo, hi, th_ptr):
+        self._check(self.lib.nnd_export_thresholds_async(self._h, int(lo), int(hi), C.c_void_p(int(th_ptr))))
+
+    def import_thresholds_async(self, lo, hi, th_ptr):
+        self._check(self.lib.nnd_import_thresholds_async(self._h, int(lo), int(hi), C.c_void_p(int(th_ptr))))
 
     def row_stride(self):
         return int(self.lib.nnd_row_stride(self._h))

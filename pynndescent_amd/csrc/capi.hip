@@ -77,7 +77,8 @@ static void free_all(nnd_ctx *ctx) {
     if (ctx->ev_spin) (void)hipEventDestroy(ctx->ev_spin);
     for (hipEvent_t e : ctx->tev) if (e) (void)hipEventDestroy(e);
     ctx->tev.clear();
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    F(ctx->shard_bounds); F(ctx->shard_cursors);
+    if (ctx->stream && ctx->stream_owned) (void)hipStreamDestroy(ctx->stream);
 }
 
 extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
@@ -622,6 +623,80 @@ extern "C" int32_t nnd_set_owned_range(nnd_handle_t ctx, int64_t lo, int64_t hi)
     return 0;
 }
 extern "C" int32_t nnd_row_stride(nnd_handle_t ctx) { return ctx ? ctx->ks : 0; }
+
+// Run on the caller's HIP stream (e.g. torch's current stream) instead of the handle's own: the library's kernels and the
+// caller's collectives are then ordered by the stream itself, no host synchronisation between them.  NULL: back to own.
+extern "C" int32_t nnd_set_stream(nnd_handle_t ctx, void *hip_stream) {
+    ENTER(ctx);
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    if (hip_stream) {
+        if (ctx->stream_owned && ctx->stream) { API_HIP(hipStreamDestroy(ctx->stream)); }
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->stream_owned = false;
+    } else if (!ctx->stream_owned) {
+        API_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->stream_owned = true;
+    }
+    return 0;
+}
+
+// bounds_host[r] = first row of rank r, bounds_host[n_ranks] = n.  Sets the owned range to this handle's slice.
+extern "C" int32_t nnd_set_shard_bounds(nnd_handle_t ctx, const int64_t *bounds_host, int32_t n_ranks, int32_t rank) {
+    ENTER(ctx);
+    if (!bounds_host || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks) { ctx->set_error("nnd_set_shard_bounds: need 1 <= n_ranks <= 64 and 0 <= rank < n_ranks"); return 1; }
+    if (bounds_host[0] != 0 || bounds_host[n_ranks] != ctx->n) { ctx->set_error("nnd_set_shard_bounds: bounds must run from 0 to n"); return 1; }
+    for (int r = 0; r < n_ranks; r++)
+        if (bounds_host[r] > bounds_host[r + 1]) { ctx->set_error("nnd_set_shard_bounds: bounds must not decrease"); return 1; }
+    if (!ctx->shard_bounds) API_HIP(hipMalloc((void **)&ctx->shard_bounds, sizeof(int64_t) * 65));
+    if (!ctx->shard_cursors) API_HIP(hipMalloc((void **)&ctx->shard_cursors, sizeof(long long) * 66));
+    API_HIP(hipMemcpyAsync(ctx->shard_bounds, bounds_host, sizeof(int64_t) * (size_t)(n_ranks + 1), hipMemcpyHostToDevice, ctx->stream));
+    API_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_ranks = n_ranks;
+    ctx->own_lo = bounds_host[rank];
+    ctx->own_hi = bounds_host[rank + 1];
+    return 0;
+}
+
+// One sampling pass of a sharded build in two halves around the offer exchange (stream-ordered, no host sync):
+//   begin : local new edges + records for targets owned elsewhere into G regions of `cap` records; counts_dev[G]
+//   finish: records received from the other ranks, local old edges, selection (new_build_candidates, utils.py:221-320)
+extern "C" int32_t nnd_sample_begin(nnd_handle_t ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, int64_t *counts_dev) {
+    ENTER(ctx);
+    static float sink;
+    const int t_ = t_begin(ctx);
+    if (nnd_launch_sample_begin(ctx, cap, targets_dev, keys_dev, (long long *)counts_dev)) return 1;
+    t_end(ctx, t_, ctx->iter < 64 ? &ctx->stats.ms_sample[ctx->iter] : &sink, false);
+    return 0;
+}
+extern "C" int32_t nnd_sample_finish(nnd_handle_t ctx, const int32_t *targets_dev, const uint64_t *keys_dev, int64_t count) {
+    ENTER(ctx);
+    static float sink;
+    const int t_ = t_begin(ctx);
+    if (nnd_launch_sample_finish(ctx, targets_dev, keys_dev, count)) return 1;
+    t_end(ctx, t_, ctx->iter < 64 ? &ctx->stats.ms_sample[ctx->iter] : &sink, true);
+    return 0;
+}
+// proposals for vertices owned elsewhere -> G regions of `cap` (key, target) records; counts_dev[G] (may exceed cap:
+// the vertices behind the limit keep their proposals for the next iteration); stream-ordered, no host sync
+extern "C" int32_t nnd_proposal_export(nnd_handle_t ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, int64_t *counts_dev) {
+    ENTER(ctx);
+    return nnd_launch_proposal_export_regions(ctx, cap, targets_dev, keys_dev, (long long *)counts_dev);
+}
+// stream-ordered variants of the exchange steps (no host wait): thresholds in / out, received proposals
+extern "C" int32_t nnd_export_thresholds_async(nnd_handle_t ctx, int64_t lo, int64_t hi, float *th_dst_dev) {
+    ENTER(ctx);
+    API_HIP(hipMemcpyAsync(th_dst_dev, ctx->th + lo, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+extern "C" int32_t nnd_import_thresholds_async(nnd_handle_t ctx, int64_t lo, int64_t hi, const float *th_src_dev) {
+    ENTER(ctx);
+    API_HIP(hipMemcpyAsync(ctx->th + lo, th_src_dev, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+extern "C" int32_t nnd_import_proposals_async(nnd_handle_t ctx, const uint64_t *keys_dev, const int32_t *targets_dev, int64_t count) {
+    ENTER(ctx);
+    return nnd_launch_import_proposals(ctx, keys_dev, targets_dev, count);
+}
 
 extern "C" int32_t nnd_export_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, uint32_t *e_dst_dev, float *d_dst_dev) {
     ENTER(ctx);

@@ -115,6 +115,17 @@ __device__ __forceinline__ void nnd_count(long long *counters, int which, long l
     if (v) atomicAdd((unsigned long long *)&counters[(size_t)(blockIdx.x & 511u) * 16 + which], (unsigned long long)v);
 }
 
+// row-sharded build: rank that owns vertex v; bounds[r] <= v < bounds[r + 1]
+__device__ __forceinline__ int nnd_owner_of(const int64_t *__restrict__ bounds, int n_ranks, int64_t v) {
+    int lo = 0, hi = n_ranks - 1;  // bounds[r] <= v < bounds[r + 1]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (v >= bounds[mid]) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+
 #define NND_HIP_CHECK(expr)                                                                         \
     do {                                                                                            \
         hipError_t _e = (expr);                                                                     \

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
                                                          int64_t v_end, int k, int ks, const uint32_t *__restrict__ knn_e,
                                                          const float *__restrict__ th, uint64_t *__restrict__ pbuf,
                                                          uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed,
-                                                         long long *__restrict__ counters) {
+                                                         long long *__restrict__ counters, int64_t own_lo, int64_t own_hi) {
     constexpr int MCP = 16, RV = 32;          // rows per vertex: [new(16) | old(16)]
     constexpr int NT = DC / 16;               // 16-byte chunks per lane, row and K block
     constexpr int KQ = KS16 * 4;              // uint4 chunks per neighbour-list row
@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
             if (!(r0 < MCP ? r0 < nn : r0 - MCP < no)) continue;
             const int idx = lane + i * 64;
             const int r = idx / KQ, c = idx % KQ;
-            const bool ok = c < kq && cb[r] >= 0;  // padding beyond k is EMPTY already
+            // padding beyond k is EMPTY already; a candidate owned by ANOTHER rank (row-sharded build) has no current
+            // neighbour list here: no membership test for it, its owner dedups in the merge (utils.py:489-492)
+            const bool ok = c < kq && cb[r] >= 0 && (int64_t)cb[r] >= own_lo && (int64_t)cb[r] < own_hi;
             const u32x4 empty = {NND_IDX_MASK, NND_IDX_MASK, NND_IDX_MASK, NND_IDX_MASK};
             *(u32x4 *)(klist + r * kls + 4 * c) = ok ? (klv[i] & NND_IDX_MASK) : empty;
         }
@@ -343,7 +345,7 @@ static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
                        nnd_vertex_order(ctx), v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed,
-                       ctx->counters);
+                       ctx->counters, ctx->own_lo, ctx->own_hi);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
                                                                        const uint32_t *__restrict__ knn_e,
                                                                        const float *__restrict__ th, uint64_t *__restrict__ pbuf,
                                                                        uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed,
-                                                                       long long *__restrict__ counters) {
+                                                                       long long *__restrict__ counters, int64_t own_lo, int64_t own_hi) {
     constexpr int NA = MCP / 16, NB = 2 * NA, RV = 2 * MCP;
     constexpr int NT = DC / 16;                       // 16-byte chunks per lane, row and K block
     constexpr int RPL = RV / 64;                      // candidate slots per lane (1 or 2)
@@ -478,6 +480,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
     };
     // is `id` among the neighbour ids of vertex `row` (global memory; the list sits in L2 more often than not)
     auto list_has = [&](int row, uint32_t id) __attribute__((always_inline)) -> bool {
+        if ((int64_t)row < own_lo || (int64_t)row >= own_hi) return false;  // owned elsewhere: its owner dedups (row-sharded build)
         const u32x4 *kl = (const u32x4 *)(knn_e + (int64_t)row * ks);
         bool present = false;
         for (int c = 0; c < kq; c += 4) {
@@ -666,7 +669,7 @@ static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
                        nnd_vertex_order(ctx), v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty,
-                       ctx->pcap, slot_seed, ctx->counters);
+                       ctx->pcap, slot_seed, ctx->counters, ctx->own_lo, ctx->own_hi);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -219,6 +219,7 @@ __global__ void k_import_proposals(const uint64_t *__restrict__ keys, const int3
     if (i >= count) return;
     const uint64_t key = keys[i];
     const int64_t t = targets[i];
+    if (t < 0) return;  // hole left by a deferred vertex (k_proposal_export_regions)
     const uint32_t s = nnd_hash2(slot_seed, nnd_key_idx(key)) & (uint32_t)(pcap - 1);
     atomicMin((unsigned long long *)&pbuf[t * pcap + s], (unsigned long long)key);
     pdirty[t] = 1;
@@ -240,6 +241,96 @@ __global__ __launch_bounds__(256) void k_merge_graph_rows(int64_t lo, int64_t hi
         dc = ds[c];
         return e != NND_EMPTY_E;
     });
+}
+
+// One launch instead of counts -> host scan -> export: 128 consecutive vertices per workgroup; the records of a vertex go
+// to the region of its owner (regions of `cap` records, one global atomic per workgroup and destination).  A vertex whose
+// records do not fit any more keeps them (slots and dirty flag untouched): they travel with the next iteration's --
+// proposals are suggestions with exact distances, a late one is as valid as a fresh one.
+__global__ __launch_bounds__(256) void k_proposal_export_regions(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
+                                                                 int64_t n, int64_t own_lo, int64_t own_hi,
+                                                                 const int64_t *__restrict__ bounds, int n_ranks, int64_t cap,
+                                                                 long long *__restrict__ cursors, int32_t *__restrict__ targets,
+                                                                 uint64_t *__restrict__ keys, long long *__restrict__ deferred) {
+    __shared__ int rcnt[128], rdest[128];
+    __shared__ long long roff[128];
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    for (int r = 0; r < 32; r++) {
+        const int li = w * 32 + r;
+        const int64_t v = row0 + li;
+        int c = 0;
+        if (v < n && (v < own_lo || v >= own_hi) && pdirty[v]) {  // wave-uniform
+            const uint64_t key = lane < pcap ? pbuf[v * pcap + lane] : NND_EMPTY_KEY;
+            c = __popcll(__ballot(key != NND_EMPTY_KEY));
+        }
+        if (lane == 0) rcnt[li] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // rows ascend, owners are contiguous ranges: a few groups per workgroup
+        int d = -1;
+        int i0 = 0;
+        long long acc = 0;
+        auto flush = [&](int i1) {
+            if (d < 0 || acc == 0) return;
+            const long long b = (long long)atomicAdd((unsigned long long *)&cursors[d], (unsigned long long)acc);
+            for (int i = i0; i < i1; i++)
+                if (rcnt[i] > 0) {
+                    roff[i] += b;
+                    if (roff[i] + rcnt[i] > cap) rcnt[i] = -rcnt[i];  // does not fit: deferred
+                }
+        };
+        for (int i = 0; i < 128; i++) {
+            if (rcnt[i] == 0) continue;
+            const int64_t v = row0 + i;
+            if (d < 0 || v >= bounds[d + 1]) {
+                flush(i);
+                d = nnd_owner_of(bounds, n_ranks, v);
+                i0 = i;
+                acc = 0;
+            }
+            rdest[i] = d;
+            roff[i] = acc;
+            acc += rcnt[i];
+        }
+        flush(128);
+    }
+    __syncthreads();
+    for (int r = 0; r < 32; r++) {
+        const int li = w * 32 + r;
+        const int c = rcnt[li];
+        if (c == 0) continue;  // wave-uniform
+        const int64_t v = row0 + li;
+        if (c < 0) {  // deferred; the part of its reservation that lies inside the region is marked invalid (target -1)
+            if (lane == 0) atomicAdd((unsigned long long *)deferred, (unsigned long long)(-c));
+            if (roff[li] < cap && roff[li] + lane < cap && lane < -c) targets[(int64_t)rdest[li] * cap + roff[li] + lane] = -1;
+            continue;
+        }
+        const uint64_t key = lane < pcap ? pbuf[v * pcap + lane] : NND_EMPTY_KEY;
+        const bool on = key != NND_EMPTY_KEY;
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int64_t idx = (int64_t)rdest[li] * cap + roff[li] + nnd_prefix_popc(m);
+            keys[idx] = key;
+            targets[idx] = (int32_t)v;
+            pbuf[v * pcap + lane] = NND_EMPTY_KEY;
+        }
+        if (lane == 0) pdirty[v] = 0;
+    }
+}
+
+int nnd_launch_proposal_export_regions(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, long long *counts_dev) {
+    if (ctx->n_ranks < 1 || !ctx->shard_bounds) { ctx->set_error("nnd_proposal_export: call nnd_set_shard_bounds first"); return 1; }
+    if (ctx->pcap > 64) { ctx->set_error("nnd_proposal_export expects at most 64 proposal slots per row"); return 1; }
+    NND_HIP_CHECK(hipMemsetAsync(ctx->shard_cursors, 0, sizeof(long long) * 66, ctx->stream));
+    hipLaunchKernelGGL(k_proposal_export_regions, dim3((unsigned)((ctx->n + 127) / 128)), dim3(256), 0, ctx->stream, ctx->pbuf, ctx->pdirty,
+                       ctx->pcap, ctx->n, ctx->own_lo, ctx->own_hi, ctx->shard_bounds, ctx->n_ranks, cap, ctx->shard_cursors, targets_dev,
+                       keys_dev, ctx->shard_cursors + 65);
+    NND_HIP_CHECK(hipGetLastError());
+    // a region holds min(cursor, cap) records ... the kernel only writes rows that fit entirely, so the count of WRITTEN
+    // records of a region is cursor minus what was deferred behind it; the host gets the exact per-region numbers:
+    NND_HIP_CHECK(hipMemcpyAsync(counts_dev, ctx->shard_cursors, sizeof(long long) * (size_t)ctx->n_ranks, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
 }
 
 int nnd_launch_proposal_counts(nnd_ctx *ctx, int32_t *cnt_dev) {

@@ -28,12 +28,12 @@
 // Thread layout: blockDim = (KSP, 256 / KSP) with KSP = the row stride rounded up to a power of two, x = slot, y = row:
 // no division per edge.  Rows are visited in `order` (spatially coherent, one contiguous eighth per XCD): the targets
 // of a window of rows are each other's neighbours, so the offers of a window land in a few slot banks that stay in L2.
-__global__ __launch_bounds__(256) void k_sample_reverse(const uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, uint32_t it_seed,
+__global__ __launch_bounds__(256) void k_sample_reverse(const uint32_t *__restrict__ knn_e, int64_t row_lo, int64_t n, int k, int ks, uint32_t it_seed,
                                                         uint64_t *__restrict__ rbuf, int rcap, int64_t own_lo, int64_t own_hi, int pass,
                                                         uint8_t *__restrict__ active, const int32_t *__restrict__ order) {
     int64_t b = blockIdx.x;
     if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
-    const int64_t g = b * blockDim.y + threadIdx.y;
+    const int64_t g = row_lo + b * blockDim.y + threadIdx.y;  // rows [row_lo, n): all of them, or the owned slice (sharded)
     const int j = threadIdx.x;
     if (g >= n || j >= k) return;
     const int64_t v = order ? (int64_t)order[g] : g;
@@ -163,27 +163,145 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
     if (valid && cls == 1u && my_rank < mc) knn_e[v * ks + lane] = u;
 }
 
-int nnd_launch_sample(nnd_ctx *ctx) {
-    const int64_t n = ctx->n;
-    uint32_t it_seed = nnd_hash2(ctx->seed ^ 0x9E3779B9u, (uint32_t)ctx->iter + 1u);
-    NND_HIP_CHECK(hipMemsetAsync(ctx->active, 0, (size_t)n, ctx->stream));
+// rows scanned for reverse offers: every row on a plain handle; the owned slice when shard bounds are set (row-sharded
+// build: offers to targets owned elsewhere travel as records, see k_offer_export)
+static void launch_reverse_pass(nnd_ctx *ctx, int pass, uint32_t it_seed) {
+    const bool shard = ctx->n_ranks > 1;
+    const int64_t row_lo = shard ? ctx->own_lo : 0, row_hi = shard ? ctx->own_hi : ctx->n;
     int ksp = 16;
     while (ksp < ctx->ks) ksp <<= 1;
     const int rows = 256 / ksp;
-    unsigned grid = (unsigned)((n + rows - 1) / rows);
+    unsigned grid = (unsigned)((row_hi - row_lo + rows - 1) / rows);
     grid = (grid + 7u) & ~7u;  // whole multiples of the XCD count
-    // the spatial order is a permutation of ALL rows: usable whenever there is a forest (the edge scan covers every row
-    // of the graph, also on a handle that owns only a slice of the targets)
-    const int32_t *order = (ctx->forest_built && ctx->p.n_trees > 0) ? ctx->perm[ctx->cur] : nullptr;
+    // the spatial order is a permutation of ALL rows: usable whenever there is a forest and all rows are scanned
+    const int32_t *order = (!shard && ctx->forest_built && ctx->p.n_trees > 0) ? ctx->perm[ctx->cur] : nullptr;
+    hipLaunchKernelGGL(k_sample_reverse, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->knn_e, row_lo, row_hi, ctx->k, ctx->ks,
+                       it_seed, ctx->rbuf, ctx->rcap, ctx->own_lo, ctx->own_hi, pass, ctx->active, order);
+}
+
+static uint32_t sample_seed(const nnd_ctx *ctx) { return nnd_hash2(ctx->seed ^ 0x9E3779B9u, (uint32_t)ctx->iter + 1u); }
+
+static void launch_select(nnd_ctx *ctx, uint32_t it_seed) {
+    hipLaunchKernelGGL(k_sample_select, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream,
+                       ctx->knn_e, ctx->n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand, ctx->own_lo,
+                       ctx->own_hi, ctx->active);
+}
+
+int nnd_launch_sample(nnd_ctx *ctx) {
+    if (ctx->n_ranks > 1) {
+        ctx->set_error("nnd_launch_sample: this handle is one shard of a row-sharded build; use nnd_sample_begin / nnd_sample_finish");
+        return 1;
+    }
+    const uint32_t it_seed = sample_seed(ctx);
+    NND_HIP_CHECK(hipMemsetAsync(ctx->active, 0, (size_t)ctx->n, ctx->stream));
     // every edge still carries the "new" flag before the first sampling pass: there are no old edges to offer
     const int n_pass = ctx->all_new ? 1 : 2;
-    for (int pass = 0; pass < n_pass; pass++)
-        hipLaunchKernelGGL(k_sample_reverse, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->knn_e, n, ctx->k, ctx->ks,
-                           it_seed, ctx->rbuf, ctx->rcap, ctx->own_lo, ctx->own_hi, pass, ctx->active, order);
+    for (int pass = 0; pass < n_pass; pass++) launch_reverse_pass(ctx, pass, it_seed);
     ctx->all_new = false;
-    hipLaunchKernelGGL(k_sample_select, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream,
-                       ctx->knn_e, n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand, ctx->own_lo,
-                       ctx->own_hi, ctx->active);
+    launch_select(ctx, it_seed);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-sharded build (exchange X2): a reverse offer (v -> u) whose target u is owned by another
+// rank is not applied here -- it becomes a 12-byte record (u | class << 31, priority << 32 | v) in the region of
+// u's owner, the host ships the regions (all-to-all-v over RCCL), and the owner folds what it receives into its slot
+// banks with the same atomicMin as a local offer.  This is the cross-process form of the ownership test of
+// new_build_candidates (utils.py:266-273): every rank scans only ITS rows instead of all n * k edges.
+// same thread layout as k_sample_reverse; records are grouped per destination inside the workgroup (LDS atomics), one
+// global atomic per workgroup and destination reserves their slots in the destination's region
+__global__ __launch_bounds__(256) void k_offer_export(const uint32_t *__restrict__ knn_e, int64_t row_lo, int64_t row_hi, int k, int ks,
+                                                      uint32_t it_seed, const int64_t *__restrict__ bounds, int n_ranks,
+                                                      int64_t own_lo, int64_t own_hi, int64_t cap, long long *__restrict__ cursors,
+                                                      int32_t *__restrict__ targets, uint64_t *__restrict__ keys,
+                                                      long long *__restrict__ dropped) {
+    __shared__ int cnt[64];
+    __shared__ long long base[64];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (tid < 64) cnt[tid] = 0;
+    __syncthreads();
+    const int64_t g = row_lo + (int64_t)blockIdx.x * blockDim.y + threadIdx.y;
+    const int j = threadIdx.x;
+    int dest = -1, my = 0;
+    uint32_t u = 0, cls = 0;
+    if (g < row_hi && j < k) {
+        const uint32_t e = knn_e[g * ks + j];
+        if (e != NND_EMPTY_E) {
+            u = e & NND_IDX_MASK;
+            cls = e >> 31;
+            if ((int64_t)u < own_lo || (int64_t)u >= own_hi) dest = nnd_owner_of(bounds, n_ranks, (int64_t)u);
+        }
+    }
+    if (dest >= 0) my = atomicAdd(&cnt[dest], 1);
+    __syncthreads();
+    if (tid < n_ranks && cnt[tid] > 0) base[tid] = (long long)atomicAdd((unsigned long long *)&cursors[tid], (unsigned long long)cnt[tid]);
+    __syncthreads();
+    if (dest >= 0) {
+        const long long at = base[dest] + my;
+        if (at < cap) {
+            const int64_t idx = (int64_t)dest * cap + at;
+            targets[idx] = (int32_t)(u | (cls << 31));
+            keys[idx] = ((uint64_t)nnd_hash3(it_seed, (uint32_t)g, u) << 32) | (uint64_t)(uint32_t)g;
+        } else {
+            atomicAdd((unsigned long long *)dropped, 1ull);  // cannot happen with cap = owned rows * k
+        }
+    }
+}
+
+__global__ void k_offer_import(const int32_t *__restrict__ targets, const uint64_t *__restrict__ keys, int64_t count, uint32_t want_cls,
+                               uint32_t it_seed, uint64_t *__restrict__ rbuf, int rcap, uint8_t *__restrict__ active,
+                               int64_t own_lo, int64_t own_hi) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t t = (uint32_t)targets[i];
+    const uint32_t cls = t >> 31, u = t & NND_IDX_MASK;
+    if (cls != want_cls || (int64_t)u < own_lo || (int64_t)u >= own_hi) return;
+    if (cls == 1u) active[u] = 1;
+    else if (!active[u]) return;  // no new candidate reaches u: its old list is never read
+    const uint64_t key = keys[i];
+    const uint32_t slot = nnd_hash2(it_seed ^ 0x68E31DA4u, (uint32_t)key) & (uint32_t)(rcap - 1);
+    atomicMin((unsigned long long *)&rbuf[((int64_t)u * 2 + cls) * rcap + slot], (unsigned long long)key);
+}
+
+// first half of a sharded sampling pass: local new edges, and the records for targets owned elsewhere (both classes)
+int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, long long *counts_dev) {
+    if (ctx->n_ranks < 1 || !ctx->shard_bounds) { ctx->set_error("nnd_sample_begin: call nnd_set_shard_bounds first"); return 1; }
+    const uint32_t it_seed = sample_seed(ctx);
+    NND_HIP_CHECK(hipMemsetAsync(ctx->active, 0, (size_t)ctx->n, ctx->stream));
+    NND_HIP_CHECK(hipMemsetAsync(ctx->shard_cursors, 0, sizeof(long long) * 66, ctx->stream));
+    launch_reverse_pass(ctx, 0, it_seed);
+    if (ctx->n_ranks > 1) {
+        int ksp = 16;
+        while (ksp < ctx->ks) ksp <<= 1;
+        const int rows = 256 / ksp;
+        const unsigned grid = (unsigned)((ctx->own_hi - ctx->own_lo + rows - 1) / rows);
+        if (grid > 0)
+            hipLaunchKernelGGL(k_offer_export, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->knn_e, ctx->own_lo, ctx->own_hi, ctx->k,
+                               ctx->ks, it_seed, ctx->shard_bounds, ctx->n_ranks, ctx->own_lo, ctx->own_hi, cap, ctx->shard_cursors,
+                               targets_dev, keys_dev, ctx->shard_cursors + 64);
+    }
+    NND_HIP_CHECK(hipGetLastError());
+    NND_HIP_CHECK(hipMemcpyAsync(counts_dev, ctx->shard_cursors, sizeof(long long) * (size_t)ctx->n_ranks, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+// second half: received records (new class first: they decide which vertices are active), local old edges, received
+// old-class records, then the per-vertex selection
+int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uint64_t *keys_dev, int64_t count) {
+    const uint32_t it_seed = sample_seed(ctx);
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (count > 0)
+        hipLaunchKernelGGL(k_offer_import, dim3(grid), dim3(256), 0, ctx->stream, targets_dev, keys_dev, count, 1u, it_seed, ctx->rbuf,
+                           ctx->rcap, ctx->active, ctx->own_lo, ctx->own_hi);
+    if (!ctx->all_new) {
+        launch_reverse_pass(ctx, 1, it_seed);
+        if (count > 0)
+            hipLaunchKernelGGL(k_offer_import, dim3(grid), dim3(256), 0, ctx->stream, targets_dev, keys_dev, count, 0u, it_seed, ctx->rbuf,
+                               ctx->rcap, ctx->active, ctx->own_lo, ctx->own_hi);
+    }
+    ctx->all_new = false;
+    launch_select(ctx, it_seed);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

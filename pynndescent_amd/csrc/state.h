@@ -50,6 +50,10 @@ struct nnd_handle_s {
     int rcap = 0, pcap = 0; // reverse-offer slots per (vertex,class); proposal slots per vertex
     int iter = 0;
     int64_t own_lo = 0, own_hi = 0; // rows this handle owns (row-sharded multi-GPU build); default [0, n)
+    int n_ranks = 0;                // > 0 once nnd_set_shard_bounds was called: this handle is one shard of n_ranks
+    int64_t *shard_bounds = nullptr;      // device (n_ranks + 1): first row of every rank, then n
+    long long *shard_cursors = nullptr;   // device (66): per-destination record cursors, [64] dropped, [65] deferred
+    bool stream_owned = true;             // false after nnd_set_stream: the caller's stream is borrowed
     uint32_t seed = 0, tree_seed = 0;
 
     // data
@@ -143,6 +147,9 @@ int nnd_launch_leaf_init(nnd_ctx *ctx);
 int nnd_launch_random_init(nnd_ctx *ctx);
 int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float *dist_dev, int width);
 int nnd_launch_sample(nnd_ctx *ctx);
+int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, long long *counts_dev);
+int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uint64_t *keys_dev, int64_t count);
+int nnd_launch_proposal_export_regions(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, long long *counts_dev);
 int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end);
 int nnd_launch_merge(nnd_ctx *ctx);
 int nnd_launch_finalize(nnd_ctx *ctx, int32_t *out_idx_dev, float *out_dist_dev);

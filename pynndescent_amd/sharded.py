@@ -9,14 +9,21 @@ vertex ranges (``apply_graph_update_array`` utils.py:709-731, ``new_build_candid
 * the RP forest is split by TREE: rank r builds ``n_trees/G`` trees over all points, seeds the k-lists
   of every point from its own leaves, and the partial lists are shipped to the owners
   (all-to-all-v of k-list row blocks) and merged there;
-* per NN-descent iteration: (1) all-gather of the k-list rows, so that every rank can offer reverse
-  candidates to the vertices it owns by scanning all edges -- exactly the reference's per-thread edge scan
-  -- and can test proposals against remote thresholds / neighbour ids; (2) local sampling + join of the
-  owned vertices; (3) all-to-all-v of the proposals whose target is owned elsewhere, as (key, target)
-  records; (4) owner-side merge; (5) all-reduce of the update count for the stop rule (pynndescent_.py:317).
+* per NN-descent iteration every rank scans only ITS OWN rows:
+  (1) **threshold all-gather**, 4 bytes per row: the worst distance of every remote row, all the join needs of a
+      remote candidate (a stale threshold only admits extra proposals);
+  (2) **reverse-offer all-to-all-v** (exchange X2): an edge ``v -> u`` whose target ``u`` lives on another rank becomes a
+      12-byte record ``(u | class, priority | v)`` for u's owner, which folds it into its slot banks exactly like a
+      local offer -- the cross-process form of the ownership test ``utils.py:266-273``;
+  (3) local join of the owned vertices; a proposal for a remote target skips the membership test (the owner
+      dedups in its merge, ``utils.py:489-492``);
+  (4) **proposal all-to-all-v** of ``(target, dist | source)`` records, owner-side merge (``utils.py:721-731``);
+  (5) **all-reduce** of the update count for the stop rule (pynndescent_.py:317).
 
-The device-side halves are C-ABI entry points of ``include/pynnd_amd.h``; this module is host
-plumbing (torch tensors as device buffers, ``torch.distributed`` -- backend "nccl" is RCCL on ROCm).
+The device-side halves are C-ABI entry points of ``include/pynnd_amd.h``; they are stream-ordered and the handle runs
+on this module's torch stream (``nnd_set_stream``), so kernels and collectives need no host synchronisation between
+them: the host waits only where it needs a number (record counts, the update count).  This module is host plumbing
+(torch tensors as device buffers, ``torch.distributed`` -- backend "nccl" is RCCL on ROCm).
 ``ThreadComm`` runs the same code with G ranks as threads of one process on one GPU (tests).
 """
 import threading
@@ -78,16 +85,23 @@ class TorchDistComm:
         self.dist.all_gather(out, pad.contiguous(), group=self.group)
         return [o[:s] for o, s in zip(out, sizes)]
 
-    def all_to_all_v(self, send):
-        """send[s] goes to rank s (first-dimension sizes arbitrary); returns the list received."""
+    def all_to_all_v(self, send, rcounts=None, return_counts=False):
+        """send[s] goes to rank s (first-dimension sizes arbitrary); returns the list received.  ``rcounts``: the
+        receive counts when they are known already (a second array with the same segmentation): no count exchange."""
         if self._host_staged() and send[0].is_cuda:
             dev0 = send[0].device
-            return [g.to(dev0) for g in self.all_to_all_v([t.cpu() for t in send])]
+            out = self.all_to_all_v([t.cpu() for t in send], rcounts, True)
+            recv = [g.to(dev0) for g in out[0]]
+            return (recv, out[1]) if return_counts else recv
         dev = send[0].device
-        counts = torch.tensor([t.shape[0] for t in send], dtype=torch.int64, device=dev)
-        rcounts = torch.empty_like(counts)
-        self.dist.all_to_all_single(rcounts, counts, group=self.group)
-        rc = [int(c) for c in rcounts.tolist()]
+        sc = [int(t.shape[0]) for t in send]
+        if rcounts is None:
+            counts = torch.tensor(sc, dtype=torch.int64, device=dev)
+            rc_t = torch.empty_like(counts)
+            self.dist.all_to_all_single(rc_t, counts, group=self.group)
+            rc = [int(c) for c in rc_t.tolist()]
+        else:
+            rc = [int(c) for c in rcounts]
         tail = tuple(send[0].shape[1:])
         recv = [torch.empty((c,) + tail, dtype=send[0].dtype, device=dev) for c in rc]
         if self.dist.get_backend(self.group) == "gloo":  # gloo has no all_to_all for lists on every build: pairwise
@@ -103,12 +117,11 @@ class TorchDistComm:
             for op in ops:
                 op.wait()
         else:  # nccl (= RCCL): one all_to_all_single with split sizes, the canonical all-to-all-v
-            sc = [int(c) for c in counts.tolist()]
             inp = torch.cat([t.reshape((t.shape[0],) + tail) for t in send], dim=0).contiguous()
             out = torch.empty((sum(rc),) + tail, dtype=send[0].dtype, device=dev)
             self.dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
             recv = list(torch.split(out, rc, dim=0))
-        return recv
+        return (recv, rc) if return_counts else recv
 
     def all_reduce_sum(self, value):
         t = torch.tensor([int(value)], dtype=torch.int64, device=self._dev())
@@ -145,22 +158,28 @@ class ThreadComm:
         sh = cls._Shared(world)
         return [cls(sh, r) for r in range(world)]
 
-    def _exchange(self, obj):
+    def _exchange(self, obj, take):
+        """Every rank posts ``obj``; ``take(all_posted)`` copies what this rank needs.  The ranks run on different
+        streams of one GPU: a rank's writes are complete before it posts, its copies before the buffers are released."""
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
         self.s.slots[self.rank] = obj
         self.s.barrier.wait()
-        got = list(self.s.slots)
+        got = take(list(self.s.slots))
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
         self.s.barrier.wait()
         return got
 
     def all_gather_v(self, t):
-        return [g.clone() for g in self._exchange(t)]
+        return self._exchange(t, lambda posted: [g.clone() for g in posted])
 
-    def all_to_all_v(self, send):
-        allsend = self._exchange(send)
-        return [allsend[src][self.rank].clone() for src in range(self.world)]
+    def all_to_all_v(self, send, rcounts=None, return_counts=False):
+        recv = self._exchange(send, lambda posted: [posted[src][self.rank].clone() for src in range(self.world)])
+        return (recv, [int(t.shape[0]) for t in recv]) if return_counts else recv
 
     def all_reduce_sum(self, value):
-        return int(sum(self._exchange(int(value))))
+        return int(sum(self._exchange(int(value), lambda posted: list(posted))))
 
     def barrier(self):
         self.s.barrier.wait()
@@ -176,6 +195,8 @@ def _sync():
 class ShardedBuilder:
     """Persistent state of one rank (HBM allocations survive across builds; bench.py times ``build``)."""
 
+    PROPOSAL_SLOTS_SHIPPED = 24  # region capacity per destination row (of 64 slots); what does not fit travels next iteration
+
     def __init__(self, comm, shard_sizes, dim, metric="euclidean", n_neighbors=15, n_trees=8, leaf_size=None,
                  max_candidates=None, n_iters=None, delta=0.001, seed=0, max_rptree_depth=200, device_index=None):
         self.comm = comm
@@ -183,7 +204,8 @@ class ShardedBuilder:
         sizes = [int(v) for v in shard_sizes]
         assert len(sizes) == world
         self.n_total = sum(sizes)
-        bounds = np.concatenate([[0], np.cumsum(sizes)])
+        bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.bounds = bounds
         self.ranges = [(int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
         self.lo, self.hi = self.ranges[rank]
         self.k = int(n_neighbors)
@@ -209,35 +231,69 @@ class ShardedBuilder:
         self.b = _capi.Builder(self.n_total, self.d, metric_code, self.k, self.local_trees, leaf_size, max_rptree_depth, mc,
                                self.n_iters, delta, rng_state, tree_states[min(t0, max(self.n_trees, 1) - 1)],
                                device=device_index)
-        self.b.set_owned_range(self.lo, self.hi)
+        # the handle runs on THIS builder's torch stream: its kernels and the collectives are ordered by the stream
+        with torch.cuda.device(self.dev):
+            self.stream = torch.cuda.Stream(device=self.dev)
+        self.b.set_stream(self.stream.cuda_stream)
+        self.b.set_shard_bounds(bounds, rank)
         self.ks = self.b.row_stride()
-        dev, ks = self.dev, self.ks
-        self.own_e = torch.empty(((self.hi - self.lo) * ks,), dtype=torch.int32, device=dev)
-        self.own_th = torch.empty((self.hi - self.lo,), dtype=torch.float32, device=dev)
-        self.cnt = torch.zeros((self.n_total,), dtype=torch.int32, device=dev)
-        self.offsets = torch.zeros((self.n_total + 1,), dtype=torch.int64, device=dev)
-        self.edge_index = torch.tensor([v for ab in self.ranges for v in ab], device=dev)
-        self.out_idx = torch.empty((self.hi - self.lo, self.k), dtype=torch.int32, device=dev)
-        self.out_dist = torch.empty((self.hi - self.lo, self.k), dtype=torch.float32, device=dev)
+        dev = self.dev
+        n_own = self.hi - self.lo
+        self.own_th = torch.empty((n_own,), dtype=torch.float32, device=dev)
+        self.out_idx = torch.empty((n_own, self.k), dtype=torch.int32, device=dev)
+        self.out_dist = torch.empty((n_own, self.k), dtype=torch.float32, device=dev)
+        # record regions, one per destination rank: reverse offers (at most every owned edge goes to one rank) and proposals
+        self.cap_o = max(1, n_own * self.k)
+        self.cap_p = max(64, max(z - a for a, z in self.ranges) * self.PROPOSAL_SLOTS_SHIPPED)
+        self.off_t = torch.empty((world * self.cap_o,), dtype=torch.int32, device=dev)
+        self.off_k = torch.empty((world * self.cap_o,), dtype=torch.int64, device=dev)
+        self.prop_t = torch.empty((world * self.cap_p,), dtype=torch.int32, device=dev)
+        self.prop_k = torch.empty((world * self.cap_p,), dtype=torch.int64, device=dev)
+        self.counts = torch.zeros((world,), dtype=torch.int64, device=dev)
+        self._empty_t = torch.empty((0,), dtype=torch.int32, device=dev)
+        self._empty_k = torch.empty((0,), dtype=torch.int64, device=dev)
 
     def close(self):
         self.b.close()
 
     def build(self, x_local, verbose=False):
         """One complete sharded build.  Returns (idx (n_local,k) GLOBAL ids, alt-space dist, info)."""
+        with torch.cuda.device(self.dev):
+            self.stream.wait_stream(torch.cuda.current_stream(self.dev))  # x_local was produced on the caller's stream
+            with torch.cuda.stream(self.stream):
+                out = self._build(x_local, verbose)
+                self.stream.synchronize()
+        return out
+
+    def _exchange_records(self, buf_t, buf_k, cap, counts):
+        """all-to-all-v of the per-destination regions [d*cap, d*cap + counts[d]); returns the records received from the
+        OTHER ranks as (targets, keys, n)."""
+        comm, rank = self.comm, self.comm.rank
+        send_t = [buf_t[d * cap: d * cap + counts[d]] for d in range(comm.world)]
+        send_k = [buf_k[d * cap: d * cap + counts[d]] for d in range(comm.world)]
+        recv_t, rc = comm.all_to_all_v(send_t, return_counts=True)
+        recv_k = comm.all_to_all_v(send_k, rcounts=rc)
+        parts_t = [t for i, t in enumerate(recv_t) if i != rank and t.numel()]
+        parts_k = [t for i, t in enumerate(recv_k) if i != rank and t.numel()]
+        if not parts_t:
+            return self._empty_t, self._empty_k, 0
+        rt = torch.cat(parts_t) if len(parts_t) > 1 else parts_t[0].contiguous()
+        rk = torch.cat(parts_k) if len(parts_k) > 1 else parts_k[0].contiguous()
+        return rt, rk, int(rt.numel())
+
+    def _build(self, x_local, verbose):
         comm, b, dev, ks, k = self.comm, self.b, self.dev, self.ks, self.k
         rank, world = comm.rank, comm.world
         lo, hi, ranges, n_total = self.lo, self.hi, self.ranges, self.n_total
         info = {"n_total": n_total, "range": (lo, hi), "local_trees": self.local_trees, "iters": 0, "c": [],
-                "exchanged_records": []}
+                "exchanged_records": [], "offer_records": [], "proposal_records": []}
         # ---- replicate the point set once (all-gather over xGMI): candidate vectors never travel again ----
         if world > 1:
             x_full = torch.cat(comm.all_gather_v(x_local.contiguous()), dim=0).contiguous()
         else:
             x_full = x_local.contiguous()
         assert x_full.shape == (n_total, self.d)
-        _sync()
-        b.set_data_device(x_full.data_ptr(), keepalive=x_full)  # prep kernel + k-list reset
+        b.set_data_device(x_full.data_ptr(), keepalive=x_full)  # prep kernel + k-list reset (stream-ordered)
 
         # ---- forest split by tree: every rank seeds ALL rows from its own trees, owners merge the partial lists ----
         if self.local_trees > 0:
@@ -251,62 +307,58 @@ class ShardedBuilder:
                 b.export_graph_rows(a, z, e.data_ptr(), dd.data_ptr())
                 send_e.append(e)
                 send_d.append(dd)
-            recv_e = comm.all_to_all_v(send_e)
-            recv_d = comm.all_to_all_v(send_d)
-            _sync()
+            recv_e, rc = comm.all_to_all_v(send_e, return_counts=True)
+            recv_d = comm.all_to_all_v(send_d, rcounts=rc)
             for src in range(world):
                 if src != rank and recv_e[src].numel():
                     b.merge_graph_rows(lo, hi, recv_e[src].data_ptr(), recv_d[src].data_ptr())
             del send_e, send_d, recv_e, recv_d
         b.init_random()  # owned rows that are still not full (pynndescent_.py:188-203)
 
+        keep = None
         for it in range(self.n_iters):
-            # (1) k-list all-gather: neighbour words (ids + new flags: dedup and reverse edges) and the per-row
-            #     worst distances (thresholds) of remote rows -- 4*ks + 4 bytes per row, not the distance rows
+            n_off = n_prop = 0
+            # (1) thresholds of the remote rows: 4 bytes per row
             if world > 1:
-                b.export_graph_rows(lo, hi, self.own_e.data_ptr(), None)
-                b.export_thresholds(lo, hi, self.own_th.data_ptr())
-                all_e = comm.all_gather_v(self.own_e)
+                b.export_thresholds_async(lo, hi, self.own_th.data_ptr())
                 all_t = comm.all_gather_v(self.own_th)
-                _sync()
                 for src, (a, z) in enumerate(ranges):
                     if src != rank and z > a:
-                        b.import_graph_rows(a, z, all_e[src].data_ptr(), None)
-                        b.import_thresholds(a, z, all_t[src].data_ptr())
-                del all_e, all_t
-            # (2) local sampling and join of the owned vertices
-            b.descent_sample()
-            b.descent_join()
-            # (3) proposals for vertices owned elsewhere -> (key, target) records -> owners
-            n_sent = 0
+                        b.import_thresholds_async(a, z, all_t[src].data_ptr())
+            # (2) sampling: own rows only; offers to remote targets travel as records
+            b.sample_begin(self.cap_o, self.off_t.data_ptr(), self.off_k.data_ptr(), self.counts.data_ptr())
             if world > 1:
-                b.proposal_counts(self.cnt.data_ptr())
-                torch.cumsum(self.cnt, dim=0, out=self.offsets[1:])
-                edge = self.offsets[self.edge_index].tolist()
-                seg = [(int(edge[2 * r]), int(edge[2 * r + 1])) for r in range(world)]  # == segment_bounds(offsets, ranges)
-                total = int(edge[-1]) if ranges[-1][1] == n_total else int(self.offsets[-1].item())
-                keys = torch.empty((max(total, 1),), dtype=torch.int64, device=dev)
-                targets = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
-                _sync()
-                b.export_proposals(self.offsets.data_ptr(), keys.data_ptr(), targets.data_ptr())
-                recv_k = comm.all_to_all_v([keys[a:z] for (a, z) in seg])
-                recv_t = comm.all_to_all_v([targets[a:z] for (a, z) in seg])
-                rk = torch.cat([t for i, t in enumerate(recv_k) if i != rank])
-                rt = torch.cat([t for i, t in enumerate(recv_t) if i != rank])
-                _sync()
-                if rk.numel():
-                    b.import_proposals(rk.data_ptr(), rt.data_ptr(), rk.numel())
-                n_sent = total
-            # (4) owner-side merge, (5) global update count for the stop rule (pynndescent_.py:317)
+                cnt = [int(c) for c in self.counts.tolist()]  # host wait: the record counts
+                assert max(cnt) <= self.cap_o
+                rt, rk, n_in = self._exchange_records(self.off_t, self.off_k, self.cap_o, cnt)
+                n_off = sum(cnt)
+            else:
+                rt, rk, n_in = self._empty_t, self._empty_k, 0
+            b.sample_finish(rt.data_ptr(), rk.data_ptr(), n_in)
+            # (3) local join of the owned vertices
+            b.descent_join()
+            # (4) proposals for vertices owned elsewhere -> owners
+            if world > 1:
+                b.proposal_export(self.cap_p, self.prop_t.data_ptr(), self.prop_k.data_ptr(), self.counts.data_ptr())
+                cnt = [min(int(c), self.cap_p) for c in self.counts.tolist()]  # host wait
+                pt, pk, n_in = self._exchange_records(self.prop_t, self.prop_k, self.cap_p, cnt)
+                if n_in:
+                    b.import_proposals_async(pk.data_ptr(), pt.data_ptr(), n_in)
+                n_prop = sum(cnt)
+                keep = (all_t, rt, rk, pt, pk)  # alive until the merge below has drained the stream
+            # (5) owner-side merge (reads the counters: host wait), global update count for the stop rule (pynndescent_.py:317)
             c = comm.all_reduce_sum(b.descent_merge()) if world > 1 else b.descent_merge()
+            keep = None
             info["c"].append(c)
-            info["exchanged_records"].append(n_sent)
+            info["offer_records"].append(n_off)
+            info["proposal_records"].append(n_prop)
+            info["exchanged_records"].append(n_off + n_prop)
             info["iters"] = it + 1
             if verbose and rank == 0:
                 print("\t", it + 1, " / ", self.n_iters, " c =", c)
             if c <= self.delta * k * n_total:
                 break
-        _sync()
+        del keep
         b.finalize_device(self.out_idx.data_ptr(), self.out_dist.data_ptr())
         b.synchronize()
         info["stats"] = b.stats()

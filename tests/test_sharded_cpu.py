@@ -47,7 +47,11 @@ def _worker(rank, world, port, out):
         # all-to-all-v with ragged (and empty) segments: the proposal records
         send = [torch.arange(rank * 100 + dst * 10, rank * 100 + dst * 10 + (dst + rank) % 3, dtype=torch.int64)
                 for dst in range(world)]
-        recv = comm.all_to_all_v(send)
+        recv, rc = comm.all_to_all_v(send, return_counts=True)
+        ok = ok and rc == [(rank + src) % 3 for src in range(world)]
+        # a second array with the same segmentation reuses the counts (no second count exchange)
+        recv2 = comm.all_to_all_v([t.to(torch.int32) * 2 for t in send], rcounts=rc)
+        ok = ok and all(torch.equal(a.to(torch.int32) * 2, b) for a, b in zip(recv, recv2))
         for src in range(world):
             n = (rank + src) % 3
             want = torch.arange(src * 100 + rank * 10, src * 100 + rank * 10 + n, dtype=torch.int64)
