@@ -226,6 +226,35 @@ int32_t nnd_diversify_csr_host(nnd_handle_t h, const int32_t *indptr, const int3
 /* degree_prune_internal (pynndescent_.py:728-738): rows longer than max_degree keep entries <= sorted(row)[max_degree] */
 int32_t nnd_degree_prune_host(nnd_handle_t h, const int32_t *indptr, float *data, int64_t nnz, int32_t max_degree);
 
+/* ---- hub search tree of NNDescent.prepare() (reference rp_trees.py:714-1312 make_hub_tree and its splits,
+ * rp_trees.py:2926-3049 convert_tree_format) ----
+ * Built level-synchronously on the device from the ORIGINAL rows (nnd_set_data_*; the handle must have been created
+ * with n_trees >= 1: the builder borrows the forest's scan / scatter buffers) and the finished graph's in-degrees:
+ * rank_order = the point ids sorted by (-in-degree, id) (compute_global_degrees, rp_trees.py:714-744, is a bincount of
+ * the neighbour array; the order is host glue).  Angular splits when the handle's metric is NND_METRIC_ALT_COSINE.
+ * Result: the reference's FlatTree in pre-order numbering: hyperplanes (n_nodes, dim), offsets (n_nodes),
+ * children (n_nodes, 2) [internal: child node ids; leaf: (-leaf_start, -leaf_end) into indices], indices (n). */
+int32_t nnd_hub_tree_build(nnd_handle_t h, const int32_t *rank_order_host, int32_t leaf_size, int32_t max_depth,
+                           int64_t *n_nodes_out);
+int32_t nnd_hub_tree_fetch(nnd_handle_t h, float *hyperplanes, float *offsets, int32_t *children, int32_t *indices,
+                           int32_t *max_leaf_size);
+
+/* ---- batched queries against a prepared index (reference NNDescent.query, pynndescent_.py:2275-2379: the search
+ * closure of _init_search_function 1793-1883, select_side / search_flat_tree rp_trees.py:2662-2741, deheap_sort) ----
+ * The searcher owns device copies of what the reference's closure captures: the (reordered) raw data, the CSR search
+ * graph, the FlatTree of the search forest's first tree (n_nodes = 0: no tree, random starts only), min_distance and
+ * n_neighbors.  All pointers are HOST pointers.  One wave per query; k <= 64.  Output rows ascending in the
+ * alternative distance space, vertex numbers in the searcher's (reordered) numbering; unfilled slots (-1, +inf). */
+typedef struct nnd_searcher_s *nnd_searcher_t;
+int32_t nnd_searcher_create(nnd_searcher_t *out, int32_t device, int64_t n, int32_t dim, int32_t metric, const float *data,
+                            const int32_t *indptr, const int32_t *indices, int64_t nnz, const float *hyperplanes,
+                            const float *offsets, const int32_t *children, const int32_t *tree_indices, int64_t n_nodes,
+                            float min_distance, int32_t n_neighbors, const int64_t *search_rng_state /* 3 */);
+int32_t nnd_searcher_query(nnd_searcher_t s, const float *queries /* (nq, dim) */, int64_t nq, int32_t k, float epsilon,
+                           int32_t *out_idx /* (nq, k) */, float *out_dist /* (nq, k) */);
+int32_t nnd_searcher_destroy(nnd_searcher_t s);
+const char *nnd_searcher_last_error(nnd_searcher_t s /* NULL: the error of a failed create */);
+
 #ifdef __cplusplus
 }
 #endif

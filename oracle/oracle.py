@@ -119,6 +119,10 @@ def load(kind="strict"):
     lib.orc_diversify_csr_p.argtypes = [_i32p, _i32p, _f32p, C.c_int64, _f32p, C.c_int, C.c_int, _i64p, C.c_float]
     lib.orc_diversify_csr_degree_aware.argtypes = [_i32p, _i32p, _f32p, C.c_int64, _f32p, C.c_int, C.c_int, _i64p, C.c_int,
                                                    C.c_float, C.c_float]
+    lib.orc_make_hub_tree.argtypes = [_f32p, C.c_int64, C.c_int, _i32p, C.c_int, _i64p, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
+                                      C.POINTER(C.POINTER(C.c_int32)), _i32p, C.POINTER(C.c_int32)]
+    lib.orc_make_hub_tree.restype = C.c_int64
     _LIBS[kind] = lib
     return lib
 
@@ -386,3 +390,26 @@ def search_graph(data, indices, distances, metric, n_neighbors, pruning_degree_m
     if return_stages:
         return out, {"forward_rows": rows, "forward_dist": dd, "reverse_nnz": int(rev.nnz), "union_nnz": int(u.nnz)}
     return out
+
+
+# ----------------------------------------------------------------------------
+# hub search tree of NNDescent.prepare (reference rp_trees.py:714-1312 + convert_tree_format rp_trees.py:2926-3049)
+
+def make_hub_tree(data, neighbor_indices, rng_state, leaf_size=30, angular=False, max_depth=200, lib=None):
+    """Returns the FlatTree fields (hyperplanes (n_nodes, dim), offsets, children (n_nodes, 2), indices (n), leaf_size)."""
+    lib = lib or load()
+    x = np.ascontiguousarray(data, np.float32)
+    nb = np.ascontiguousarray(neighbor_indices, np.int32)
+    n, dim = x.shape
+    st = np.ascontiguousarray(rng_state, np.int64).copy()
+    ph, po, pc = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.POINTER(C.c_int32)()
+    indices = np.empty(n, np.int32)
+    ml = C.c_int32()
+    nn = lib.orc_make_hub_tree(x, n, dim, nb, nb.shape[1], st, int(leaf_size), int(bool(angular)), int(max_depth),
+                               C.byref(ph), C.byref(po), C.byref(pc), indices, C.byref(ml))
+    hyper = np.ctypeslib.as_array(ph, shape=(nn, dim)).copy()
+    offs = np.ctypeslib.as_array(po, shape=(nn,)).copy()
+    children = np.ctypeslib.as_array(pc, shape=(nn, 2)).copy()
+    for p_ in (ph, po, pc):
+        lib.orc_free(C.cast(p_, C.c_void_p))
+    return hyper, offs, children, indices, int(ml.value)

@@ -145,6 +145,14 @@ _SIGNATURES = [
     ("nnd_diversify_csr_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(NNDPruneOpts),
                                            C.c_void_p]),
     ("nnd_degree_prune_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    ("nnd_hub_tree_build", C.c_int32, [_H, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    ("nnd_hub_tree_fetch", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    ("nnd_searcher_create", C.c_int32, [C.POINTER(_H), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int32,
+                                        C.c_void_p]),
+    ("nnd_searcher_query", C.c_int32, [_H, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    ("nnd_searcher_destroy", C.c_int32, [_H]),
+    ("nnd_searcher_last_error", C.c_char_p, [_H]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -411,9 +419,70 @@ class Builder:
         self._check(self.lib.nnd_degree_prune_host(self._h, _ptr(indptr), _ptr(data), data.shape[0], int(max_degree)))
         return data
 
+    def hub_tree(self, rank_order, leaf_size, max_depth):
+        """make_hub_tree + convert_tree_format on the device; returns (hyperplanes, offsets, children, indices, leaf_size)."""
+        ro = np.ascontiguousarray(rank_order, np.int32)
+        assert ro.shape == (self.n,)
+        nn = C.c_int64()
+        self._check(self.lib.nnd_hub_tree_build(self._h, _ptr(ro), int(leaf_size), int(max_depth), C.byref(nn)))
+        hyper = np.empty((nn.value, self.dim), np.float32)
+        offs = np.empty((nn.value,), np.float32)
+        children = np.empty((nn.value, 2), np.int32)
+        indices = np.empty((self.n,), np.int32)
+        ml = C.c_int32()
+        self._check(self.lib.nnd_hub_tree_fetch(self._h, _ptr(hyper), _ptr(offs), _ptr(children), _ptr(indices), C.byref(ml)))
+        return hyper, offs, children, indices, int(ml.value)
+
     def pairwise_gram(self, rows_a, rows_b):
         a = np.ascontiguousarray(rows_a, np.int32)
         b = np.ascontiguousarray(rows_b, np.int32)
         out = np.empty((a.shape[0], b.shape[0]), np.float32)
         self._check(self.lib.nnd_pairwise_gram(self._h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out)))
         return out
+
+
+class Searcher:
+    """Thin wrapper over an ``nnd_searcher_t``: device copies of a prepared index, batched queries (one wave per query)."""
+
+    def __init__(self, data, search_graph, tree, metric, min_distance, n_neighbors, search_rng_state, device=0):
+        self.lib = load_library()
+        data = np.ascontiguousarray(data, np.float32)
+        self.n, self.dim = data.shape
+        indptr = np.ascontiguousarray(search_graph.indptr, np.int32)
+        indices = np.ascontiguousarray(search_graph.indices, np.int32)
+        if tree is not None:
+            hyper = np.ascontiguousarray(tree.hyperplanes, np.float32)
+            offs = np.ascontiguousarray(tree.offsets, np.float32)
+            children = np.ascontiguousarray(tree.children, np.int32)
+            tidx = np.ascontiguousarray(tree.indices, np.int32)
+            n_nodes = hyper.shape[0]
+        else:
+            hyper = offs = children = tidx = None
+            n_nodes = 0
+        rng = np.ascontiguousarray(search_rng_state, np.int64)
+        self._h = _H()
+        rc = self.lib.nnd_searcher_create(C.byref(self._h), int(device), self.n, self.dim, int(metric), _ptr(data), _ptr(indptr),
+                                          _ptr(indices), int(indices.shape[0]), _ptr(hyper), _ptr(offs), _ptr(children), _ptr(tidx),
+                                          int(n_nodes), float(min_distance), int(n_neighbors), _ptr(rng))
+        if rc != 0:
+            raise NNDError(self.lib.nnd_searcher_last_error(None).decode())
+
+    def query(self, queries, k, epsilon):
+        q = np.ascontiguousarray(queries, np.float32)
+        assert q.ndim == 2 and q.shape[1] == self.dim
+        idx = np.empty((q.shape[0], k), np.int32)
+        dist = np.empty((q.shape[0], k), np.float32)
+        if self.lib.nnd_searcher_query(self._h, _ptr(q), q.shape[0], int(k), float(epsilon), _ptr(idx), _ptr(dist)) != 0:
+            raise NNDError(self.lib.nnd_searcher_last_error(self._h).decode())
+        return idx, dist
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.nnd_searcher_destroy(self._h)
+            self._h = _H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

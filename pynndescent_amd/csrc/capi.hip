@@ -78,6 +78,7 @@ static void free_all(nnd_ctx *ctx) {
     for (hipEvent_t e : ctx->tev) if (e) (void)hipEventDestroy(e);
     ctx->tev.clear();
     F(ctx->shard_bounds); F(ctx->shard_cursors);
+    nnd_hub_tree_free(ctx);
     if (ctx->stream && ctx->stream_owned) (void)hipStreamDestroy(ctx->stream);
 }
 
@@ -873,4 +874,20 @@ extern "C" int32_t nnd_degree_prune_host(nnd_handle_t ctx, const int32_t *indptr
     API_HIP(hipMemcpyAsync(data, dd, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
     API_HIP(nnd_sync_spin(ctx));
     return 0;
+}
+
+// ---- hub search tree of NNDescent.prepare() (reference rp_trees.py:714-1312, 2926-3049; host glue: search_tree.py) ----
+extern "C" int32_t nnd_hub_tree_build(nnd_handle_t ctx, const int32_t *rank_order /* host (n): ids by (-in-degree, id) */,
+                                      int32_t leaf_size, int32_t max_depth, int64_t *n_nodes_out) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    if (!rank_order) { ctx->set_error("nnd_hub_tree_build: null rank order"); return 1; }
+    if (nnd_hub_tree_build_impl(ctx, rank_order, leaf_size, max_depth, ctx->p.metric == NND_METRIC_ALT_COSINE)) return 1;
+    if (n_nodes_out) *n_nodes_out = nnd_hub_tree_nodes(ctx);
+    return 0;
+}
+extern "C" int32_t nnd_hub_tree_fetch(nnd_handle_t ctx, float *hyperplanes, float *offsets, int32_t *children, int32_t *indices,
+                                      int32_t *max_leaf_size) {
+    ENTER(ctx);
+    return nnd_hub_tree_fetch_impl(ctx, hyperplanes, offsets, children, indices, max_leaf_size);
 }

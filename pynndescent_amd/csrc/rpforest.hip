@@ -1339,6 +1339,23 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     return 0;
 }
 
+// One stable partition step for another builder (hubtree.hip): positions with pos >= 0 and side == 0 move to the front of
+// their segment, the others behind them; pos_out = seg_child[2 * segment + side] (or -1 for positions already final).
+void nnd_forest_stable_partition(nnd_ctx *ctx, int64_t n, const int32_t *ord, const int32_t *pos, uint8_t *side, const int32_t *seg_start,
+                                 const int32_t *seg_len, int n_segs, int32_t *nleft, const int32_t *seg_child, int32_t *ord_out,
+                                 int32_t *pos_out) {
+    int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
+    const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, 0, pos, side, n, ctx->scan_blk, (const int32_t *)nullptr,
+                       (const uint8_t *)nullptr, n);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->scan_blk, nb, scan_total);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, 0, pos, side, n, ctx->scan_blk, ctx->scan_out);
+    hipLaunchKernelGGL(k_seg_count, dim3((unsigned)((n_segs + 255) / 256)), dim3(256), 0, ctx->stream, seg_start, seg_len, n_segs,
+                       ctx->scan_out, scan_total, n, nleft);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ord, pos, side, ctx->scan_out, seg_start,
+                       nleft, seg_child, n, n, ord_out, pos_out, (int32_t *)nullptr);
+}
+
 // host copies of the leaf table, fetched on demand (work-list cutting for over-long leaves)
 int nnd_fetch_leaf_tables(nnd_ctx *ctx) {
     if (ctx->h_leaf_valid) return 0;

@@ -29,7 +29,8 @@ enum {
 // would serialise a million-wave launch.  nnd_read_counters sums the stripes.
 #define NND_CNT_STRIPES 512
 
-struct nnd_tlog { int ev; float *dst; bool add; };  // a pending stage timer: events ev, ev+1 -> *dst
+struct nnd_tlog { int ev; float *dst; bool add; };
+struct nnd_hub_result;  // hubtree.hip: the last hub search tree built on this handle (FlatTree arrays, host side)  // a pending stage timer: events ev, ev+1 -> *dst
 
 struct nnd_handle_s {
     nnd_params p{};
@@ -123,6 +124,8 @@ struct nnd_handle_s {
     bool forest_built = false;
     bool all_new = false;  // every edge of the graph still carries the "new" flag (true from reset until the first sampling pass)
 
+    nnd_hub_result *hub = nullptr;
+
     long long *counters = nullptr;      // device NND_CNT_STRIPES x CNT_COUNT (stripe 0 doubles as scratch for single-block kernels)
     long long h_counters[CNT_COUNT] = {0};
     long long *counters_sum = nullptr;        // (CNT_COUNT) device: stripes summed by k_counters_reduce
@@ -166,6 +169,13 @@ int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev, c
 int nnd_launch_diversify_csr(nnd_ctx *ctx, const int32_t *indptr_dev, const int32_t *indices_dev, float *data_dev,
                              int *too_long_dev, const nnd_prune_opts *opts, const int32_t *degree_dev);
 int nnd_launch_degree_prune(nnd_ctx *ctx, const int32_t *indptr_dev, float *data_dev, int max_degree);
+void nnd_forest_stable_partition(nnd_ctx *ctx, int64_t n, const int32_t *ord, const int32_t *pos, uint8_t *side, const int32_t *seg_start,
+                                 const int32_t *seg_len, int n_segs, int32_t *nleft, const int32_t *seg_child, int32_t *ord_out,
+                                 int32_t *pos_out);
+int nnd_hub_tree_build_impl(nnd_ctx *ctx, const int32_t *rank_order_host, int leaf_size, int max_depth, int angular);
+int nnd_hub_tree_fetch_impl(nnd_ctx *ctx, float *hyperplanes, float *offsets, int32_t *children, int32_t *indices, int32_t *max_leaf);
+int64_t nnd_hub_tree_nodes(const nnd_ctx *ctx);
+void nnd_hub_tree_free(nnd_ctx *ctx);
 int nnd_read_counters(nnd_ctx *ctx);  // device -> ctx->h_counters (synchronises the stream)
 int nnd_zero_counters(nnd_ctx *ctx);
 

@@ -257,16 +257,18 @@ class NNDescent:
 
     def build_search_graph(self):
         """The pruning pass of ``_init_search_graph`` (pynndescent_.py:1451-1611: diversify, reverse diversify,
-        degree prune) on the GPU; sets and returns ``_search_graph`` (CSR uint8, NOT yet reordered by a search
-        tree: hub tree / reordering / query stay with the reference)."""
+        degree prune) on the GPU alone; returns the CSR uint8 graph in the ORIGINAL vertex numbering (``prepare()``
+        runs the same pass and then re-indexes everything by the hub search tree's leaf order)."""
         from .search_graph import build_search_graph
 
-        self._search_graph = build_search_graph(
+        if hasattr(self, "_vertex_order"):
+            raise RuntimeError("the index is prepared already: its search graph is index._search_graph (in leaf order)")
+        self._pruned_graph = build_search_graph(
             self._raw_data, self._neighbor_graph[0], self._neighbor_graph[1], self.metric, self.n_neighbors,
             self.prune_degree_multiplier, self.diversify_prob, self.diversify_method,
             degree_prune_aggressiveness=self.degree_prune_aggressiveness,
             seed=int(self.rng_state[0]) & 0xFFFFFFFF, device=self.device)
-        return self._search_graph
+        return self._pruned_graph
 
     # attributes of the reference class that prepare() / query() / update() read (pynndescent_.py:1014-1113)
     _HANDOVER = (
@@ -287,10 +289,22 @@ class NNDescent:
 
         ref = object.__new__(pynndescent.NNDescent)
         for name in self._HANDOVER:
-            setattr(ref, name, getattr(self, name))
-        ref._neighbor_graph = (self._neighbor_graph[0].copy(), self._neighbor_graph[1].copy())
+            if hasattr(self, name):
+                setattr(ref, name, getattr(self, name))
+        if hasattr(self, "_neighbor_graph"):
+            ref._neighbor_graph = (self._neighbor_graph[0].copy(), self._neighbor_graph[1].copy())
         ref._distance_correction = None
         ref._set_distance_func()  # pynndescent_.py:1271-1298: numba distance, correction, proxy flags
+        if hasattr(self, "_search_graph"):  # prepared on the GPU: the reference's prepare() has nothing left to build
+            from pynndescent.rp_trees import FlatTree as RefFlatTree
+
+            ref._search_graph = self._search_graph.copy()
+            ref._search_forest = [RefFlatTree(*t) for t in self._search_forest]
+            ref._vertex_order = np.asarray(self._vertex_order).copy()
+            ref._min_distance = self._min_distance
+            ref._visited = np.zeros_like(self._visited)
+            if hasattr(ref, "_rp_forest"):
+                del ref._rp_forest
         return ref
 
     @classmethod
@@ -349,17 +363,100 @@ class NNDescent:
         self._neighbor_graph = (indices, distances)
         return self
 
-    def _out_of_scope(self, what):
-        raise NotImplementedError(
-            "%s is out of scope for pynndescent_amd (build path only; SURVEY.md section 8f). "
-            "Use index.to_reference() to continue with pynndescent.NNDescent on this graph without rebuilding." % what
-        )
+    # ------------------------------------------------------------------------------------------------ prepare / query
+    def _init_search_graph(self):
+        """``NNDescent._init_search_graph`` (pynndescent_.py:1333-1662) on the GPU: the hub search tree built from the
+        data and the finished graph (csrc/hubtree.hip), the pruning pass (csrc/prune.hip), then data, graph and tree
+        re-indexed by the tree's leaf order (pynndescent_.py:1629-1651)."""
+        from .search_graph import build_search_graph
+        from .search_tree import make_hub_tree, reorder_by_tree
+
+        search_leaf_size = (self.search_tree_leaf_size if self.search_tree_leaf_size is not None
+                            else (self.leaf_size if self.leaf_size is not None else 30))  # pynndescent_.py:1341-1345
+        search_tree_depth = (self.max_search_tree_depth if self.max_search_tree_depth is not None
+                             else self.max_rptree_depth)                                   # pynndescent_.py:1346-1350
+        if not hasattr(self, "_search_forest"):
+            if getattr(self, "_rp_forest", None) is None and not self.tree_init:
+                self._search_forest = []  # pynndescent_.py:1377-1378: no tree, queries start from random vertices
+            else:
+                if self.verbose:
+                    print(ts(), "Building hub-based search tree")
+                self._search_forest = [make_hub_tree(self._raw_data, self._neighbor_graph[0], self.metric, search_leaf_size,
+                                                     search_tree_depth, device=self.device,
+                                                     seed=int(self.rng_state[0]) & 0x7FFFFFFF)]
+                self._rp_forest = None  # the reference deletes it here (pynndescent_.py:1444)
+        if self.verbose:
+            print(ts(), "Diversifying and pruning the search graph")
+        graph, stages = build_search_graph(
+            self._raw_data, self._neighbor_graph[0], self._neighbor_graph[1], self.metric, self.n_neighbors,
+            self.prune_degree_multiplier, self.diversify_prob, self.diversify_method,
+            degree_prune_aggressiveness=self.degree_prune_aggressiveness, seed=int(self.rng_state[0]) & 0xFFFFFFFF,
+            device=self.device, return_stages=True)
+        self._min_distance = np.float32(stages["min_distance"])                     # pynndescent_.py:1539
+        self._visited = np.zeros((self._raw_data.shape[0] // 8) + 1, dtype=np.uint8, order="C")  # pynndescent_.py:1624-1626
+        if self.verbose:
+            print(ts(), "Resorting data and graph based on tree order")
+        if self._search_forest:
+            graph, data, self._vertex_order, tree = reorder_by_tree(graph, self._raw_data, self._search_forest[0])
+            self._raw_data = data
+            self._search_forest = [tree] + list(self._search_forest[1: self.n_search_trees])
+        else:
+            self._vertex_order = np.arange(self._raw_data.shape[0])
+        self._search_graph = graph
+        self._searcher = None
+        if self.compressed:  # pynndescent_.py:1653-1658
+            if hasattr(self, "_rp_forest"):
+                del self._rp_forest
+            del self._neighbor_graph
 
     def prepare(self):
-        self._out_of_scope("NNDescent.prepare (pynndescent_.py:2174)")
+        """``NNDescent.prepare`` (pynndescent_.py:2174-2273): build everything a query needs."""
+        if self.quantization is not None:
+            raise NotImplementedError("quantized search (quantization=%r) is out of scope for pynndescent_amd; use "
+                                      "index.to_reference()" % (self.quantization,))
+        if not hasattr(self, "_search_graph"):
+            self._init_search_graph()
+        if getattr(self, "_searcher", None) is None:
+            tree = self._search_forest[0] if self._search_forest else None
+            self._searcher = _capi.Searcher(self._raw_data, self._search_graph, tree, _METRIC_CODES[self.metric],
+                                            self._min_distance, self.n_neighbors, self.search_rng_state, device=self.device)
 
-    def query(self, query_data, k=10, epsilon=0.1):
-        self._out_of_scope("NNDescent.query (pynndescent_.py:2275)")
+    def query(self, query_data, k=10, epsilon=0.1, proxy_beam_size=4):
+        """``NNDescent.query`` (pynndescent_.py:2275-2379) on the GPU: one wave per query (csrc/query.hip).
+        Returns (indices (n_queries, k) in the ORIGINAL numbering, true distances (n_queries, k))."""
+        if k > 64:
+            raise NotImplementedError("pynndescent_amd answers queries with k <= 64; use index.to_reference() for k = %d" % k)
+        if not hasattr(self, "_search_graph") or getattr(self, "_searcher", None) is None:
+            self.prepare()
+        query_data = np.asarray(query_data).astype(np.float32, order="C")  # pynndescent_.py:2316
+        if query_data.ndim != 2 or query_data.shape[1] != self._raw_data.shape[1]:
+            raise ValueError("query_data must have shape (n_queries, %d)" % self._raw_data.shape[1])
+        indices, dists = self._searcher.query(query_data, k, epsilon)
+        found = indices >= 0
+        indices = np.where(found, self._vertex_order[np.where(found, indices, 0)], -1).astype(np.int32)  # pynndescent_.py:2373
+        if self._distance_correction is not None:  # pynndescent_.py:2375-2376
+            dists = self._distance_correction(dists)
+        return indices, dists
+
+    # ------------------------------------------------------------------------------------------------ pickling
+    def __getstate__(self):
+        """pynndescent_.py:1306-1320: a pickled index is a PREPARED index; device handles and the build forest stay behind."""
+        if not hasattr(self, "_search_graph"):
+            self._init_search_graph()
+        state = self.__dict__.copy()
+        state.pop("_rp_forest", None)
+        state.pop("_searcher", None)
+        state["_search_forest"] = tuple(tuple(t) for t in self._search_forest)  # rp_trees.py:3060-3069 denumbaify_tree
+        return state
+
+    def __setstate__(self, d):
+        """pynndescent_.py:1322-1331: rebuild what cannot be pickled (here: the device copy, lazily on the first query)."""
+        from .search_tree import FlatTree
+
+        self.__dict__ = d
+        self._distance_correction = _DISTANCE_CORRECTIONS[self.metric]
+        self._search_forest = [FlatTree(*t) for t in d["_search_forest"]]  # rp_trees.py:3072-3081 renumbaify_tree
+        self._searcher = None
 
     def update(self, xs_fresh=None, xs_updated=None, updated_indices=None):
         """``pynndescent.NNDescent.update`` (pynndescent_.py:2381-2553) on the GPU: fresh rows are appended, updated
@@ -394,8 +491,11 @@ class NNDescent:
         else:
             xs_fresh = check_array(xs_fresh, dtype=self._input_dtype, order="C")
 
-        # data and graph invalidation (pynndescent_.py:2476-2493), vectorised
+        # data and graph invalidation (pynndescent_.py:2461-2493), vectorised; a prepared index keeps its rows in the
+        # search tree's leaf order: back to the original order first (pynndescent_.py:2462-2465, 2476)
         raw = np.array(self._raw_data, copy=True)
+        if hasattr(self, "_vertex_order"):
+            raw = raw[np.argsort(self._vertex_order), :]
         for x_updated, i_fresh in zip(xs_updated, updated_indices):
             raw[i_fresh] = x_updated
         n_old = raw.shape[0]
@@ -450,8 +550,10 @@ class NNDescent:
             builder.close()
         self._raw_data = raw
         if hasattr(self, "_search_graph"):  # pynndescent_.py:2538-2553: the derived structures are rebuilt
-            del self._search_graph
-            self.build_search_graph()
+            for name in ("_search_graph", "_search_forest", "_vertex_order", "_searcher"):
+                if hasattr(self, name):
+                    delattr(self, name)
+            self.prepare()
 
 
 def _check_supported_sizes(n_neighbors, max_candidates, init_graph):

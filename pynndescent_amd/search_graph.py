@@ -74,6 +74,7 @@ def build_search_graph(data, indices, distances, metric="euclidean", n_neighbors
         indptr = np.concatenate([[0], np.cumsum(keep.sum(1))]).astype(np.int32)
         f_indices, f_data = rows[keep].astype(np.int32), dd[keep].astype(np.float32)
         forward_nnz = int(f_data.shape[0])
+        min_distance = float(f_data.min()) if forward_nnz else 0.0  # self._min_distance (pynndescent_.py:1539)
         # "Reverse graph" (1549-1587): the forward rows again (shared arrays, see the module docstring)
         if aware:  # max_degree = n_neighbors (1567)
             rdata = b.diversify_csr(indptr, f_indices, f_data, degree=compute_degrees_csr(indptr, f_indices),
@@ -101,5 +102,6 @@ def build_search_graph(data, indices, distances, metric="euclidean", n_neighbors
         b.close()
     if return_stages:
         return graph, {"forward_rows": rows, "forward_dist": dd, "nnz_pre_diversify": nnz_pre, "forward_nnz": forward_nnz,
-                       "reverse_nnz": int(rev.nnz), "union_nnz": nnz_pre_prune, "final_nnz": int(graph.nnz)}
+                       "reverse_nnz": int(rev.nnz), "union_nnz": nnz_pre_prune, "final_nnz": int(graph.nnz),
+                       "min_distance": min_distance}
     return graph

@@ -464,6 +464,43 @@ def gen_search_graph_modes(ref):
     save("search_graph_modes", **out)
 
 
+def gen_hub_tree(ref):
+    """The graph-informed search tree of NNDescent.prepare(): the reference's own make_hub_tree + convert_tree_format
+    (rp_trees.py:1233-1312, 3019-3049) on a reference-built graph, and the whole prepared state of the class
+    (vertex order, reordered search graph) for the reordering step (pynndescent_.py:1629-1651)."""
+    import numba
+    from pynndescent import rp_trees as R
+
+    numba.set_num_threads(1)
+    out = {}
+    for metric, seed in (("euclidean", 61), ("cosine", 62)):
+        x = clustered(2500, 16, 5, 20, seed=seed)
+        index = ref.NNDescent(x, metric=metric, n_neighbors=15, random_state=np.random.RandomState(9))
+        idx, dst = (np.asarray(a).copy() for a in index._neighbor_graph)
+        rng = np.asarray(index.rng_state, np.int64).copy()
+        tree = R.make_hub_tree(x, idx, rng.copy(), leaf_size=30, angular=(metric == "cosine"), max_depth=200)
+        flat = R.convert_tree_format(tree, x.shape[0], x.shape[1])
+        index.prepare()
+        sg = index._search_graph.tocsr()
+        sg.sort_indices()
+        print("hub tree", metric, "nodes", flat.hyperplanes.shape[0], "leaf_size", flat.leaf_size, "search graph nnz", sg.nnz)
+        out.update({metric + "_gen": np.array([2500, 16, 5, 20, seed]), metric + "_idx": idx.astype(np.int32),
+                    metric + "_dist": dst.astype(np.float32), metric + "_rng": rng,
+                    metric + "_hyperplanes": np.asarray(flat.hyperplanes, np.float32),
+                    metric + "_offsets": np.asarray(flat.offsets, np.float32),
+                    metric + "_children": np.asarray(flat.children, np.int32),
+                    metric + "_indices": np.asarray(flat.indices, np.int32), metric + "_leaf_size": np.int32(flat.leaf_size),
+                    metric + "_vertex_order": np.asarray(index._vertex_order, np.int32),
+                    metric + "_sg_indptr": sg.indptr.astype(np.int32), metric + "_sg_indices": sg.indices.astype(np.int32),
+                    metric + "_prepared_tree_indices": np.asarray(index._search_forest[0].indices, np.int32),
+                    metric + "_raw_after": np.asarray(index._raw_data, np.float32)})
+        # the reference's own queries on the prepared index (query path: pynndescent_.py:2275-2379)
+        q = clustered(200, 16, 5, 20, seed=seed + 100)
+        qi, qd = index.query(q, k=10, epsilon=0.1)
+        out.update({metric + "_queries": q, metric + "_query_idx": qi.astype(np.int32), metric + "_query_dist": qd.astype(np.float32)})
+    save("hub_tree", **out)
+
+
 def gen_update(ref):
     """NNDescent.update (pynndescent_.py:2381-2553): fresh rows appended + some rows replaced, warm start from the
     old graph (flag 0) + a smaller forest, no random init."""
@@ -501,6 +538,7 @@ GENERATORS = {
     "reference_testdata": gen_reference_testdata,
     "search_graph": gen_search_graph,
     "search_graph_modes": gen_search_graph_modes,
+    "hub_tree": gen_hub_tree,
     "update": gen_update,
 }
 

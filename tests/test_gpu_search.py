@@ -1,0 +1,167 @@
+"""prepare() and query() on the GPU: the hub search tree (csrc/hubtree.hip), the
+reordering by its leaf order, the batched best-first search (csrc/query.hip) and the pickle round trip, against the
+reference's own run (tests/golden/hub_tree.npz) and the CPU oracle."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from pynndescent_amd import NNDescent
+from pynndescent_amd.search_tree import make_hub_tree, search_flat_tree
+from tests.util_data import clustered, nn_data_like
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _exact(x, q, k, metric):
+    """Exact k nearest rows of x for every row of q (float64), ids only."""
+    xi, qi = x.astype(np.float64), q.astype(np.float64)
+    out = np.empty((q.shape[0], k), np.int64)
+    for a in range(0, q.shape[0], 256):
+        qq = qi[a:a + 256]
+        if metric == "euclidean":
+            dd = (qq * qq).sum(1)[:, None] + (xi * xi).sum(1)[None, :] - 2.0 * qq @ xi.T
+        else:
+            nq, nx = np.linalg.norm(qq, axis=1)[:, None], np.linalg.norm(xi, axis=1)[None, :]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                dd = 1.0 - (qq @ xi.T) / (nq * nx)
+            dd = np.where(np.isfinite(dd), dd, 2.0)
+        out[a:a + 256] = np.argsort(dd, axis=1, kind="stable")[:, :k]
+    return out
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_hub_tree_matches_reference_fixture(metric):
+    """make_hub_tree + convert_tree_format (rp_trees.py:714-1312, 2926-3049) of the reference on a reference-built
+    graph: the tree is deterministic given the graph -- the GPU build must return the same FlatTree."""
+    g = np.load(os.path.join(GOLDEN, "hub_tree.npz"))
+    n, d, latent, ncl, seed = (int(v) for v in g[metric + "_gen"])
+    x = clustered(n, d, latent, ncl, seed)
+    tree = make_hub_tree(x, g[metric + "_idx"], metric, leaf_size=30, max_depth=200)
+    assert tree.hyperplanes.shape == g[metric + "_hyperplanes"].shape
+    np.testing.assert_array_equal(tree.children, g[metric + "_children"])
+    np.testing.assert_array_equal(tree.indices, g[metric + "_indices"])
+    assert tree.leaf_size == int(g[metric + "_leaf_size"])
+    if metric == "euclidean":
+        np.testing.assert_array_equal(tree.hyperplanes, g[metric + "_hyperplanes"])
+        np.testing.assert_array_equal(tree.offsets, g[metric + "_offsets"])
+    else:
+        np.testing.assert_allclose(tree.hyperplanes, g[metric + "_hyperplanes"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("metric,n,d,leaf", [("euclidean", 60000, 24, 30), ("cosine", 40000, 40, 30), ("euclidean", 30000, 130, 12)])
+def test_hub_tree_matches_oracle_at_size(metric, n, d, leaf):
+    """Same comparison at a size the un-jitted reference cannot reach: GPU-built graph -> hub tree on the GPU and by the
+    CPU oracle (pinned to the reference fixture in tests/test_oracle_builds.py): identical structure."""
+    x = clustered(n, d, 8, 100, seed=n % 97)
+    index = NNDescent(x, metric, n_neighbors=15, random_state=3)
+    nbr = index._neighbor_graph[0]
+    tree = make_hub_tree(x, nbr, metric, leaf_size=leaf, max_depth=200)
+    oh, oo, oc, oi, ol = O.make_hub_tree(x, nbr, index.rng_state, leaf, metric == "cosine", 200)
+    assert tree.children.shape == oc.shape, (tree.children.shape, oc.shape)
+    same_nodes = (tree.children == oc).all(1).mean()
+    same_idx = (tree.indices == oi).mean()
+    print("hub tree %s n=%d: nodes %d, identical node rows %.5f, identical leaf order %.5f, max leaf %d (oracle %d)" % (
+        metric, n, oc.shape[0], same_nodes, same_idx, tree.leaf_size, ol))
+    if metric == "euclidean":
+        np.testing.assert_array_equal(tree.children, oc)
+        np.testing.assert_array_equal(tree.indices, oi)
+        np.testing.assert_array_equal(tree.hyperplanes, oh)
+    else:  # the oracle's libm / division rounding may flip a member that sits within an ulp of a hyperplane
+        assert same_nodes > 0.995 and same_idx > 0.99
+    assert np.array_equal(np.sort(tree.indices), np.arange(n))
+    # every member of a leaf really descends to that leaf
+    rows = np.random.RandomState(1).choice(n, 500, replace=False)
+    ls, le = search_flat_tree(tree, x[rows] if metric == "euclidean" else x[rows])
+    pos = np.empty(n, np.int64)
+    pos[tree.indices] = np.arange(n)
+    inside = (pos[rows] >= ls) & (pos[rows] < le)
+    assert inside.mean() > 0.99, inside.mean()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_prepare_against_reference_fixture(metric):
+    """NNDescent.prepare (pynndescent_.py:2174-2273) on the reference's own graph: vertex order, reordered data, reordered
+    search graph and the re-indexed tree as the reference's prepare() left them."""
+    g = np.load(os.path.join(GOLDEN, "hub_tree.npz"))
+    n, d, latent, ncl, seed = (int(v) for v in g[metric + "_gen"])
+    x = clustered(n, d, latent, ncl, seed)
+    index = NNDescent.from_graph(x, g[metric + "_idx"], g[metric + "_dist"], metric=metric, random_state=9)
+    index.prepare()
+    np.testing.assert_array_equal(index._vertex_order, g[metric + "_vertex_order"])
+    np.testing.assert_array_equal(index._raw_data, g[metric + "_raw_after"])
+    np.testing.assert_array_equal(index._search_forest[0].indices, g[metric + "_prepared_tree_indices"])
+    sg = index._search_graph
+    assert sg.shape == (n, n) and sg.dtype == np.uint8
+    a = set(zip(np.repeat(np.arange(n), np.diff(sg.indptr)).tolist(), sg.indices.tolist()))
+    b = set(zip(np.repeat(np.arange(n), np.diff(g[metric + "_sg_indptr"])).tolist(), g[metric + "_sg_indices"].tolist()))
+    print("prepared search graph: nnz %d (reference %d), symmetric difference %d" % (len(a), len(b), len(a ^ b)))
+    assert len(a ^ b) <= (0 if metric == "euclidean" else 0.01 * len(b))
+    # the reference's own queries: same neighbours found (recall of each side against exact search within 1 %)
+    q = g[metric + "_queries"]
+    qi, qd = index.query(q, k=10, epsilon=0.1)
+    ti = _exact(x, q, 10, metric)
+    r_gpu, r_ref = O.recall(ti, qi), O.recall(ti, g[metric + "_query_idx"])
+    print("query recall@10: gpu %.4f reference %.4f" % (r_gpu, r_ref))
+    assert abs(r_gpu - r_ref) <= 0.01  # (these queries come from another mixture: hard for both sides alike)
+    # distances are the true metric's (corrected) values for the returned ids
+    xi = x.astype(np.float64)
+    if metric == "euclidean":
+        truth = np.sqrt(((q.astype(np.float64)[:, None, :] - xi[qi]) ** 2).sum(-1))
+        np.testing.assert_allclose(qd, truth, rtol=1e-4, atol=1e-5)
+    assert np.all(np.diff(qd, axis=1) >= -1e-7)
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_query_accuracy_reference_test_shape(metric):
+    """tests/test_pynndescent_.py:133-202: index on nn_data[200:], query nn_data[:200], k = 10, epsilon = 0.2;
+    at least 95 % of the true neighbours."""
+    data = nn_data_like()
+    train, test = data[200:], data[:200]
+    index = NNDescent(train, metric, {}, 10, random_state=np.random.RandomState(189212))
+    qi, qd = index.query(test, k=10, epsilon=0.2)
+    keep = np.ones(len(test), bool) if metric == "euclidean" else (np.abs(test).sum(1) > 0)
+    ti = _exact(train, test, 10, metric)
+    rec = O.recall(ti[keep], qi[keep])
+    print("query accuracy (%s): %.4f" % (metric, rec))
+    assert rec >= 0.95
+    assert qi.shape == (200, 10) and qi.dtype == np.int32
+    for row in qi[keep][::7]:
+        assert len(set(row.tolist())) == 10
+
+
+def test_query_at_size_and_pickle_round_trip():
+    """200 k points: prepare + 5000 queries; recall vs exact; a pickled index answers identically after loading
+    (pynndescent_.py:1306-1331: pickling prepares, drops the build forest and the device state)."""
+    x = clustered(200_000, 48, 10, 300, seed=5)
+    q = clustered(5000, 48, 10, 300, seed=5)[::-1].copy() + 0.05
+    index = NNDescent(x, "euclidean", n_neighbors=15, random_state=2)
+    qi, qd = index.query(q, k=10, epsilon=0.15)
+    rows = np.arange(0, 5000, 10)
+    ti = _exact(x, q[rows], 10, "euclidean")
+    rec = O.recall(ti, qi[rows])
+    print("query recall (200k points, eps 0.15): %.4f" % rec)
+    assert rec >= 0.95
+    blob = pickle.dumps(index)
+    index2 = pickle.loads(blob)
+    assert not hasattr(index2, "_rp_forest") and index2._searcher is None
+    qi2, qd2 = index2.query(q[:500], k=10, epsilon=0.15)
+    np.testing.assert_array_equal(qi2, qi[:500])
+    np.testing.assert_allclose(qd2, qd[:500], rtol=1e-6)
+    # neighbor_graph survives, in the original numbering
+    np.testing.assert_array_equal(index2._neighbor_graph[0], index._neighbor_graph[0])
+
+
+def test_query_without_tree_and_errors():
+    x = clustered(3000, 12, 4, 10, seed=8)
+    index = NNDescent(x, "euclidean", n_neighbors=10, tree_init=False, random_state=1)
+    qi, qd = index.query(x[:100] + 0.01, k=5)
+    ti, _ = O.brute_force_knn(x, 5, "euclidean", rows=np.arange(100))
+    assert O.recall(ti, qi) > 0.8  # random starts only (pynndescent_.py:1834-1848)
+    with pytest.raises(NotImplementedError, match="k <= 64"):
+        index.query(x[:3], k=100)
+    with pytest.raises(ValueError, match="shape"):
+        index.query(x[:3, :5], k=5)

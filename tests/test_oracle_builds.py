@@ -237,3 +237,23 @@ def test_update_matches_reference(golden_dir, metric):
     else:  # cosine distances differ in the last bits between C and numpy -> ties may resolve differently
         same = np.mean([len(np.intersect1d(a, b)) / len(a) for a, b in zip(idx, g["after_idx"])])
         assert same > 0.97, same
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_hub_tree_matches_reference(golden_dir, metric):
+    """make_hub_tree + convert_tree_format (rp_trees.py:714-1312, 2926-3049): the graph-informed search tree is
+    deterministic given the graph; the oracle reproduces the reference's FlatTree (un-jitted run) exactly."""
+    g = _g(golden_dir, "hub_tree")
+    n, d, latent, ncl, seed = (int(v) for v in g[metric + "_gen"])
+    x = clustered(n, d, latent, ncl, seed)
+    hyper, offs, children, indices, leaf = O.make_hub_tree(x, g[metric + "_idx"], g[metric + "_rng"], 30, metric == "cosine", 200)
+    np.testing.assert_array_equal(children, g[metric + "_children"])
+    np.testing.assert_array_equal(indices, g[metric + "_indices"])
+    assert leaf == int(g[metric + "_leaf_size"])
+    if metric == "euclidean":
+        np.testing.assert_array_equal(hyper, g[metric + "_hyperplanes"])
+        np.testing.assert_array_equal(offs, g[metric + "_offsets"])
+    else:
+        np.testing.assert_allclose(hyper, g[metric + "_hyperplanes"], rtol=1e-5, atol=1e-7)
+    # every point in exactly one leaf; leaves partition [0, n)
+    assert np.array_equal(np.sort(indices), np.arange(n))
