@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void k_hub_children(const int32_t *__restrict_
                                                       const int32_t *__restrict__ choice, const int32_t *__restrict__ nl, int n_segs,
                                                       int leaf_size, int child_can_split, int32_t *__restrict__ next_start,
                                                       int32_t *__restrict__ next_len, uint8_t *__restrict__ next_split,
-                                                      int32_t *__restrict__ seg_child, int32_t *__restrict__ out_counts) {
+                                                      int32_t *__restrict__ seg_child, int32_t *__restrict__ split_rank,
+                                                      int32_t *__restrict__ out_counts) {
     __shared__ int part[256], parts[256];
     const int chunk = (n_segs + 255) / 256;
     const int s0 = threadIdx.x * chunk, s1 = s0 + chunk < n_segs ? s0 + chunk : n_segs;
@@ -210,8 +211,10 @@ __global__ __launch_bounds__(256) void k_hub_children(const int32_t *__restrict_
     for (int s = s0; s < s1; s++) {
         if (choice[s] < 0) {
             seg_child[2 * s] = seg_child[2 * s + 1] = -1;
+            split_rank[s] = -1;
             continue;
         }
+        split_rank[s] = run;
         const int a = seg_start[s], len = seg_len[s], l = nl[s];
         const int lens[2] = {l, len - l}, starts[2] = {a, a + l};
 #pragma unroll
@@ -235,6 +238,18 @@ __global__ __launch_bounds__(256) void k_hub_children(const int32_t *__restrict_
     }
 }
 
+// the winning hyperplane of the r-th splitting segment -> win[r] (what the host needs of this level's 3 * S candidates)
+__global__ void k_hub_winners(const float *__restrict__ hv, const float *__restrict__ off, const int32_t *__restrict__ choice,
+                              const int32_t *__restrict__ split_rank, int n_segs, int d, float *__restrict__ win,
+                              float *__restrict__ win_off) {
+    const int s = blockIdx.x;
+    if (s >= n_segs) return;
+    const int r = split_rank[s], c = choice[s];
+    if (r < 0) return;
+    for (int j = threadIdx.x; j < d; j += blockDim.x) win[(int64_t)r * d + j] = c < 3 ? hv[((int64_t)s * 3 + c) * d + j] : 0.0f;
+    if (threadIdx.x == 0) win_off[r] = c < 3 ? off[s * 4 + c] : 0.0f;  // fallback split: zero hyperplane, offset 0 (rp_trees.py:843-845)
+}
+
 // per position of one ordering: the side under the segment's winning candidate; members of nodes that do not split
 // leave the passes (pos = -1)
 __global__ void k_hub_sides(const int32_t *__restrict__ ord, int32_t *__restrict__ pos, const int32_t *__restrict__ choice,
@@ -255,8 +270,8 @@ __global__ void k_hub_sides(const int32_t *__restrict__ ord, int32_t *__restrict
 struct hub_level {
     int n_segs = 0;
     std::vector<int32_t> start, len, choice, nl;
-    std::vector<float> hv;   // (n_segs, 3, d) candidate hyperplanes (only the winner of a splitting segment is used)
-    std::vector<float> off;  // (n_segs, 4)
+    std::vector<float> hv;   // (n_splitting, d) winning hyperplanes, in segment order
+    std::vector<float> off;  // (n_splitting)
 };
 
 struct nnd_hub_result {
@@ -299,7 +314,8 @@ int nnd_hub_tree_build_impl(nnd_ctx *ctx, const int32_t *rank_order_host, int le
     int32_t *choice = (int32_t *)dev(4 * S_max), *nl = (int32_t *)dev(4 * S_max), *nleft4 = (int32_t *)dev(16 * S_max);
     int32_t *nleft_a = (int32_t *)dev(4 * S_max), *nleft_b = (int32_t *)dev(4 * S_max), *seg_child = (int32_t *)dev(8 * S_max);
     float *hv = (float *)dev(sizeof(float) * 3 * (size_t)d * (size_t)S_max), *off = (float *)dev(16 * S_max);
-    int32_t *counts = (int32_t *)dev(8);
+    int32_t *counts = (int32_t *)dev(8), *split_rank = (int32_t *)dev(4 * S_max);
+    float *win = (float *)dev(sizeof(float) * (size_t)d * (size_t)(S_max / 2 + 2)), *win_off = (float *)dev(sizeof(float) * (size_t)(S_max / 2 + 2));
     std::vector<hub_level> levels;
     nnd_hub_result *res = new nnd_hub_result();
     int32_t *ord_id[2] = {ctx->perm[0], ctx->perm[1]}, *pos_id[2] = {ctx->pos_seg[0], ctx->pos_seg[1]};
@@ -331,7 +347,9 @@ int nnd_hub_tree_build_impl(nnd_ctx *ctx, const int32_t *rank_order_host, int le
             hipLaunchKernelGGL(k_hub_choose, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, sln[cur], ssp[cur], S, nleft4, choice, nl);
             const int child_can_split = (max_depth - (depth + 1)) > 0 ? 1 : 0;
             hipLaunchKernelGGL(k_hub_children, dim3(1), dim3(256), 0, ctx->stream, sst[cur], sln[cur], choice, nl, S, leaf_size, child_can_split,
-                               sst[1 - cur], sln[1 - cur], ssp[1 - cur], seg_child, counts);
+                               sst[1 - cur], sln[1 - cur], ssp[1 - cur], seg_child, split_rank, counts);
+            if (n_split > 0)
+                hipLaunchKernelGGL(k_hub_winners, dim3((unsigned)S), dim3(64), 0, ctx->stream, hv, off, choice, split_rank, S, d, win, win_off);
             HUB_HIP(hipGetLastError());
             // this level's tables -> host (the tree is assembled there)
             lv.start.resize(S); lv.len.resize(S); lv.choice.resize(S); lv.nl.resize(S);
@@ -339,14 +357,16 @@ int nnd_hub_tree_build_impl(nnd_ctx *ctx, const int32_t *rank_order_host, int le
             HUB_HIP(hipMemcpyAsync(lv.len.data(), sln[cur], 4 * (size_t)S, hipMemcpyDeviceToHost, ctx->stream));
             HUB_HIP(hipMemcpyAsync(lv.choice.data(), choice, 4 * (size_t)S, hipMemcpyDeviceToHost, ctx->stream));
             HUB_HIP(hipMemcpyAsync(lv.nl.data(), nl, 4 * (size_t)S, hipMemcpyDeviceToHost, ctx->stream));
-            if (n_split > 0) {
-                lv.hv.resize((size_t)S * 3 * d);
-                lv.off.resize((size_t)S * 4);
-                HUB_HIP(hipMemcpyAsync(lv.hv.data(), hv, sizeof(float) * lv.hv.size(), hipMemcpyDeviceToHost, ctx->stream));
-                HUB_HIP(hipMemcpyAsync(lv.off.data(), off, sizeof(float) * lv.off.size(), hipMemcpyDeviceToHost, ctx->stream));
-            }
             int32_t hc[2] = {0, 0};
             HUB_HIP(hipMemcpyAsync(hc, counts, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HUB_HIP(hipStreamSynchronize(ctx->stream));
+            if (hc[0] > 0) {  // the winners of this level's hc[0] / 2 splitting segments
+                const size_t ns = (size_t)hc[0] / 2;
+                lv.hv.resize(ns * d);
+                lv.off.resize(ns);
+                HUB_HIP(hipMemcpyAsync(lv.hv.data(), win, sizeof(float) * lv.hv.size(), hipMemcpyDeviceToHost, ctx->stream));
+                HUB_HIP(hipMemcpyAsync(lv.off.data(), win_off, sizeof(float) * lv.off.size(), hipMemcpyDeviceToHost, ctx->stream));
+            }
             HUB_HIP(hipStreamSynchronize(ctx->stream));
             levels.push_back(std::move(lv));
             if (hc[0] == 0) break;  // nothing split on this level
@@ -403,12 +423,9 @@ int nnd_hub_tree_build_impl(nnd_ctx *ctx, const int32_t *rank_order_host, int le
                 leaf_start += len;
                 if (len > res->max_leaf) res->max_leaf = len;
             } else {
-                if (c < 3) {
-                    std::copy(lv.hv.begin() + ((size_t)it.s * 3 + c) * d, lv.hv.begin() + ((size_t)it.s * 3 + c + 1) * d,
-                              res->hyperplanes.begin() + (size_t)me * d);
-                    res->offsets[me] = lv.off[(size_t)it.s * 4 + c];
-                }  // fallback split (c == 3): the reference stores best_hyperplane = zeros, offset 0 (rp_trees.py:843-845)
                 const int r = srank[it.l][it.s];
+                std::copy(lv.hv.begin() + (size_t)r * d, lv.hv.begin() + (size_t)(r + 1) * d, res->hyperplanes.begin() + (size_t)me * d);
+                res->offsets[me] = lv.off[(size_t)r];
                 // left child is numbered next (me + 1): push right first, then left
                 stack.push_back({it.l + 1, 2 * r + 1, 2 * me + 1});
                 stack.push_back({it.l + 1, 2 * r, 2 * me});
