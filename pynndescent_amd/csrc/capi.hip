@@ -160,7 +160,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
                 ctx->s_m = p->n / ctx->s_stride;
                 const char *cl = getenv("NND_CELL_LEAF");
                 const char *es = getenv("NND_EARLY_STOP");
-                ctx->early_stop = es ? atoi(es) : 8;
+                ctx->early_stop = es ? atoi(es) : 0;
                 ctx->cell_leaf = cl ? atoi(cl) : 48;  // x stride: cells of <= ~450 points, ~215 on average (one wave per cell)
                 if (ctx->cell_leaf < 8) ctx->cell_leaf = 8;
                 const int64_t Ps = (int64_t)p->n_trees * ctx->s_m;

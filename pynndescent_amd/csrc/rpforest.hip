@@ -386,10 +386,11 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
                                                   int32_t *__restrict__ fin_start, int32_t *__restrict__ fin_len,
                                                   int32_t *__restrict__ fin_depth, long long *__restrict__ counters,
                                                   int32_t *__restrict__ node_child, int node_base, int next_base,
-                                                  int32_t *__restrict__ leaf_depth) {
+                                                  int32_t *__restrict__ leaf_depth, int node_top) {
     // node_child != nullptr (sample forest, see nnd_launch_forest): the tree itself is recorded -- node (node_base + s)
-    // gets its two children: >= 0 the child's node id (next_base + its index in the next level), <= -2 a final
-    // leaf ("cell") encoded as -2 - first position; leaf_depth[first position] = its depth.
+    // gets its two children: >= 0 the child's node id (next_base + its index in the next level; node_top - its index in
+    // the finisher's work list when its subtree is recorded by k_finish_subtrees<.., RECORD>), <= -2 a final leaf
+    // ("cell") encoded as -2 - first position; leaf_depth[first position] = its depth.
     // a child that splits again either stays in the level-synchronous passes (len > fin_max) or is handed to
     // k_finish_subtrees (len <= fin_max: its whole subtree fits in one workgroup's LDS)
     __shared__ int part[256], partf[256];
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
                     fin_start[runf] = starts[c];
                     fin_len[runf] = lens[c];
                     fin_depth[runf] = child_depth;
+                    if (node_child) node_child[2 * (node_base + s) + c] = node_top - runf;
                     runf++;
                     seg_child[2 * s + c] = -1;  // leaves the level-synchronous passes
                 }
@@ -538,10 +540,24 @@ __device__ __forceinline__ uint64_t rp_shfl_xor_u64(uint64_t v, int o) {
 // BIG = true: the same node loop for segments of any length: member ids, partition scratch and side bits live in
 // global memory (perm itself, the other perm buffer, side[]), and a node that has shrunk to <= fin_max points is
 // appended to the LDS finisher's work list instead of being split here.
+// RECORD = true (the sample forest of the routing pass): the subtree is RECORDED instead of written out as leaves --
+// every split stores its hyperplane and children in the node tables (node ids: the segment's own id comes from
+// k_children, deeper nodes take ids downwards from `down_base` through an atomic counter; ids are table slots, nothing
+// depends on their order), a child that stops splitting becomes a cell: child = -2 - its first position, leaf mark and
+// depth at that position.
+struct rp_record {
+    float *hf;            // (node_cap, hs) f32 hyperplane + offset + |h|
+    uint16_t *hh;         // (node_cap, dp) bf16 hyperplane
+    int32_t *child;       // (node_cap, 2)
+    int32_t *leaf_depth;  // per sample position
+    int hs, node_top, down_base, lvl_end;
+    int *counter, *overflow;
+};
+
 // NTHR threads per workgroup, CAP = most points of a segment whose ids live in LDS.  Small cells run with ONE WAVE per
 // cell (NTHR = 64, CAP = 512: ~6 KB of LDS, the barriers are single-wave): a node of a hundred points is a chain of
 // dependent latencies (pivot rows, member rows), so what pays is many independent cells per CU, not many lanes per cell.
-template <bool BIG, int NTHR, int CAP>
+template <bool BIG, int NTHR, int CAP, bool RECORD = false>
 __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
                                                          const float *__restrict__ nrm, int metric, int dp, int64_t n,
                                                          int32_t *__restrict__ perm,
@@ -552,7 +568,8 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
                                                          uint8_t *__restrict__ leaf_flag, int32_t *__restrict__ tmp_g,
                                                          uint8_t *__restrict__ side_g, int fin_max,
                                                          int32_t *__restrict__ fin_start, int32_t *__restrict__ fin_len,
-                                                         int32_t *__restrict__ fin_depth, long long *__restrict__ fin_count) {
+                                                         int32_t *__restrict__ fin_depth, long long *__restrict__ fin_count,
+                                                         rp_record rec = rp_record{}) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     const int s = blockIdx.x;
     if (s >= n_segs) return;
@@ -565,8 +582,8 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
     uint8_t *sd = BIG ? side_g + a : (uint8_t *)((int32_t *)fsm + 2 * NLDS);  // side bits
     float *h = (float *)(fsm + (size_t)NLDS * 9);  // dp + 4 hyperplane + offset
     uint16_t *hb = (uint16_t *)(h + dp + 4);       // dp: bf16 copy of the normal (dp is a multiple of 32)
-    int32_t *stk = (int32_t *)(hb + dp);           // FIN_STACK * 3: (start, len, depth)
-    int32_t *wsum = stk + FIN_STACK * 3;           // FIN_WS: per-wave partial sums / scalars (FIN_STACK entries: see the push below)
+    int32_t *stk = (int32_t *)(hb + dp);           // FIN_STACK * 4: (start, len, depth, node id when recording)
+    int32_t *wsum = stk + FIN_STACK * 4;           // FIN_WS: per-wave partial sums / scalars (FIN_STACK entries: see the push below)
     uint64_t *wkeys = (uint64_t *)(wsum + 8);      // 8 keys (16 words): per-wave top-2 of the pivot draw
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
     const uint32_t seedt = seed ^ ((uint32_t)((int64_t)a / n) * 0x9E3779B9u);  // per tree
@@ -574,18 +591,19 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
         for (int i = tid; i < len; i += NTHR) ids[i] = perm[a + i];
     if (tid == 0) {
         stk[0] = 0; stk[1] = len; stk[2] = seg_depth ? seg_depth[s] : depth0;
+        stk[3] = RECORD ? rec.node_top - s : 0;  // k_children numbered the finisher segments downwards from node_top
         wsum[7] = 1;  // stack size
     }
     __syncthreads();
     while (true) {
         const int sp = wsum[7];
         if (sp == 0) break;
-        const int ss = stk[(sp - 1) * 3], l = stk[(sp - 1) * 3 + 1], dep = stk[(sp - 1) * 3 + 2];
+        const int ss = stk[(sp - 1) * 4], l = stk[(sp - 1) * 4 + 1], dep = stk[(sp - 1) * 4 + 2], me = stk[(sp - 1) * 4 + 3];
         __syncthreads();
         if (tid == 0) wsum[7] = sp - 1;
         if (!(l > leaf_size && (max_depth - dep) > 0)) {  // rp_trees.py:2188: this node is a leaf
             if (tid == 0 && l > 0) leaf_flag[a + ss] = 1;
-            if (l > 1) {  // canonical order: ascending ids (rank by counting; leaves are small)
+            if (!RECORD && l > 1) {  // canonical order: ascending ids (rank by counting; leaves are small)
                 for (int i = tid; i < l; i += NTHR) {
                     const int32_t id = ids[ss + i];
                     int r = 0;
@@ -669,6 +687,18 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
         // fetches are in flight per lane; the bf16 hyperplane comes from LDS
         for (int j = tid; j < dp; j += NTHR) hb[j] = nnd_f32_to_bf16(h[j]);
         __syncthreads();
+        if (RECORD) {
+            float *rh = rec.hf + (int64_t)me * rec.hs;
+            uint16_t *rb = rec.hh + (int64_t)me * dp;
+            for (int j = tid; j < dp; j += NTHR) {
+                rh[j] = h[j];
+                rb[j] = hb[j];
+            }
+            if (tid == 0) {
+                rh[dp] = h[dp];
+                rh[dp + 1] = h[dp + 1];
+            }
+        }
         const int sub = tid & 3, grp = tid >> 2;
         const int nch = dp >> 3;
         const float off = h[dp], hnorm = h[dp + 1];
@@ -754,10 +784,32 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
                          // holds more than log2(len) + 1 entries (the order in which nodes are split is immaterial)
             int top = wsum[7];
             const bool left_big = nl >= l - nl;
-            stk[top * 3] = left_big ? ss : ss + nl; stk[top * 3 + 1] = left_big ? nl : l - nl; stk[top * 3 + 2] = dep + 1;
-            top++;
-            stk[top * 3] = left_big ? ss + nl : ss; stk[top * 3 + 1] = left_big ? l - nl : nl; stk[top * 3 + 2] = dep + 1;
-            wsum[7] = top + 1;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const bool left = (q == 0) == left_big;
+                const int cs = left ? ss : ss + nl, cl = left ? nl : l - nl;
+                int cid = 0;
+                if (RECORD) {
+                    bool split = cl > leaf_size && (max_depth - (dep + 1)) > 0;
+                    if (split) {
+                        cid = rec.down_base - atomicAdd(rec.counter, 1);
+                        if (cid <= rec.lvl_end) {  // node tables exhausted: the host falls back to the whole-set passes
+                            *rec.overflow = 1;
+                            split = false;
+                        }
+                    }
+                    if (!split) {  // a cell
+                        rec.child[2 * me + (left ? 0 : 1)] = -2 - (a + cs);
+                        leaf_flag[a + cs] = 1;
+                        rec.leaf_depth[a + cs] = dep + 1;
+                        continue;
+                    }
+                    rec.child[2 * me + (left ? 0 : 1)] = cid;
+                }
+                stk[top * 4] = cs; stk[top * 4 + 1] = cl; stk[top * 4 + 2] = dep + 1; stk[top * 4 + 3] = cid;
+                top++;
+            }
+            wsum[7] = top;
         }
         __syncthreads();
     }
@@ -906,7 +958,10 @@ __global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, con
                 for (int u = 0; u < TB; u++) any |= node[u] >= 0;
                 if (!__ballot(any)) break;  // wave-uniform
                 uint4 p[TB][NC], meta[TB];
-                if (depth < l_top) {  // every live walk is at depth `depth`: its node id is < n_top
+                bool high = false;  // a subtree recorded by the finisher has its nodes at the far end of the table
+#pragma unroll
+                for (int u = 0; u < TB; u++) high |= node[u] >= n_top;
+                if (depth < l_top && !__ballot(high)) {  // wave-uniform: every live walk is at a node of the LDS copy
 #pragma unroll
                     for (int u = 0; u < TB; u++) {
                         const uint4 *r8 = (const uint4 *)(top_tab + (size_t)(node[u] >= 0 ? node[u] : 0) * rec);
@@ -1028,7 +1083,7 @@ static int run_scan(nnd_ctx *ctx, int mode, const int32_t *pos_seg, uint8_t *byt
 }
 
 static size_t fin_smem_bytes(int dp, int cap /* 0: ids in global memory */) {
-    const size_t tail = sizeof(float) * (dp + 4) + sizeof(uint16_t) * dp + sizeof(int32_t) * (FIN_STACK * 3 + FIN_WS);
+    const size_t tail = sizeof(float) * (dp + 4) + sizeof(uint16_t) * dp + sizeof(int32_t) * (FIN_STACK * 4 + FIN_WS);
     return (size_t)cap * 9 + tail;
 }
 
@@ -1153,11 +1208,12 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
         // Recording: once only a few sample positions are still in splittable nodes the recorded tree stops: the
         // children of this level all become cells, however long (a straggler level costs a full pass over the sample
         // for a handful of nodes; an over-long cell just goes to a workgroup finisher instead of a single wave).
-        if (v.record && active_pos * ctx->early_stop < P) child_can_split = 0;
+        if (v.record && ctx->early_stop > 0 && active_pos * ctx->early_stop < P) child_can_split = 0;
         hipLaunchKernelGGL(k_children, dim3(1), dim3(256), 0, ctx->stream, ctx->seg_start[cur], ctx->seg_len[cur],
                            ctx->seg_nleft, (int)S, leaf_size, child_can_split, fin_max, depth + 1, ctx->seg_start[1 - cur],
                            ctx->seg_len[1 - cur], ctx->seg_child, ctx->leaf_flag, fin_start, fin_len, fin_depth, ctx->counters,
-                           v.record ? ctx->node_child : (int32_t *)nullptr, (int)node_base, (int)(node_base + S), ctx->s_leaf_depth);
+                           v.record ? ctx->node_child : (int32_t *)nullptr, (int)node_base, (int)(node_base + S), ctx->s_leaf_depth,
+                           (int)ctx->node_cap - 1);
         hipLaunchKernelGGL(k_scatter, dim3(gridP), dim3(256), 0, ctx->stream, ctx->perm[cur], ctx->pos_seg[cur], ctx->side,
                            ctx->scan_out, ctx->seg_start[cur], ctx->seg_nleft, ctx->seg_child, P, n, ctx->perm[1 - cur],
                            ctx->pos_seg[1 - cur], inv_live ? ctx->inv : (int32_t *)nullptr);
@@ -1187,8 +1243,31 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
     v.cur = cur;
     v.depth = depth;
     v.n_nodes = node_base;
-    if (v.record) v.level_base.push_back(node_base);
-    if (!v.record && launch_finishers(ctx, ctx->perm[cur], ctx->perm[1 - cur], nullptr, nullptr, nullptr, 0, 0)) return 1;
+    if (v.record) {
+        v.level_base.push_back(node_base);
+        // the subtrees that left the passes are recorded one workgroup each (k_finish_subtrees<.., RECORD>)
+        NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 34, ctx->counters + CNT_SCRATCH + 1, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        NND_HIP_CHECK(nnd_sync_spin(ctx));
+        const long long nfin = ctx->h_pin[34];
+        if (nfin > ctx->max_segs || node_base + nfin + 1 >= ctx->node_cap) return 2;
+        if (nfin > 0) {
+            int *flags = (int *)(ctx->counters + CNT_SCRATCH + 2);  // [0] id counter, [1] overflow
+            NND_HIP_CHECK(hipMemsetAsync(flags, 0, 2 * sizeof(int), ctx->stream));
+            rp_record rec{ctx->node_hf, ctx->node_hh, ctx->node_child, ctx->s_leaf_depth, hs, (int)ctx->node_cap - 1,
+                          (int)(ctx->node_cap - 1 - nfin), (int)node_base, flags, flags + 1};
+            hipLaunchKernelGGL((k_finish_subtrees<false, 256, FIN_MAX, true>), dim3((unsigned)nfin), dim3(256), fin_smem_bytes(dp, FIN_MAX),
+                               ctx->stream, v.xp, v.xh, v.nrm, ctx->p.metric, dp, n, ctx->perm[cur], fin_start, fin_len, fin_depth, 0,
+                               (int)nfin, angular, ctx->tree_seed, max_depth, leaf_size, ctx->leaf_flag, (int32_t *)nullptr,
+                               (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, ctx->counters + CNT_SCRATCH + 1, rec);
+            NND_HIP_CHECK(hipGetLastError());
+            NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 38, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            NND_HIP_CHECK(nnd_sync_spin(ctx));
+            if (((const int *)(ctx->h_pin + 38))[1]) return 2;  // node tables exhausted
+        }
+        v.n_nodes = ctx->node_cap;  // ids are spread over the table: level-synchronous nodes upwards, recorded subtrees downwards
+        return 0;
+    }
+    if (launch_finishers(ctx, ctx->perm[cur], ctx->perm[1 - cur], nullptr, nullptr, nullptr, 0, 0)) return 1;
     return 0;
 }
 
@@ -1220,7 +1299,7 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
     hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm, dp,
                        M, ctx->s_stride, ctx->tree_seed, ctx->xs, ctx->xsh, ctx->nrms);
-    forest_view v{ctx->xs, ctx->xsh, ctx->nrms, M, Ps, ctx->cell_leaf, 0, true};
+    forest_view v{ctx->xs, ctx->xsh, ctx->nrms, M, Ps, ctx->cell_leaf, FIN_MAX, true};
     int rc = forest_levels(ctx, v);
     if (rc) return rc;
     // cells = leaves of the recorded trees, numbered in position order (tree-major)
