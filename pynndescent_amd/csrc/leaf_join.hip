@@ -18,7 +18,7 @@
 #include "merge.h"
 #include "state.h"
 
-template <int NT, int NW, int DC>
+template <int NT, int NW, int DC, bool QW = false>
 struct leaf_cfg {
     static constexpr int MP = NT * 16;                      // max leaf rows
     static constexpr int TR = (NT + NW - 1) / NW;           // tile rows per wave
@@ -31,13 +31,15 @@ struct leaf_cfg {
     // waves) and every off-diagonal tile is written twice, once transposed
     static constexpr int TPW = (NT * (NT + 1) / 2 + NW - 1) / NW;
     static constexpr int DB_FLOATS = FULLD ? MP * DSTRIDE : NW * 16 * DSTRIDE;
-    static constexpr bool PREFETCH = FULLD;                  // k-list prefetch buffers sit next to the distance block
+    static constexpr int QPASS = (MP + NW * 4 - 1) / (NW * 4);  // k <= 16: four rows per wave and pass (merge.h, quarter-wave merge)
+    static constexpr bool PREFETCH = FULLD && !QW;           // k-list prefetch buffers sit next to the distance block
     static constexpr int PRE_FLOATS = PREFETCH ? MP * 16 * 2 : 0;  // budgeted for k <= 16; larger k uses what Xs leaves free
     static constexpr int EPI_FLOATS = DB_FLOATS + PRE_FLOATS;
     static constexpr int BIG_FLOATS = XS_FLOATS > EPI_FLOATS ? XS_FLOATS : EPI_FLOATS;  // Xs aliases the epilogue buffers
 };
 
-template <int NT, int NW, int DC>
+// QW (host: k <= 16 and the whole distance block in LDS): quarter-wave merges, four rows per wave (merge.h)
+template <int NT, int NW, int DC, bool QW = false>
 __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_join(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
                                                        int metric, const int32_t *__restrict__ perm,
                                                        const int32_t *__restrict__ wl_start,
@@ -45,7 +47,8 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_
                                                        int64_t n_leaves, int k, int ks, uint32_t *__restrict__ knn_e,
                                                        float *__restrict__ knn_d, float *__restrict__ th,
                                                        long long *__restrict__ counters) {
-    using C = leaf_cfg<NT, NW, DC>;
+    using C = leaf_cfg<NT, NW, DC, QW>;
+    static_assert(!QW || C::FULLD, "quarter-wave merges read the whole distance block from LDS");
     __shared__ __attribute__((aligned(16))) float big[C::BIG_FLOATS];
     __shared__ int32_t ids[C::MP];
     __shared__ float nrs[C::MP];
@@ -68,7 +71,10 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_
     constexpr int NTHR = NW * 64;
     constexpr int NLD = (C::MP * (DC / 4) + NTHR - 1) / NTHR;  // 16-byte row chunks per thread
     constexpr int NKL = (C::MP * 16 + NTHR - 1) / NTHR;        // k-list words per thread (row stride <= 16)
-    const bool use_pre = C::PREFETCH && ks <= 16 && (m * ks * 2 <= C::BIG_FLOATS - C::DB_FLOATS);
+    constexpr bool quarter = QW;  // four rows per wave, k-lists prefetched straight into the lanes that merge them
+    const bool use_pre = !quarter && C::PREFETCH && ks <= 16 && (m * ks * 2 <= C::BIG_FLOATS - C::DB_FLOATS);
+    uint32_t qe[C::QPASS];
+    float qd[C::QPASS];
     float *Xs = big;
     uint32_t pe[NKL];
     float pd[NKL];
@@ -112,6 +118,18 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_
                     const int id = ids[tid];
                     my_nrm = nrm[id >= 0 ? id : 0];
                 }
+                if constexpr (quarter) {
+#pragma unroll
+                    for (int q = 0; q < C::QPASS; q++) {
+                        const int i = q * NW * 4 + (tid >> 4), j = lane & 15;
+                        const bool on = i < m && j < k;
+                        const int64_t v = ids[i < m ? i : 0];
+                        const uint32_t ev = knn_e[v * ks + (on ? j : 0)];
+                        const float dv = knn_d[v * ks + (on ? j : 0)];
+                        qe[q] = on ? ev : NND_EMPTY_E;
+                        qd[q] = on ? dv : INFINITY;
+                    }
+                }
                 if (use_pre) {
 #pragma unroll
                     for (int q = 0; q < NKL; q++) {
@@ -136,7 +154,11 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_
         __syncthreads();
         if constexpr (C::FULLD) {
             const int lr = lane & 15, lg = lane >> 4;
+#ifdef NND_LEAF_NOGRAM  // timing experiments only
+            for (int t = 0; t < 1; t++) {
+#else
             for (int t = 0; t < (cw >> 4); t++) {
+#endif
                 const int c = 4 * t + lg;
                 float4 a[C::TPW], b[C::TPW];
 #pragma unroll
@@ -196,6 +218,22 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_
             }
         }
         __syncthreads();
+        if constexpr (quarter) {
+#pragma unroll
+            for (int q = 0; q < C::QPASS; q++) {
+                if (q * NW * 4 + w * 4 >= m) break;  // wave-uniform: no row left for this wave
+                const int i = q * NW * 4 + (tid >> 4);
+                const bool on = i < m;
+                const float *Drow = Dm + (on ? i : 0) * C::DSTRIDE;
+                const int64_t v = ids[on ? i : 0];
+                accepted += nnd_merge_rows_q16<NT>(on, knn_e + v * ks, knn_d + v * ks, th + v, qe[q], qd[q], k, m,
+                                                   [&](int c, uint32_t &id, float &dc) {
+                                                       id = (uint32_t)ids[c];
+                                                       dc = Drow[c];
+                                                       return c != i;  // pynndescent_.py:97: p != q
+                                                   });
+            }
+        } else
         for (int i = w; i < m; i += NW) {  // rows dealt round-robin: every wave gets ~m/NW merges
             const float *Drow = Dm + i * C::DSTRIDE;
             const int64_t v = ids[i];
@@ -341,10 +379,17 @@ int nnd_launch_leaf_init(nnd_ctx *ctx) {
         dim3 grid((unsigned)cnt);
 #define LEAF_ARGS ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, perm, d_ws, d_wl, tb[t], tb[t + 1], ctx->k, ctx->ks, \
                   ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters
-        if (maxlen <= 64)
+        const bool qw = ctx->k <= 16;
+        if (maxlen <= 64 && qw)
+            hipLaunchKernelGGL((k_leaf_join<4, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 64)
             hipLaunchKernelGGL((k_leaf_join<4, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
-        else if (maxlen <= 80)  // the default leaf_size (<= 75 points): 36 KB of LDS, 4 workgroups per CU
+        else if (maxlen <= 80 && qw)  // the default leaf_size (<= 75 points) with k <= 16
+            hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 80)
             hipLaunchKernelGGL((k_leaf_join<5, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 96 && qw)
+            hipLaunchKernelGGL((k_leaf_join<6, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 96)
             hipLaunchKernelGGL((k_leaf_join<6, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 128)

@@ -195,3 +195,91 @@ __device__ __forceinline__ int nnd_merge_row(int64_t v, int k, int ks, uint32_t 
     }
     return nnd_merge_row_regs<NCHUNK>(row_e, row_d, th + v, e, d, k, ncand, cand);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Quarter-wave variant for k <= 16: FOUR rows per wave, 16 lanes each.  Lane j of a row's 16-lane group holds list
+// entry j in (e, d) (lanes >= k: EMPTY / +inf) and, per block of 16 candidates, candidate blk*16 + j of ITS row.
+// Same result as nnd_merge_row_regs (the k smallest keys of row U {candidates that beat the row's worst distance as it
+// was at the start and are not in the row}), same return value (summed over the wave's rows), a quarter of the
+// instructions: the row-wide steps are DPP row operations (rotate / shift by one inside a 16-lane row) instead of
+// v_readlane + ballot over the whole wave.
+//   filter : one compare per lane; duplicates by rotating the row's 16 neighbour ids past the 16 candidates;
+//   insert : candidates are taken in lane order; the candidate is broadcast inside every row with ds_bpermute (the
+//            next broadcast is in flight while the current one is inserted) and every list lane decides locally:
+//            key > candidate: take the left neighbour's entry if that one moves too, else the candidate.
+// row_on is false for the groups of a wave that have no row (they still execute, nothing is stored).
+__device__ __forceinline__ int nnd_dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); }
+__device__ __forceinline__ int nnd_dpp_row_ror1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false); }
+
+template <int NBLK, typename CandFn>
+__device__ __forceinline__ int nnd_merge_rows_q16(bool row_on, uint32_t *__restrict__ row_e, float *__restrict__ row_d,
+                                                  float *__restrict__ th_slot, uint32_t e, float d, int k, int ncand,
+                                                  CandFn cand) {
+    const int lane = nnd_lane(), j = lane & 15, gbase = lane & 48;
+    const uint32_t e_in = e;
+    const float d_in = d;
+    uint32_t klo = e & NND_IDX_MASK, khi = __float_as_uint(d);  // key = khi:klo; empty slots: 0x7FFFFFFF / +inf bits
+    if (e == NND_EMPTY_E) { klo = 0xFFFFFFFFu; khi = 0xFFFFFFFFu; }
+    uint32_t flag = e == NND_EMPTY_E ? 0u : (e & NND_NEW_BIT);
+    const uint32_t myidx = e & NND_IDX_MASK;  // 0x7FFFFFFF for empty slots: never a valid id
+    // worst distance of my row as it is now (+inf while the row is not full)
+    const float th = __int_as_float(__builtin_amdgcn_ds_bpermute((gbase + k - 1) << 2, __float_as_int(d)));
+    int pushed = 0;
+#pragma unroll
+    for (int blk = 0; blk < NBLK; blk++) {
+        if (blk * 16 >= ncand) break;  // wave-uniform
+        const int c = blk * 16 + j;
+        uint32_t cid = 0;
+        float dc = 0.0f;
+        bool ok = row_on && c < ncand && cand(c, cid, dc);
+        ok = ok && (dc < th);  // strict, utils.py:484
+        if (!__ballot(ok)) continue;
+        {   // utils.py:489-492: drop candidates already in the row
+            uint32_t rid = myidx;
+            bool dup = false;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                dup |= rid == cid;
+                rid = (uint32_t)nnd_dpp_row_ror1((int)rid);
+            }
+            ok = ok && !dup;
+        }
+        const unsigned long long mask = __ballot(ok);
+        if (!mask) continue;
+        pushed += __popcll(mask);
+        const uint32_t clo = ok ? cid : 0xFFFFFFFFu, chi = ok ? __float_as_uint(dc) : 0xFFFFFFFFu;
+        uint32_t u = (uint32_t)(mask | (mask >> 16) | (mask >> 32) | (mask >> 48)) & 0xFFFFu;  // positions live in some row
+        int pnext = __builtin_ctz(u);
+        uint32_t nlo = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + pnext) << 2, (int)clo);
+        uint32_t nhi = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + pnext) << 2, (int)chi);
+        while (u) {
+            const uint32_t blo = nlo, bhi = nhi;  // this step's candidate of my row (all-ones: nothing to insert)
+            u &= u - 1;
+            if (u) {
+                pnext = __builtin_ctz(u);
+                nlo = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + pnext) << 2, (int)clo);
+                nhi = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + pnext) << 2, (int)chi);
+            }
+            const uint64_t mykey = ((uint64_t)khi << 32) | klo, ck = ((uint64_t)bhi << 32) | blo;
+            const bool gt = mykey > ck;  // my entry moves one slot to the right (an all-ones candidate moves nothing)
+            const int gtl = nnd_dpp_row_shr1(gt ? 1 : 0);  // does my left neighbour move too?  (lane 0 of the row: no)
+            const uint32_t llo = (uint32_t)nnd_dpp_row_shr1((int)klo), lhi = (uint32_t)nnd_dpp_row_shr1((int)khi);
+            const uint32_t lfl = (uint32_t)nnd_dpp_row_shr1((int)flag);
+            if (gt) {
+                klo = gtl ? llo : blo;
+                khi = gtl ? lhi : bhi;
+                flag = gtl ? lfl : NND_NEW_BIT;
+            }
+        }
+    }
+    if (pushed == 0) return 0;
+    const bool empty = (klo & khi) == 0xFFFFFFFFu;
+    const uint32_t e_out = empty ? NND_EMPTY_E : (klo | flag);
+    const float d_out = empty ? INFINITY : __uint_as_float(khi);
+    if (row_on && j < k && (e_out != e_in || d_out != d_in)) {
+        row_e[j] = e_out;
+        row_d[j] = d_out;
+        if (j == k - 1) *th_slot = d_out;  // new worst distance of the row
+    }
+    return pushed;
+}
