@@ -13,11 +13,16 @@
 // (the reference round-trips 12-byte (p,q,d) triples through memory and scans them once per
 // thread, pynndescent_.py:154-185).  Trees are processed one launch after another, so thresholds
 // tighten between trees exactly like the reference's leaf blocks tighten them (pynndescent_.py:137-152).
+#include <type_traits>
+
 #include "common.h"
 #include "gram.h"
 #include "merge.h"
 #include "state.h"
 
+#ifndef NND_LEAF_QW_OCC
+#define NND_LEAF_QW_OCC 6
+#endif
 template <int NT, int NW, int DC, bool QW = false>
 struct leaf_cfg {
     static constexpr int MP = NT * 16;                      // max leaf rows
@@ -40,7 +45,7 @@ struct leaf_cfg {
 
 // QW (host: k <= 16 and the whole distance block in LDS): quarter-wave merges, four rows per wave (merge.h)
 template <int NT, int NW, int DC, bool QW = false>
-__global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_join(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
+__global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : (QW && NT <= 5 && NW == 4) ? NND_LEAF_QW_OCC : 1) void k_leaf_join(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
                                                        int metric, const int32_t *__restrict__ perm,
                                                        const int32_t *__restrict__ wl_start,
                                                        const int32_t *__restrict__ wl_len, int64_t leaf0,
@@ -102,13 +107,14 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_
     for (int c0 = 0; c0 < dp; c0 += DC) {
         const int cw = (dp - c0) < DC ? (dp - c0) : DC;
         {
-            const int nch = cw >> 2, total = mp * nch;
+            static_assert(DC == 64, "cw is 32 or 64 (dp is a multiple of 32): chunk index by shift");
+            const int nch = cw >> 2, total = mp * nch, nsh = cw == 64 ? 4 : 3;
             f32x4 rv[NLD];
 #pragma unroll
             for (int q = 0; q < NLD; q++) {
                 // unconditional (clamped) loads: a conditionally assigned register array costs whole-array copies
                 const int idx = tid + q * NTHR, idc = idx < total ? idx : 0;
-                const int r = idc / nch, ch = idc - r * nch;
+                const int r = idc >> nsh, ch = idc & (nch - 1);
                 const int id = ids[r];
                 rv[q] = *(const f32x4 *)(xp + (int64_t)(id >= 0 ? id : 0) * dp + c0 + 4 * ch);  // rows >= m: row 0, never used
             }
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_
             for (int q = 0; q < NLD; q++) {
                 const int idx = tid + q * NTHR;
                 if (idx < total) {
-                    const int r = idx / nch, ch = idx - r * nch;
+                    const int r = idx >> nsh, ch = idx & (nch - 1);
                     *(f32x4 *)&Xs[nnd_swz<DC>(r, ch)] = rv[q];
                 }
             }
@@ -154,27 +160,40 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : 1) void k_leaf_
         __syncthreads();
         if constexpr (C::FULLD) {
             const int lr = lane & 15, lg = lane >> 4;
+            // only the slots that hold a tile issue LDS reads and MFMAs (they are a prefix: t = w + q * NW grows with q;
+            // the count is wave-uniform): a 41-point leaf has 6 tiles for 8 waves x TPW slots
+            auto run = [&](auto nq_tag) {
+                constexpr int NQ = decltype(nq_tag)::value;
 #ifdef NND_LEAF_NOGRAM  // timing experiments only
-            for (int t = 0; t < 1; t++) {
+                for (int t = 0; t < 1; t++) {
 #else
-            for (int t = 0; t < (cw >> 4); t++) {
+                for (int t = 0; t < (cw >> 4); t++) {
 #endif
-                const int c = 4 * t + lg;
-                float4 a[C::TPW], b[C::TPW];
+                    const int c = 4 * t + lg;
+                    float4 a[NQ], b[NQ];
 #pragma unroll
-                for (int q = 0; q < C::TPW; q++) {
-                    a[q] = *(const float4 *)&Xs[nnd_swz<DC>(tI[q] * 16 + lr, c)];
-                    b[q] = *(const float4 *)&Xs[nnd_swz<DC>(tJ[q] * 16 + lr, c)];
+                    for (int q = 0; q < NQ; q++) {
+                        a[q] = *(const float4 *)&Xs[nnd_swz<DC>(tI[q] * 16 + lr, c)];
+                        b[q] = *(const float4 *)&Xs[nnd_swz<DC>(tJ[q] * 16 + lr, c)];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b[q].x, acct[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, b[q].y, acct[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, b[q].z, acct[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, b[q].w, acct[q], 0, 0, 0);
                 }
+            };
+            int nq = 0;
 #pragma unroll
-                for (int q = 0; q < C::TPW; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b[q].x, acct[q], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < C::TPW; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, b[q].y, acct[q], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < C::TPW; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, b[q].z, acct[q], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < C::TPW; q++) acct[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, b[q].w, acct[q], 0, 0, 0);
-            }
+            for (int q = 0; q < C::TPW; q++) nq += tOn[q] ? 1 : 0;
+            static_assert(C::TPW <= 4, "slot dispatch below");
+            if (nq == 1) run(std::integral_constant<int, 1>{});
+            else if (nq == 2) run(std::integral_constant<int, C::TPW >= 2 ? 2 : 1>{});
+            else if (nq == 3) run(std::integral_constant<int, C::TPW >= 3 ? 3 : 1>{});
+            else if (nq == 4) run(std::integral_constant<int, C::TPW >= 4 ? 4 : 1>{});
         } else {
 #pragma unroll
             for (int tr = 0; tr < C::TR; tr++) {
@@ -385,7 +404,11 @@ int nnd_launch_leaf_init(nnd_ctx *ctx) {
         else if (maxlen <= 64)
             hipLaunchKernelGGL((k_leaf_join<4, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 80 && qw)  // the default leaf_size (<= 75 points) with k <= 16
+#ifdef NND_LEAF_QW_NW4
+            hipLaunchKernelGGL((k_leaf_join<5, 4, 64, true>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+#else
             hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+#endif
         else if (maxlen <= 80)
             hipLaunchKernelGGL((k_leaf_join<5, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 96 && qw)
