@@ -245,6 +245,10 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : (QW && NT <= 5 
                 const bool on = i < m;
                 const float *Drow = Dm + (on ? i : 0) * C::DSTRIDE;
                 const int64_t v = ids[on ? i : 0];
+#ifdef NND_LEAF_NOMERGE  // timing experiments only
+                if (qe[q] == 12345u && qd[q] == 3.0f && Drow[lane] == 7.0f) accepted++;
+                if (false)
+#endif
                 accepted += nnd_merge_rows_q16<NT>(on, knn_e + v * ks, knn_d + v * ks, th + v, qe[q], qd[q], k, m,
                                                    [&](int c, uint32_t &id, float &dc) {
                                                        id = (uint32_t)ids[c];

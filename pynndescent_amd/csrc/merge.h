@@ -224,6 +224,7 @@ __device__ __forceinline__ int nnd_merge_rows_q16(bool row_on, uint32_t *__restr
     const uint32_t myidx = e & NND_IDX_MASK;  // 0x7FFFFFFF for empty slots: never a valid id
     // worst distance of my row as it is now (+inf while the row is not full)
     const float th = __int_as_float(__builtin_amdgcn_ds_bpermute((gbase + k - 1) << 2, __float_as_int(d)));
+    const bool any_list = __ballot(e != NND_EMPTY_E) != 0;  // first tree: every row of the wave is still empty
     int pushed = 0;
 #pragma unroll
     for (int blk = 0; blk < NBLK; blk++) {
@@ -234,7 +235,7 @@ __device__ __forceinline__ int nnd_merge_rows_q16(bool row_on, uint32_t *__restr
         bool ok = row_on && c < ncand && cand(c, cid, dc);
         ok = ok && (dc < th);  // strict, utils.py:484
         if (!__ballot(ok)) continue;
-        {   // utils.py:489-492: drop candidates already in the row
+        if (any_list) {  // utils.py:489-492: drop candidates already in the row
             uint32_t rid = myidx;
             bool dup = false;
 #pragma unroll

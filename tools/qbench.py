@@ -85,8 +85,21 @@ def main():
     ap.add_argument("--env", action="append", default=[], help="KEY=VAL[,KEY=VAL...] one configuration per --env")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--leaf-check", action="store_true")
+    ap.add_argument("--reorder", action="store_true", help="experiment: permute the input rows into the first tree's leaf order first")
     args = ap.parse_args()
     x = sift_like_np(args.n, args.d, latent=args.latent)
+    if args.reorder:
+        n_iters = max(5, int(round(np.log2(args.n))))
+        b = _capi.Builder(args.n, args.d, args.metric, args.k, args.trees, max(60, min(256, 5 * args.k)), 200, min(60, args.k), n_iters,
+                          0.001, (11, 22, 33), (44, 55, 66))
+        b.set_data_host(x)
+        b.make_forest()
+        la = b.leaf_array()
+        b.close()
+        ids = la[la >= 0]
+        order = ids[: args.n]  # leaves are listed tree by tree: the first n ids are tree 0, a permutation of all points
+        assert np.array_equal(np.sort(order), np.arange(args.n))
+        x = np.ascontiguousarray(x[order])
     rows = ti = None
     if not args.no_recall:
         from oracle import oracle as O  # checker only
