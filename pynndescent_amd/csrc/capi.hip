@@ -117,6 +117,10 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
     // reverse-offer slots per (vertex, class): at least max_candidates rounded up to a power of two, so that a vertex
     // can fill its list from reverse offers alone, as the reference's max_candidates-deep heaps can (utils.py:277-306)
     ctx->rcap = p->max_candidates <= 32 ? 32 : 64;
+    if (const char *rc_env = getenv("NND_RCAP")) {  // experiments: reverse-offer slots per (vertex, class), a power of two
+        const int r = atoi(rc_env);
+        if (r == 16 || r == 32 || r == 64) ctx->rcap = r;
+    }
     ctx->pcap = 64;  // one candidate per lane in k_merge (merge.h NCHUNK = 1)
     if (ctx->p.join_blocks < 1) ctx->p.join_blocks = 1;
     ctx->seed = nnd_mix32((uint32_t)p->rng_state[0] ^ nnd_mix32((uint32_t)p->rng_state[1] + 0x9E3779B9u) ^

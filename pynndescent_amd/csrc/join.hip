@@ -145,6 +145,9 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
             const int64_t ide = nx_id >= 0 ? nx_id : 0;
             nx_nrm = nrm[ide];
             nx_th = th[ide];  // compact per-row worst distance (L2 resident), not a 128-byte line per candidate
+#ifdef NND_JOIN_EXTRA_LOAD  // perturbation experiment: what does one more random 4-byte load per candidate cost?
+            nx_nrm += nrm[(uint32_t)(((uint64_t)(uint32_t)ide * 2654435761ull) % (uint64_t)own_hi)] * 0.0f;
+#endif
         }
 #pragma clang loop unroll(full)
         for (int i = 0; i < KQL; i++) {
