@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : (QW && NT <= 5 
             }
             float my_nrm = 0.0f;
             if (c0 == 0) {
-                if (tid < C::MP) {
+                if (!QW && tid < C::MP) {  // QW: the squared norms are the diagonal of the Gram block (see below)
                     const int id = ids[tid];
                     my_nrm = nrm[id >= 0 ? id : 0];
                 }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : (QW && NT <= 5 
                     *(f32x4 *)&Xs[nnd_swz<DC>(r, ch)] = rv[q];
                 }
             }
-            if (c0 == 0 && tid < C::MP) nrs[tid] = my_nrm;
+            if (!QW && c0 == 0 && tid < C::MP) nrs[tid] = my_nrm;
         }
         __syncthreads();
         if constexpr (C::FULLD) {
@@ -200,6 +200,19 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : (QW && NT <= 5 
                 const int I = w + tr * NW;
                 if (I < nt) nnd_gram_chunk<DC, NT>(Xs, I * 16, 0, cw, acc[tr], [nt](int J) { return J < nt; });
             }
+        }
+    }
+    if constexpr (QW) {
+        // |x_i|^2 = G[i][i]: the diagonal tiles hold the squared norms of this leaf's rows, in the SAME arithmetic as the
+        // off-diagonal products (d(i, i) is exactly 0), and the leaf needs no gather of n random 4-byte norms -- each of
+        // which costs a 128-byte line: 128 MB of the ~1 GB a launch moves at 1 M points.
+        const int r16d = lane & 15, gd = lane >> 4;
+#pragma unroll
+        for (int q = 0; q < C::TPW; q++) {
+            if (!tOn[q] || tI[q] != tJ[q]) continue;  // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (4 * gd + r == r16d) nrs[tI[q] * 16 + r16d] = acct[q][r];
         }
     }
     __syncthreads();  // Xs is overwritten by the distance blocks below
