@@ -62,11 +62,11 @@ static void free_all(nnd_ctx *ctx) {
         if (p) (void)hipFree(p);
     };
     if (ctx->x_owned) F((void *)ctx->x_orig);
-    F(ctx->xp); F(ctx->nrm); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->cand); F(ctx->rbuf); F(ctx->pbuf);
+    F(ctx->xp); F(ctx->nrm); F(ctx->nr2); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->cand); F(ctx->rbuf); F(ctx->pbuf);
     F(ctx->pdirty); F(ctx->active);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
-    F(ctx->xs); F(ctx->xsh); F(ctx->nrms); F(ctx->node_hf); F(ctx->node_hh); F(ctx->node_child); F(ctx->node_pack); F(ctx->s_leaf_depth);
+    F(ctx->xs); F(ctx->xsh); F(ctx->nr2s); F(ctx->node_hf); F(ctx->node_hh); F(ctx->node_child); F(ctx->node_pack); F(ctx->s_leaf_depth);
     F(ctx->cell_count); F(ctx->cell_start); F(ctx->cell_depth); F(ctx->small_list);
     F(ctx->hyper); F(ctx->hyper_h); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->wl_start); F(ctx->wl_len); F(ctx->colsum_partial); F(ctx->counters_sum);
     if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; }
@@ -136,6 +136,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
         if ((rc = dalloc(ctx, &ctx->xp, n * ctx->dp))) break;
         if ((rc = dalloc(ctx, &ctx->nrm, n))) break;
         if (p->n_trees > 0 && (rc = dalloc(ctx, &ctx->xh, n * ctx->dp))) break;
+        if (p->n_trees > 0 && (rc = dalloc(ctx, &ctx->nr2, n))) break;
         if ((rc = dalloc(ctx, &ctx->mean, (size_t)ctx->dp))) break;
         if ((rc = dalloc(ctx, &ctx->knn_e, n * ctx->ks))) break;
         if ((rc = dalloc(ctx, &ctx->knn_d, n * ctx->ks))) break;
@@ -173,7 +174,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
                 ctx->max_segs += ctx->cell_cap;
                 if ((rc = dalloc(ctx, &ctx->xs, (size_t)ctx->s_m * ctx->dp))) break;
                 if ((rc = dalloc(ctx, &ctx->xsh, (size_t)ctx->s_m * ctx->dp))) break;
-                if ((rc = dalloc(ctx, &ctx->nrms, (size_t)ctx->s_m))) break;
+                if ((rc = dalloc(ctx, &ctx->nr2s, (size_t)ctx->s_m))) break;
                 if ((rc = dalloc(ctx, &ctx->node_hf, (size_t)ctx->node_cap * (ctx->dp + 4)))) break;
                 if ((rc = dalloc(ctx, &ctx->node_hh, (size_t)ctx->node_cap * ctx->dp))) break;
                 if ((rc = dalloc(ctx, &ctx->node_child, (size_t)ctx->node_cap * 2))) break;

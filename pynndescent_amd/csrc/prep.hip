@@ -40,24 +40,36 @@ __global__ __launch_bounds__(256) void k_colsum_final(const double *__restrict__
 }
 
 // ---- one wave per row: pad + centre / normalise + norm ----
+// nr2[row] = (nrm[row], |xp_row - bf16(xp_row)| rounded up): the norm and how far the bf16 copy the forest screens with
+// is from the row, side by side (one 8-byte load per point in the margin kernels)
 __global__ __launch_bounds__(256) void k_prep_rows(const float *__restrict__ x, int64_t n, int d, int dp, int metric,
                                                    const float *__restrict__ mean, float *__restrict__ xp,
-                                                   float *__restrict__ nrm, uint16_t *__restrict__ xh) {
+                                                   float *__restrict__ nrm, uint16_t *__restrict__ xh,
+                                                   float2 *__restrict__ nr2) {
     int lane = nnd_lane();
     int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n) return;
     const float *src = x + row * d;
     float *dst = xp + row * dp;
     if (metric == 0) {
-        float s = 0.0f;
+        float s = 0.0f, r2 = 0.0f;
         for (int j = lane; j < dp; j += 64) {
             float v = j < d ? src[j] - mean[j] : 0.0f;
             dst[j] = v;
-            if (xh) xh[row * dp + j] = nnd_f32_to_bf16(v);
+            if (xh) {
+                const uint16_t b = nnd_f32_to_bf16(v);
+                xh[row * dp + j] = b;
+                const float e = v - __uint_as_float((uint32_t)b << 16);
+                r2 += e * e;
+            }
             s += v * v;
         }
         s = nnd_wave_sum_f32(s);
-        if (lane == 0) nrm[row] = s;
+        if (xh) r2 = nnd_wave_sum_f32(r2);
+        if (lane == 0) {
+            nrm[row] = s;
+            if (xh) nr2[row] = make_float2(s, sqrtf(r2) * 1.000001f);
+        }
     } else {
         float s = 0.0f;
         for (int j = lane; j < d; j += 64) {
@@ -66,12 +78,22 @@ __global__ __launch_bounds__(256) void k_prep_rows(const float *__restrict__ x, 
         }
         s = nnd_wave_sum_f32(s);
         float inv = s > 0.0f ? 1.0f / sqrtf(s) : 0.0f;
+        float r2 = 0.0f;
         for (int j = lane; j < dp; j += 64) {
             const float v = j < d ? src[j] * inv : 0.0f;
             dst[j] = v;
-            if (xh) xh[row * dp + j] = nnd_f32_to_bf16(v);
+            if (xh) {
+                const uint16_t b = nnd_f32_to_bf16(v);
+                xh[row * dp + j] = b;
+                const float e = v - __uint_as_float((uint32_t)b << 16);
+                r2 += e * e;
+            }
         }
-        if (lane == 0) nrm[row] = s > 0.0f ? 1.0f : 0.0f;
+        if (xh) r2 = nnd_wave_sum_f32(r2);
+        if (lane == 0) {
+            nrm[row] = s > 0.0f ? 1.0f : 0.0f;
+            if (xh) nr2[row] = make_float2(s > 0.0f ? 1.0f : 0.0f, sqrtf(r2) * 1.000001f);
+        }
     }
 }
 
@@ -99,7 +121,7 @@ int nnd_launch_prep(nnd_ctx *ctx) {
     }
     int64_t blocks = (n + 3) / 4;
     hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->x_orig, n, d, dp,
-                       ctx->p.metric, ctx->mean, ctx->xp, ctx->nrm, ctx->xh);
+                       ctx->p.metric, ctx->mean, ctx->xp, ctx->nrm, ctx->xh, ctx->nr2);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

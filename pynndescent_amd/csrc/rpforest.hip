@@ -76,12 +76,17 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
     const float *xr = xp + (int64_t)perm[a + ri] * dp;
     float *h = hyper + (int64_t)s * hs;
     uint16_t *hb = hyper_h + (int64_t)s * dp;  // bf16 copy read by the screening pass of the margin kernels
-    float acc = 0.0f, sq = 0.0f;
+    float acc = 0.0f, sq = 0.0f, res = 0.0f;
     for (int j = lane; j < dp; j += 64) {
         float l = xl[j], r = xr[j];
         float v = l - r;
         h[j] = v;
-        if (!angular) hb[j] = nnd_f32_to_bf16(v);
+        if (!angular) {
+            const uint16_t b = nnd_f32_to_bf16(v);
+            hb[j] = b;
+            const float e = v - __uint_as_float((uint32_t)b << 16);
+            res += e * e;
+        }
         acc += angular ? v * v : v * (l + r);
         sq += v * v;
     }
@@ -93,15 +98,24 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
         for (int j = lane; j < dp; j += 64) {
             const float v = h[j] * inv;
             h[j] = v;
-            hb[j] = nnd_f32_to_bf16(v);
+            const uint16_t b = nnd_f32_to_bf16(v);
+            hb[j] = b;
+            const float e = v - __uint_as_float((uint32_t)b << 16);
+            res += e * e;
         }
+        res = nnd_wave_sum_f32(res);
         if (lane == 0) {
             h[dp] = 0.0f;
             h[dp + 1] = nh * inv;  // |h| after normalisation (1, or |h| itself when degenerate)
+            h[dp + 2] = sqrtf(res) * 1.000001f;  // |h - bf16(h)|
         }
-    } else if (lane == 0) {
-        h[dp] = -0.5f * acc;
-        h[dp + 1] = sqrtf(sq);
+    } else {
+        res = nnd_wave_sum_f32(res);
+        if (lane == 0) {
+            h[dp] = -0.5f * acc;
+            h[dp + 1] = sqrtf(sq);
+            h[dp + 2] = sqrtf(res) * 1.000001f;  // |h - bf16(h)|
+        }
     }
 }
 
@@ -117,6 +131,18 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
 // the band (a few percent at the top of a tree, more in small dense nodes) are recomputed from the f32 row and the
 // f32 hyperplane, so the split is exactly the f32 split.
 #define RP_BAND 0.00786f
+// The bound actually used is tighter: with r_x = |x - bf16(x)| (stored per point by the prep kernel) and
+// r_h = |h - bf16(h)| (stored per hyperplane),
+//     x.h - bf(x).bf(h) = (x - bf(x)).h + bf(x).(h - bf(h))   =>   |error| <= r_x |h| + (|x| + r_x) r_h
+// by Cauchy-Schwarz on the two residual vectors -- rounding errors do not line up with the other operand the way the
+// elementwise worst case assumes, and r is ~0.4 * 2^-8 of the norm on average, so the band is ~2.6x narrower than
+// RP_BAND |h||x| and as rigorous.  RP_ACC covers the f32 accumulation-order differences of both sums.
+#define RP_ACC 3e-5f
+__device__ __forceinline__ float rp_band(float xnorm, float rx, float hnorm, float rh) {
+    return rx * hnorm + (xnorm + rx) * rh + RP_ACC * hnorm * xnorm + RP_EPS;  // + RP_EPS: outside the band the exact margin is no coin flip either
+}
+// non-negative f32 -> bf16 bits, rounded UP (packed bounds stay bounds)
+__device__ __forceinline__ uint32_t rp_bf16_up(float v) { return (__float_as_uint(v) + 0xFFFFu) >> 16; }
 typedef __attribute__((ext_vector_type(2))) __bf16 rp_bf16x2;
 __device__ __forceinline__ float rp_dot8(uint4 q, uint4 p, float acc) {
     acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2, q.x), __builtin_bit_cast(rp_bf16x2, p.x), acc, false);
@@ -145,14 +171,18 @@ __device__ __forceinline__ float rp_exact_quad(const float *__restrict__ xf_row,
 // side of the split from a screened margin; `key` feeds the coin flip of rp_trees.py:380-385
 __device__ __forceinline__ uint8_t rp_side(float m, float band, const float *__restrict__ xf_row, const float *h, float off,
                                            int dp, int sub, uint32_t seed, uint32_t key, int depth) {
+#ifdef NND_RP_NORECHECK  // timing experiments only
+    if (band < 0.0f) m = rp_exact_quad(xf_row, h, dp, sub) + off;
+#else
     if (!(fabsf(m) > band)) m = rp_exact_quad(xf_row, h, dp, sub) + off;  // uniform inside the quad
+#endif
     if (fabsf(m) < RP_EPS) return (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, key, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
     return m > 0.0f ? 0 : 1;                                                                              // rp_trees.py:386-391
 }
 
 // position-major: neighbouring positions share a hyperplane; rows are gathered through perm
 __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
-                                                const float *__restrict__ nrm, int metric, int dp,
+                                                const float2 *__restrict__ nr, int metric, int dp,
                                                 const int32_t *__restrict__ perm, const int32_t *__restrict__ pos_seg,
                                                 int64_t P, const float *__restrict__ hyper, int hs,
                                                 const uint16_t *__restrict__ hyper_h, uint32_t seed, int depth,
@@ -165,7 +195,8 @@ __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, co
     const uint4 *x8 = (const uint4 *)(xh + pt * dp);
     const uint4 *h8 = (const uint4 *)(hyper_h + (int64_t)s * dp);
     const float *h = hyper + (int64_t)s * hs;
-    const float xn = nrm[pt], off = h[dp], hnorm = h[dp + 1];
+    const float2 nrv = nr[pt];  // (|x|^2 or the unit-norm flag, |x - bf16(x)|)
+    const float xn = nrv.x, rx = nrv.y, off = h[dp], hnorm = h[dp + 1], rh = h[dp + 2];
     float acc = 0.0f;
     for (int c = sub; c < (dp >> 3); c += 16) {  // 4 chunks per lane and step: the 8 loads are issued together
         uint4 q[4], p[4];
@@ -180,7 +211,7 @@ __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, co
             if (c + 4 * j < (dp >> 3)) acc = rp_dot8(q[j], p[j], acc);
     }
     const float m = rp_quad_sum(acc) + off;
-    const float band = RP_BAND * hnorm * (metric == 0 ? sqrtf(xn) : xn) + 1e-30f;
+    const float band = rp_band(metric == 0 ? sqrtf(xn) : xn, rx, hnorm, rh);
     const uint8_t sd = rp_side(m, band, xp + pt * dp, h, off, dp, sub, seed, (uint32_t)g, depth);
     if (sub == 0) side[g] = sd;
 }
@@ -190,7 +221,7 @@ __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, co
 // to side_pt[t*n + i] -- so apart from the hyperplane look-ups (a table that sits in L2) all its traffic is sequential.
 // The scan that follows brings the sides into position order (k_scan_reduce mode 2).
 __global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
-                                                      const float *__restrict__ nrm, int metric, int dp, int64_t n,
+                                                      const float2 *__restrict__ nr, int metric, int dp, int64_t n,
                                                       int n_trees, const int32_t *__restrict__ seg_pt,
                                                       const float *__restrict__ hyper, int hs,
                                                       const uint16_t *__restrict__ hyper_h, uint32_t seed, int depth,
@@ -199,7 +230,8 @@ __global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ 
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
     if (i >= n) return;  // whole quad
     const uint4 *x8 = (const uint4 *)(xh + i * dp);
-    const float xn = nrm[i];
+    const float2 nrv = nr[i];
+    const float xn = nrv.x, rx = nrv.y;
     const float xnorm = metric == 0 ? sqrtf(xn) : xn;
     const int nch = dp >> 3;
     // trees in batches of 4: segment ids, then hyperplane chunks of the whole batch, are independent loads issued together
@@ -231,9 +263,9 @@ __global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ 
         for (int u = 0; u < 4; u++) {
             if (sg[u] < 0) continue;  // whole quad
             const float *h = hyper + (int64_t)sg[u] * hs;
-            const float off = h[dp], hnorm = h[dp + 1];
+            const float off = h[dp], hnorm = h[dp + 1], rh = h[dp + 2];
             const float m = rp_quad_sum(acc[u]) + off;
-            const float band = RP_BAND * hnorm * xnorm + 1e-30f;
+            const float band = rp_band(xnorm, rx, hnorm, rh);
             const int64_t slot = (int64_t)(t0 + u) * n + i;
             const uint8_t sd = rp_side(m, band, xp + i * dp, h, off, dp, sub, seed, (uint32_t)slot, depth);
             if (sub == 0) side_pt[slot] = sd;
@@ -559,7 +591,7 @@ struct rp_record {
 // dependent latencies (pivot rows, member rows), so what pays is many independent cells per CU, not many lanes per cell.
 template <bool BIG, int NTHR, int CAP, bool RECORD = false>
 __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
-                                                         const float *__restrict__ nrm, int metric, int dp, int64_t n,
+                                                         const float2 *__restrict__ nr, int metric, int dp, int64_t n,
                                                          int32_t *__restrict__ perm,
                                                          const int32_t *__restrict__ seg_start,
                                                          const int32_t *__restrict__ seg_len,
@@ -685,8 +717,21 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
         __syncthreads();
         // margins: one quad per member (bf16-screened like k_margin), two members per quad and step so that 8 row
         // fetches are in flight per lane; the bf16 hyperplane comes from LDS
-        for (int j = tid; j < dp; j += NTHR) hb[j] = nnd_f32_to_bf16(h[j]);
+        float pres = 0.0f;  // |h - bf16(h)|^2: the hyperplane's share of the screening band (rp_band)
+        for (int j = tid; j < dp; j += NTHR) {
+            const float v = h[j];
+            const uint16_t b = nnd_f32_to_bf16(v);
+            hb[j] = b;
+            const float e = v - __uint_as_float((uint32_t)b << 16);
+            pres += e * e;
+        }
+        pres = nnd_wave_sum_f32(pres);
+        if (lane == 0) ((float *)wsum)[w] = pres;
         __syncthreads();
+        float rhv = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NW; q++) rhv += ((float *)wsum)[q];
+        rhv = sqrtf(rhv) * 1.000001f;
         if (RECORD) {
             float *rh = rec.hf + (int64_t)me * rec.hs;
             uint16_t *rb = rec.hh + (int64_t)me * dp;
@@ -697,6 +742,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
             if (tid == 0) {
                 rh[dp] = h[dp];
                 rh[dp + 1] = h[dp + 1];
+                rh[dp + 2] = rhv;
             }
         }
         const int sub = tid & 3, grp = tid >> 2;
@@ -706,7 +752,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
         constexpr int GQ = NTHR / 4;  // quads per workgroup
         for (int i0 = 0; i0 < l; i0 += 2 * GQ) {
             int64_t pt[2];
-            float acc[2], xn[2];
+            float acc[2], xn[2], rxv[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int i = i0 + u * GQ + grp;
@@ -714,7 +760,11 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
                 acc[u] = 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 2; u++) xn[u] = nrm[pt[u]];
+            for (int u = 0; u < 2; u++) {
+                const float2 nrv = nr[pt[u]];
+                xn[u] = nrv.x;
+                rxv[u] = nrv.y;
+            }
             for (int c = sub; c < nch; c += 16) {
                 uint4 q[2][4], p[4];
 #pragma unroll
@@ -734,7 +784,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
                 const int i = i0 + u * GQ + grp;
                 if (i >= l) continue;  // whole quad
                 const float m = rp_quad_sum(acc[u]) + off;
-                const float band = RP_BAND * hnorm * (metric == 0 ? sqrtf(xn[u]) : xn[u]) + 1e-30f;
+                const float band = rp_band(metric == 0 ? sqrtf(xn[u]) : xn[u], rxv[u], hnorm, rhv);
                 const uint8_t side = rp_side(m, band, xp + pt[u] * dp, h, off, dp, sub, seedt, (uint32_t)pt[u], dep);
                 if (sub == 0) sd[i] = side;
             }
@@ -868,16 +918,16 @@ __global__ void k_fill_leaf_array(const int32_t *__restrict__ perm, const int32_
 // trees and levels, only hyperplanes are fetched (bf16 screen from L2, exact f32 recheck inside the error band, same
 // coin flips for |margin| < eps), the point's cell is counted with one atomicAdd whose return value is its slot in
 // the cell, and k_place writes the permutation.  Cells are finished by k_finish_subtrees, which is order independent.
-__global__ void k_gather_sample(const float *__restrict__ xp, const uint16_t *__restrict__ xh, const float *__restrict__ nrm,
+__global__ void k_gather_sample(const float *__restrict__ xp, const uint16_t *__restrict__ xh, const float2 *__restrict__ nr,
                                 int dp, int64_t m, int64_t stride, uint32_t seed, float *__restrict__ xs,
-                                uint16_t *__restrict__ xsh, float *__restrict__ nrms) {
+                                uint16_t *__restrict__ xsh, float2 *__restrict__ nrs) {
     const int sub = threadIdx.x & 15;
     const int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     if (j >= m) return;
     const int64_t i = j * stride + (int64_t)(nnd_hash2(seed ^ 0x7F4A7C15u, (uint32_t)j) % (uint32_t)stride);
     for (int c = sub; c < (dp >> 2); c += 16) ((float4 *)(xs + j * dp))[c] = ((const float4 *)(xp + i * dp))[c];
     for (int c = sub; c < (dp >> 3); c += 16) ((uint4 *)(xsh + j * dp))[c] = ((const uint4 *)(xh + i * dp))[c];
-    if (sub == 0) nrms[j] = nrm[i];
+    if (sub == 0) nrs[j] = nr[i];
 }
 
 __device__ __forceinline__ uint32_t rp_pack_bf16(float a, float b) {
@@ -887,8 +937,9 @@ __device__ __forceinline__ float rp_dot4f(float4 a, float4 b, float acc) {
     return acc + a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
 
-// Recorded nodes are packed for the walk: [dp bf16 hyperplane | f32 offset | f32 |h| | child 0 | child 1], one record of
-// 2 * dp + 16 bytes per node (a walk step touches ONE contiguous record instead of three tables).
+// Recorded nodes are packed for the walk: [dp bf16 hyperplane | f32 offset | bf16 |h| : bf16 |h - bf16(h)| (both rounded
+// up) | child 0 | child 1], one record of 2 * dp + 16 bytes per node (a walk step touches ONE contiguous record instead
+// of three tables).
 __global__ void k_pack_nodes(const uint16_t *__restrict__ node_hh, const float *__restrict__ node_hf, int hs,
                              const int32_t *__restrict__ node_child, int dp, int64_t n_nodes, unsigned char *__restrict__ pack) {
     const int sub = threadIdx.x & 15;
@@ -900,8 +951,8 @@ __global__ void k_pack_nodes(const uint16_t *__restrict__ node_hh, const float *
     for (int c = sub; c < (dp >> 3); c += 16) dst[c] = src[c];
     if (sub == 0) {
         const float *h = node_hf + v * hs;
-        dst[dp >> 3] = make_uint4(__float_as_uint(h[dp]), __float_as_uint(h[dp + 1]), (uint32_t)node_child[2 * v],
-                                  (uint32_t)node_child[2 * v + 1]);
+        dst[dp >> 3] = make_uint4(__float_as_uint(h[dp]), (rp_bf16_up(h[dp + 1]) << 16) | rp_bf16_up(h[dp + 2]),
+                                  (uint32_t)node_child[2 * v], (uint32_t)node_child[2 * v + 1]);
     }
 }
 
@@ -911,7 +962,7 @@ __global__ void k_pack_nodes(const uint16_t *__restrict__ node_hh, const float *
 // [0, n_top), the level-synchronous build numbers nodes level by level) are served from an LDS copy, deeper ones from
 // L2.  Persistent workgroups (the LDS copy is loaded once per workgroup).
 template <int NC, int TB>
-__global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, const float *__restrict__ nrm, int metric, int dp,
+__global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, const float2 *__restrict__ nr, int metric, int dp,
                                                int64_t n, int n_trees, const unsigned char *__restrict__ node_pack,
                                                const float *__restrict__ node_hf, int hs,
                                                const int32_t *__restrict__ leafscan, uint32_t seed,
@@ -946,7 +997,8 @@ __global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, con
                 xq[q] = make_uint4(rp_pack_bf16(xa[q].x, xa[q].y), rp_pack_bf16(xa[q].z, xa[q].w), rp_pack_bf16(xb[q].x, xb[q].y),
                                    rp_pack_bf16(xb[q].z, xb[q].w));
         }
-        const float xn = nrm[i];
+        const float2 nrv = nr[i];
+        const float xn = nrv.x, rx = nrv.y;
         const float xnorm = metric == 0 ? sqrtf(xn) : xn;
         for (int t0 = 0; t0 < n_trees; t0 += TB) {
             int node[TB];  // >= 0: current node (the root of tree t is node t); -1: this walk is over
@@ -988,9 +1040,10 @@ __global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, con
 #pragma unroll
                 for (int u = 0; u < TB; u++) {
                     if (node[u] < 0) continue;  // whole quad
-                    const float off = __uint_as_float(meta[u].x), hnorm = __uint_as_float(meta[u].y);
+                    const float off = __uint_as_float(meta[u].x), hnorm = __uint_as_float(meta[u].y & 0xFFFF0000u),
+                                rh = __uint_as_float(meta[u].y << 16);
                     float m = rp_quad_sum(acc[u]) + off;
-                    const float band = RP_BAND * hnorm * xnorm + 1e-30f;
+                    const float band = rp_band(xnorm, rx, hnorm, rh);
                     if (!(fabsf(m) > band)) {  // inside the bf16 error band: the exact f32 margin decides (quad-uniform)
                         const float4 *h4 = (const float4 *)(node_hf + (int64_t)node[u] * hs);
                         float e = 0.0f;
@@ -1016,6 +1069,160 @@ __global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, con
                         node[u] = -1;
                     } else {
                         node[u] = nxt;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// One tree per XCD.  k_route above walks every tree from every workgroup, so each XCD's L2 (4 MB) has to hold the node
+// records of ALL trees (10 MB at 1 M points, 8 trees): the deep levels miss and come over the fabric -- 10 GB of
+// fetches per build, 20 x the rows themselves.  Here the workgroups of XCD x (workgroups are dealt round-robin, so
+// that is blockIdx.x & 7) walk only trees x, x + 8, ...: one tree's records (1.3 MB) stay in that XCD's L2, and the
+// first l_top levels of the tree -- ALL its nodes at those depths, whoever recorded them -- sit in LDS in heap order
+// (slot 1 = root, children of slot s at 2s and 2s + 1), so a walk reads LDS while depth < l_top and L2 after that.
+// The price: a point's row is fetched once per tree instead of once -- but only its bf16 copy (the screening operand,
+// 2 * dp bytes); the f32 row is touched only when a margin falls inside the bf16 error band.  PB points per quad walk
+// in lock step (independent chains to cover the L2 latency).  Same arithmetic, same coins, same cells as k_route.
+#ifndef NND_RX_OCC
+#define NND_RX_OCC 4  // waves per SIMD the register budget is sized for (two 512-thread workgroups per CU)
+#endif
+#ifndef NND_RX_LDS_KB
+#define NND_RX_LDS_KB 72
+#endif
+template <int NC, int PB>
+__global__ __launch_bounds__(512, NND_RX_OCC) void k_route_xcd(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
+                                                   const float2 *__restrict__ nr, int metric, int dp, int64_t n, int n_trees,
+                                                   const unsigned char *__restrict__ node_pack,
+                                                   const float *__restrict__ node_hf, int hs,
+                                                   const int32_t *__restrict__ leafscan, uint32_t seed,
+                                                   int32_t *__restrict__ cell_count, int32_t *__restrict__ cell_of,
+                                                   int32_t *__restrict__ rank_of, int l_top) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char top_tab[];
+    const int rec = 2 * dp + 16, r16 = rec >> 4, nslots = 1 << l_top;
+    int32_t *top_node = (int32_t *)(top_tab + (size_t)nslots * rec);  // node id of every heap slot (-1: no node there)
+    const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+    const int sub = threadIdx.x & 3, qpb = blockDim.x >> 2;
+    for (int t = xcd; t < n_trees; t += 8) {
+        __syncthreads();  // the previous tree's table is no longer read
+        if (threadIdx.x == 0) {
+            top_node[0] = -1;
+            top_node[1] = t;  // the root of tree t is node t
+        }
+        __syncthreads();
+        for (int l = 0; l + 1 < l_top; l++) {  // children of the slots of level l
+            for (int sl = (1 << l) + threadIdx.x; sl < (2 << l); sl += blockDim.x) {
+                const int nd = top_node[sl];
+                int c0 = -1, c1 = -1;
+                if (nd >= 0) {
+                    const uint4 meta = *(const uint4 *)(node_pack + (int64_t)nd * rec + 2 * dp);
+                    c0 = (int)meta.z;
+                    c1 = (int)meta.w;
+                }
+                top_node[2 * sl] = c0 >= 0 ? c0 : -1;  // cells (<= -2) have no record
+                top_node[2 * sl + 1] = c1 >= 0 ? c1 : -1;
+            }
+            __syncthreads();
+        }
+        for (int q = threadIdx.x; q < nslots * r16; q += blockDim.x) {
+            const int sl = q / r16, wd = q - sl * r16;
+            const int nd = top_node[sl];
+            if (nd >= 0) ((uint4 *)top_tab)[q] = ((const uint4 *)(node_pack + (int64_t)nd * rec))[wd];
+        }
+        __syncthreads();
+        for (int64_t i0 = (int64_t)bx * qpb * PB; i0 < n; i0 += (int64_t)nbx * qpb * PB) {
+            int64_t pi[PB];
+            uint4 xq[PB][NC];
+            float xnorm[PB], rxv[PB];
+            int node[PB], hidx[PB];
+#pragma unroll
+            for (int u = 0; u < PB; u++) {
+                pi[u] = i0 + (int64_t)u * qpb + (threadIdx.x >> 2);
+                const bool on = pi[u] < n;
+                const int64_t ic = on ? pi[u] : 0;
+                const uint4 *row = (const uint4 *)(xh + ic * dp);
+#pragma unroll
+                for (int q = 0; q < NC; q++) xq[u][q] = row[sub + 4 * q];
+                const float2 nrv = nr[ic];
+                const float xn = nrv.x;
+                rxv[u] = nrv.y;
+                xnorm[u] = metric == 0 ? sqrtf(xn) : xn;
+                node[u] = on ? t : -1;  // >= 0: current node; -1: this walk is over (whole quad)
+                hidx[u] = 1;
+            }
+            for (int depth = 0;; depth++) {
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < PB; u++) any |= node[u] >= 0;
+                if (!__ballot(any)) break;  // wave-uniform
+                uint4 p[PB][NC], meta[PB];
+                if (depth < l_top) {  // every live walk is at depth `depth`: heap slot hidx < 2^l_top
+#pragma unroll
+                    for (int u = 0; u < PB; u++) {
+                        const uint4 *r8 = (const uint4 *)(top_tab + (size_t)(node[u] >= 0 ? hidx[u] : 1) * rec);
+#pragma unroll
+                        for (int q = 0; q < NC; q++) p[u][q] = r8[sub + 4 * q];
+                        meta[u] = r8[dp >> 3];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PB; u++) {
+                        const uint4 *r8 = (const uint4 *)(node_pack + (int64_t)(node[u] >= 0 ? node[u] : t) * rec);
+#pragma unroll
+                        for (int q = 0; q < NC; q++) p[u][q] = r8[sub + 4 * q];
+                        meta[u] = r8[dp >> 3];
+                    }
+                }
+                float acc[PB];
+#pragma unroll
+                for (int u = 0; u < PB; u++) {
+                    acc[u] = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < NC; q++) acc[u] = rp_dot8(xq[u][q], p[u][q], acc[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < PB; u++) {
+                    if (node[u] < 0) continue;  // whole quad
+                    const float off = __uint_as_float(meta[u].x), hnorm = __uint_as_float(meta[u].y & 0xFFFF0000u),
+                                rh = __uint_as_float(meta[u].y << 16);
+                    float m = rp_quad_sum(acc[u]) + off;
+                    const float band = rp_band(xnorm[u], rxv[u], hnorm, rh);
+#ifdef NND_RX_NORECHECK  // timing experiments only
+                    if (band < 0.0f) {
+#else
+                    if (!(fabsf(m) > band)) {  // inside the bf16 error band: the exact f32 margin decides (quad-uniform)
+#endif
+                        const float4 *h4 = (const float4 *)(node_hf + (int64_t)node[u] * hs);
+                        const float4 *x4 = (const float4 *)(xp + pi[u] * dp);
+                        float e = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < NC; q++) {
+                            const int c = sub + 4 * q;
+                            e = rp_dot4f(x4[2 * c], h4[2 * c], e);
+                            e = rp_dot4f(x4[2 * c + 1], h4[2 * c + 1], e);
+                        }
+                        m = rp_quad_sum(e) + off;
+                    }
+                    const int64_t slot = (int64_t)t * n + pi[u];
+                    int side;
+                    if (fabsf(m) < RP_EPS) side = (int)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)slot, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
+                    else side = m > 0.0f ? 0 : 1;                                                                             // rp_trees.py:386-391
+                    const int nxt = (int)(side ? meta[u].w : meta[u].z);
+                    if (nxt <= -2) {  // reached a cell: first sample position -2 - nxt -> cell index
+                        if (sub == 0) {
+                            const int cell = leafscan[-2 - nxt];
+                            cell_of[slot] = cell;
+#ifdef NND_RX_NOATOMIC  // timing experiments only
+                            rank_of[slot] = 0;
+#else
+                            rank_of[slot] = atomicAdd(&cell_count[cell], 1);
+#endif
+                        }
+                        node[u] = -1;
+                    } else {
+                        node[u] = nxt;
+                        hidx[u] = 2 * hidx[u] + side;
                     }
                 }
             }
@@ -1091,7 +1298,7 @@ static size_t fin_smem_bytes(int dp, int cap /* 0: ids in global memory */) {
 struct forest_view {
     const float *xp;
     const uint16_t *xh;
-    const float *nrm;
+    const float2 *nr;  // per row: (|x|^2 -- 1 / 0 for normalised rows --, |x - bf16(x)|: the point's share of the screening band)
     int64_t n, P;     // points per tree, n_trees * n
     int leaf_size;    // split while len > leaf_size (rp_trees.py:2188)
     int fin_max;      // children of <= fin_max points leave the passes for k_finish_subtrees (0: never)
@@ -1109,7 +1316,7 @@ static int launch_finishers(nnd_ctx *ctx, int32_t *perm, int32_t *other, const i
     int32_t *fin_len = fin_start + ctx->max_segs;
     int32_t *fin_depth = fin_len + ctx->max_segs;
     long long *fin_count = ctx->counters + CNT_SCRATCH + 1;
-#define FIN_ARGS(st, ln, dpth, d0, cnt) ctx->xp, ctx->xh, ctx->nrm, ctx->p.metric, dp, ctx->n, perm, st, ln, dpth, d0, (int)(cnt), angular, \
+#define FIN_ARGS(st, ln, dpth, d0, cnt) ctx->xp, ctx->xh, ctx->nr2, ctx->p.metric, dp, ctx->n, perm, st, ln, dpth, d0, (int)(cnt), angular, \
                  ctx->tree_seed, ctx->p.max_depth, ctx->p.leaf_size, ctx->leaf_flag
     if (n_small > 0) {  // one wave per cell
         const int32_t *sl = ctx->small_list;
@@ -1193,11 +1400,11 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
         // streaming every row once (it costs n rows regardless of how many positions are active)
         const bool fused = inv_live && (S * (int64_t)dp * 2 <= (int64_t)6 << 20) && (active_pos * 2 >= 3 * n);
         if (fused) {
-            hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, v.xp, v.xh, v.nrm,
+            hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, v.xp, v.xh, v.nr,
                                ctx->p.metric, dp, n, T, ctx->inv, hyper, hs, hyper_h, ctx->tree_seed, depth, ctx->side_pt);
         } else {
             inv_live = false;
-            hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, ctx->stream, v.xp, v.xh, v.nrm,
+            hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, ctx->stream, v.xp, v.xh, v.nr,
                                ctx->p.metric, dp, ctx->perm[cur], ctx->pos_seg[cur], P, hyper, hs, hyper_h, ctx->tree_seed, depth,
                                ctx->side);
         }
@@ -1256,7 +1463,7 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
             rp_record rec{ctx->node_hf, ctx->node_hh, ctx->node_child, ctx->s_leaf_depth, hs, (int)ctx->node_cap - 1,
                           (int)(ctx->node_cap - 1 - nfin), (int)node_base, flags, flags + 1};
             hipLaunchKernelGGL((k_finish_subtrees<false, 256, FIN_MAX, true>), dim3((unsigned)nfin), dim3(256), fin_smem_bytes(dp, FIN_MAX),
-                               ctx->stream, v.xp, v.xh, v.nrm, ctx->p.metric, dp, n, ctx->perm[cur], fin_start, fin_len, fin_depth, 0,
+                               ctx->stream, v.xp, v.xh, v.nr, ctx->p.metric, dp, n, ctx->perm[cur], fin_start, fin_len, fin_depth, 0,
                                (int)nfin, angular, ctx->tree_seed, max_depth, leaf_size, ctx->leaf_flag, (int32_t *)nullptr,
                                (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, ctx->counters + CNT_SCRATCH + 1, rec);
             NND_HIP_CHECK(hipGetLastError());
@@ -1285,9 +1492,33 @@ static int launch_route(nnd_ctx *ctx, const int32_t *leafscan, int n_top, int l_
     }
     int64_t blocks = (ctx->n + 127) / 128;
     if (blocks > 2 * (int64_t)n_cu) blocks = 2 * (int64_t)n_cu;  // persistent: two 512-thread workgroups per CU
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), smem, ctx->stream, ctx->xp, ctx->nrm, ctx->p.metric, ctx->dp, ctx->n,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), smem, ctx->stream, ctx->xp, ctx->nr2, ctx->p.metric, ctx->dp, ctx->n,
                        ctx->p.n_trees, ctx->node_pack, ctx->node_hf, ctx->dp + 4, leafscan, ctx->tree_seed, ctx->cell_count,
                        ctx->pos_seg[0], ctx->pos_seg[1], n_top, l_top);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int NC, int PB>
+static int launch_route_xcd(nnd_ctx *ctx, const int32_t *leafscan) {
+    auto kern = k_route_xcd<NC, PB>;
+    const int rec = 2 * ctx->dp + 16;
+    int l_top = 1;
+    while (((size_t)2 << l_top) * (rec + 4) <= NND_RX_LDS_KB * 1024) l_top++;  // 2^l_top heap slots (+ their node ids)
+    const size_t smem = ((size_t)1 << l_top) * (rec + 4);
+    static int n_cu_dev[64] = {0};
+    int &n_cu = n_cu_dev[ctx->p.device & 63];
+    if (n_cu == 0) {
+        NND_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        hipDeviceProp_t prop;
+        NND_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->p.device));
+        n_cu = prop.multiProcessorCount;
+    }
+    int64_t blocks = (NND_RX_OCC / 2) * (int64_t)n_cu;  // persistent: NND_RX_OCC / 2 512-thread workgroups per CU
+    blocks = blocks < 8 ? 8 : (blocks & ~(int64_t)7);  // the same number of workgroups on every XCD
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), smem, ctx->stream, ctx->xp, ctx->xh, ctx->nr2, ctx->p.metric, ctx->dp,
+                       ctx->n, ctx->p.n_trees, ctx->node_pack, ctx->node_hf, ctx->dp + 4, leafscan, ctx->tree_seed, ctx->cell_count,
+                       ctx->pos_seg[0], ctx->pos_seg[1], l_top);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1297,9 +1528,9 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     const int64_t n = ctx->n, P = ctx->P, M = ctx->s_m, Ps = (int64_t)ctx->p.n_trees * M;
     const int T = ctx->p.n_trees, dp = ctx->dp;
     int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
-    hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nrm, dp,
-                       M, ctx->s_stride, ctx->tree_seed, ctx->xs, ctx->xsh, ctx->nrms);
-    forest_view v{ctx->xs, ctx->xsh, ctx->nrms, M, Ps, ctx->cell_leaf, FIN_MAX, true};
+    hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nr2,
+                       dp, M, ctx->s_stride, ctx->tree_seed, ctx->xs, ctx->xsh, ctx->nr2s);
+    forest_view v{ctx->xs, ctx->xsh, ctx->nr2s, M, Ps, ctx->cell_leaf, FIN_MAX, true};
     int rc = forest_levels(ctx, v);
     if (rc) return rc;
     // cells = leaves of the recorded trees, numbered in position order (tree-major)
@@ -1318,6 +1549,26 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     while (l_top + 1 < (int)v.level_base.size() && v.level_base[l_top + 1] * (2 * dp + 16) <= 72 * 1024) l_top++;
     const int n_top = (int)v.level_base[l_top];
     int rrc = 2;
+    // one tree per XCD (k_route_xcd) measured no faster than all trees per point (2.8-3.2 ms vs 2.8 ms at 1 M points):
+    // the walk is bound by its dependent record fetches and rechecks, not by where the records are cached.  Opt-in.
+    static const bool route_xcd = [] { const char *e = getenv("NND_ROUTE_XCD"); return e && atoi(e) != 0; }();
+    if (route_xcd && T % 8 == 0 && dp % 32 == 0 && dp <= 256) {  // every XCD gets the same number of trees
+        switch (dp / 32) {
+            case 1: rrc = launch_route_xcd<1, 4>(ctx, ctx->scan_out); break;
+            case 2: rrc = launch_route_xcd<2, 2>(ctx, ctx->scan_out); break;
+            case 3: rrc = launch_route_xcd<3, 2>(ctx, ctx->scan_out); break;
+#ifdef NND_RX_PB
+            case 4: rrc = launch_route_xcd<4, NND_RX_PB>(ctx, ctx->scan_out); break;
+#else
+            case 4: rrc = launch_route_xcd<4, 2>(ctx, ctx->scan_out); break;
+#endif
+            case 5: rrc = launch_route_xcd<5, 1>(ctx, ctx->scan_out); break;
+            case 6: rrc = launch_route_xcd<6, 1>(ctx, ctx->scan_out); break;
+            case 7: rrc = launch_route_xcd<7, 1>(ctx, ctx->scan_out); break;
+            case 8: rrc = launch_route_xcd<8, 1>(ctx, ctx->scan_out); break;
+            default: break;
+        }
+    } else
     switch (dp / 32) {  // NC = 8-float chunks per lane; trees per batch sized for <= 128 VGPRs
         case 1: rrc = launch_route<1, 4>(ctx, ctx->scan_out, n_top, l_top); break;
         case 2: rrc = launch_route<2, 4>(ctx, ctx->scan_out, n_top, l_top); break;
@@ -1374,7 +1625,7 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     if (ctx->s_m > 0) rc = forest_by_routing(ctx, &levels);
     if (rc == 1) return 1;
     if (rc == 2) {  // small point set, very wide rows, or the recorded tree outgrew its tables: whole-set passes
-        forest_view v{ctx->xp, ctx->xh, ctx->nrm, n, P, leaf_size, FIN_MAX, false};
+        forest_view v{ctx->xp, ctx->xh, ctx->nr2, n, P, leaf_size, FIN_MAX, false};
         if (forest_levels(ctx, v)) return 1;
         ctx->cur = v.cur;
         levels = v.depth;

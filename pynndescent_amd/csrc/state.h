@@ -62,6 +62,7 @@ struct nnd_handle_s {
     bool x_owned = false;
     float *xp = nullptr;   // (n,dp) prepared rows: centred (euclid) or L2-normalised (cosine), zero padded
     float *nrm = nullptr;  // (n) |x-mu|^2 (euclid) or 1/0 non-zero flag (cosine)
+    float2 *nr2 = nullptr;                    // (n) (nrm, |x - bf16(x)|) per row: what the forest's margin kernels read (rpforest.hip rp_band)
     uint16_t *xh = nullptr; // (n,dp) bf16 copy of xp: screening pass of the rp-forest margins (half the bytes)
     float *mean = nullptr; // (dp)
 
@@ -99,7 +100,7 @@ struct nnd_handle_s {
     int early_stop = 8;                       // ... or when fewer than 1 / early_stop of the sample positions are still splittable
     float *xs = nullptr;                      // (s_m, dp) compact copy of the sample rows
     uint16_t *xsh = nullptr;                  // (s_m, dp) bf16
-    float *nrms = nullptr;                    // (s_m)
+    float2 *nr2s = nullptr;                   // (s_m) the sample's copy of nr2
     int64_t node_cap = 0, cell_cap = 0;
     float *node_hf = nullptr;                 // (node_cap, dp + 4) f32 hyperplane + offset + |h|
     uint16_t *node_hh = nullptr;              // (node_cap, dp) bf16 hyperplane
