@@ -1002,8 +1002,13 @@ __global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, con
         const float xnorm = metric == 0 ? sqrtf(xn) : xn;
         for (int t0 = 0; t0 < n_trees; t0 += TB) {
             int node[TB];  // >= 0: current node (the root of tree t is node t); -1: this walk is over
+            int rk[TB];    // the point's slot in its cell: the atomic's return value is not touched before the walks of
+                           // this batch are over, so its round trip overlaps the other walks' record fetches
 #pragma unroll
-            for (int u = 0; u < TB; u++) node[u] = t0 + u < n_trees ? t0 + u : -1;
+            for (int u = 0; u < TB; u++) {
+                node[u] = t0 + u < n_trees ? t0 + u : -1;
+                rk[u] = 0;
+            }
             for (int depth = 0;; depth++) {
                 bool any = false;
 #pragma unroll
@@ -1064,13 +1069,18 @@ __global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, con
                         if (sub == 0) {
                             const int cell = leafscan[-2 - nxt];
                             cell_of[slot] = cell;
-                            rank_of[slot] = atomicAdd(&cell_count[cell], 1);
+                            rk[u] = atomicAdd(&cell_count[cell], 1);
                         }
                         node[u] = -1;
                     } else {
                         node[u] = nxt;
                     }
                 }
+            }
+            if (sub == 0) {
+#pragma unroll
+                for (int u = 0; u < TB; u++)
+                    if (t0 + u < n_trees) rank_of[(int64_t)(t0 + u) * n + i] = rk[u];
             }
         }
     }
