@@ -584,6 +584,7 @@ struct rp_record {
     int32_t *leaf_depth;  // per sample position
     int hs, node_top, down_base, lvl_end;
     int *counter, *overflow;
+    int min_len, max_len;  // this launch takes the segments with min_len <= len <= max_len (two launches share one work list)
 };
 
 // NTHR threads per workgroup, CAP = most points of a segment whose ids live in LDS.  Small cells run with ONE WAVE per
@@ -607,6 +608,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
     if (s >= n_segs) return;
     const int a = seg_start[s], len = seg_len[s];
     if (len <= 0) return;
+    if (RECORD && (len < rec.min_len || len > rec.max_len)) return;
     constexpr int NLDS = BIG ? 0 : CAP;
     constexpr int NW = NTHR / 64;
     int32_t *ids = BIG ? perm + a : (int32_t *)fsm;               // member ids of the segment
@@ -1471,11 +1473,20 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
             int *flags = (int *)(ctx->counters + CNT_SCRATCH + 2);  // [0] id counter, [1] overflow
             NND_HIP_CHECK(hipMemsetAsync(flags, 0, 2 * sizeof(int), ctx->stream));
             rp_record rec{ctx->node_hf, ctx->node_hh, ctx->node_child, ctx->s_leaf_depth, hs, (int)ctx->node_cap - 1,
-                          (int)(ctx->node_cap - 1 - nfin), (int)node_base, flags, flags + 1};
-            hipLaunchKernelGGL((k_finish_subtrees<false, 256, FIN_MAX, true>), dim3((unsigned)nfin), dim3(256), fin_smem_bytes(dp, FIN_MAX),
+                          (int)(ctx->node_cap - 1 - nfin), (int)node_base, flags, flags + 1, 0, FIN_MAX};
+            // short subtrees: one wave each (a chain of dependent latencies wants concurrency, not width); the rest: a workgroup
+            rp_record rs = rec, rl = rec;
+            rs.min_len = 0; rs.max_len = FIN_SMALL;
+            rl.min_len = FIN_SMALL + 1; rl.max_len = FIN_MAX;
+            hipLaunchKernelGGL((k_finish_subtrees<false, 64, FIN_SMALL, true>), dim3((unsigned)nfin), dim3(64), fin_smem_bytes(dp, FIN_SMALL),
                                ctx->stream, v.xp, v.xh, v.nr, ctx->p.metric, dp, n, ctx->perm[cur], fin_start, fin_len, fin_depth, 0,
                                (int)nfin, angular, ctx->tree_seed, max_depth, leaf_size, ctx->leaf_flag, (int32_t *)nullptr,
-                               (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, ctx->counters + CNT_SCRATCH + 1, rec);
+                               (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, ctx->counters + CNT_SCRATCH + 1, rs);
+            if (v.fin_max > FIN_SMALL)
+                hipLaunchKernelGGL((k_finish_subtrees<false, 256, FIN_MAX, true>), dim3((unsigned)nfin), dim3(256), fin_smem_bytes(dp, FIN_MAX),
+                                   ctx->stream, v.xp, v.xh, v.nr, ctx->p.metric, dp, n, ctx->perm[cur], fin_start, fin_len, fin_depth, 0,
+                                   (int)nfin, angular, ctx->tree_seed, max_depth, leaf_size, ctx->leaf_flag, (int32_t *)nullptr,
+                                   (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, ctx->counters + CNT_SCRATCH + 1, rl);
             NND_HIP_CHECK(hipGetLastError());
             NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 38, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             NND_HIP_CHECK(nnd_sync_spin(ctx));
@@ -1540,7 +1551,10 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
     hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nr2,
                        dp, M, ctx->s_stride, ctx->tree_seed, ctx->xs, ctx->xsh, ctx->nr2s);
-    forest_view v{ctx->xs, ctx->xsh, ctx->nr2s, M, Ps, ctx->cell_leaf, FIN_MAX, true};
+    // sample subtrees of <= 512 members leave the level-synchronous passes for the (one-wave) recording finisher;
+    // 2048 (+ a workgroup class) means 4 fewer levels but a slower finisher: 6.9-7.2 ms vs 6.6 ms per forest at 1 M points
+    static const int rec_fin = [] { const char *e = getenv("NND_REC_FIN"); const int r = e ? atoi(e) : FIN_SMALL; return r <= FIN_SMALL ? FIN_SMALL : FIN_MAX; }();
+    forest_view v{ctx->xs, ctx->xsh, ctx->nr2s, M, Ps, ctx->cell_leaf, rec_fin, true};
     int rc = forest_levels(ctx, v);
     if (rc) return rc;
     // cells = leaves of the recorded trees, numbered in position order (tree-major)
