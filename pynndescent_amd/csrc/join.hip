@@ -68,7 +68,10 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
     constexpr int KQL = RV * KQ / 64;         // of which per lane
     constexpr int RPK = 64 / KQ;              // rows per neighbour-list load
     constexpr int kls = KS16 * 16 + 4;        // padded neighbour-list row stride (words)
-    constexpr int QCAP = 8 * 64;              // pair queue: 8 (tile, row) combinations x 64 lanes
+#ifndef NND_J16_QCAP
+#define NND_J16_QCAP (8 * 64)
+#endif
+    constexpr int QCAP = NND_J16_QCAP;        // pair queue: 8 (tile, row) combinations x 64 lanes; 4 x 64: drained after every tile
     constexpr int WAVE_BYTES = QCAP * 8 + 2 * RV * 4 + 4 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;
     // klist rows are read / written as 16-byte vectors: everything in front of them is a multiple of 16 bytes
     static_assert((QCAP * 8 + 2 * RV * 4 + 4 * 4 + 5 * RV * 4) % 16 == 0 && (kls * 4) % 16 == 0, "klist must be 16-byte aligned");
@@ -242,9 +245,38 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
                 pth4[r] = cth[4 * gq + r];
             }
             int qn = 0;
+            auto drain = [&]() __attribute__((always_inline)) {
+                nnd_wave_lds_sync();
+                for (int base = 0; base < qn; base += 64) {
+                    const int t = base + lane;
+                    if (t < qn) {
+                        const uint2 en = queue[t];
+                        const int a = en.x & 31, b = (en.x >> 5) & 31;
+                        const float d = __uint_as_float(en.y);
+                        const int pid = cid[a], qid = cid[b];
+                        if ((en.x & 1024u) && !klist_has<KS16>(klist + a * kls, (uint32_t)qid)) {  // p <- q
+                            atomicMin((unsigned long long *)&pbuf[(int64_t)pid * pcap + cslot[b]],
+                                      (unsigned long long)nnd_make_key(d, (uint32_t)qid));
+                            cflag[a] = 1;
+                            tot_prop++;
+                        }
+                        if ((en.x & 2048u) && !klist_has<KS16>(klist + b * kls, (uint32_t)pid)) {  // q <- p
+                            atomicMin((unsigned long long *)&pbuf[(int64_t)qid * pcap + cslot[a]],
+                                      (unsigned long long)nnd_make_key(d, (uint32_t)pid));
+                            cflag[b] = 1;
+                            tot_prop++;
+                        }
+                    }
+                }
+                qn = 0;
+            };
 #pragma unroll
             for (int J = 0; J < 2; J++) {
                 if (J == 1 && !has_old) break;  // first iteration: there are no old candidates at all
+                if (QCAP < 8 * 64 && J == 1) {  // small queue: the first tile's pairs leave before the second tile's arrive
+                    drain();
+                    nnd_wave_lds_sync();
+                }
                 const int jj = J * 16 + r16;  // index inside [new | old]
                 const int qid = cid[jj];
                 const float qn_ = cnrm[jj], qth = cth[jj];
@@ -272,28 +304,7 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
                     }
                 }
             }
-            nnd_wave_lds_sync();
-            for (int base = 0; base < qn; base += 64) {
-                const int t = base + lane;
-                if (t < qn) {
-                    const uint2 en = queue[t];
-                    const int a = en.x & 31, b = (en.x >> 5) & 31;
-                    const float d = __uint_as_float(en.y);
-                    const int pid = cid[a], qid = cid[b];
-                    if ((en.x & 1024u) && !klist_has<KS16>(klist + a * kls, (uint32_t)qid)) {  // p <- q
-                        atomicMin((unsigned long long *)&pbuf[(int64_t)pid * pcap + cslot[b]],
-                                  (unsigned long long)nnd_make_key(d, (uint32_t)qid));
-                        cflag[a] = 1;
-                        tot_prop++;
-                    }
-                    if ((en.x & 2048u) && !klist_has<KS16>(klist + b * kls, (uint32_t)pid)) {  // q <- p
-                        atomicMin((unsigned long long *)&pbuf[(int64_t)qid * pcap + cslot[a]],
-                                  (unsigned long long)nnd_make_key(d, (uint32_t)pid));
-                        cflag[b] = 1;
-                        tot_prop++;
-                    }
-                }
-            }
+            drain();
             nnd_wave_lds_sync();
             if (lane < RV && cflag[lane]) pdirty[cid[lane]] = 1;
             if (lane < RV) tot_rows += cid[lane] >= 0;
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
 template <int DC, int KS16>
 static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     constexpr int RV = 32, kls = KS16 * 16 + 4;
-    constexpr int WAVE_BYTES = 8 * 64 * 8 + 2 * RV * 4 + 4 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;  // = the kernel's
+    constexpr int WAVE_BYTES = NND_J16_QCAP * 8 + 2 * RV * 4 + 4 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;  // = the kernel's
     size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
     auto kern = k_local_join16<DC, KS16>;
     // function attributes and occupancy are per DEVICE: cached per device ordinal, not per process
@@ -339,6 +350,10 @@ static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
         int occ = 0;
         NND_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, 256, smem));
         wg_per_cu = occ < 1 ? 1 : occ;
+        if (const char *cap = getenv("NND_J16_WGCAP")) {  // experiments: fewer resident workgroups per CU
+            const int c = atoi(cap);
+            if (c >= 1 && c < wg_per_cu) wg_per_cu = c;
+        }
     }
     int64_t nv = v_end - v_begin;
     int64_t groups = (nv + 3) / 4;
