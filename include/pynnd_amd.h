@@ -96,7 +96,10 @@ int32_t nnd_destroy(nnd_handle_t h);
 
 /* Point set, float32 C-contiguous (n, dim) -- NNDescent._raw_data (pynndescent_.py:1054-1057).
  * Host variant copies H2D; device variant BORROWS the pointer (it must outlive the handle's
- * build calls).  Both then run the prep kernel (pad to 32 floats, centre / L2-normalise, norms). */
+ * build calls).  Both then run the prep kernel (pad to 32 floats, centre / L2-normalise, norms)
+ * on the handle's stream, immediately: the device buffer must be COMPLETE when the call is made --
+ * synchronise the stream that produced it first, or make the handle run on that stream
+ * (nnd_set_stream).  The prepared copy is made once per call, not once per build. */
 int32_t nnd_set_data_host(nnd_handle_t h, const float *x);
 int32_t nnd_set_data_device(nnd_handle_t h, const float *x_dev);
 

@@ -230,7 +230,10 @@ class Builder:
         self._check(self.lib.nnd_set_data_host(self._h, _ptr(x)))
 
     def set_data_device(self, dev_ptr, keepalive=None):
-        """dev_ptr: integer address of a float32 (n, dim) C-contiguous device buffer (e.g. tensor.data_ptr())."""
+        """dev_ptr: integer address of a float32 (n, dim) C-contiguous device buffer (e.g. tensor.data_ptr()).
+
+        The prep kernel reads the buffer right away on the handle's stream: the producer must be done
+        (``torch.cuda.synchronize()`` / stream sync) unless the handle runs on the producing stream (``set_stream``)."""
         self._keepalive = keepalive
         self._check(self.lib.nnd_set_data_device(self._h, C.c_void_p(int(dev_ptr))))
 

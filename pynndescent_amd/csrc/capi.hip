@@ -34,6 +34,10 @@ extern "C" const char *nnd_last_error(nnd_handle_t h) { return h ? h->err : g_er
 template <typename T>
 static int dalloc(nnd_ctx *ctx, T **p, size_t count) {
     API_HIP(hipMalloc((void **)p, sizeof(T) * (count ? count : 1)));
+    // debugging aid: fresh hipMalloc pages are usually zero, recycled ones are not -- NND_POISON=<byte> fills every buffer with
+    // that byte (try 165: negative ints / tiny floats, and 1 or 127: positive ints) before the build initialises it
+    static const int poison = [] { const char *e = getenv("NND_POISON"); return e ? atoi(e) : 0; }();  // the fill byte
+    if (poison) API_HIP(hipMemset(*p, poison & 0xFF, sizeof(T) * (count ? count : 1)));
     return 0;
 }
 

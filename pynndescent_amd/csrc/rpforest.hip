@@ -1400,7 +1400,10 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
             ctx->set_error("rp-forest: %lld segments exceed the allocation of %lld", (long long)S, (long long)ctx->max_segs);
             return 1;
         }
-        if (v.record && node_base + S > ctx->node_cap) return 2;
+        if (v.record && node_base + S > ctx->node_cap) {
+            if (getenv("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+            return 2;
+        }
         if (v.record) v.level_base.push_back(node_base);
         // recording: this level's hyperplanes are written straight into the node tables at [node_base, node_base + S)
         float *hyper = v.record ? ctx->node_hf + node_base * hs : ctx->hyper;
@@ -1468,7 +1471,10 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
         NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 34, ctx->counters + CNT_SCRATCH + 1, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
         NND_HIP_CHECK(nnd_sync_spin(ctx));
         const long long nfin = ctx->h_pin[34];
-        if (nfin > ctx->max_segs || node_base + nfin + 1 >= ctx->node_cap) return 2;
+        if (nfin > ctx->max_segs || node_base + nfin + 1 >= ctx->node_cap) {
+            if (getenv("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+            return 2;
+        }
         if (nfin > 0) {
             int *flags = (int *)(ctx->counters + CNT_SCRATCH + 2);  // [0] id counter, [1] overflow
             NND_HIP_CHECK(hipMemsetAsync(flags, 0, 2 * sizeof(int), ctx->stream));
@@ -1490,7 +1496,10 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
             NND_HIP_CHECK(hipGetLastError());
             NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 38, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             NND_HIP_CHECK(nnd_sync_spin(ctx));
-            if (((const int *)(ctx->h_pin + 38))[1]) return 2;  // node tables exhausted
+            if (((const int *)(ctx->h_pin + 38))[1]) {  // node tables exhausted
+                if (getenv("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+                return 2;
+            }
         }
         v.n_nodes = ctx->node_cap;  // ids are spread over the table: level-synchronous nodes upwards, recorded subtrees downwards
         return 0;
@@ -1562,7 +1571,10 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 35, scan_total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     NND_HIP_CHECK(nnd_sync_spin(ctx));
     const int32_t n_cells = *(const int32_t *)(ctx->h_pin + 35);
-    if (n_cells > ctx->cell_cap || n_cells + P / (ctx->p.leaf_size + 1) > ctx->max_segs) return 2;
+    if (n_cells > ctx->cell_cap || n_cells + P / (ctx->p.leaf_size + 1) > ctx->max_segs) {
+        if (getenv("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+        return 2;
+    }
     hipLaunchKernelGGL(k_cell_depths, dim3((unsigned)((Ps + 255) / 256)), dim3(256), 0, ctx->stream, ctx->leaf_flag, ctx->scan_out,
                        ctx->s_leaf_depth, Ps, ctx->cell_depth);
     NND_HIP_CHECK(hipMemsetAsync(ctx->cell_count, 0, sizeof(int32_t) * (size_t)n_cells, ctx->stream));
@@ -1622,7 +1634,10 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 36, counts + 1, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     NND_HIP_CHECK(nnd_sync_spin(ctx));
     const long long n_big = ctx->h_pin[36], n_small = ctx->h_pin[37];
-    if (n_big > ctx->max_segs) return 2;
+    if (n_big > ctx->max_segs) {
+        if (getenv("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+        return 2;
+    }
     if (launch_finishers(ctx, ctx->perm[0], ctx->perm[1], big_start, big_len, big_depth, 0, n_big, n_small)) return 1;
     *levels_out = v.depth;
     ctx->cur = 0;
@@ -1647,6 +1662,9 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     unsigned gridP = (unsigned)((P + 255) / 256);
     int levels = 0, rc = 2;
     if (ctx->s_m > 0) rc = forest_by_routing(ctx, &levels);
+    if (getenv("NND_FOREST_DEBUG"))
+        fprintf(stderr, "forest: n=%lld T=%d s_m=%lld routing rc=%d levels=%d node_cap=%lld cell_cap=%lld max_segs=%lld\n", (long long)n, T,
+                (long long)ctx->s_m, rc, levels, (long long)ctx->node_cap, (long long)ctx->cell_cap, (long long)ctx->max_segs);
     if (rc == 1) return 1;
     if (rc == 2) {  // small point set, very wide rows, or the recorded tree outgrew its tables: whole-set passes
         forest_view v{ctx->xp, ctx->xh, ctx->nr2, n, P, leaf_size, FIN_MAX, false};

@@ -10,6 +10,7 @@ def run(n_trees, n=1_000_000, reps=3):
     xd = bench.sift_like(n, 128, seed=1, device="cuda:0", sample_seed=100)
     b = _capi.Builder(n=n, dim=128, metric=0, n_neighbors=15, n_trees=n_trees, leaf_size=75, max_depth=200,
                       max_candidates=15, n_iters=5, delta=0.001, rng_state=(1, 2, 3), tree_rng=(4, 5, 6), device=0)
+    torch.cuda.synchronize()  # xd must be complete: the library reads it on its own stream
     b.set_data_device(xd.data_ptr())
     out = []
     for r in range(reps):

@@ -79,6 +79,7 @@ def run(name):
                       rng_state, ts[0])
     idx = torch.empty((n, k), dtype=torch.int32, device=dev)
     dist = torch.empty((n, k), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()  # x is produced on torch's stream; the library reads it on its own stream
     b.set_data_device(x.data_ptr(), keepalive=x)
     times = []
     for rep in range(3):
