@@ -187,18 +187,45 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
         }
     };
 
+    // The wave walks only the vertices of its sequence g, g + stride, ... that HAVE a new candidate (the lists are filled
+    // from the front: slot 0 tells).  64 of them are tested at a time, one per lane, so a run of idle vertices costs
+    // one pair of loads instead of one trip through the pipeline each -- in the last iterations, where a few percent
+    // of the vertices still join, that trip (~1.5 us of dependent latency) was most of the kernel's time.
+    int64_t scan_g = g;            // first vertex of the next block of 64 to test
+    unsigned long long scan_m = 0; // vertices of the current block still to visit
+    int64_t scan_base = g;
+    auto next_active = [&]() __attribute__((always_inline)) -> int64_t {
+        while (scan_m == 0) {
+            if (scan_g >= n_v) return n_v;  // wave-uniform
+            const int64_t gl = scan_g + (int64_t)lane * stride;
+            int c0 = -1;
+            if (gl < n_v) {
+                const int64_t v = order ? (int64_t)order[v_begin + gl] : v_begin + gl;
+                c0 = cand[v * RV];
+            }
+            scan_m = __ballot(c0 >= 0);
+            scan_base = scan_g;
+            scan_g += 64 * stride;
+        }
+        const int bit = __builtin_ctzll(scan_m);
+        scan_m &= scan_m - 1;
+        return scan_base + (int64_t)bit * stride;
+    };
+    g = next_active();
+    int64_t g1 = next_active(), g2 = n_v;
     store_cand(0, load_cand(g));
-    store_cand(1, load_cand(g + stride));
+    store_cand(1, load_cand(g1));
     nnd_wave_lds_sync();
     issue_gather(0);
 
     int tot_pairs = 0, tot_prop = 0, tot_rows = 0, tot_act = 0, tot_tiles = 0;
-    for (int it = 0; g < n_v; g += stride, it++) {
+    for (int it = 0; g < n_v; g = g1, g1 = g2, it++) {
+        g2 = next_active();
         const int cur = it & 1;
         const int my_cnt = nnewbuf[cur], my_new = my_cnt & 255;
         const bool has_old = (my_cnt >> 8) > 0;
         if (my_new > 0) tot_tiles += has_old ? 2 : 1;  // 16x16 Gram tiles of this vertex (wave-uniform)
-        const int c2 = load_cand(g + 2 * stride);
+        const int c2 = load_cand(g2);
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         if (my_new > 0) {
             land_gather(cur);
@@ -230,7 +257,7 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
             }
         }
         // the row registers are free: the gather of this wave's next vertex flies during the epilogue
-        if (g + stride < n_v) issue_gather(cur ^ 1);
+        if (g1 < n_v) issue_gather(cur ^ 1);
         if (my_new > 0) {
             // Epilogue in two steps.  (a) every lane screens its 8 pairs against the two thresholds and pushes the few
             // that pass into a wave-private queue; (b) the queue is drained 64 entries at a time, so the neighbour-list
