@@ -13,51 +13,73 @@
 #include "merge.h"
 #include "state.h"
 
-// One wave per TWO consecutive rows: the slots and k-lists of both rows are fetched before the first merge starts, so a
-// wave pays one exposed memory latency for two rows (the kernel is latency bound: a million short waves).
+// One wave per 64 consecutive rows: their dirty flags are read with one load, and only the rows that HAVE pending
+// proposals are visited, two at a time (slots and k-lists of both rows are fetched before the first merge starts, and
+// the next pair's while the current pair is merged: the kernel is latency bound).  Past the first iterations a few
+// percent of the rows are dirty; a wave per two rows spent its time finding that out.
 __global__ __launch_bounds__(256) void k_merge(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
                                                int64_t lo, int64_t n, int k, int ks, uint32_t *__restrict__ knn_e,
                                                float *__restrict__ knn_d, float *__restrict__ th,
                                                long long *__restrict__ counters) {
     __shared__ int wacc[4];
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t v0 = lo + ((int64_t)blockIdx.x * 4 + w) * 2;  // [lo, n): the rows this handle owns
+    const int64_t base = lo + ((int64_t)blockIdx.x * 4 + w) * 64;  // [lo, n): the rows this handle owns
     int acc = 0;
-    bool on[2];
-    uint64_t key[2];
-    uint32_t e[2];
-    float d[2];
+    unsigned long long m = 0;
+    if (base < n) m = __ballot(base + lane < n && pdirty[base + lane < n ? base + lane : lo] != 0);
+    struct pair_t {
+        int64_t v[2];
+        uint64_t key[2];
+        uint32_t e[2];
+        float d[2];
+    };
+    auto fetch = [&](pair_t &p) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int64_t v = v0 + u;
-        on[u] = v < n && pdirty[v < n ? v : lo];
-        const int64_t vv = on[u] ? v : lo;
-        key[u] = lane < pcap ? pbuf[vv * pcap + lane] : NND_EMPTY_KEY;  // pcap <= 64: one slot per lane
-        e[u] = lane < k ? knn_e[vv * ks + lane] : NND_EMPTY_E;
-        d[u] = lane < k ? knn_d[vv * ks + lane] : INFINITY;
-    }
+        for (int u = 0; u < 2; u++) {
+            p.v[u] = -1;
+            if (m) {  // wave-uniform
+                p.v[u] = base + __builtin_ctzll(m);
+                m &= m - 1;
+            }
+            const int64_t vv = p.v[u] >= 0 ? p.v[u] : lo;
+            p.key[u] = lane < pcap ? pbuf[vv * pcap + lane] : NND_EMPTY_KEY;  // pcap <= 64: one slot per lane
+            p.e[u] = lane < k ? knn_e[vv * ks + lane] : NND_EMPTY_E;
+            p.d[u] = lane < k ? knn_d[vv * ks + lane] : INFINITY;
+        }
+    };
+    pair_t cur, nxt;
+    if (m) fetch(cur);
+    else cur.v[0] = cur.v[1] = -1;
+    while (cur.v[0] >= 0) {
+        if (m) fetch(nxt);
+        else nxt.v[0] = nxt.v[1] = -1;
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        if (!on[u]) continue;  // wave-uniform
-        const int64_t v = v0 + u;
-        const uint64_t mykey = key[u];
-        acc += nnd_merge_row_regs<1>(knn_e + v * ks, knn_d + v * ks, th + v, e[u], d[u], k, pcap,
-                                     [&](int c, uint32_t &id, float &dc) {
-                                         id = nnd_key_idx(mykey);
-                                         dc = nnd_key_dist(mykey);
-                                         return mykey != NND_EMPTY_KEY;
-                                     });
-        if (lane < pcap && mykey != NND_EMPTY_KEY) pbuf[v * pcap + lane] = NND_EMPTY_KEY;
-        if (lane == 0) pdirty[v] = 0;
+        for (int u = 0; u < 2; u++) {
+            if (cur.v[u] < 0) continue;  // wave-uniform
+            const int64_t v = cur.v[u];
+            const uint64_t mykey = cur.key[u];
+            acc += nnd_merge_row_regs<1>(knn_e + v * ks, knn_d + v * ks, th + v, cur.e[u], cur.d[u], k, pcap,
+                                         [&](int c, uint32_t &id, float &dc) {
+                                             id = nnd_key_idx(mykey);
+                                             dc = nnd_key_dist(mykey);
+                                             return mykey != NND_EMPTY_KEY;
+                                         });
+            if (lane < pcap && mykey != NND_EMPTY_KEY) pbuf[v * pcap + lane] = NND_EMPTY_KEY;
+            if (lane == 0) pdirty[v] = 0;
+        }
+        cur = nxt;
     }
     if (lane == 0) wacc[w] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) nnd_count(counters, CNT_ACCEPT, (long long)wacc[0] + wacc[1] + wacc[2] + wacc[3]);
+    if (threadIdx.x == 0) {
+        const long long a = (long long)wacc[0] + wacc[1] + wacc[2] + wacc[3];
+        if (a) nnd_count(counters, CNT_ACCEPT, a);
+    }
 }
 
 int nnd_launch_merge(nnd_ctx *ctx) {
     if (ctx->pcap > 64) { ctx->set_error("k_merge expects at most 64 proposal slots per row"); return 1; }
-    hipLaunchKernelGGL(k_merge, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 7) / 8)), dim3(256), 0, ctx->stream, ctx->pbuf,
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 255) / 256)), dim3(256), 0, ctx->stream, ctx->pbuf,
                        ctx->pdirty, ctx->pcap, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
