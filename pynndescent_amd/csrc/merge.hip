@@ -77,9 +77,86 @@ __global__ __launch_bounds__(256) void k_merge(uint64_t *__restrict__ pbuf, uint
     }
 }
 
+// k <= 16: the same walk, FOUR dirty rows per step -- quarter-wave merges (merge.h nnd_merge_rows_q16: 16 lanes hold a
+// row's sorted list, its 64 proposal slots are taken in four blocks of 16).
+__global__ __launch_bounds__(256) void k_merge_q(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int64_t lo,
+                                                 int64_t n, int k, int ks, uint32_t *__restrict__ knn_e,
+                                                 float *__restrict__ knn_d, float *__restrict__ th,
+                                                 long long *__restrict__ counters) {
+    constexpr int PCAP = 64, NB = PCAP / 16;
+    __shared__ int wacc[4];
+    const int lane = nnd_lane(), w = threadIdx.x >> 6, j = lane & 15, grp = lane >> 4;
+    const int64_t base = lo + ((int64_t)blockIdx.x * 4 + w) * 64;  // [lo, n): the rows this handle owns
+    int acc = 0;
+    unsigned long long m = 0;
+    if (base < n) m = __ballot(base + lane < n && pdirty[base + lane < n ? base + lane : lo] != 0);
+    struct quad_t {
+        int64_t v;         // this 16-lane group's row (-1: none)
+        uint64_t key[NB];  // slot blk * 16 + j of that row
+        uint32_t e;
+        float d;
+    };
+    auto fetch = [&](quad_t &q) __attribute__((always_inline)) {
+        // the next (up to) four dirty rows: group g takes the g-th of them
+        int64_t vg = -1;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            if (m) {  // wave-uniform
+                const int64_t v = base + __builtin_ctzll(m);
+                m &= m - 1;
+                if (grp == g) vg = v;
+            }
+        }
+        q.v = vg;
+        const int64_t vv = vg >= 0 ? vg : lo;
+#pragma unroll
+        for (int b = 0; b < NB; b++) q.key[b] = pbuf[vv * PCAP + b * 16 + j];
+        q.e = j < k ? knn_e[vv * ks + j] : NND_EMPTY_E;
+        q.d = j < k ? knn_d[vv * ks + j] : INFINITY;
+    };
+    quad_t cur, nxt;
+    cur.v = nxt.v = -1;
+    bool have = m != 0;
+    if (have) fetch(cur);
+    while (have) {
+        have = m != 0;
+        if (have) fetch(nxt);
+        const bool on = cur.v >= 0;
+        const int64_t v = on ? cur.v : lo;
+        const uint32_t e0 = on ? cur.e : NND_EMPTY_E;
+        const float d0 = on ? cur.d : INFINITY;
+        acc += nnd_merge_rows_q16<NB>(on, knn_e + v * ks, knn_d + v * ks, th + v, e0, d0, k, PCAP,
+                                      [&](int c, uint32_t &id, float &dc) {
+                                          const int b = c >> 4;
+                                          const uint64_t kk = b == 0 ? cur.key[0] : (b == 1 ? cur.key[1] : (b == 2 ? cur.key[2] : cur.key[3]));
+                                          id = nnd_key_idx(kk);
+                                          dc = nnd_key_dist(kk);
+                                          return kk != NND_EMPTY_KEY;
+                                      });
+        if (on) {
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+                if (cur.key[b] != NND_EMPTY_KEY) pbuf[v * PCAP + b * 16 + j] = NND_EMPTY_KEY;
+            if (j == 0) pdirty[v] = 0;
+        }
+        cur = nxt;
+    }
+    if (lane == 0) wacc[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long a = (long long)wacc[0] + wacc[1] + wacc[2] + wacc[3];
+        if (a) nnd_count(counters, CNT_ACCEPT, a);
+    }
+}
+
 int nnd_launch_merge(nnd_ctx *ctx) {
     if (ctx->pcap > 64) { ctx->set_error("k_merge expects at most 64 proposal slots per row"); return 1; }
-    hipLaunchKernelGGL(k_merge, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 255) / 256)), dim3(256), 0, ctx->stream, ctx->pbuf,
+    const dim3 grid((unsigned)((ctx->own_hi - ctx->own_lo + 255) / 256));
+    if (ctx->k <= 16 && ctx->pcap == 64)
+        hipLaunchKernelGGL(k_merge_q, grid, dim3(256), 0, ctx->stream, ctx->pbuf, ctx->pdirty, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks,
+                           ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters);
+    else
+    hipLaunchKernelGGL(k_merge, grid, dim3(256), 0, ctx->stream, ctx->pbuf,
                        ctx->pdirty, ctx->pcap, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
