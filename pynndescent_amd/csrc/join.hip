@@ -388,6 +388,7 @@ static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     unsigned grid = (unsigned)(groups < resident ? groups : resident);
     if (grid > 8) grid &= ~7u;  // whole multiples of the XCD count: every XCD walks its own slice of the order
     uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
+    ctx->pbuf_clean = false;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
                        nnd_vertex_order(ctx), v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed,
                        ctx->counters, ctx->own_lo, ctx->own_hi);
@@ -712,6 +713,7 @@ static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     unsigned grid = (unsigned)(groups < resident ? groups : resident);
     if (grid > 8) grid &= ~7u;
     uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
+    ctx->pbuf_clean = false;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
                        nnd_vertex_order(ctx), v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty,
                        ctx->pcap, slot_seed, ctx->counters, ctx->own_lo, ctx->own_hi);

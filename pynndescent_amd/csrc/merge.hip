@@ -159,6 +159,7 @@ int nnd_launch_merge(nnd_ctx *ctx) {
     hipLaunchKernelGGL(k_merge, grid, dim3(256), 0, ctx->stream, ctx->pbuf,
                        ctx->pdirty, ctx->pcap, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters);
     NND_HIP_CHECK(hipGetLastError());
+    if (ctx->n_ranks <= 1) ctx->pbuf_clean = true;  // every row with proposals was merged and its slots re-armed
     return 0;
 }
 
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(256) void k_random_init(const float *__restrict__ x
 }
 
 int nnd_launch_random_init(nnd_ctx *ctx) {
+    ctx->pbuf_clean = false;
     hipLaunchKernelGGL(k_random_init, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp,
                        ctx->dp, ctx->nrm, ctx->p.metric, ctx->n, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, ctx->seed ^ 0x3C6EF372u, ctx->pbuf,
                        ctx->pdirty, ctx->pcap);
@@ -241,6 +243,7 @@ int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float
         ctx->set_error("init graph width %d exceeds %d", width, ctx->pcap < 64 ? ctx->pcap : 64);
         return 1;
     }
+    ctx->pbuf_clean = false;
     hipLaunchKernelGGL(k_graph_init, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, ctx->dp,
                        ctx->nrm, ctx->p.metric, ctx->n, idx_dev, dist_dev, width, ctx->pbuf, ctx->pdirty, ctx->pcap);
     NND_HIP_CHECK(hipGetLastError());
@@ -448,6 +451,7 @@ int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_
     if (count <= 0) return 0;
     // same slot hash as the join of the iteration that produced the records (iter was not advanced yet)
     uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
+    ctx->pbuf_clean = false;
     hipLaunchKernelGGL(k_import_proposals, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, keys, targets, count,
                        ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed);
     NND_HIP_CHECK(hipGetLastError());

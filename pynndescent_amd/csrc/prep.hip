@@ -142,8 +142,11 @@ int nnd_launch_reset_graph(nnd_ctx *ctx) {
     int64_t total = ctx->n * ctx->ks;
     hipLaunchKernelGGL(k_reset_graph, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e,
                        ctx->knn_d, total, ctx->th, ctx->n);
-    NND_HIP_CHECK(hipMemsetAsync(ctx->pbuf, 0xFF, sizeof(uint64_t) * (size_t)ctx->n * ctx->pcap, ctx->stream));
-    NND_HIP_CHECK(hipMemsetAsync(ctx->rbuf, 0xFF, sizeof(uint64_t) * (size_t)ctx->n * 2 * ctx->rcap, ctx->stream));
+    // k_merge and k_sample_select re-arm every slot they consume, so after a complete single-GPU iteration both slot
+    // tables are EMPTY again; the flags are cleared by every kernel launch that writes slots
+    if (!ctx->pbuf_clean) NND_HIP_CHECK(hipMemsetAsync(ctx->pbuf, 0xFF, sizeof(uint64_t) * (size_t)ctx->n * ctx->pcap, ctx->stream));
+    if (!ctx->rbuf_clean) NND_HIP_CHECK(hipMemsetAsync(ctx->rbuf, 0xFF, sizeof(uint64_t) * (size_t)ctx->n * 2 * ctx->rcap, ctx->stream));
+    ctx->pbuf_clean = ctx->rbuf_clean = true;
     NND_HIP_CHECK(hipGetLastError());
     ctx->iter = 0;
     return 0;

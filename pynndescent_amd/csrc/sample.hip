@@ -175,6 +175,7 @@ static void launch_reverse_pass(nnd_ctx *ctx, int pass, uint32_t it_seed) {
     grid = (grid + 7u) & ~7u;  // whole multiples of the XCD count
     // the spatial order is a permutation of ALL rows: usable whenever there is a forest and all rows are scanned
     const int32_t *order = (!shard && ctx->forest_built && ctx->p.n_trees > 0) ? ctx->perm[ctx->cur] : nullptr;
+    ctx->rbuf_clean = false;
     hipLaunchKernelGGL(k_sample_reverse, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->knn_e, row_lo, row_hi, ctx->k, ctx->ks,
                        it_seed, ctx->rbuf, ctx->rcap, ctx->own_lo, ctx->own_hi, pass, ctx->active, order);
 }
@@ -185,6 +186,7 @@ static void launch_select(nnd_ctx *ctx, uint32_t it_seed) {
     hipLaunchKernelGGL(k_sample_select, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream,
                        ctx->knn_e, ctx->n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand, ctx->own_lo,
                        ctx->own_hi, ctx->active);
+    if (ctx->n_ranks <= 1) ctx->rbuf_clean = true;  // every bank that received an offer belongs to an active vertex and was re-armed
 }
 
 int nnd_launch_sample(nnd_ctx *ctx) {
@@ -292,6 +294,7 @@ int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uin
     const uint32_t it_seed = sample_seed(ctx);
     const unsigned grid = (unsigned)((count + 255) / 256);
     if (count > 0)
+        ctx->rbuf_clean = false;
         hipLaunchKernelGGL(k_offer_import, dim3(grid), dim3(256), 0, ctx->stream, targets_dev, keys_dev, count, 1u, it_seed, ctx->rbuf,
                            ctx->rcap, ctx->active, ctx->own_lo, ctx->own_hi);
     if (!ctx->all_new) {

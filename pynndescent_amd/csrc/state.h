@@ -124,6 +124,7 @@ struct nnd_handle_s {
     std::vector<int64_t> tree_leaf_begin; // per tree: first leaf index (host)
     bool forest_built = false;
     bool all_new = false;  // every edge of the graph still carries the "new" flag (true from reset until the first sampling pass)
+    bool pbuf_clean = false, rbuf_clean = false;  // every proposal / reverse-offer slot is EMPTY (their consumers re-arm what they read): nnd_launch_reset_graph then skips the 2 x 512 MB memsets
 
     nnd_hub_result *hub = nullptr;
 
