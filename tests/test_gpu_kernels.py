@@ -257,3 +257,34 @@ def test_forest_routing_pass(metric, n, d, k, T):
     la2 = b.leaf_array()
     assert np.array_equal(la, la2), "forest not reproducible for a seed"
     b.close()
+
+
+def test_repeated_builds_on_one_handle_are_identical():
+    """The proposal / reverse-offer slot tables are memset only when a previous call may have left something in them
+    (their consumers re-arm what they read): a second build on the same handle, and a build after a half-finished
+    iteration (offers and proposals written, neither selected nor merged), must both reproduce the first build."""
+    x = clustered(20000, 32, 8, 30, seed=3)
+    b = make_builder(x, "euclidean", k=15, n_trees=4)
+
+    def full():
+        b.reset_graph()
+        b.make_forest()
+        b.init_from_leaves()
+        b.init_random()
+        b.descent()
+        return b.finalize()
+
+    i0, d0 = full()
+    i1, d1 = full()  # both tables are known to be empty here: no memset
+    np.testing.assert_array_equal(i0, i1)
+    np.testing.assert_array_equal(d0, d1)
+    b.reset_graph()
+    b.make_forest()
+    b.init_from_leaves()
+    b.init_random()
+    b.descent_sample()
+    b.descent_join()  # proposals stay in their slots: the next reset has to clear them
+    i2, d2 = full()
+    np.testing.assert_array_equal(i0, i2)
+    np.testing.assert_array_equal(d0, d2)
+    b.close()
