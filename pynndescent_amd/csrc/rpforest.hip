@@ -361,11 +361,30 @@ __global__ __launch_bounds__(256) void k_scan_blocks(int32_t *__restrict__ blk, 
     }
 }
 
+// RAW: blk[] holds the tiles' sums, not their exclusive scan -- every workgroup adds up the sums in front of it itself
+// (a few hundred L2-resident words) and the last one writes the grand total: the single-workgroup k_scan_blocks launch
+// between reduce and apply (7-8 us, once per level of the forest) is gone.
+template <bool RAW>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(int mode, const int32_t *__restrict__ pos_seg,
                                                            const uint8_t *__restrict__ bytes, int64_t P,
-                                                           const int32_t *__restrict__ blk, int32_t *__restrict__ out) {
+                                                           const int32_t *__restrict__ blk, int32_t *__restrict__ out,
+                                                           int32_t *__restrict__ total_out) {
     __shared__ int wsum[SCAN_BLOCK / 64];
     int lane = nnd_lane(), w = threadIdx.x >> 6;
+    int blk_prefix = 0;
+    if (RAW) {
+        __shared__ int psum[SCAN_BLOCK / 64];
+        int part = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_BLOCK) part += blk[b];
+        part = nnd_wave_sum_i32(part);
+        if (lane == 0) psum[w] = part;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SCAN_BLOCK / 64; i++) blk_prefix += psum[i];
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) total_out[0] = blk_prefix + blk[blockIdx.x];
+    } else {
+        blk_prefix = blk[blockIdx.x];
+    }
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int f[SCAN_ITEMS];
     int s = 0;
@@ -385,7 +404,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(int mode, const int32
     __syncthreads();
     int woff = 0;
     for (int i = 0; i < w; i++) woff += wsum[i];
-    int run = blk[blockIdx.x] + woff + incl - s;
+    int run = blk_prefix + woff + incl - s;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
         if (base + i < P) out[base + i] = run;
@@ -1294,9 +1313,8 @@ static int run_scan(nnd_ctx *ctx, int mode, const int32_t *pos_seg, uint8_t *byt
     int nb = (int)((P + SCAN_TILE - 1) / SCAN_TILE);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, mode, pos_seg, bytes, P, ctx->scan_blk, perm,
                        ctx->side_pt, n);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->scan_blk, nb, total_dev);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, mode == 2 ? 0 : mode, pos_seg, bytes, P,
-                       ctx->scan_blk, ctx->scan_out);
+    hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, mode == 2 ? 0 : mode, pos_seg, bytes, P,
+                       ctx->scan_blk, ctx->scan_out, total_dev);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1721,7 +1739,8 @@ void nnd_forest_stable_partition(nnd_ctx *ctx, int64_t n, const int32_t *ord, co
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, 0, pos, side, n, ctx->scan_blk, (const int32_t *)nullptr,
                        (const uint8_t *)nullptr, n);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->scan_blk, nb, scan_total);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, 0, pos, side, n, ctx->scan_blk, ctx->scan_out);
+    hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, 0, pos, side, n, ctx->scan_blk, ctx->scan_out,
+                       (int32_t *)nullptr);
     hipLaunchKernelGGL(k_seg_count, dim3((unsigned)((n_segs + 255) / 256)), dim3(256), 0, ctx->stream, seg_start, seg_len, n_segs,
                        ctx->scan_out, scan_total, n, nleft);
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ord, pos, side, ctx->scan_out, seg_start,
