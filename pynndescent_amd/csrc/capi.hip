@@ -126,6 +126,10 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
         if (r == 16 || r == 32 || r == 64) ctx->rcap = r;
     }
     ctx->pcap = 64;  // one candidate per lane in k_merge (merge.h NCHUNK = 1)
+    if (const char *pc_env = getenv("NND_PCAP")) {  // experiments: proposal slots per vertex, a power of two <= 64
+        const int r = atoi(pc_env);
+        if (r == 16 || r == 32 || r == 64) ctx->pcap = r;
+    }
     if (ctx->p.join_blocks < 1) ctx->p.join_blocks = 1;
     ctx->seed = nnd_mix32((uint32_t)p->rng_state[0] ^ nnd_mix32((uint32_t)p->rng_state[1] + 0x9E3779B9u) ^
                           nnd_mix32((uint32_t)p->rng_state[2] + 0x7F4A7C15u));
