@@ -283,16 +283,22 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
                         const int pid = cid[a], qid = cid[b];
                         if ((en.x & 1024u) && !klist_has<KS16>(klist + a * kls, (uint32_t)qid)) {  // p <- q
 #ifndef NND_JOIN_NOATOMIC  // timing experiments only
-                            atomicMin((unsigned long long *)&pbuf[(int64_t)pid * pcap + cslot[b]],
-                                      (unsigned long long)nnd_make_key(d, (uint32_t)qid));
+                            {
+                                unsigned long long *slot = (unsigned long long *)&pbuf[(int64_t)pid * pcap + cslot[b]];
+                                const unsigned long long key = (unsigned long long)nnd_make_key(d, (uint32_t)qid);
+                                atomicMin(slot, key);
+                            }
 #endif
                             cflag[a] = 1;
                             tot_prop++;
                         }
                         if ((en.x & 2048u) && !klist_has<KS16>(klist + b * kls, (uint32_t)pid)) {  // q <- p
 #ifndef NND_JOIN_NOATOMIC
-                            atomicMin((unsigned long long *)&pbuf[(int64_t)qid * pcap + cslot[a]],
-                                      (unsigned long long)nnd_make_key(d, (uint32_t)pid));
+                            {
+                                unsigned long long *slot = (unsigned long long *)&pbuf[(int64_t)qid * pcap + cslot[a]];
+                                const unsigned long long key = (unsigned long long)nnd_make_key(d, (uint32_t)pid);
+                                atomicMin(slot, key);
+                            }
 #endif
                             cflag[b] = 1;
                             tot_prop++;
