@@ -63,8 +63,16 @@ typedef struct nnd_params {
     int64_t tree_rng[3];    /* first row of make_forest's per-tree draw (rp_trees.py:2850) */
     int32_t device;         /* HIP device ordinal */
     int32_t join_blocks;    /* descent sub-steps per iteration (>=1); reference blocks by 16384 vertices (pynndescent_.py:279) */
-    int32_t reserved[6];
+    int32_t flags;          /* NND_FLAG_*; 0 for a build handle */
+    int32_t reserved[5];
 } nnd_params;
+
+/* Auxiliary handles (the pruning pass and the hub search tree of NNDescent.prepare() run on a handle of their own):
+ * NND_FLAG_NO_GRAPH skips the k-lists, candidate / proposal / reverse-offer tables and the routing-forest tables -- a
+ * handle for nnd_diversify_*_host / nnd_degree_prune_host / nnd_hub_tree_*; every build entry point fails on it.
+ * NND_FLAG_NO_PREP additionally skips the prepared (padded, centred / normalised) copy of the rows: hub tree only. */
+#define NND_FLAG_NO_GRAPH 1
+#define NND_FLAG_NO_PREP 2
 
 /* Run-time statistics for measurement (bench.py roofline). */
 typedef struct nnd_stats {
@@ -246,7 +254,7 @@ int32_t nnd_hub_tree_fetch(nnd_handle_t h, float *hyperplanes, float *offsets, i
  * closure of _init_search_function 1793-1883, select_side / search_flat_tree rp_trees.py:2662-2741, deheap_sort) ----
  * The searcher owns device copies of what the reference's closure captures: the (reordered) raw data, the CSR search
  * graph, the FlatTree of the search forest's first tree (n_nodes = 0: no tree, random starts only), min_distance and
- * n_neighbors.  All pointers are HOST pointers.  One wave per query; k <= 64.  Output rows ascending in the
+ * n_neighbors.  All pointers are HOST pointers.  One wave per query; k <= 64 (the query's k, not the index's).  Output rows ascending in the
  * alternative distance space, vertex numbers in the searcher's (reordered) numbering; unfilled slots (-1, +inf). */
 typedef struct nnd_searcher_s *nnd_searcher_t;
 int32_t nnd_searcher_create(nnd_searcher_t *out, int32_t device, int64_t n, int32_t dim, int32_t metric, const float *data,
@@ -255,6 +263,13 @@ int32_t nnd_searcher_create(nnd_searcher_t *out, int32_t device, int64_t n, int3
                             float min_distance, int32_t n_neighbors, const int64_t *search_rng_state /* 3 */);
 int32_t nnd_searcher_query(nnd_searcher_t s, const float *queries /* (nq, dim) */, int64_t nq, int32_t k, float epsilon,
                            int32_t *out_idx /* (nq, k) */, float *out_dist /* (nq, k) */);
+/* The search runs in two tiers: per-query LDS structures (3400 visited vertices, 512 frontier entries) and, for exactly
+ * the queries that would overflow them (large k / epsilon, oversized tree leaves), a global-memory tier with the
+ * reference's own structures (visited bitset over all n points, utils.py:323-349; frontier of 65536 entries).  No answer
+ * comes from a truncated search.  nnd_searcher_last_spilled: queries of the last call that ran on the second tier;
+ * nnd_searcher_set_tier(s, 1) sends every query there (tests), 0 = automatic. */
+int64_t nnd_searcher_last_spilled(nnd_searcher_t s);
+int32_t nnd_searcher_set_tier(nnd_searcher_t s, int32_t tier);
 int32_t nnd_searcher_destroy(nnd_searcher_t s);
 const char *nnd_searcher_last_error(nnd_searcher_t s /* NULL: the error of a failed create */);
 

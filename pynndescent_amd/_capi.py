@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get("PYNND_AMD_LIB", os.path.join(_HERE, "libpynnd_amd.so"
 
 NND_METRIC_SQEUCLIDEAN = 0
 NND_METRIC_ALT_COSINE = 1
+NND_FLAG_NO_GRAPH = 1  # auxiliary handle: no k-lists / candidate / proposal tables (pruning pass, hub tree)
+NND_FLAG_NO_PREP = 2   # ... and no prepared copy of the rows (hub tree only)
 
 
 class NNDParams(C.Structure):
@@ -31,7 +33,8 @@ class NNDParams(C.Structure):
         ("tree_rng", C.c_int64 * 3),
         ("device", C.c_int32),
         ("join_blocks", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("flags", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -151,6 +154,8 @@ _SIGNATURES = [
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int32,
                                         C.c_void_p]),
     ("nnd_searcher_query", C.c_int32, [_H, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    ("nnd_searcher_last_spilled", C.c_int64, [_H]),
+    ("nnd_searcher_set_tier", C.c_int32, [_H, C.c_int32]),
     ("nnd_searcher_destroy", C.c_int32, [_H]),
     ("nnd_searcher_last_error", C.c_char_p, [_H]),
 ]
@@ -190,7 +195,7 @@ class Builder:
     """Thin object wrapper over an ``nnd_handle_t`` (one GPU, one stream)."""
 
     def __init__(self, n, dim, metric, n_neighbors, n_trees, leaf_size, max_depth, max_candidates, n_iters, delta,
-                 rng_state, tree_rng, device=0, join_blocks=1):
+                 rng_state, tree_rng, device=0, join_blocks=1, flags=0):
         self.lib = load_library()
         p = NNDParams()
         p.n, p.dim, p.metric = int(n), int(dim), int(metric)
@@ -200,7 +205,7 @@ class Builder:
         for i in range(3):
             p.rng_state[i] = int(rng_state[i])
             p.tree_rng[i] = int(tree_rng[i])
-        p.device, p.join_blocks = int(device), int(join_blocks)
+        p.device, p.join_blocks, p.flags = int(device), int(join_blocks), int(flags)
         self.params = p
         self.n, self.dim, self.k, self.mc = int(n), int(dim), int(n_neighbors), int(max_candidates)
         self._h = _H()
@@ -478,6 +483,15 @@ class Searcher:
         if self.lib.nnd_searcher_query(self._h, _ptr(q), q.shape[0], int(k), float(epsilon), _ptr(idx), _ptr(dist)) != 0:
             raise NNDError(self.lib.nnd_searcher_last_error(self._h).decode())
         return idx, dist
+
+    def last_spilled(self):
+        """Queries of the last call whose search outgrew the LDS structures and ran on the global-memory tier."""
+        return int(self.lib.nnd_searcher_last_spilled(self._h))
+
+    def set_tier(self, tier):
+        """0: automatic (LDS tier, overflowing queries re-run on the global-memory tier); 1: every query on the latter."""
+        if self.lib.nnd_searcher_set_tier(self._h, int(tier)) != 0:
+            raise NNDError(self.lib.nnd_searcher_last_error(self._h).decode())
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

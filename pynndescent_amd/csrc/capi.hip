@@ -141,23 +141,29 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_spin, hipEventDisableTiming) != hipSuccess) { ctx->set_error("hipEventCreate failed"); rc = 1; break; }
         const size_t n = (size_t)ctx->n;
-        if ((rc = dalloc(ctx, &ctx->xp, n * ctx->dp))) break;
-        if ((rc = dalloc(ctx, &ctx->nrm, n))) break;
-        if (p->n_trees > 0 && (rc = dalloc(ctx, &ctx->xh, n * ctx->dp))) break;
-        if (p->n_trees > 0 && (rc = dalloc(ctx, &ctx->nr2, n))) break;
-        if ((rc = dalloc(ctx, &ctx->mean, (size_t)ctx->dp))) break;
-        if ((rc = dalloc(ctx, &ctx->knn_e, n * ctx->ks))) break;
-        if ((rc = dalloc(ctx, &ctx->knn_d, n * ctx->ks))) break;
-        if ((rc = dalloc(ctx, &ctx->th, n))) break;
-        if ((rc = dalloc(ctx, &ctx->cand, n * 2 * ctx->mcp))) break;
-        if ((rc = dalloc(ctx, &ctx->rbuf, n * 2 * ctx->rcap))) break;
-        if ((rc = dalloc(ctx, &ctx->pbuf, n * ctx->pcap))) break;
-        if ((rc = dalloc(ctx, &ctx->pdirty, n))) break;
-        if ((rc = dalloc(ctx, &ctx->active, n))) break;
+        const bool graph = !(p->flags & NND_FLAG_NO_GRAPH), prepared = !(p->flags & NND_FLAG_NO_PREP);
+        if (!prepared && graph) { ctx->set_error("NND_FLAG_NO_PREP needs NND_FLAG_NO_GRAPH (the build reads the prepared rows)"); rc = 1; break; }
+        if (prepared) {
+            if ((rc = dalloc(ctx, &ctx->xp, n * ctx->dp))) break;
+            if ((rc = dalloc(ctx, &ctx->nrm, n))) break;
+            if (p->n_trees > 0 && (rc = dalloc(ctx, &ctx->xh, n * ctx->dp))) break;
+            if (p->n_trees > 0 && (rc = dalloc(ctx, &ctx->nr2, n))) break;
+            if ((rc = dalloc(ctx, &ctx->mean, (size_t)ctx->dp))) break;
+        }
+        if (graph) {
+            if ((rc = dalloc(ctx, &ctx->knn_e, n * ctx->ks))) break;
+            if ((rc = dalloc(ctx, &ctx->knn_d, n * ctx->ks))) break;
+            if ((rc = dalloc(ctx, &ctx->th, n))) break;
+            if ((rc = dalloc(ctx, &ctx->cand, n * 2 * ctx->mcp))) break;
+            if ((rc = dalloc(ctx, &ctx->rbuf, n * 2 * ctx->rcap))) break;
+            if ((rc = dalloc(ctx, &ctx->pbuf, n * ctx->pcap))) break;
+            if ((rc = dalloc(ctx, &ctx->pdirty, n))) break;
+            if ((rc = dalloc(ctx, &ctx->active, n))) break;
+            if (hipMemset(ctx->pdirty, 0, n) != hipSuccess) { ctx->set_error("hipMemset failed"); rc = 1; break; }
+        }
         if ((rc = dalloc(ctx, &ctx->counters, (size_t)CNT_COUNT * NND_CNT_STRIPES))) break;
         if ((rc = dalloc(ctx, &ctx->counters_sum, (size_t)CNT_COUNT))) break;
         if (hipHostMalloc((void **)&ctx->h_pin, sizeof(long long) * 64, hipHostMallocDefault) != hipSuccess) { ctx->set_error("hipHostMalloc failed"); rc = 1; break; }
-        if (hipMemset(ctx->pdirty, 0, n) != hipSuccess) { ctx->set_error("hipMemset failed"); rc = 1; break; }
         if (p->n_trees > 0) {
             ctx->P = (int64_t)p->n_trees * ctx->n;
             const size_t P = (size_t)ctx->P;
@@ -166,7 +172,7 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
             // enough for that sample to resolve cells of a few hundred points, and rows fit the route kernel's registers.
             // NND_FOREST_WHOLE=1 forces the whole-set level-synchronous build (A/B measurements).
             const char *whole = getenv("NND_FOREST_WHOLE");
-            if (p->n >= 131072 && ctx->dp <= 256 && !(whole && whole[0] == '1')) {
+            if (graph && p->n >= 131072 && ctx->dp <= 256 && !(whole && whole[0] == '1')) {
                 const char *ss = getenv("NND_SAMPLE_STRIDE");
                 ctx->s_stride = ss ? atoi(ss) : 8;
                 if (ctx->s_stride < 2) ctx->s_stride = 2;
@@ -238,6 +244,16 @@ extern "C" int32_t nnd_destroy(nnd_handle_t ctx) {
     if (!ctx) { gerr("null handle"); return 1; }             \
     API_HIP(hipSetDevice(ctx->p.device));
 
+static int need_data(nnd_ctx *ctx) {
+    if (!ctx->x_orig) { ctx->set_error("no data set (call nnd_set_data_host/device first)"); return 1; }
+    return 0;
+}
+// build entry points: the handle must hold the graph state (not an auxiliary NND_FLAG_NO_GRAPH handle)
+static int need_graph(nnd_ctx *ctx) {
+    if (ctx->p.flags & NND_FLAG_NO_GRAPH) { ctx->set_error("this handle was created with NND_FLAG_NO_GRAPH: it has no k-lists / candidate tables (pruning pass and hub tree only)"); return 1; }
+    return 0;
+}
+
 // Stage timers are DEFERRED: begin/end events are recorded on the stream and read back in one go (t_flush) where the
 // host waits anyway, so timing a stage never drains the GPU pipeline between stages.
 static int t_begin(nnd_ctx *ctx) {
@@ -269,9 +285,10 @@ static void t_flush(nnd_ctx *ctx) {
 }
 
 static int after_data(nnd_ctx *ctx) {
+    if (ctx->p.flags & NND_FLAG_NO_PREP) return 0;  // hub-tree handle: the original rows are all it reads
     const int t_ = t_begin(ctx);
     if (nnd_launch_prep(ctx)) return 1;
-    if (nnd_launch_reset_graph(ctx)) return 1;
+    if (!(ctx->p.flags & NND_FLAG_NO_GRAPH) && nnd_launch_reset_graph(ctx)) return 1;
     t_end(ctx, t_, &ctx->stats.ms_prep, false);
     t_flush(ctx);
     return 0;
@@ -298,13 +315,9 @@ extern "C" int32_t nnd_set_data_device(nnd_handle_t ctx, const float *x_dev) {
     return after_data(ctx);
 }
 
-static int need_data(nnd_ctx *ctx) {
-    if (!ctx->x_orig) { ctx->set_error("no data set (call nnd_set_data_host/device first)"); return 1; }
-    return 0;
-}
-
 extern "C" int32_t nnd_make_forest(nnd_handle_t ctx) {
     ENTER(ctx);
+    if (ctx->p.flags & NND_FLAG_NO_PREP) { ctx->set_error("nnd_make_forest: this handle holds no prepared rows (NND_FLAG_NO_PREP)"); return 1; }
     if (need_data(ctx)) return 1;
     const int t_ = t_begin(ctx);
     if (nnd_launch_forest(ctx)) return 1;
@@ -343,11 +356,13 @@ extern "C" int32_t nnd_get_leaf_array(nnd_handle_t ctx, int32_t *out_host) {
 
 extern "C" int32_t nnd_reset_graph(nnd_handle_t ctx) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     return nnd_launch_reset_graph(ctx);
 }
 
 extern "C" int32_t nnd_init_from_leaves(nnd_handle_t ctx) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
     const int t_ = t_begin(ctx);
     if (nnd_launch_leaf_init(ctx)) return 1;
@@ -358,6 +373,7 @@ extern "C" int32_t nnd_init_from_leaves(nnd_handle_t ctx) {
 
 extern "C" int32_t nnd_init_random(nnd_handle_t ctx) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
     const int t_ = t_begin(ctx);
     if (nnd_launch_random_init(ctx)) return 1;
@@ -368,6 +384,7 @@ extern "C" int32_t nnd_init_random(nnd_handle_t ctx) {
 
 extern "C" int32_t nnd_init_from_graph(nnd_handle_t ctx, const int32_t *init_idx, const float *init_dist, int32_t width) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
     if (!init_idx || width < 1) { ctx->set_error("nnd_init_from_graph: bad arguments"); return 1; }
     size_t cnt = (size_t)ctx->n * width;
@@ -396,6 +413,7 @@ extern "C" int32_t nnd_init_from_neighbor_graph(nnd_handle_t ctx, const int32_t 
 
 extern "C" int32_t nnd_sample_candidates(nnd_handle_t ctx) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     return nnd_launch_sample(ctx);
 }
 
@@ -441,6 +459,7 @@ static int descent_iter(nnd_ctx *ctx, int64_t *c_out, bool timed) {
 
 extern "C" int32_t nnd_descent_iter(nnd_handle_t ctx, int64_t *c_out) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
     int64_t c = 0;
     if (descent_iter(ctx, &c, true)) return 1;
@@ -469,12 +488,14 @@ static int descent_loop(nnd_ctx *ctx, bool timed) {
 
 extern "C" int32_t nnd_descent(nnd_handle_t ctx) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
     return descent_loop(ctx, true);
 }
 
 extern "C" int32_t nnd_finalize_device(nnd_handle_t ctx, int32_t *out_idx_dev, float *out_dist_dev) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
     const int t_ = t_begin(ctx);
     if (nnd_launch_finalize(ctx, out_idx_dev, out_dist_dev)) return 1;
@@ -485,6 +506,7 @@ extern "C" int32_t nnd_finalize_device(nnd_handle_t ctx, int32_t *out_idx_dev, f
 
 extern "C" int32_t nnd_finalize_host(nnd_handle_t ctx, int32_t *out_idx, float *out_dist) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
     size_t cnt = (size_t)(ctx->own_hi - ctx->own_lo) * ctx->k;  // owned rows only
     nnd_scratch tmp;
@@ -501,6 +523,7 @@ extern "C" int32_t nnd_finalize_host(nnd_handle_t ctx, int32_t *out_idx, float *
 // nn_descent (pynndescent_.py:323-366) on a resident point set: EMPTY_GRAPH branch
 extern "C" int32_t nnd_build_device(nnd_handle_t ctx, int32_t *out_idx_dev, float *out_dist_dev) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
     if (nnd_launch_reset_graph(ctx)) return 1;
     if (ctx->p.n_trees > 0) {
@@ -581,6 +604,7 @@ extern "C" int32_t nnd_synchronize(nnd_handle_t ctx) {
 // ---- introspection for the parity tests ----
 extern "C" int32_t nnd_get_graph(nnd_handle_t ctx, int32_t *idx, float *dist, uint8_t *flags) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     size_t cnt = (size_t)ctx->n * ctx->ks;
     std::vector<uint32_t> he(cnt);
     std::vector<float> hd(cnt);
@@ -600,6 +624,7 @@ extern "C" int32_t nnd_get_graph(nnd_handle_t ctx, int32_t *idx, float *dist, ui
 
 extern "C" int32_t nnd_get_candidates(nnd_handle_t ctx, int32_t *new_idx, int32_t *old_idx) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     size_t cnt = (size_t)ctx->n * 2 * ctx->mcp;
     std::vector<int32_t> hc(cnt);
     API_HIP(hipMemcpyAsync(hc.data(), ctx->cand, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
@@ -615,6 +640,7 @@ extern "C" int32_t nnd_get_candidates(nnd_handle_t ctx, int32_t *new_idx, int32_
 extern "C" int32_t nnd_pairwise_gram(nnd_handle_t ctx, const int32_t *rows_a, int32_t na, const int32_t *rows_b,
                                      int32_t nb, float *out) {
     ENTER(ctx);
+    if (ctx->p.flags & NND_FLAG_NO_PREP) { ctx->set_error("nnd_pairwise_gram: this handle holds no prepared rows (NND_FLAG_NO_PREP)"); return 1; }
     if (need_data(ctx)) return 1;
     nnd_scratch tmp;
     int32_t *da = tmp.get<int32_t>(ctx, (size_t)na), *db = tmp.get<int32_t>(ctx, (size_t)nb);
@@ -676,6 +702,7 @@ extern "C" int32_t nnd_set_shard_bounds(nnd_handle_t ctx, const int64_t *bounds_
 //   finish: records received from the other ranks, local old edges, selection (new_build_candidates, utils.py:221-320)
 extern "C" int32_t nnd_sample_begin(nnd_handle_t ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, int64_t *counts_dev) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     static float sink;
     const int t_ = t_begin(ctx);
     if (nnd_launch_sample_begin(ctx, cap, targets_dev, keys_dev, (long long *)counts_dev)) return 1;
@@ -684,6 +711,7 @@ extern "C" int32_t nnd_sample_begin(nnd_handle_t ctx, int64_t cap, int32_t *targ
 }
 extern "C" int32_t nnd_sample_finish(nnd_handle_t ctx, const int32_t *targets_dev, const uint64_t *keys_dev, int64_t count) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     static float sink;
     const int t_ = t_begin(ctx);
     if (nnd_launch_sample_finish(ctx, targets_dev, keys_dev, count)) return 1;
@@ -694,26 +722,31 @@ extern "C" int32_t nnd_sample_finish(nnd_handle_t ctx, const int32_t *targets_de
 // the vertices behind the limit keep their proposals for the next iteration); stream-ordered, no host sync
 extern "C" int32_t nnd_proposal_export(nnd_handle_t ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, int64_t *counts_dev) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     return nnd_launch_proposal_export_regions(ctx, cap, targets_dev, keys_dev, (long long *)counts_dev);
 }
 // stream-ordered variants of the exchange steps (no host wait): thresholds in / out, received proposals
 extern "C" int32_t nnd_export_thresholds_async(nnd_handle_t ctx, int64_t lo, int64_t hi, float *th_dst_dev) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     API_HIP(hipMemcpyAsync(th_dst_dev, ctx->th + lo, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
 extern "C" int32_t nnd_import_thresholds_async(nnd_handle_t ctx, int64_t lo, int64_t hi, const float *th_src_dev) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     API_HIP(hipMemcpyAsync(ctx->th + lo, th_src_dev, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
 extern "C" int32_t nnd_import_proposals_async(nnd_handle_t ctx, const uint64_t *keys_dev, const int32_t *targets_dev, int64_t count) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     return nnd_launch_import_proposals(ctx, keys_dev, targets_dev, count);
 }
 
 extern "C" int32_t nnd_export_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, uint32_t *e_dst_dev, float *d_dst_dev) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     size_t cnt = (size_t)(hi - lo) * ctx->ks;
     API_HIP(hipMemcpyAsync(e_dst_dev, ctx->knn_e + lo * ctx->ks, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
     if (d_dst_dev)
@@ -724,6 +757,7 @@ extern "C" int32_t nnd_export_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t h
 extern "C" int32_t nnd_import_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, const uint32_t *e_src_dev, const float *d_src_dev) {
     if (ctx) ctx->all_new = false;  // imported rows may carry cleared flags
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     size_t cnt = (size_t)(hi - lo) * ctx->ks;
     API_HIP(hipMemcpyAsync(ctx->knn_e + lo * ctx->ks, e_src_dev, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
     if (d_src_dev) {  // full rows; d_src_dev == NULL: neighbour words only (thresholds come through nnd_import_thresholds)
@@ -736,12 +770,14 @@ extern "C" int32_t nnd_import_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t h
 // per-row worst distances (thresholds): 4 bytes per row instead of the 4*ks-byte distance rows
 extern "C" int32_t nnd_export_thresholds(nnd_handle_t ctx, int64_t lo, int64_t hi, float *th_dst_dev) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     API_HIP(hipMemcpyAsync(th_dst_dev, ctx->th + lo, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
     API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_import_thresholds(nnd_handle_t ctx, int64_t lo, int64_t hi, const float *th_src_dev) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     API_HIP(hipMemcpyAsync(ctx->th + lo, th_src_dev, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
     API_HIP(nnd_sync_spin(ctx));
     return 0;
@@ -749,12 +785,14 @@ extern "C" int32_t nnd_import_thresholds(nnd_handle_t ctx, int64_t lo, int64_t h
 extern "C" int32_t nnd_merge_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, const uint32_t *e_src_dev, const float *d_src_dev) {
     if (ctx) ctx->all_new = false;  // imported rows may carry cleared flags
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (nnd_launch_merge_graph_rows(ctx, lo, hi, e_src_dev, d_src_dev)) return 1;
     API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_descent_sample(nnd_handle_t ctx) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     static float sink;
     const int t_ = t_begin(ctx);
     if (nnd_launch_sample(ctx)) return 1;
@@ -763,6 +801,7 @@ extern "C" int32_t nnd_descent_sample(nnd_handle_t ctx) {
 }
 extern "C" int32_t nnd_descent_join(nnd_handle_t ctx) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (nnd_zero_counters(ctx)) return 1;
     static float sink;
     const int t_ = t_begin(ctx);
@@ -772,24 +811,28 @@ extern "C" int32_t nnd_descent_join(nnd_handle_t ctx) {
 }
 extern "C" int32_t nnd_proposal_counts(nnd_handle_t ctx, int32_t *cnt_dev) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (nnd_launch_proposal_counts(ctx, cnt_dev)) return 1;
     API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_export_proposals(nnd_handle_t ctx, const int64_t *offsets_dev, uint64_t *keys_out_dev, int32_t *targets_out_dev) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (nnd_launch_export_proposals(ctx, offsets_dev, keys_out_dev, targets_out_dev)) return 1;
     API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_import_proposals(nnd_handle_t ctx, const uint64_t *keys_dev, const int32_t *targets_dev, int64_t count) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     if (nnd_launch_import_proposals(ctx, keys_dev, targets_dev, count)) return 1;
     API_HIP(nnd_sync_spin(ctx));
     return 0;
 }
 extern "C" int32_t nnd_descent_merge(nnd_handle_t ctx, int64_t *c_local) {
     ENTER(ctx);
+    if (need_graph(ctx)) return 1;
     const int it = ctx->iter;
     static float sink;
     const int t_ = t_begin(ctx);
@@ -825,6 +868,7 @@ static nnd_prune_opts prune_defaults(const nnd_prune_opts *o) {
 extern "C" int32_t nnd_diversify_host(nnd_handle_t ctx, int32_t *idx /* (n,k) in/out */, float *dist /* (n,k) in/out */,
                                       const nnd_prune_opts *opts, const int32_t *degree /* (n), degree-aware only */) {
     ENTER(ctx);
+    if (ctx->p.flags & NND_FLAG_NO_PREP) { ctx->set_error("nnd_diversify_host: this handle holds no prepared rows (NND_FLAG_NO_PREP)"); return 1; }
     if (need_data(ctx)) return 1;
     const nnd_prune_opts o = prune_defaults(opts);
     if (o.degree_aware && (!degree || o.max_degree < 1)) { ctx->set_error("nnd_diversify_host: the degree-aware method needs degrees and max_degree >= 1"); return 1; }
@@ -848,6 +892,7 @@ extern "C" int32_t nnd_diversify_csr_host(nnd_handle_t ctx, const int32_t *indpt
                                           float *data /* nnz in/out */, int64_t nnz, const nnd_prune_opts *opts,
                                           const int32_t *degree /* (n), degree-aware only */) {
     ENTER(ctx);
+    if (ctx->p.flags & NND_FLAG_NO_PREP) { ctx->set_error("nnd_diversify_csr_host: this handle holds no prepared rows (NND_FLAG_NO_PREP)"); return 1; }
     if (need_data(ctx)) return 1;
     const nnd_prune_opts o = prune_defaults(opts);
     if (o.degree_aware && !degree) { ctx->set_error("nnd_diversify_csr_host: the degree-aware method needs degrees"); return 1; }

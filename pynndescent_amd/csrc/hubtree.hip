@@ -171,13 +171,9 @@ __global__ void k_hub_choose(const int32_t *__restrict__ seg_len, const uint8_t 
             bnl = nl;
         }
     }
-    if (bc < 0) {  // no valid candidate: random assignment (rp_trees.py:902-910)
-        const int nl = nleft4[s * 4 + 3], nr = len - nl;
-        best = __fdiv_rn((float)(nl < nr ? nl : nr), (float)len);
-        bc = 3;
-        bnl = nl;
-        if (nl == 0 || nr == 0) best = 0.0f;
-    }
+    // No valid candidate: the reference assigns sides at random (rp_trees.py:902-910) but returns best_balance = 0, so
+    // make_hub_*_tree always turns that node into a leaf (balance < MIN_SPLIT_BALANCE, rp_trees.py:1079-1084): the coin
+    // split never survives.  Same here: bc stays -1.
     if (best < HUB_MIN_BALANCE) bc = -1;  // too unbalanced: a leaf instead (rp_trees.py:1079-1084)
     choice[s] = bc;
     nl_out[s] = bc >= 0 ? bnl : 0;

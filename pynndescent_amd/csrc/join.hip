@@ -401,7 +401,7 @@ static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     ctx->pbuf_clean = false;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
                        nnd_vertex_order(ctx), v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed,
-                       ctx->counters, ctx->own_lo, ctx->own_hi);
+                       ctx->counters, nnd_list_lo(ctx), nnd_list_hi(ctx));
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -726,7 +726,7 @@ static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     ctx->pbuf_clean = false;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
                        nnd_vertex_order(ctx), v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty,
-                       ctx->pcap, slot_seed, ctx->counters, ctx->own_lo, ctx->own_hi);
+                       ctx->pcap, slot_seed, ctx->counters, nnd_list_lo(ctx), nnd_list_hi(ctx));
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

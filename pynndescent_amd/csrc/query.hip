@@ -27,9 +27,16 @@
 #include "common.h"
 #include "../../include/pynnd_amd.h"
 
-#define Q_FRONTIER 512   // frontier entries per query
-#define Q_VISITED 4096   // visited-set slots per query (power of two)
-#define Q_VISITED_MAX 3400  // entries after which the set counts as full: nothing new is explored any more
+#define Q_FRONTIER 512   // frontier entries per query (LDS tier)
+#define Q_VISITED 4096   // visited-set slots per query (power of two; LDS tier)
+#define Q_VISITED_MAX 3400  // entries after which the LDS set counts as full
+#define Q_BIG_FRONTIER 65536  // frontier entries per query of the global-memory tier
+#define Q_BIG_BATCH 256       // queries per launch of the global-memory tier (scratch = batch * (n / 8 + 512 KB))
+// Two tiers.  The LDS tier (visited = hash set of Q_VISITED_MAX vertices, frontier of Q_FRONTIER entries) covers what a
+// search with the usual k / epsilon touches.  A query that would overflow either structure is NOT answered from a
+// truncated search: the wave raises the query's flag and stops, and the host re-runs exactly those queries on the
+// global-memory tier -- visited = a bitset over all n points (the reference's own structure, utils.py:323-349), frontier
+// of Q_BIG_FRONTIER entries in HBM -- so no result ever comes from a search the reference would have continued.
 #define Q_CHUNK 64       // candidates handled per step
 #define Q_EMPTY 0xFFFFFFFFu
 
@@ -45,6 +52,8 @@ struct nnd_searcher_s {
     float *hyper = nullptr, *offsets = nullptr;  // (n_nodes, dp), (n_nodes)
     int32_t *children = nullptr, *tree_idx = nullptr;
     hipStream_t stream = nullptr;
+    int64_t last_spilled = 0;  // queries of the last call that ran on the global-memory tier
+    bool force_big = false;    // nnd_searcher_set_tier(1): every query on the global-memory tier (tests)
     char err[512] = {0};
     void set_error(const char *fmt, ...) {
         va_list ap;
@@ -85,26 +94,45 @@ __device__ __forceinline__ float q_quad_dist(const float *__restrict__ x, const 
     return r > 1.0f ? log2f(r) : 0.0f;
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, const float *__restrict__ xn2, int dp, int d, int metric,
                                                int64_t n, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                const float *__restrict__ hyper, const float *__restrict__ offsets,
                                                const int32_t *__restrict__ children, const int32_t *__restrict__ tree_idx,
                                                int64_t n_nodes, const float *__restrict__ queries, int64_t nq, int k, float epsilon,
                                                float min_distance, int n_neighbors, uint32_t seed, int32_t *__restrict__ out_idx,
-                                               float *__restrict__ out_dist) {
+                                               float *__restrict__ out_dist, uint8_t *__restrict__ overflow /* (nq) LDS tier: set when the query needs the big tier */,
+                                               const int32_t *__restrict__ qlist /* BIG: the queries of this batch */,
+                                               int n_list, unsigned char *__restrict__ scratch, size_t scratch_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qsm[];
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t qi = (int64_t)blockIdx.x * 4 + w;
-    if (qi >= nq) return;  // whole wave; no workgroup barrier below
-    const size_t per_wave = (size_t)dp * 4 + Q_FRONTIER * 8 + Q_VISITED * 4 + Q_CHUNK * 8;
+    const int64_t slot = (int64_t)blockIdx.x * 4 + w;
+    if (BIG ? slot >= n_list : slot >= nq) return;  // whole wave; no workgroup barrier below
+    const int64_t qi = BIG ? (int64_t)qlist[slot] : slot;
+    constexpr int FCAP = BIG ? Q_BIG_FRONTIER : Q_FRONTIER;
+    const size_t per_wave = BIG ? (size_t)dp * 4 + Q_CHUNK * 8 : (size_t)dp * 4 + Q_FRONTIER * 8 + Q_VISITED * 4 + Q_CHUNK * 8;
     unsigned char *mine = qsm + (size_t)w * ((per_wave + 15) & ~(size_t)15);
     float *qs = (float *)mine;                       // dp
-    float *fd = qs + dp;                             // Q_FRONTIER distances
-    int32_t *fv = (int32_t *)(fd + Q_FRONTIER);      // Q_FRONTIER vertices
-    uint32_t *vis = (uint32_t *)(fv + Q_FRONTIER);   // Q_VISITED
-    int32_t *cl = (int32_t *)(vis + Q_VISITED);      // Q_CHUNK candidate ids
+    float *fd;                                       // FCAP distances
+    int32_t *fv;                                     // FCAP vertices
+    uint32_t *vis;                                   // LDS tier: Q_VISITED hash slots; big tier: (n + 31) / 32 bit words
+    int32_t *cl;                                     // Q_CHUNK candidate ids
+    if (BIG) {
+        unsigned char *gs = scratch + (size_t)slot * scratch_stride;
+        fd = (float *)gs;
+        fv = (int32_t *)(fd + FCAP);
+        vis = (uint32_t *)(fv + FCAP);
+        cl = (int32_t *)(qs + dp);
+    } else {
+        fd = qs + dp;
+        fv = (int32_t *)(fd + FCAP);
+        vis = (uint32_t *)(fv + FCAP);
+        cl = (int32_t *)(vis + Q_VISITED);
+    }
     float *cd = (float *)(cl + Q_CHUNK);             // Q_CHUNK candidate distances
     const int sub = lane & 3, grp = lane >> 2;
+    const int64_t vis_words = BIG ? (n + 31) / 32 : Q_VISITED;
+    bool spilled = false;  // LDS tier: a structure overflowed -- the query is handed to the big tier (wave-uniform)
 
     // ---- the query: cosine queries are normalised (pynndescent_.py:1808-1815); a zero cosine query returns nothing ----
     float part = 0.0f;
@@ -114,7 +142,7 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
         part += v * v;
     }
     float qn2 = nnd_wave_sum_f32(part);
-    for (int s = lane; s < Q_VISITED; s += 64) vis[s] = Q_EMPTY;
+    for (int64_t s = lane; s < vis_words; s += 64) vis[s] = BIG ? 0u : Q_EMPTY;
     bool dead = false;
     if (metric == 1) {
         const float nrm = sqrtf(qn2);
@@ -150,9 +178,9 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
         if (lane == pos) { rd = dc; rv = vc; }
     };
     auto frontier_push = [&](float dc, int32_t vc) {
-        if (fn == Q_FRONTIER) {  // drop what can never be expanded any more (the bound only shrinks)
+        if (fn == FCAP) {  // drop what can never be expanded any more (the bound only shrinks)
             int kept = 0;
-            for (int s0 = 0; s0 < Q_FRONTIER; s0 += 64) {
+            for (int s0 = 0; s0 < FCAP; s0 += 64) {
                 const float e = fd[s0 + lane];
                 const int32_t ev = fv[s0 + lane];
                 const bool keep = e < bound;
@@ -166,7 +194,10 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
                 nnd_wave_lds_sync();
             }
             fn = kept;
-            if (fn == Q_FRONTIER) return;  // still full: the candidate is not queued (it stays in the result list)
+            if (fn == FCAP) {  // still full: the reference's heap would have grown -- LDS tier: hand the query over
+                if (!BIG) spilled = true;  // (big tier, 65536 live entries: the candidate stays in the result list only)
+                return;
+            }
         }
         if (lane == 0) {
             fd[fn] = dc;
@@ -174,11 +205,15 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
         }
         fn++;
     };
-    // check_and_mark_visited (utils.py:335-349): true if `u` had not been seen.  Once the set holds Q_VISITED_MAX
-    // vertices (far beyond what a search with a sensible epsilon visits) unknown vertices count as seen: the search
-    // finishes with what it has instead of cycling through vertices it can no longer remember.
+    // check_and_mark_visited (utils.py:335-349): true if `u` had not been seen.  Big tier: the reference's bitset over
+    // all n points.  LDS tier: a hash set; once it holds Q_VISITED_MAX vertices the query is handed to the big tier
+    // (the callers test nvis after every batch).
     int nvis = 0;  // wave-uniform (updated with ballots by the callers)
     auto mark_fresh = [&](uint32_t u) -> bool {
+        if (BIG) {
+            const uint32_t bit = 1u << (u & 31u);
+            return (atomicOr(&vis[u >> 5], bit) & bit) == 0u;
+        }
         if (nvis >= Q_VISITED_MAX) return false;
         uint32_t h = nnd_mix32(u) & (Q_VISITED - 1);
         for (int probe = 0; probe < Q_VISITED; probe++) {
@@ -231,6 +266,7 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
                 fr = mark_fresh((uint32_t)u);
             }
             nvis += __popcll(__ballot(fr));
+            if (!BIG && nvis >= Q_VISITED_MAX) spilled = true;
             nnd_wave_lds_sync();
             chunk_dists(nc);
             for (int j = 0; j < nc; j++) {  // pynndescent_.py:1826-1832
@@ -238,10 +274,11 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
                 frontier_push(cd[j], cl[j]);
             }
             nnd_wave_lds_sync();
+            if (spilled) break;
         }
         // ---- random start vertices if the leaf was small (pynndescent_.py:1834-1848) ----
         const int n_random = (k < n_neighbors ? k : n_neighbors) - n_initial;
-        for (int j = 0; j < n_random; j++) {
+        for (int j = 0; j < n_random && !spilled; j++) {
             const uint32_t u = nnd_hash3(seed ^ 0x3C6EF372u, (uint32_t)qi, (uint32_t)j) % (uint32_t)n;
             bool fresh = false;
             if (lane == 0) fresh = mark_fresh(u);
@@ -258,7 +295,7 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
         update_bound();
 
         // ---- best-first search (pynndescent_.py:1850-1881) ----
-        while (fn > 0) {
+        while (fn > 0 && !spilled) {
             nnd_wave_lds_sync();
             // pop the nearest frontier vertex
             float bd = INFINITY;
@@ -293,6 +330,7 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
                 const unsigned long long m = __ballot(fresh);
                 const int nc = __popcll(m);
                 nvis += nc;
+                if (!BIG && nvis >= Q_VISITED_MAX) spilled = true;  // this batch is still exact (the set has room for it)
                 if (nc == 0) continue;
                 nnd_wave_lds_sync();
                 if (fresh) cl[nnd_prefix_popc(m)] = u;
@@ -308,9 +346,11 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
                     }
                 }
                 nnd_wave_lds_sync();
+                if (spilled) break;
             }
         }
     }
+    if (!BIG && lane == 0) overflow[qi] = spilled ? 1 : 0;  // the host re-runs flagged queries on the big tier
     if (lane < k) {  // ascending, like deheap_sort; unfilled slots (-1, inf)
         out_idx[qi * k + lane] = rv;
         out_dist[qi * k + lane] = rd;
@@ -427,28 +467,68 @@ extern "C" int32_t nnd_searcher_create(nnd_searcher_t *out, int32_t device, int6
     return 0;
 }
 
+extern "C" int64_t nnd_searcher_last_spilled(nnd_searcher_t s) { return s ? s->last_spilled : -1; }
+extern "C" int32_t nnd_searcher_set_tier(nnd_searcher_t s, int32_t tier) {
+    if (!s) { snprintf(g_serr, sizeof(g_serr), "nnd_searcher_set_tier: null searcher"); return 1; }
+    if (tier != 0 && tier != 1) { s->set_error("nnd_searcher_set_tier: tier must be 0 (automatic) or 1 (global-memory tier for every query)"); return 1; }
+    s->force_big = tier == 1;
+    return 0;
+}
+
 extern "C" int32_t nnd_searcher_query(nnd_searcher_t s, const float *queries, int64_t nq, int32_t k, float epsilon, int32_t *out_idx,
                                       float *out_dist) {
     if (!s) { snprintf(g_serr, sizeof(g_serr), "nnd_searcher_query: null searcher"); return 1; }
     if (k < 1 || k > 64) { s->set_error("nnd_searcher_query: k must be in 1..64 (got %d)", k); return 1; }
     if (nq <= 0) return 0;
+    if (nq >= (int64_t)0x7FFFFFF0) { s->set_error("nnd_searcher_query: too many queries in one call"); return 1; }
     S_HIP(hipSetDevice(s->device));
     float *dq = nullptr, *dd = nullptr;
-    int32_t *di = nullptr;
+    int32_t *di = nullptr, *dlist = nullptr;
+    uint8_t *dov = nullptr;
+    unsigned char *scratch = nullptr;
     int rc = 0;
     const size_t per_wave = ((size_t)s->dp * 4 + Q_FRONTIER * 8 + Q_VISITED * 4 + Q_CHUNK * 8 + 15) & ~(size_t)15;
     const size_t smem = 4 * per_wave;
+    const size_t per_wave_big = ((size_t)s->dp * 4 + Q_CHUNK * 8 + 15) & ~(size_t)15;
+    s->last_spilled = 0;
+    std::vector<uint8_t> hov((size_t)nq, 1);
     do {
         if (hipMalloc((void **)&dq, sizeof(float) * (size_t)nq * s->d) != hipSuccess || hipMalloc((void **)&di, sizeof(int32_t) * (size_t)nq * k) != hipSuccess ||
-            hipMalloc((void **)&dd, sizeof(float) * (size_t)nq * k) != hipSuccess) { s->set_error("nnd_searcher_query: out of device memory"); rc = 1; break; }
+            hipMalloc((void **)&dd, sizeof(float) * (size_t)nq * k) != hipSuccess || hipMalloc((void **)&dov, (size_t)nq) != hipSuccess) { s->set_error("nnd_searcher_query: out of device memory"); rc = 1; break; }
         if (hipMemcpyAsync(dq, queries, sizeof(float) * (size_t)nq * s->d, hipMemcpyHostToDevice, s->stream) != hipSuccess) { s->set_error("H2D of the queries failed"); rc = 1; break; }
-        if (smem > 64 * 1024 && hipFuncSetAttribute((const void *)k_query, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
-            s->set_error("nnd_searcher_query: rows of %d floats need %zu bytes of LDS per workgroup", s->d, smem); rc = 1; break;
+        if (!s->force_big) {
+            if (smem > 64 * 1024 && hipFuncSetAttribute((const void *)k_query<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+                s->set_error("nnd_searcher_query: rows of %d floats need %zu bytes of LDS per workgroup", s->d, smem); rc = 1; break;
+            }
+            hipLaunchKernelGGL(k_query<false>, dim3((unsigned)((nq + 3) / 4)), dim3(256), smem, s->stream, s->x, s->xn2, s->dp, s->d, s->metric, s->n,
+                               s->indptr, s->indices, s->hyper, s->offsets, s->children, s->tree_idx, s->n_nodes, dq, nq, k, epsilon,
+                               s->min_distance, s->n_neighbors, s->seed, di, dd, dov, (const int32_t *)nullptr, 0, (unsigned char *)nullptr, (size_t)0);
+            if (hipGetLastError() != hipSuccess) { s->set_error("k_query launch failed"); rc = 1; break; }
+            if (hipMemcpyAsync(hov.data(), dov, (size_t)nq, hipMemcpyDeviceToHost, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) {
+                s->set_error("nnd_searcher_query: kernel or D2H failed: %s", hipGetErrorString(hipGetLastError())); rc = 1; break;
+            }
         }
-        hipLaunchKernelGGL(k_query, dim3((unsigned)((nq + 3) / 4)), dim3(256), smem, s->stream, s->x, s->xn2, s->dp, s->d, s->metric, s->n,
-                           s->indptr, s->indices, s->hyper, s->offsets, s->children, s->tree_idx, s->n_nodes, dq, nq, k, epsilon,
-                           s->min_distance, s->n_neighbors, s->seed, di, dd);
-        if (hipGetLastError() != hipSuccess) { s->set_error("k_query launch failed"); rc = 1; break; }
+        // queries whose search outgrew the LDS structures (or all of them, nnd_searcher_set_tier(1)): global-memory tier
+        std::vector<int32_t> again;
+        for (int64_t i = 0; i < nq; i++)
+            if (hov[(size_t)i]) again.push_back((int32_t)i);
+        s->last_spilled = (int64_t)again.size();
+        if (!again.empty()) {
+            const size_t stride = ((size_t)Q_BIG_FRONTIER * 8 + (size_t)((s->n + 31) / 32) * 4 + 255) & ~(size_t)255;
+            const size_t batch = again.size() < Q_BIG_BATCH ? again.size() : (size_t)Q_BIG_BATCH;
+            if (hipMalloc((void **)&scratch, stride * batch) != hipSuccess || hipMalloc((void **)&dlist, sizeof(int32_t) * again.size()) != hipSuccess) {
+                s->set_error("nnd_searcher_query: out of device memory for the global-memory tier (%zu bytes)", stride * batch); rc = 1; break;
+            }
+            if (hipMemcpyAsync(dlist, again.data(), sizeof(int32_t) * again.size(), hipMemcpyHostToDevice, s->stream) != hipSuccess) { s->set_error("H2D of the query list failed"); rc = 1; break; }
+            for (size_t b0 = 0; b0 < again.size() && !rc; b0 += batch) {
+                const int nb = (int)(again.size() - b0 < batch ? again.size() - b0 : batch);
+                hipLaunchKernelGGL(k_query<true>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 4 * per_wave_big, s->stream, s->x, s->xn2, s->dp, s->d, s->metric,
+                                   s->n, s->indptr, s->indices, s->hyper, s->offsets, s->children, s->tree_idx, s->n_nodes, dq, nq, k, epsilon,
+                                   s->min_distance, s->n_neighbors, s->seed, di, dd, (uint8_t *)nullptr, (const int32_t *)(dlist + b0), nb, scratch, stride);
+                if (hipGetLastError() != hipSuccess) { s->set_error("k_query (global-memory tier) launch failed"); rc = 1; }
+            }
+            if (rc) break;
+        }
         if (hipMemcpyAsync(out_idx, di, sizeof(int32_t) * (size_t)nq * k, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
             hipMemcpyAsync(out_dist, dd, sizeof(float) * (size_t)nq * k, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
             hipStreamSynchronize(s->stream) != hipSuccess) { s->set_error("nnd_searcher_query: kernel or D2H failed: %s", hipGetErrorString(hipGetLastError())); rc = 1; break; }
@@ -456,5 +536,8 @@ extern "C" int32_t nnd_searcher_query(nnd_searcher_t s, const float *queries, in
     if (dq) (void)hipFree(dq);
     if (di) (void)hipFree(di);
     if (dd) (void)hipFree(dd);
+    if (dov) (void)hipFree(dov);
+    if (dlist) (void)hipFree(dlist);
+    if (scratch) (void)hipFree(scratch);
     return rc;
 }

@@ -403,10 +403,11 @@ int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uin
 int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uint64_t *keys_dev, int64_t count) {
     const uint32_t it_seed = sample_seed(ctx);
     const unsigned grid = (unsigned)((count + 255) / 256);
-    if (count > 0)
+    if (count > 0) {
         ctx->rbuf_clean = false;
         hipLaunchKernelGGL(k_offer_import, dim3(grid), dim3(256), 0, ctx->stream, targets_dev, keys_dev, count, 1u, it_seed, ctx->rbuf,
                            ctx->rcap, ctx->active, ctx->own_lo, ctx->own_hi);
+    }
     if (!ctx->all_new) {
         launch_reverse_pass(ctx, 1, it_seed);
         if (count > 0)

@@ -189,6 +189,13 @@ static inline const int32_t *nnd_vertex_order(const nnd_ctx *ctx) {
     return ctx->perm[ctx->cur];
 }
 
+// Rows whose CURRENT neighbour lists this handle holds (the join's membership test reads them): only the owned slice on
+// a shard of a row-sharded build (nnd_set_shard_bounds: remote rows are never imported, their owners dedup in the merge,
+// utils.py:489-492); every row otherwise -- including handles driven through nnd_set_owned_range + nnd_import_graph_rows,
+// which do import the remote rows.
+static inline int64_t nnd_list_lo(const nnd_ctx *ctx) { return ctx->n_ranks > 1 ? ctx->own_lo : 0; }
+static inline int64_t nnd_list_hi(const nnd_ctx *ctx) { return ctx->n_ranks > 1 ? ctx->own_hi : ctx->n; }
+
 // Wait for everything queued on the handle's stream by polling an event: the per-level read-backs of the forest build
 // are latency critical (the GPU idles until the host has the segment count), and a blocking wait wakes up late.
 static inline hipError_t nnd_sync_spin(nnd_ctx *ctx) {

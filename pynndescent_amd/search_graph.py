@@ -58,7 +58,8 @@ def build_search_graph(data, indices, distances, metric="euclidean", n_neighbors
     k = indices.shape[1]
     n_neighbors = k if n_neighbors is None else n_neighbors
     code = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN, "cosine": _capi.NND_METRIC_ALT_COSINE}[metric]
-    b = _capi.Builder(n, d, code, k, 0, 60, 200, min(60, k), 1, 0.001, [1, 2, 3], [4, 5, 6], device=device)
+    b = _capi.Builder(n, d, code, k, 0, 60, 200, min(60, k), 1, 0.001, [1, 2, 3], [4, 5, 6], device=device,
+                      flags=_capi.NND_FLAG_NO_GRAPH)  # the pass reads rows and norms only: no k-lists / proposal tables
     try:
         b.set_data_host(x)
         nnz_pre = int((np.asarray(indices) >= 0).sum())

@@ -165,3 +165,32 @@ def test_query_without_tree_and_errors():
         index.query(x[:3], k=100)
     with pytest.raises(ValueError, match="shape"):
         index.query(x[:3, :5], k=5)
+
+
+def test_query_large_k_and_epsilon_two_tiers():
+    """k = 64 with a large epsilon visits far more than the per-query LDS structures hold (3400 visited vertices, 512
+    frontier entries): those queries must be re-run on the global-memory tier (the reference's bitset over all n points,
+    utils.py:323-349), never answered from a truncated search.  The automatic run must (a) actually spill, (b) agree with a
+    run that sends EVERY query to the global-memory tier, and (c) reach near-exact recall, as an untruncated search does."""
+    x = clustered(60_000, 32, 10, 50, seed=11)
+    q = clustered(600, 32, 10, 50, seed=11)[::-1].copy() + 0.02
+    index = NNDescent(x, "euclidean", n_neighbors=30, random_state=4)
+    qi, qd = index.query(q, k=64, epsilon=1.0)
+    spilled = index._searcher.last_spilled()
+    print("k=64 eps=1.0: %d of %d queries ran on the global-memory tier" % (spilled, len(q)))
+    assert spilled > 0
+    index._searcher.set_tier(1)
+    qi_big, qd_big = index.query(q, k=64, epsilon=1.0)
+    assert index._searcher.last_spilled() == len(q)
+    index._searcher.set_tier(0)
+    ti = _exact(x, q, 64, "euclidean")
+    r_auto, r_big = O.recall(ti, qi), O.recall(ti, qi_big)
+    print("recall@64: automatic %.4f, all on the global-memory tier %.4f" % (r_auto, r_big))
+    assert r_big >= 0.99 and abs(r_auto - r_big) <= 0.002
+    # a query answered by both tiers without spilling gives the same list; spilled ones were re-run from scratch
+    assert np.all(np.diff(qd, axis=1) >= -1e-7) and np.all(np.diff(qd_big, axis=1) >= -1e-7)
+    for row in qi[::29]:
+        assert len(set(row.tolist())) == 64
+    # small searches stay on the LDS tier
+    index.query(q[:50], k=10, epsilon=0.1)
+    assert index._searcher.last_spilled() == 0
