@@ -121,6 +121,11 @@ int32_t nnd_get_leaf_array(nnd_handle_t h, int32_t *out_host);
 int32_t nnd_reset_graph(nnd_handle_t h);
 /* init_rp_tree + generate_leaf_updates (pynndescent_.py:73-185): all-pairs inside every leaf. */
 int32_t nnd_init_from_leaves(nnd_handle_t h);
+/* The same on a CALLER-PROVIDED leaf array: the `leaf_array` argument of the reference's nn_descent
+ * (pynndescent_.py:324-337) -- host int32 (n_leaves, max_leaf_size), -1 padded, as rptree_leaf_array returns it
+ * (rp_trees.py:2891-2922); a row ends at its first negative entry (pynndescent_.py:88-92).  A caller that keeps the
+ * reference's make_forest hands its leaves in here; the handle needs no forest of its own (n_trees may be 0). */
+int32_t nnd_init_from_leaf_array(nnd_handle_t h, const int32_t *leaf_array, int64_t n_leaves, int32_t max_leaf_size);
 /* init_random (pynndescent_.py:188-203): top up rows that are not full with random points. */
 int32_t nnd_init_random(nnd_handle_t h);
 /* initalize_heap_from_graph_indices[_and_distances] (utils.py:836-860), used for init_graph /

@@ -174,6 +174,22 @@ def make_leaf_array(data, n_trees, leaf_size, tree_states, angular, max_depth=20
     return arr
 
 
+def init_rp_tree(data, n_neighbors, metric, leaf_array, lib=None):
+    """make_heap + init_rp_tree (reference pynndescent_.py:116-185, utils.py:130-158) on a given leaf array.
+    Returns the heap triple (indices, distances, flags), heap-ordered rows."""
+    lib = lib or load()
+    data = np.ascontiguousarray(data, np.float32)
+    n, dim = data.shape
+    k = int(n_neighbors)
+    hi = np.empty((n, k), np.int32)
+    hd = np.empty((n, k), np.float32)
+    hf = np.empty((n, k), np.uint8)
+    lib.orc_make_heap(hi, hd, hf, n, k)
+    la = np.ascontiguousarray(leaf_array, np.int32)
+    lib.orc_init_rp_tree(data, n, dim, METRICS[metric], hi, hd, hf, k, la, la.shape[0], la.shape[1], 8)
+    return hi, hd, hf
+
+
 def nn_descent(data, n_neighbors, rng_state, max_candidates, metric, n_iters, delta, leaf_array,
                n_threads=8, init=None, lib=None, return_trace=False):
     """reference pynndescent_.py:323-366. Returns (indices, alt-space distances), rows ascending."""

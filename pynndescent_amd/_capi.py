@@ -107,6 +107,7 @@ _SIGNATURES = [
     ("nnd_get_leaf_array", C.c_int32, [_H, C.c_void_p]),
     ("nnd_reset_graph", C.c_int32, [_H]),
     ("nnd_init_from_leaves", C.c_int32, [_H]),
+    ("nnd_init_from_leaf_array", C.c_int32, [_H, C.c_void_p, C.c_int64, C.c_int32]),
     ("nnd_init_random", C.c_int32, [_H]),
     ("nnd_init_from_graph", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int32]),
     ("nnd_init_from_neighbor_graph", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -258,6 +259,12 @@ class Builder:
 
     def init_from_leaves(self):
         self._check(self.lib.nnd_init_from_leaves(self._h))
+
+    def init_from_leaf_array(self, leaf_array):
+        """init_rp_tree on the caller's leaves: int32 (n_leaves, max_leaf_size), -1 padded (rptree_leaf_array's table)."""
+        la = np.ascontiguousarray(leaf_array, dtype=np.int32)
+        assert la.ndim == 2
+        self._check(self.lib.nnd_init_from_leaf_array(self._h, _ptr(la), la.shape[0], la.shape[1]))
 
     def init_random(self):
         self._check(self.lib.nnd_init_random(self._h))

@@ -371,6 +371,19 @@ extern "C" int32_t nnd_init_from_leaves(nnd_handle_t ctx) {
     return 0;
 }
 
+// init_rp_tree with the caller's leaf_array (the `leaf_array` argument of nn_descent, pynndescent_.py:324-337)
+extern "C" int32_t nnd_init_from_leaf_array(nnd_handle_t ctx, const int32_t *leaf_array, int64_t n_leaves, int32_t max_leaf_size) {
+    ENTER(ctx);
+    if (need_graph(ctx)) return 1;
+    if (need_data(ctx)) return 1;
+    if (!leaf_array || n_leaves < 0 || max_leaf_size < 1) { ctx->set_error("nnd_init_from_leaf_array: bad arguments"); return 1; }
+    const int t_ = t_begin(ctx);
+    if (nnd_launch_leaf_init_array(ctx, leaf_array, n_leaves, max_leaf_size)) return 1;
+    t_end(ctx, t_, &ctx->stats.ms_leaf_init, false);
+    t_flush(ctx);
+    return 0;
+}
+
 extern "C" int32_t nnd_init_random(nnd_handle_t ctx) {
     ENTER(ctx);
     if (need_graph(ctx)) return 1;

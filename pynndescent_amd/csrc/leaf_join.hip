@@ -362,6 +362,52 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : (QW && NT <= 5 
 // rp_trees.py:2188) are cut into runs of <= 256 consecutive positions for seeding purposes.
 static constexpr int LEAF_MAX = 256;
 
+// Seed the k-lists from leaves given as a work list: members of leaf i are members[wl_start[i] .. + wl_len[i]); the leaves
+// of round r are [tb[r], tb[r + 1]).  Inside a round no point may belong to two leaves -- the workgroup of a leaf owns
+// the k-lists of its points -- so rounds run launch after launch (the library's own forest: one round per tree).
+static int run_leaf_rounds(nnd_ctx *ctx, const int32_t *perm, const int32_t *d_ws, const int32_t *d_wl,
+                           const std::vector<int64_t> &tb, int maxlen) {
+    if (nnd_zero_counters(ctx)) return 1;
+    const int T = (int)tb.size() - 1;
+    for (int t = 0; t < T; t++) {
+        int64_t cnt = tb[t + 1] - tb[t];
+        if (cnt <= 0) continue;
+        dim3 grid((unsigned)cnt);
+#define LEAF_ARGS ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, perm, d_ws, d_wl, tb[t], tb[t + 1], ctx->k, ctx->ks, \
+                  ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters
+        const bool qw = ctx->k <= 16;
+        if (maxlen <= 64 && qw)
+            hipLaunchKernelGGL((k_leaf_join<4, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 64)
+            hipLaunchKernelGGL((k_leaf_join<4, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 80 && qw)  // the default leaf_size (<= 75 points) with k <= 16
+#ifdef NND_LEAF_QW_NW4
+            hipLaunchKernelGGL((k_leaf_join<5, 4, 64, true>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+#else
+            hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+#endif
+        else if (maxlen <= 80)
+            hipLaunchKernelGGL((k_leaf_join<5, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 96 && qw)
+            hipLaunchKernelGGL((k_leaf_join<6, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 96)
+            hipLaunchKernelGGL((k_leaf_join<6, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 128)
+            hipLaunchKernelGGL((k_leaf_join<8, 4, 64>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 160)  // k = 30 (leaf_size 150): 10 x 10 tiles instead of 16 x 16
+            hipLaunchKernelGGL((k_leaf_join<10, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+        else
+            hipLaunchKernelGGL((k_leaf_join<16, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+#undef LEAF_ARGS
+    }
+    NND_HIP_CHECK(hipGetLastError());
+    if (nnd_read_counters(ctx)) return 1;
+    ctx->stats.leaf_pairs = ctx->h_counters[CNT_PAIRS];
+    ctx->stats.leaf_rows = ctx->h_counters[CNT_ROWS];
+    ctx->stats.leaf_mfma = ctx->h_counters[CNT_MFMA];
+    return 0;
+}
+
 int nnd_launch_leaf_init(nnd_ctx *ctx) {
     if (!ctx->forest_built || ctx->n_leaves == 0) return 0;
     const int T = ctx->p.n_trees;
@@ -407,43 +453,80 @@ int nnd_launch_leaf_init(nnd_ctx *ctx) {
         d_ws = ctx->wl_start;
         d_wl = ctx->wl_len;
     }
-    if (nnd_zero_counters(ctx)) return 1;
-    const int32_t *perm = ctx->perm[ctx->cur];
-    for (int t = 0; t < T; t++) {
-        int64_t cnt = tb[t + 1] - tb[t];
-        if (cnt <= 0) continue;
-        dim3 grid((unsigned)cnt);
-#define LEAF_ARGS ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, perm, d_ws, d_wl, tb[t], tb[t + 1], ctx->k, ctx->ks, \
-                  ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters
-        const bool qw = ctx->k <= 16;
-        if (maxlen <= 64 && qw)
-            hipLaunchKernelGGL((k_leaf_join<4, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
-        else if (maxlen <= 64)
-            hipLaunchKernelGGL((k_leaf_join<4, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
-        else if (maxlen <= 80 && qw)  // the default leaf_size (<= 75 points) with k <= 16
-#ifdef NND_LEAF_QW_NW4
-            hipLaunchKernelGGL((k_leaf_join<5, 4, 64, true>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
-#else
-            hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
-#endif
-        else if (maxlen <= 80)
-            hipLaunchKernelGGL((k_leaf_join<5, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
-        else if (maxlen <= 96 && qw)
-            hipLaunchKernelGGL((k_leaf_join<6, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
-        else if (maxlen <= 96)
-            hipLaunchKernelGGL((k_leaf_join<6, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
-        else if (maxlen <= 128)
-            hipLaunchKernelGGL((k_leaf_join<8, 4, 64>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
-        else if (maxlen <= 160)  // k = 30 (leaf_size 150): 10 x 10 tiles instead of 16 x 16
-            hipLaunchKernelGGL((k_leaf_join<10, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
-        else
-            hipLaunchKernelGGL((k_leaf_join<16, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
-#undef LEAF_ARGS
+    return run_leaf_rounds(ctx, ctx->perm[ctx->cur], d_ws, d_wl, tb, maxlen);
+}
+
+
+// init_rp_tree on a CALLER-PROVIDED leaf array -- the `leaf_array` argument of the reference's nn_descent
+// (pynndescent_.py:324-337; rptree_leaf_array's int32 (n_leaves, max_leaf_size) table, -1 padded; a row ends at its first
+// negative entry, pynndescent_.py:88-92).  A caller that keeps the reference's make_forest hands its leaves in here.
+// The leaf kernel lets a workgroup own the k-lists of its leaf's points, so the leaves are dealt into ROUNDS in which no
+// point occurs twice (round of a leaf = the first round after the last one that used any of its points; a forest's
+// leaf array -- trees concatenated, each a partition of the points -- falls into one round per tree) and the rounds run
+// launch after launch.  The seeded k-lists are the k nearest leaf-mates of every point over all leaves, as the
+// reference's pushes leave them (ties in distance aside).  Leaves longer than 256 points are cut into runs of 256.
+int nnd_launch_leaf_init_array(nnd_ctx *ctx, const int32_t *leaf_host, int64_t n_leaves, int32_t max_leaf_size) {
+    if (n_leaves <= 0 || max_leaf_size <= 0) return 0;
+    const int64_t n = ctx->n;
+    std::vector<int32_t> seen((size_t)n, 0);
+    struct piece { int64_t off; int32_t len; int32_t round; };
+    std::vector<piece> pieces;
+    pieces.reserve((size_t)n_leaves);
+    int n_rounds = 0, maxlen = 0;
+    for (int64_t l = 0; l < n_leaves; l++) {
+        const int32_t *row = leaf_host + l * max_leaf_size;
+        int32_t len = 0;
+        while (len < max_leaf_size && row[len] >= 0) {
+            if ((int64_t)row[len] >= n) { ctx->set_error("nnd_init_from_leaf_array: leaf %lld holds point %d but n = %lld", (long long)l, row[len], (long long)n); return 1; }
+            len++;
+        }
+        if (len < 2) continue;  // no pairs
+        int32_t r = 0;
+        for (int32_t i = 0; i < len; i++) r = seen[row[i]] > r ? seen[row[i]] : r;
+        for (int32_t i = 0; i < len; i++) {
+            if (seen[row[i]] == r + 1) { ctx->set_error("nnd_init_from_leaf_array: point %d occurs twice in leaf %lld", row[i], (long long)l); return 1; }
+            seen[row[i]] = r + 1;
+        }
+        if (r + 1 > n_rounds) n_rounds = r + 1;
+        for (int32_t a = 0; a < len; a += LEAF_MAX) {  // pieces of one leaf share no point: same round
+            const int32_t pl = len - a > LEAF_MAX ? LEAF_MAX : len - a;
+            if (pl < 2) continue;
+            pieces.push_back({l * max_leaf_size + a, pl, r});
+            if (pl > maxlen) maxlen = pl;
+        }
     }
-    NND_HIP_CHECK(hipGetLastError());
-    if (nnd_read_counters(ctx)) return 1;
-    ctx->stats.leaf_pairs = ctx->h_counters[CNT_PAIRS];
-    ctx->stats.leaf_rows = ctx->h_counters[CNT_ROWS];
-    ctx->stats.leaf_mfma = ctx->h_counters[CNT_MFMA];
-    return 0;
+    if (pieces.empty()) return 0;
+    // counting sort by round; members stay where they are in the uploaded table (wl_start indexes into it)
+    std::vector<int64_t> tb((size_t)n_rounds + 1, 0);
+    for (const piece &pc : pieces) tb[(size_t)pc.round + 1]++;
+    for (int r = 0; r < n_rounds; r++) tb[(size_t)r + 1] += tb[(size_t)r];
+    std::vector<int64_t> cur(tb.begin(), tb.end() - 1);
+    if ((int64_t)n_leaves * max_leaf_size >= (int64_t)0x7FFFFFF0) { ctx->set_error("nnd_init_from_leaf_array: leaf table too large for int32 offsets"); return 1; }
+    std::vector<int32_t> ws(pieces.size()), wl(pieces.size());
+    for (const piece &pc : pieces) {
+        const int64_t at = cur[(size_t)pc.round]++;
+        ws[(size_t)at] = (int32_t)pc.off;
+        wl[(size_t)at] = pc.len;
+    }
+    int32_t *d_tab = nullptr, *d_ws = nullptr, *d_wl = nullptr;
+    const size_t tab = (size_t)n_leaves * max_leaf_size, np = pieces.size();
+    int rc = 0;
+    if (hipMalloc((void **)&d_tab, sizeof(int32_t) * tab) != hipSuccess || hipMalloc((void **)&d_ws, sizeof(int32_t) * np) != hipSuccess ||
+        hipMalloc((void **)&d_wl, sizeof(int32_t) * np) != hipSuccess) {
+        ctx->set_error("nnd_init_from_leaf_array: out of device memory");
+        rc = 1;
+    }
+    if (!rc && (hipMemcpyAsync(d_tab, leaf_host, sizeof(int32_t) * tab, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(d_ws, ws.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(d_wl, wl.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)) {
+        ctx->set_error("nnd_init_from_leaf_array: H2D copy failed");
+        rc = 1;
+    }
+    if (!rc) rc = run_leaf_rounds(ctx, d_tab, d_ws, d_wl, tb, maxlen);  // ends with a counter read-back: the stream has drained
+    (void)hipStreamSynchronize(ctx->stream);
+    if (d_tab) (void)hipFree(d_tab);
+    if (d_ws) (void)hipFree(d_ws);
+    if (d_wl) (void)hipFree(d_wl);
+    if (!rc) ctx->stats.n_leaves = n_leaves;
+    return rc;
 }

@@ -149,6 +149,7 @@ int nnd_launch_forest(nnd_ctx *ctx);
 int nnd_launch_leaf_array(nnd_ctx *ctx, int32_t *out_dev /* (n_leaves,max_leaf) */);
 int nnd_fetch_leaf_tables(nnd_ctx *ctx);
 int nnd_launch_leaf_init(nnd_ctx *ctx);
+int nnd_launch_leaf_init_array(nnd_ctx *ctx, const int32_t *leaf_host, int64_t n_leaves, int32_t max_leaf_size);
 int nnd_launch_random_init(nnd_ctx *ctx);
 int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float *dist_dev, int width);
 int nnd_launch_sample(nnd_ctx *ctx);

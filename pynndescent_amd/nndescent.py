@@ -556,6 +556,66 @@ class NNDescent:
             self.prepare()
 
 
+EMPTY_GRAPH = (np.array([[-1]], dtype=np.int32), np.array([[np.inf]], dtype=np.float32),
+               np.array([[0]], dtype=np.uint8))  # pynndescent_.py:64-68
+
+# distance arguments nn_descent understands: name (or __name__ of the reference's function) -> (kernel metric, correction)
+_ND_DISTS = {"squared_euclidean": (_capi.NND_METRIC_SQEUCLIDEAN, None), "sqeuclidean": (_capi.NND_METRIC_SQEUCLIDEAN, None),
+             "euclidean": (_capi.NND_METRIC_SQEUCLIDEAN, np.sqrt), "l2": (_capi.NND_METRIC_SQEUCLIDEAN, np.sqrt),
+             "alternative_cosine": (_capi.NND_METRIC_ALT_COSINE, None),
+             "cosine": (_capi.NND_METRIC_ALT_COSINE, correct_alternative_cosine)}
+
+
+def nn_descent(data, n_neighbors, rng_state, max_candidates=50, dist="squared_euclidean", n_iters=10, delta=0.001,
+               init_graph=EMPTY_GRAPH, rp_tree_init=True, leaf_array=None, low_memory=True, verbose=False, device=0):
+    """The reference's ``nn_descent`` (pynndescent_.py:323-366) with the same arguments, on the GPU: the seam a caller
+    uses who keeps the reference's ``make_forest`` / ``rptree_leaf_array`` and hands the leaves in.
+
+    data float32 (n, d); rng_state int64[3]; ``dist``: "squared_euclidean" / "alternative_cosine" (what NNDescent passes,
+    pynndescent_.py:1247-1260), "euclidean" / "cosine" (true distances: the same kernels, corrected on return), or the
+    reference function of one of those names; ``init_graph``: EMPTY_GRAPH, or the heap triple ``(indices (n, k),
+    distances (n, k), flags (n, k))`` the reference accepts (entries with index -1 are empty); ``leaf_array`` int32
+    (n_leaves, max_leaf_size), -1 padded, used when ``rp_tree_init``.  ``low_memory`` is accepted and unused, as in the
+    reference (pynndescent_.py:335).  Returns ``(indices int32 (n, k), distances float32 (n, k))``, rows ascending."""
+    name = dist if isinstance(dist, str) else getattr(dist, "__name__", None)
+    if name not in _ND_DISTS:
+        raise NotImplementedError("pynndescent_amd.nn_descent: dist must be one of %s (got %r)" % (sorted(_ND_DISTS), dist))
+    code, correction = _ND_DISTS[name]
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    n = data.shape[0]
+    _check_supported_sizes(n_neighbors, max_candidates, None)
+    empty = init_graph[0].shape[0] == 1  # EMPTY_GRAPH
+    if not empty and not (init_graph[0].shape[0] == n and init_graph[0].shape[1] == n_neighbors):
+        raise ValueError("Invalid initial graph specified!")  # pynndescent_.py:352
+    builder = _capi.Builder(n, data.shape[1], code, n_neighbors, 0, max(60, min(256, 5 * int(n_neighbors))), 200,
+                            max_candidates, n_iters, delta, np.asarray(rng_state, np.int64), np.zeros(3, np.int64),
+                            device=device)
+    try:
+        builder.set_data_host(data)
+        if empty:
+            if rp_tree_init:
+                if leaf_array is None:
+                    raise ValueError("rp_tree_init=True needs a leaf_array (rptree_leaf_array of a forest)")
+                builder.init_from_leaf_array(leaf_array)
+            builder.init_random()
+        else:  # a heap handed over: its entries, with their distances (flags restart as "new": they were never sampled here)
+            builder.init_from_graph(np.asarray(init_graph[0], np.int32), np.asarray(init_graph[1], np.float32))
+        for it in range(n_iters):  # nn_descent_internal (pynndescent_.py:296-320)
+            if verbose:
+                print("\t", it + 1, " / ", n_iters)
+            c = builder.descent_iter()
+            if c <= delta * n_neighbors * n:
+                if verbose:
+                    print("\tStopping threshold met -- exiting after", it + 1, "iterations")
+                break
+        idx, dst = builder.finalize()
+    finally:
+        builder.close()
+    if correction is not None:
+        dst = correction(dst).astype(np.float32)
+    return idx, dst
+
+
 def _check_supported_sizes(n_neighbors, max_candidates, init_graph):
     """The GPU k-lists / candidate lists hold at most 64 entries (one wave); the reference has no such bound
     (pynndescent_.py:976-982), so the limit is reported up front and by name."""

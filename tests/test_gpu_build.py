@@ -337,3 +337,36 @@ def test_unsupported_sizes_are_reported_up_front():
         NNDescent(x, n_neighbors=10, max_candidates=80)
     with pytest.raises(NotImplementedError, match="manhattan"):
         NNDescent(x, metric="manhattan")
+
+
+@pytest.mark.parametrize("metric,dist", [("euclidean", "squared_euclidean"), ("cosine", "alternative_cosine"), ("euclidean", "euclidean")])
+def test_nn_descent_function_with_reference_leaf_array(metric, dist):
+    """pynndescent_amd.nn_descent mirrors the reference function (pynndescent_.py:323-366), leaf_array included: fed the
+    reference algorithm's own forest (oracle make_forest + rptree_leaf_array) it must reach the recall the reference's
+    nn_descent reaches from those leaves (two-sided, 0.5 %)."""
+    import pynndescent_amd
+
+    n, d, k = 20000, 32, 15
+    x = clustered(n, d, 8, 60, seed=21)
+    rng_state, _, ts = O.draw_rng_states(11, 6)
+    la = O.make_leaf_array(x, 6, O.default_leaf_size(k), ts, metric == "cosine")
+    n_iters = O.default_n_iters(n)
+    gi, gd = pynndescent_amd.nn_descent(x, k, rng_state, max_candidates=k, dist=dist, n_iters=n_iters, delta=0.001,
+                                        rp_tree_init=True, leaf_array=la)
+    oi, od = O.nn_descent(x, k, rng_state.copy(), k, metric, n_iters, 0.001, la)
+    ti, td = O.brute_force_knn(x, 10, metric)
+    rg, ro = O.recall(ti, gi), O.recall(ti, oi)
+    print("nn_descent(%s) from the reference's leaves: GPU %.4f, oracle %.4f" % (dist, rg, ro))
+    assert abs(rg - ro) <= 0.005 and rg > 0.9
+    assert gi.dtype == np.int32 and gd.dtype == np.float32 and gi.shape == (n, k)
+    assert np.all(np.diff(gd, axis=1) >= 0)
+    if dist == "euclidean":  # true distances on return
+        truth = np.sqrt(((x[:50, None, :].astype(np.float64) - x[gi[:50]].astype(np.float64)) ** 2).sum(-1))
+        np.testing.assert_allclose(gd[:50], truth, rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError, match="Invalid initial graph"):
+        pynndescent_amd.nn_descent(x, k, rng_state, init_graph=(np.zeros((5, k), np.int32), np.zeros((5, k), np.float32),
+                                                                np.zeros((5, k), np.uint8)))
+    # a heap triple of the right shape continues from there (no forest, no random fill)
+    hi, hd, hf = O.init_rp_tree(x, k, metric, la)
+    gi2, _ = pynndescent_amd.nn_descent(x, k, rng_state, max_candidates=k, dist=dist, n_iters=n_iters, init_graph=(hi, hd, hf))
+    assert abs(O.recall(ti, gi2) - ro) <= 0.005

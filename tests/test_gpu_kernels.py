@@ -317,3 +317,62 @@ def test_half_wave_select_equals_wave_select(k, mc, monkeypatch):
     # the old lists of vertices without new candidates are not defined (the join skips them): compare where they are
     has_new = outs[0][4][:, 0] >= 0
     assert has_new.any()
+
+
+@pytest.mark.parametrize("metric,n,d,k,T", [("euclidean", 6000, 32, 15, 4), ("cosine", 3000, 20, 10, 3),
+                                            ("euclidean", 2500, 12, 30, 3)])
+def test_leaf_array_seam_matches_reference_init_rp_tree(metric, n, d, k, T):
+    """The `leaf_array` seam of nn_descent (pynndescent_.py:324-337): the ORACLE's forest (a restatement of the
+    reference's make_forest + rptree_leaf_array) is handed to nnd_init_from_leaf_array; the k-lists must then hold what
+    the reference's init_rp_tree leaves in its heaps on the SAME leaves -- compared exactly, row by row, as sets."""
+    x = clustered(n, d, 6, 25, seed=n + k)
+    _, _, ts = O.draw_rng_states(5, T)
+    la = O.make_leaf_array(x, T, O.default_leaf_size(k), ts, metric == "cosine")
+    b = make_builder(x, metric, k=k, n_trees=0)  # no forest of its own
+    b.init_from_leaf_array(la)
+    idx, dist, flags = b.graph()
+    check_graph_invariants(x, metric, idx, dist, name="leaf_array_seam")
+    assert np.all(flags[idx >= 0] == 1)
+    oi, od, of = O.init_rp_tree(x, k, metric, la)
+    same = 0
+    for r in range(n):
+        a, c = set(idx[r][idx[r] >= 0].tolist()), set(oi[r][oi[r] >= 0].tolist())
+        if a == c:
+            same += 1
+            continue
+        # rows may differ only through a tie (or an ulp) at the boundary distance: same sorted distances
+        np.testing.assert_allclose(np.sort(dist[r][idx[r] >= 0]), np.sort(od[r][oi[r] >= 0]), rtol=2e-5, atol=1e-6)
+    print("leaf_array seam %s: %d of %d rows identical as sets" % (metric, same, n))
+    assert same >= 0.999 * n
+    # leaves in an arbitrary ORDER (rounds are found by the library, not assumed to be trees): same result
+    perm = np.random.RandomState(3).permutation(la.shape[0])
+    b.reset_graph()
+    b.init_from_leaf_array(la[perm])
+    idx2, dist2, _ = b.graph()
+    assert (np.sort(idx2, axis=1) == np.sort(idx, axis=1)).all(1).mean() >= 0.999
+    b.close()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_leaf_init_recall_gpu_forest_vs_reference_forest(metric):
+    """Isolates the forest: recall of the k-lists right after leaf seeding, with the GPU's own forest (top of every tree
+    drawn from a 1/8 sample at this size) against the reference algorithm's forest (oracle) through the SAME seeding
+    kernel.  Both are random forests of the same family: the recalls must agree within 1.5 % (two-sided)."""
+    n, d, k, T = 200_000, 48, 15, 8
+    x = clustered(n, d, 10, 400, seed=17)
+    rows = np.random.RandomState(0).choice(n, 2000, replace=False)
+    ti, _ = O.brute_force_knn(x, 11, metric, rows=rows, kind="fast")
+    b = make_builder(x, metric, k=k, n_trees=T)
+    b.make_forest()
+    assert b.stats()["n_cells"] > 0  # the routing forest (sampled tops) is what is being tested
+    b.init_from_leaves()
+    g_idx, _, _ = b.graph()
+    _, _, ts = O.draw_rng_states(1, T)
+    la = O.make_leaf_array(x, T, O.default_leaf_size(k), ts, metric == "cosine")
+    b.reset_graph()
+    b.init_from_leaf_array(la)
+    o_idx, _, _ = b.graph()
+    rg, ro = O.recall(ti, g_idx[rows]), O.recall(ti, o_idx[rows])
+    print("recall@10 after leaf seeding (%s, %d trees): GPU forest %.4f, reference forest %.4f" % (metric, T, rg, ro))
+    assert abs(rg - ro) <= 0.015
+    b.close()
