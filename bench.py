@@ -21,7 +21,13 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying, besides t
                          box's host cores on the same 1 M points
   value_host_inclusive : the same build through nnd_build (host buffers in, host buffers out: H2D + build + D2H)
   workload_hard        : a second, slow-converging input (latent dimension 48) so tuning is not judged on one workload
+  value_class_api      : wall time of the drop-in call itself, pynndescent_amd.NNDescent(x, ...).neighbor_graph (SURVEY 8d's metric)
+  workload_k30         : the same points with the reference's default n_neighbors = 30
+  roofline.build       : whole-build algorithmic bytes (SURVEY 8d model with the measured counts) / wall time vs 8 TB/s
   recall_at_10         : recall vs exact brute force on a sample of points (reference-test convention)
+
+--data FILE (.fvecs / .npy / .hdf5 with a "train" dataset): build THAT point set instead of the synthetic one (real SIFT-1M /
+GloVe / NYTimes when a file is on disk; there is none in this image), N = 1 only.
 """
 import argparse
 import json
@@ -98,7 +104,7 @@ def cpu_baseline(O, xs, k, n_trees, true_rows=None, true_idx=None):
     O.build()
     probe = xs[: min(200_000, xs.shape[0])]
     best_t, best = None, None
-    for t in sorted({min(cores, c) for c in (32, 64, 128)}):
+    for t in sorted({min(cores, c) for c in (32, 64, 128, 256, cores)}):
         t1 = time.perf_counter()
         O.build_index(probe, "euclidean", n_neighbors=k, n_trees=n_trees, random_state=1234, n_threads=t, kind="fast")
         dt = time.perf_counter() - t1
@@ -112,9 +118,11 @@ def cpu_baseline(O, xs, k, n_trees, true_rows=None, true_idx=None):
         rec = round(float(O.recall(true_idx, oidx[true_rows])), 4)
     return {"value": round(xs.shape[0] / dt, 1), "unit": "points/s", "cores": best_t, "host_cores": cores, "kind": "port",
             "seconds": round(dt, 2), "recall_at_10": rec,
-            "sample": "all %d points of the same synthetic set, same k/n_trees/defaults; CPU restatement of the "
-                      "reference algorithm (numba unavailable), gcc -O3 -ffast-math + OpenMP, %d threads "
-                      "(fastest of a probe over 32/64/128 on the first %d points)" % (xs.shape[0], best_t, probe.shape[0])}
+            "note": "PORT: a C/OpenMP restatement of the reference algorithm (oracle/), NOT the reference's numba code "
+                    "(numba is not installable in this image)",
+            "sample": "all %d points of the same set, same k/n_trees/defaults; gcc -O3 -ffast-math + OpenMP, %d threads "
+                      "(fastest of a probe over 32/64/128/256/all cores on the first %d points; the reference's scheme makes "
+                      "every thread scan all edges, so more threads is not always faster)" % (xs.shape[0], best_t, probe.shape[0])}
 
 
 def host_inclusive(_capi, x_host, k, n_trees, leaf_size, n_iters, rng_state, tree_state, device, reps=2):
@@ -146,6 +154,42 @@ def host_inclusive(_capi, x_host, k, n_trees, leaf_size, n_iters, rng_state, tre
                     % (x_host.nbytes >> 20, (idx.nbytes + dist.nbytes) >> 20, reps)}
 
 
+def class_api(x_host, k, n_trees, device, reps=2):
+    """SURVEY.md section 8d's metric, literally: n / wall(NNDescent(x, ...) -> neighbor_graph arrays on the host), warm."""
+    import pynndescent_amd
+
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        idx, dist = pynndescent_amd.NNDescent(x_host, "euclidean", n_neighbors=k, n_trees=n_trees, random_state=1234,
+                                              device=device).neighbor_graph
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    n = x_host.shape[0]
+    return {"value": round(n / best, 1), "unit": "points/s", "ms": round(best * 1e3, 2),
+            "what": "pynndescent_amd.NNDescent(x, 'euclidean', n_neighbors=%d, n_trees=%d).neighbor_graph: check_array + handle "
+                    "creation + H2D + build (host-driven iteration loop) + D2H + sqrt correction, best of %d" % (k, n_trees, reps)}
+
+
+def load_points(path):
+    """float32 (n, d) from .fvecs (TEXMEX: int32 d, then d floats, per row), .npy, or .hdf5/.h5 with a 'train' dataset."""
+    if path.endswith(".fvecs"):
+        raw = np.fromfile(path, dtype=np.int32)
+        d = int(raw[0])
+        return np.ascontiguousarray(raw.reshape(-1, d + 1)[:, 1:].view(np.float32))
+    if path.endswith(".npy"):
+        return np.ascontiguousarray(np.load(path), dtype=np.float32)
+    if path.endswith((".hdf5", ".h5")):
+        try:
+            import h5py
+        except ImportError:
+            sys.exit("bench.py: --data %s needs h5py, which is not installed in this image; convert the 'train' dataset to "
+                     ".npy or .fvecs" % path)
+        with h5py.File(path, "r") as f:
+            return np.ascontiguousarray(f["train"][:], dtype=np.float32)
+    sys.exit("bench.py: --data expects a .fvecs, .npy or .hdf5 file")
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -170,7 +214,8 @@ def main():
     ap.add_argument("--join-blocks", type=int, default=1)
     ap.add_argument("--latent", type=int, default=16, help="latent dimension of the synthetic mixture (48 = the hard workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip value_host_inclusive and workload_hard")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_host_inclusive, value_class_api, workload_hard, workload_k30")
+    ap.add_argument("--data", default=None, help="build this point set (.fvecs / .npy / .hdf5 'train') instead of the synthetic one")
     args = ap.parse_args()
 
     share_gpu = os.environ.get("PYNND_BENCH_SHARE_GPU") == "1"  # debug: all ranks on GPU 0 over gloo
@@ -217,10 +262,23 @@ def main():
         n_total = n * world
         shard_sizes = [n] * world
     n_trees = args.n_trees
-    if n_trees is None:  # configs[1] names 8 trees; configs[3] names none -> the reference default (pynndescent_.py:1009-1010)
+    if n_trees is None and args.data is None:  # configs[1] names 8 trees; configs[3] names none -> the reference default (pynndescent_.py:1009-1010)
         n_trees = max(3, min(12, int(round(2.0 * np.log10(n_total))))) if strong else 8
-    x = sift_like(n, d, seed=1, device=device, sample_seed=100 + rank, latent=args.latent)
+    data_name = None
+    if args.data is not None:
+        if world != 1:
+            sys.exit("bench.py: --data is a single-GPU workload")
+        xh_file = load_points(args.data)
+        n, d = xh_file.shape
+        n_total, shard_sizes = n, [n]
+        x = torch.from_numpy(xh_file).to(device)
+        data_name = os.path.basename(args.data)
+        del xh_file
+    else:
+        x = sift_like(n, d, seed=1, device=device, sample_seed=100 + rank, latent=args.latent)
     torch.cuda.synchronize()
+    if n_trees is None and args.data is not None:
+        n_trees = max(3, min(12, int(round(2.0 * np.log10(n_total)))))
     n_iters = max(5, int(round(np.log2(n_total))))  # pynndescent_.py:1011-1012
     leaf_size = max(60, min(256, 5 * k))              # rp_trees.py:2845-2846
     lim = np.iinfo(np.int32)
@@ -241,9 +299,11 @@ def main():
             builder.build_device(out_idx.data_ptr(), out_dist.data_ptr())
             return builder.stats(), None
     else:
-        comm = sharded.TorchDistComm()
+        # the rank's communicator: RCCL (nccl backend; only the 128-byte unique id travels through torch) -- the exchanges
+        # themselves are issued by libpynnd_amd.so (ncclGroupStart / ncclSend / ncclRecv) on the build's HIP stream
+        comm = sharded.make_comm(local_rank)
         sb = sharded.ShardedBuilder(comm, shard_sizes, d, "euclidean", k, n_trees, seed=1234, device_index=local_rank)
-        builder = sb.b
+        builder = None
         out_idx, out_dist = sb.out_idx, sb.out_dist
 
         def step():
@@ -254,7 +314,8 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
-        builder.synchronize()
+        if builder is not None:
+            builder.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -321,9 +382,13 @@ def main():
             achieved, kernel = join_gbs, "k_local_join"
         else:
             achieved, kernel = leaf_gbs, "k_leaf_join"
-        n_here = builder.n
-        tree_bytes = steps * (n_here * 4.0 * builder_dp(d) * last["tree_levels"] +
-                              n_here * 8.0 * last["tree_levels"] * local_trees)
+        n_here = n_total
+        row = 4.0 * builder_dp(d)
+        # Levels = ceil(log2(n / mean leaf fill)) -- NOT the measured level count (the routing forest never
+        # reads a row once per level of its deepest branch)
+        leaf_fill = local_trees * n_here / max(last["n_leaves"], 1)
+        levels = int(np.ceil(np.log2(max(n_here / max(leaf_fill, 1.0), 2.0))))
+        tree_bytes = steps * (n_here * row * levels + n_here * 8.0 * levels * local_trees)
         forest_gbs = tree_bytes / (stage["forest"] * 1e-3) / 1e9 if stage["forest"] > 0 else 0.0
         # HBM traffic per launch from the committed PMC passes (tools/pmc_traffic.py; separate --pmc runs, FETCH_SIZE
         # corrected by the factor calibrated for this access pattern); null if no profile of this kernel is committed
@@ -358,14 +423,53 @@ def main():
                                     "avg_launch_ms": round(stage["leaf_init"] / steps / local_trees, 4),
                                     "bytes_per_launch": round(leaf_bytes / steps / local_trees)},
                     "rp_forest_stage": {"achieved": round(forest_gbs, 2), "frac": round(forest_gbs / HBM_PEAK_GBS, 5),
-                                        "ms": round(stage["forest"] / steps, 3)},
+                                        "ms": round(stage["forest"] / steps, 3), "levels_in_model": levels},
                     "mfma": mfma}
+        # whole build (single GPU): SURVEY 8d's B = B_tree + B_leaf + sum_i B_iter + B_final with the measured counts,
+        # over the wall time of the timed region -- so that the headline fraction is not only the best kernel's
+        if world == 1:
+            c_rows = float(sum(last["join_rows"]))
+            b_tree = n_here * row * levels + n_here * 8.0 * levels * n_trees
+            b_leaf = n_trees * n_here * row + n_trees * n_here * 4.0
+            b_iter = c_rows * row + last["n_iters_run"] * (2.0 * n_here * k * 9.0 + n_here * k * 5.0) + 2.0 * c_rows * 4.0
+            b_final = n_here * k * row + n_here * k * 8.0
+            b_all = b_tree + b_leaf + b_iter + b_final
+            gbs = b_all / (ms_per_step * 1e-3) / 1e9
+            roofline["build"] = {"algorithmic_bytes": round(b_all), "achieved": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5),
+                                 "parts_gb": {"tree": round(b_tree / 1e9, 2), "leaf": round(b_leaf / 1e9, 2),
+                                              "iters": round(b_iter / 1e9, 2), "final": round(b_final / 1e9, 2)}}
 
-        cpu = host_incl = hard = None
+        cpu = host_incl = hard = cls_api = k30 = None
         if world == 1 and not args.no_extras:
-            host_incl = host_inclusive(_capi, x.cpu().numpy(), k, n_trees, leaf_size, n_iters, rng_state, tree_states[0],
-                                       local_rank)
-            if args.latent == 16:  # second perf line: same generator, latent dimension 48 (converges slowly)
+            x_host = x.cpu().numpy()
+            host_incl = host_inclusive(_capi, x_host, k, n_trees, leaf_size, n_iters, rng_state, tree_states[0], local_rank)
+            cls_api = class_api(x_host, k, n_trees, local_rank)
+            del x_host
+            if args.latent == 16 and args.data is None:  # the reference's default n_neighbors on the same points
+                k3 = 30
+                b30 = _capi.Builder(n, d, _capi.NND_METRIC_SQEUCLIDEAN, k3, n_trees, max(60, min(256, 5 * k3)), 200, min(60, k3), n_iters,
+                                    0.001, rng_state, tree_states[0], device=local_rank)
+                o_i = torch.empty((n, k3), dtype=torch.int32, device=device)
+                o_d = torch.empty((n, k3), dtype=torch.float32, device=device)
+                b30.set_data_device(x.data_ptr(), keepalive=x)
+                b30.build_device(o_i.data_ptr(), o_d.data_ptr())  # warm-up
+                b30.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    b30.set_data_device(x.data_ptr(), keepalive=x)
+                    b30.build_device(o_i.data_ptr(), o_d.data_ptr())
+                b30.synchronize()
+                dt = (time.perf_counter() - t1) / 2
+                s30 = b30.stats()
+                k30 = {"workload": "the same %dx%d points, n_neighbors=30 (the reference's default), n_trees=%d" % (n, d, n_trees),
+                       "value": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 3), "iters": s30["n_iters_run"],
+                       "recall_at_10": round(recall_at(true_idx, o_i[rows], 10), 4),
+                       "stage_ms": {"forest": round(s30["ms_forest"], 3), "leaf_init": round(s30["ms_leaf_init"], 3),
+                                    "join": round(sum(s30["ms_join"]), 3), "sample": round(sum(s30["ms_sample"]), 3),
+                                    "merge": round(sum(s30["ms_merge"]), 3), "finalize": round(s30["ms_finalize"], 3)}}
+                b30.close()
+                del o_i, o_d
+            if args.latent == 16 and args.data is None:  # second perf line: same generator, latent dimension 48 (converges slowly)
                 xh = sift_like(n, d, seed=1, device=device, sample_seed=100, latent=48)
                 torch.cuda.synchronize()
                 builder.set_data_device(xh.data_ptr(), keepalive=xh)
@@ -392,7 +496,9 @@ def main():
 
             cpu = cpu_baseline(O, x.cpu().numpy(), k, n_trees, rows_np, true_idx.cpu().numpy())
 
-        if strong:
+        if data_name is not None:
+            workload = "%s: %dx%d float32 euclidean k=%d n_trees=%d (file given with --data)" % (data_name, n_total, d, k, n_trees)
+        elif strong:
             workload = ("BASELINE configs[3] stand-in: ONE SIFT-like %dx%d float32 euclidean k=%d set (n_trees=%d) row-sharded "
                         "over %d GPUs, %d rows per rank" % (n_total, d, k, n_trees, world, n))
         else:
@@ -410,12 +516,13 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if data_name is None else "file:" + data_name,
             "config": {"workload": workload,
                        "parallelism": "1 GPU" if world == 1 else
                        "rows sharded over %d GPUs (one global index of %d points): point set all-gathered once, forest split "
-                       "by tree, per iteration reverse-offer all-to-all-v + threshold all-gather + proposal all-to-all-v + "
-                       "count all-reduce over RCCL" % (world, n_total),
+                       "by tree, per iteration threshold all-gather + reverse-offer all-to-all-v + proposal all-to-all-v, the "
+                       "update counts riding on the record-count exchange; ncclSend/ncclRecv groups issued by libpynnd_amd.so "
+                       "on the build's stream (%s transport)" % (world, n_total, "gloo HOST-staged debug" if share_gpu else "RCCL"),
                        "join_blocks": args.join_blocks},
             "recall_at_10": round(rec_all, 4),
             "recall_at_10_strict_first10": round(rec_strict, 4),
@@ -429,15 +536,21 @@ def main():
                        "join_pairs": last["join_pairs"], "join_rows": last["join_rows"], "proposals": last["proposals"],
                        "updates": last["updates"]},
             "exchanged_records_rank0": None if info is None else info["exchanged_records"],
+            "shard_rank0": None if info is None else {kk: info[kk] for kk in ("c", "offer_records", "proposal_records", "deferred",
+                                                                                "dropped_offers", "bytes_sent", "ms_total",
+                                                                                "ms_allgather", "ms_klist_exchange", "local_trees")},
             "roofline": roofline,
             "value_host_inclusive": host_incl,
+            "value_class_api": cls_api,
             "workload_hard": hard,
+            "workload_k30": k30,
             "cpu_baseline": cpu,
         }
         print(json.dumps(result))
         sys.stdout.flush()
     if sb is not None:
         sb.close()
+        comm.close()
     else:
         builder.close()
     if world > 1:

@@ -41,7 +41,7 @@ extern "C" {
 #define NND_METRIC_SQEUCLIDEAN 0 /* reference distances.py:63  squared_euclidean  */
 #define NND_METRIC_ALT_COSINE 1  /* reference distances.py:583 alternative_cosine */
 
-#define NND_ABI_VERSION 2
+#define NND_ABI_VERSION 3
 
 typedef struct nnd_handle_s *nnd_handle_t;
 
@@ -173,51 +173,83 @@ int32_t nnd_sample_candidates(nnd_handle_t h);
 int32_t nnd_pairwise_gram(nnd_handle_t h, const int32_t *rows_a, int32_t na, const int32_t *rows_b, int32_t nb,
                           float *out);
 
-/* ---- row-sharded multi-GPU build (one handle per GPU) ----
- * The reference is single-process; its sharding idea is the owner-computes rule of
- * apply_graph_update_array / new_build_candidates (utils.py:709-731, 259-306: each thread owns a contiguous
- * vertex range).  Here every handle is created with the GLOBAL n and the full (replicated) point set, but
- * owns rows [lo, hi): sampling, join, merge and finalize act on owned rows only.  The exchange steps
- * (k-list all-gather, proposal all-to-all-v, update-count all-reduce) are driven by the host over RCCL
- * (pynndescent_amd/sharded.py); these entry points are their device-side halves.  All pointers below are
- * DEVICE pointers. */
-int32_t nnd_set_owned_range(nnd_handle_t h, int64_t lo, int64_t hi);
-int32_t nnd_row_stride(nnd_handle_t h); /* ks: uint32/float words per k-list row */
-/* raw k-list rows [lo,hi): neighbour words (idx | new<<31, 0xFFFFFFFF empty) and alt-space distances */
-int32_t nnd_export_graph_rows(nnd_handle_t h, int64_t lo, int64_t hi, uint32_t *e_dst, float *d_dst);
-int32_t nnd_import_graph_rows(nnd_handle_t h, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
-/* d_dst / d_src may be NULL: then only the neighbour words move and the per-row worst distances (the only part of
- * a remote row's distances the join needs) travel as 4 bytes per row through the two calls below */
-int32_t nnd_export_thresholds(nnd_handle_t h, int64_t lo, int64_t hi, float *th_dst);
-int32_t nnd_import_thresholds(nnd_handle_t h, int64_t lo, int64_t hi, const float *th_src);
-/* merge another handle's rows [lo,hi) into ours (combining per-rank forests' leaf seeding at the owner) */
-int32_t nnd_merge_graph_rows(nnd_handle_t h, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
-/* one descent iteration in three steps, with the proposal exchange between join and merge */
+/* ---- row-sharded multi-GPU build ----
+ * The reference is single-process; its sharding idea is the owner-computes rule of apply_graph_update_array /
+ * new_build_candidates / init_rp_tree (utils.py:709-731, 259-306; pynndescent_.py:154-185: each thread owns a contiguous
+ * vertex range) and its knob is n_jobs (pynndescent_.py:1141-1143).  Here the same rule crosses GPUs: rank r owns rows
+ * [lo_r, hi_r) of the k-lists; the point set is replicated once (all-gather over xGMI: candidate vectors never travel
+ * again); the forest is split by tree (rank r builds its share of the trees over all points and seeds every row from
+ * them; partial k-list rows go to their owners and are merged there); per NN-descent iteration
+ *   (1) threshold all-gather, 4 bytes per row; (2) reverse-offer all-to-all-v of 12-byte records (the cross-process form
+ *   of the ownership test utils.py:266-273); (3) local sampling + join of the owned vertices; (4) proposal
+ *   all-to-all-v, owner-side merge (utils.py:721-731); the update counts of all ranks (stop rule, pynndescent_.py:317)
+ *   ride on the record-count exchange.
+ * The whole per-rank build runs inside the library (csrc/shard.hip) on one HIP stream; the exchanges are issued from
+ * the C side on that stream -- ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd (RCCL) -- so kernels and collectives
+ * need no host synchronisation between them; the host waits twice per iteration, for the record counts.
+ *
+ * Communicators.  One per rank.  RCCL: rank 0 calls nnd_comm_unique_id, the launcher hands the 128 bytes to the other
+ * ranks (any side channel), every rank calls nnd_comm_create_rccl.  LOCAL: world ranks as threads of ONE process that
+ * may share a GPU (tests, nnd_build_multi with repeated device ids).  HOST: device buffers staged through pinned host
+ * memory and exchanged by a caller-supplied callback (debugging transport; gloo in the tests). */
+typedef struct nnd_comm_s *nnd_comm_t;
+#define NND_COMM_ID_BYTES 128
+int32_t nnd_comm_unique_id(void *id_out /* NND_COMM_ID_BYTES */);
+int32_t nnd_comm_create_rccl(nnd_comm_t *out, const void *id, int32_t world, int32_t rank, int32_t device);
+int32_t nnd_comm_create_local(nnd_comm_t *out /* [world] */, int32_t world, const int32_t *devices /* [world], NULL: all 0 */);
+/* all-to-all-v on HOST memory: byte segment [send_off[d], + send_bytes[d]) of `send` goes to rank d; what rank s sends
+ * arrives at recv + recv_off[s] (recv_bytes[s] bytes, known to the receiver).  Returns 0 on success. */
+typedef int32_t (*nnd_host_exchange_fn)(void *user, const void *send, const int64_t *send_off, const int64_t *send_bytes,
+                                        void *recv, const int64_t *recv_off, const int64_t *recv_bytes);
+int32_t nnd_comm_create_host(nnd_comm_t *out, int32_t world, int32_t rank, int32_t device, nnd_host_exchange_fn fn, void *user);
+int32_t nnd_comm_destroy(nnd_comm_t c);
+int32_t nnd_comm_abort(nnd_comm_t c); /* LOCAL: a rank failed -- release the ranks waiting for it */
+/* LOCAL only: compute sections of the ranks run one at a time (per-rank timings on a shared GPU; tools/rank_critical_path.py) */
+int32_t nnd_comm_local_set_serial(nnd_comm_t c, int32_t on);
+const char *nnd_comm_last_error(nnd_comm_t c /* NULL: the error of a failed create */);
+
+/* One rank of a sharded build.  params: n = the GLOBAL point count, n_trees = the GLOBAL tree count, device = this
+ * rank's GPU, everything else as for nnd_create (the reference's derived defaults are taken on the global n by the
+ * host).  shard_sizes[world]: rows per rank, in rank order (rank r owns the rows after those of ranks < r). */
+typedef struct nnd_shard_s *nnd_shard_t;
+typedef struct nnd_shard_info {
+    int64_t n_total, own_lo, own_hi;
+    int32_t world, rank, local_trees, iters;
+    int64_t c[64];                /* GLOBAL update count per iteration (the stop rule's c, pynndescent_.py:317) */
+    int64_t offer_records[64];    /* reverse-offer records this rank sent to other ranks, per iteration */
+    int64_t proposal_records[64]; /* proposal records this rank sent to other ranks, per iteration */
+    int64_t deferred[64];         /* proposal records that did not fit their destination's region and were kept for the next iteration */
+    int64_t dropped_offers;       /* must stay 0: the offer regions are sized for every owned edge */
+    int64_t bytes_sent;           /* payload bytes this rank sent to other ranks during the build */
+    float ms_total;               /* this rank's wall time of the last build, exchanges included */
+    float ms_allgather, ms_klist_exchange; /* stream time of the two bulk exchanges */
+    int32_t n_sections;           /* compute sections of the last build (timeline below) */
+    float section_ms[256];        /* LOCAL serial mode: GPU time of each compute section of this rank, in program order */
+    int64_t section_bytes[256];   /* payload bytes this rank sent in the exchange that FOLLOWS the section */
+} nnd_shard_info;
+int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, nnd_comm_t comm, const int64_t *shard_sizes);
+/* x_local_dev: this rank's rows, float32 (n_local, dim) on its GPU, complete when the call is made (or produced on
+ * x_stream, which the build then waits for).  Outputs: device buffers (n_local, k): GLOBAL neighbour ids, alt-space
+ * distances, rows ascending.  Blocks until this rank's rows are final. */
+int32_t nnd_shard_build(nnd_shard_t s, const float *x_local_dev, void *x_stream, int32_t *out_idx_dev, float *out_dist_dev);
+int32_t nnd_shard_get_info(nnd_shard_t s, nnd_shard_info *out);
+int32_t nnd_shard_get_stats(nnd_shard_t s, nnd_stats *out); /* this rank's kernels */
+int32_t nnd_shard_destroy(nnd_shard_t s);
+const char *nnd_shard_last_error(nnd_shard_t s /* NULL: the error of a failed create */);
+
+/* nnd_build over n_devices GPUs of this node: host buffers in, host buffers out, one host thread per GPU inside the
+ * library (the reference's analogue is n_jobs, pynndescent_.py:1141-1143).  devices: HIP ordinals, NULL = 0..n_devices-1.
+ * Distinct ordinals talk over RCCL; a list that repeats an ordinal (several ranks on one GPU: tests on a one-GPU box)
+ * uses the LOCAL transport.  Results depend on n_devices as the reference's depend on its thread count.  stats: rank 0's. */
+int32_t nnd_build_multi(const nnd_params *params, const float *x, int32_t n_devices, const int32_t *devices, int32_t *out_idx,
+                        float *out_dist, nnd_stats *stats, nnd_shard_info *info_rank0 /* nullable */, char *err, int32_t errlen);
+
+/* Stream the handle runs on: the caller's HIP stream (e.g. the one that produces the point set) instead of the handle's
+ * own, so the device-pointer entry points need no synchronisation with it.  NULL: the handle's own stream again. */
+int32_t nnd_set_stream(nnd_handle_t h, void *hip_stream);
+/* one descent iteration in two steps (the state between them is what nnd_reset_graph has to clear: tests) */
 int32_t nnd_descent_sample(nnd_handle_t h);
 int32_t nnd_descent_join(nnd_handle_t h);
-int32_t nnd_proposal_counts(nnd_handle_t h, int32_t *cnt /* (n) pending records per NON-owned vertex */);
-int32_t nnd_export_proposals(nnd_handle_t h, const int64_t *offsets /* exclusive scan of cnt */, uint64_t *keys_out,
-                             int32_t *targets_out);
-int32_t nnd_import_proposals(nnd_handle_t h, const uint64_t *keys, const int32_t *targets, int64_t count);
-int32_t nnd_descent_merge(nnd_handle_t h, int64_t *c_local);
-
-/* Sharded build, exchange X2 of SURVEY.md section 8e: every rank scans only its OWN rows; a reverse offer or a proposal
- * whose target is owned by another rank becomes a record in that owner's region and is applied there (the cross-process
- * form of the ownership tests utils.py:266-273 and utils.py:721-731).  These entry points are stream-ordered (no host
- * wait): with nnd_set_stream the handle runs on the caller's stream, so RCCL collectives issued by the caller between
- * them need no synchronisation. */
-int32_t nnd_set_stream(nnd_handle_t h, void *hip_stream /* NULL: the handle's own stream again */);
-int32_t nnd_set_shard_bounds(nnd_handle_t h, const int64_t *bounds_host /* n_ranks + 1 */, int32_t n_ranks, int32_t rank);
-/* new_build_candidates (utils.py:221-320) in two halves around the offer all-to-all-v.  Regions: records of destination
- * d at [d * cap, d * cap + counts[d]); record = (target | class << 31, priority << 32 | source). */
-int32_t nnd_sample_begin(nnd_handle_t h, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, int64_t *counts_dev);
-int32_t nnd_sample_finish(nnd_handle_t h, const int32_t *targets_dev, const uint64_t *keys_dev, int64_t count);
-/* apply_graph_update_array's ownership split (utils.py:721-731): proposals for vertices owned elsewhere, same region
- * layout, record = (target, dist_bits << 32 | source); target -1 = hole, skipped by the importer */
-int32_t nnd_proposal_export(nnd_handle_t h, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, int64_t *counts_dev);
-int32_t nnd_import_proposals_async(nnd_handle_t h, const uint64_t *keys_dev, const int32_t *targets_dev, int64_t count);
-int32_t nnd_export_thresholds_async(nnd_handle_t h, int64_t lo, int64_t hi, float *th_dst_dev);
-int32_t nnd_import_thresholds_async(nnd_handle_t h, int64_t lo, int64_t hi, const float *th_src_dev);
 
 /* ---- search-graph pruning pass (BASELINE config 5; reference NNDescent._init_search_graph, pynndescent_.py:1451-1611) ----
  * Host arrays in / out: like the reference, the conversions between these kernels (COO->CSR, transpose, maximum,

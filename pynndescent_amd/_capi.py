@@ -80,6 +80,41 @@ class NNDStats(C.Structure):
         return out
 
 
+class NNDShardInfo(C.Structure):
+    _fields_ = [
+        ("n_total", C.c_int64), ("own_lo", C.c_int64), ("own_hi", C.c_int64),
+        ("world", C.c_int32), ("rank", C.c_int32), ("local_trees", C.c_int32), ("iters", C.c_int32),
+        ("c", C.c_int64 * 64),
+        ("offer_records", C.c_int64 * 64),
+        ("proposal_records", C.c_int64 * 64),
+        ("deferred", C.c_int64 * 64),
+        ("dropped_offers", C.c_int64),
+        ("bytes_sent", C.c_int64),
+        ("ms_total", C.c_float), ("ms_allgather", C.c_float), ("ms_klist_exchange", C.c_float),
+        ("n_sections", C.c_int32),
+        ("section_ms", C.c_float * 256),
+        ("section_bytes", C.c_int64 * 256),
+    ]
+
+    def as_dict(self):
+        it = min(int(self.iters), 64)
+        ns = int(self.n_sections)
+        return {"n_total": int(self.n_total), "range": (int(self.own_lo), int(self.own_hi)), "world": int(self.world),
+                "rank": int(self.rank), "local_trees": int(self.local_trees), "iters": int(self.iters),
+                "c": [int(v) for v in self.c[:it]], "offer_records": [int(v) for v in self.offer_records[:it]],
+                "proposal_records": [int(v) for v in self.proposal_records[:it]],
+                "exchanged_records": [int(a) + int(b) for a, b in zip(self.offer_records[:it], self.proposal_records[:it])],
+                "deferred": [int(v) for v in self.deferred[:it]], "dropped_offers": int(self.dropped_offers),
+                "bytes_sent": int(self.bytes_sent), "ms_total": float(self.ms_total),
+                "ms_allgather": float(self.ms_allgather), "ms_klist_exchange": float(self.ms_klist_exchange),
+                "section_ms": [float(v) for v in self.section_ms[:ns]],
+                "section_bytes": [int(v) for v in self.section_bytes[:ns]]}
+
+
+HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
+                               C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+
+
 class NNDPruneOpts(C.Structure):
     _fields_ = [
         ("prune_probability", C.c_float),
@@ -124,27 +159,25 @@ _SIGNATURES = [
     ("nnd_get_candidates", C.c_int32, [_H, C.c_void_p, C.c_void_p]),
     ("nnd_sample_candidates", C.c_int32, [_H]),
     ("nnd_pairwise_gram", C.c_int32, [_H, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
-    ("nnd_set_owned_range", C.c_int32, [_H, C.c_int64, C.c_int64]),
-    ("nnd_row_stride", C.c_int32, [_H]),
-    ("nnd_export_graph_rows", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
-    ("nnd_import_graph_rows", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
-    ("nnd_merge_graph_rows", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
-    ("nnd_export_thresholds", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p]),
-    ("nnd_import_thresholds", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p]),
     ("nnd_descent_sample", C.c_int32, [_H]),
     ("nnd_descent_join", C.c_int32, [_H]),
-    ("nnd_proposal_counts", C.c_int32, [_H, C.c_void_p]),
-    ("nnd_export_proposals", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
-    ("nnd_import_proposals", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
-    ("nnd_descent_merge", C.c_int32, [_H, C.POINTER(C.c_int64)]),
     ("nnd_set_stream", C.c_int32, [_H, C.c_void_p]),
-    ("nnd_set_shard_bounds", C.c_int32, [_H, C.c_void_p, C.c_int32, C.c_int32]),
-    ("nnd_sample_begin", C.c_int32, [_H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    ("nnd_sample_finish", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
-    ("nnd_proposal_export", C.c_int32, [_H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    ("nnd_import_proposals_async", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
-    ("nnd_export_thresholds_async", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p]),
-    ("nnd_import_thresholds_async", C.c_int32, [_H, C.c_int64, C.c_int64, C.c_void_p]),
+    ("nnd_comm_unique_id", C.c_int32, [C.c_void_p]),
+    ("nnd_comm_create_rccl", C.c_int32, [C.POINTER(_H), C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    ("nnd_comm_create_local", C.c_int32, [C.POINTER(_H), C.c_int32, C.c_void_p]),
+    ("nnd_comm_create_host", C.c_int32, [C.POINTER(_H), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("nnd_comm_destroy", C.c_int32, [_H]),
+    ("nnd_comm_abort", C.c_int32, [_H]),
+    ("nnd_comm_local_set_serial", C.c_int32, [_H, C.c_int32]),
+    ("nnd_comm_last_error", C.c_char_p, [_H]),
+    ("nnd_shard_create", C.c_int32, [C.POINTER(_H), C.POINTER(NNDParams), _H, C.c_void_p]),
+    ("nnd_shard_build", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nnd_shard_get_info", C.c_int32, [_H, C.POINTER(NNDShardInfo)]),
+    ("nnd_shard_get_stats", C.c_int32, [_H, C.POINTER(NNDStats)]),
+    ("nnd_shard_destroy", C.c_int32, [_H]),
+    ("nnd_shard_last_error", C.c_char_p, [_H]),
+    ("nnd_build_multi", C.c_int32, [C.POINTER(NNDParams), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.POINTER(NNDStats), C.POINTER(NNDShardInfo), C.c_char_p, C.c_int32]),
     ("nnd_diversify_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.POINTER(NNDPruneOpts), C.c_void_p]),
     ("nnd_diversify_csr_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(NNDPruneOpts),
                                            C.c_void_p]),
@@ -291,9 +324,8 @@ class Builder:
         self._check(self.lib.nnd_sample_candidates(self._h))
 
     def finalize(self):
-        lo, hi = getattr(self, "own", (0, self.n))
-        idx = np.empty((hi - lo, self.k), np.int32)
-        dist = np.empty((hi - lo, self.k), np.float32)
+        idx = np.empty((self.n, self.k), np.int32)
+        dist = np.empty((self.n, self.k), np.float32)
         self._check(self.lib.nnd_finalize_host(self._h, _ptr(idx), _ptr(dist)))
         return idx, dist
 
@@ -325,58 +357,9 @@ class Builder:
         self._check(self.lib.nnd_get_candidates(self._h, _ptr(new), _ptr(old)))
         return new, old
 
-    # -- row-sharded build: device-side halves of the exchange steps (pointers are integer device addresses)
-    def set_owned_range(self, lo, hi):
-        self._check(self.lib.nnd_set_owned_range(self._h, int(lo), int(hi)))
-        self.own = (int(lo), int(hi))
-
     def set_stream(self, stream_ptr):
+        """Run the handle on the caller's HIP stream (integer address; 0 / None: the handle's own stream again)."""
         self._check(self.lib.nnd_set_stream(self._h, C.c_void_p(int(stream_ptr)) if stream_ptr else None))
-
-    def set_shard_bounds(self, bounds, rank):
-        b = np.ascontiguousarray(bounds, np.int64)
-        self._check(self.lib.nnd_set_shard_bounds(self._h, _ptr(b), b.shape[0] - 1, int(rank)))
-        self.own = (int(b[rank]), int(b[rank + 1]))
-
-    def sample_begin(self, cap, targets_ptr, keys_ptr, counts_ptr):
-        self._check(self.lib.nnd_sample_begin(self._h, int(cap), C.c_void_p(int(targets_ptr)), C.c_void_p(int(keys_ptr)),
-                                              C.c_void_p(int(counts_ptr))))
-
-    def sample_finish(self, targets_ptr, keys_ptr, count):
-        self._check(self.lib.nnd_sample_finish(self._h, C.c_void_p(int(targets_ptr)), C.c_void_p(int(keys_ptr)), int(count)))
-
-    def proposal_export(self, cap, targets_ptr, keys_ptr, counts_ptr):
-        self._check(self.lib.nnd_proposal_export(self._h, int(cap), C.c_void_p(int(targets_ptr)), C.c_void_p(int(keys_ptr)),
-                                                 C.c_void_p(int(counts_ptr))))
-
-    def import_proposals_async(self, keys_ptr, targets_ptr, count):
-        self._check(self.lib.nnd_import_proposals_async(self._h, C.c_void_p(int(keys_ptr)), C.c_void_p(int(targets_ptr)), int(count)))
-
-    def export_thresholds_async(self, lo, hi, th_ptr):
-        self._check(self.lib.nnd_export_thresholds_async(self._h, int(lo), int(hi), C.c_void_p(int(th_ptr))))
-
-    def import_thresholds_async(self, lo, hi, th_ptr):
-        self._check(self.lib.nnd_import_thresholds_async(self._h, int(lo), int(hi), C.c_void_p(int(th_ptr))))
-
-    def row_stride(self):
-        return int(self.lib.nnd_row_stride(self._h))
-
-    def export_graph_rows(self, lo, hi, e_ptr, d_ptr=None):
-        self._check(self.lib.nnd_export_graph_rows(self._h, int(lo), int(hi), C.c_void_p(int(e_ptr)),
-                                                   None if d_ptr is None else C.c_void_p(int(d_ptr))))
-
-    def import_graph_rows(self, lo, hi, e_ptr, d_ptr=None):
-        self._check(self.lib.nnd_import_graph_rows(self._h, int(lo), int(hi), C.c_void_p(int(e_ptr)),
-                                                   None if d_ptr is None else C.c_void_p(int(d_ptr))))
-
-    def export_thresholds(self, lo, hi, th_ptr):
-        self._check(self.lib.nnd_export_thresholds(self._h, int(lo), int(hi), C.c_void_p(int(th_ptr))))
-
-    def import_thresholds(self, lo, hi, th_ptr):
-        self._check(self.lib.nnd_import_thresholds(self._h, int(lo), int(hi), C.c_void_p(int(th_ptr))))
-
-    def merge_graph_rows(self, lo, hi, e_ptr, d_ptr):
-        self._check(self.lib.nnd_merge_graph_rows(self._h, int(lo), int(hi), C.c_void_p(int(e_ptr)), C.c_void_p(int(d_ptr))))
 
     def descent_sample(self):
         self._check(self.lib.nnd_descent_sample(self._h))
@@ -384,22 +367,6 @@ class Builder:
     def descent_join(self):
         self._check(self.lib.nnd_descent_join(self._h))
 
-    def proposal_counts(self, cnt_ptr):
-        self._check(self.lib.nnd_proposal_counts(self._h, C.c_void_p(int(cnt_ptr))))
-
-    def export_proposals(self, offsets_ptr, keys_ptr, targets_ptr):
-        self._check(self.lib.nnd_export_proposals(self._h, C.c_void_p(int(offsets_ptr)), C.c_void_p(int(keys_ptr)),
-                                                  C.c_void_p(int(targets_ptr))))
-
-    def import_proposals(self, keys_ptr, targets_ptr, count):
-        self._check(self.lib.nnd_import_proposals(self._h, C.c_void_p(int(keys_ptr)), C.c_void_p(int(targets_ptr)), int(count)))
-
-    def descent_merge(self):
-        c = C.c_int64()
-        self._check(self.lib.nnd_descent_merge(self._h, C.byref(c)))
-        return c.value
-
-    # -- search-graph pruning pass (numpy arrays in / out, like the reference's numba kernels)
     @staticmethod
     def _prune_opts(prune_probability=1.0, degree_aware=False, max_degree=1, aggressiveness=1.0, alpha=1.0, seed=0):
         o = NNDPruneOpts()

@@ -66,8 +66,9 @@ static void free_all(nnd_ctx *ctx) {
         if (p) (void)hipFree(p);
     };
     if (ctx->x_owned) F((void *)ctx->x_orig);
-    F(ctx->xp); F(ctx->nrm); F(ctx->nr2); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->cand); F(ctx->rbuf); F(ctx->pbuf);
-    F(ctx->pdirty); F(ctx->active);
+    for (void *&a : ctx->slim_alloc) { F(a); a = nullptr; }  // cand / rbuf / active (the working pointers may be biased)
+    F(ctx->xp); F(ctx->nrm); F(ctx->nr2); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->pbuf);
+    F(ctx->pdirty);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
     F(ctx->xs); F(ctx->xsh); F(ctx->nr2s); F(ctx->node_hf); F(ctx->node_hh); F(ctx->node_child); F(ctx->node_pack); F(ctx->s_leaf_depth);
@@ -86,7 +87,9 @@ static void free_all(nnd_ctx *ctx) {
     if (ctx->stream && ctx->stream_owned) (void)hipStreamDestroy(ctx->stream);
 }
 
-extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
+extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) { return nnd_create_impl(out, p, nullptr, 0, 0); }
+
+int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bounds_host, int n_ranks, int rank) {
     if (!out || !p) { gerr("nnd_create: null argument"); return 1; }
     *out = nullptr;
     if (p->n < 1 || p->dim < 1) { gerr("nnd_create: need n >= 1 and dim >= 1 (got n=%lld dim=%d)", (long long)p->n, p->dim); return 1; }
@@ -112,6 +115,19 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
     ctx->n = p->n;
     ctx->own_lo = 0;
     ctx->own_hi = p->n;
+    if (bounds_host) {  // one shard of a row-sharded build: the geometry is known before anything is allocated
+        if (n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks || bounds_host[0] != 0 || bounds_host[n_ranks] != p->n) {
+            gerr("nnd_create: bad shard bounds (need 1 <= n_ranks <= 64, bounds from 0 to n)");
+            delete ctx;
+            return 1;
+        }
+        for (int r = 0; r < n_ranks; r++)
+            if (bounds_host[r] > bounds_host[r + 1]) { gerr("nnd_create: shard bounds must not decrease"); delete ctx; return 1; }
+        ctx->n_ranks = n_ranks;
+        ctx->own_lo = bounds_host[rank];
+        ctx->own_hi = bounds_host[rank + 1];
+        ctx->slim = n_ranks > 1;
+    }
     ctx->d = p->dim;
     ctx->dp = (p->dim + 31) & ~31;
     ctx->k = p->n_neighbors;
@@ -154,12 +170,29 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) {
             if ((rc = dalloc(ctx, &ctx->knn_e, n * ctx->ks))) break;
             if ((rc = dalloc(ctx, &ctx->knn_d, n * ctx->ks))) break;
             if ((rc = dalloc(ctx, &ctx->th, n))) break;
-            if ((rc = dalloc(ctx, &ctx->cand, n * 2 * ctx->mcp))) break;
-            if ((rc = dalloc(ctx, &ctx->rbuf, n * 2 * ctx->rcap))) break;
+            const size_t rows = ctx->slim ? (size_t)(ctx->own_hi - ctx->own_lo) : n;  // per-OWNED-row tables
+            int32_t *a_cand = nullptr;
+            uint64_t *a_rbuf = nullptr;
+            uint8_t *a_active = nullptr;
+            if ((rc = dalloc(ctx, &a_cand, rows * 2 * ctx->mcp))) break;
+            ctx->slim_alloc[0] = a_cand;
+            if ((rc = dalloc(ctx, &a_rbuf, rows * 2 * ctx->rcap))) break;
+            ctx->slim_alloc[1] = a_rbuf;
+            if ((rc = dalloc(ctx, &a_active, rows))) break;
+            ctx->slim_alloc[2] = a_active;
+            // the working pointers are biased by -own_lo rows (0 on a plain handle): kernels index by global vertex id
+            ctx->cand = a_cand - (size_t)ctx->own_lo * (ctx->slim ? 1 : 0) * 2 * ctx->mcp;
+            ctx->rbuf = a_rbuf - (size_t)ctx->own_lo * (ctx->slim ? 1 : 0) * 2 * ctx->rcap;
+            ctx->active = a_active - (size_t)ctx->own_lo * (ctx->slim ? 1 : 0);
             if ((rc = dalloc(ctx, &ctx->pbuf, n * ctx->pcap))) break;
             if ((rc = dalloc(ctx, &ctx->pdirty, n))) break;
-            if ((rc = dalloc(ctx, &ctx->active, n))) break;
             if (hipMemset(ctx->pdirty, 0, n) != hipSuccess) { ctx->set_error("hipMemset failed"); rc = 1; break; }
+            if (ctx->n_ranks > 0) {
+                if (hipMalloc((void **)&ctx->shard_bounds, sizeof(int64_t) * 65) != hipSuccess || hipMalloc((void **)&ctx->shard_cursors, sizeof(long long) * 66) != hipSuccess ||
+                    hipMemcpy(ctx->shard_bounds, bounds_host, sizeof(int64_t) * (size_t)(n_ranks + 1), hipMemcpyHostToDevice) != hipSuccess) {
+                    ctx->set_error("allocation of the shard tables failed"); rc = 1; break;
+                }
+            }
         }
         if ((rc = dalloc(ctx, &ctx->counters, (size_t)CNT_COUNT * NND_CNT_STRIPES))) break;
         if ((rc = dalloc(ctx, &ctx->counters_sum, (size_t)CNT_COUNT))) break;
@@ -252,36 +285,6 @@ static int need_data(nnd_ctx *ctx) {
 static int need_graph(nnd_ctx *ctx) {
     if (ctx->p.flags & NND_FLAG_NO_GRAPH) { ctx->set_error("this handle was created with NND_FLAG_NO_GRAPH: it has no k-lists / candidate tables (pruning pass and hub tree only)"); return 1; }
     return 0;
-}
-
-// Stage timers are DEFERRED: begin/end events are recorded on the stream and read back in one go (t_flush) where the
-// host waits anyway, so timing a stage never drains the GPU pipeline between stages.
-static int t_begin(nnd_ctx *ctx) {
-    const int idx = ctx->tev_used;
-    while ((int)ctx->tev.size() < idx + 2) {
-        hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess) return -1;  // callers skip the timer
-        ctx->tev.push_back(e);
-    }
-    (void)hipEventRecord(ctx->tev[idx], ctx->stream);
-    ctx->tev_used += 2;
-    return idx;
-}
-static void t_end(nnd_ctx *ctx, int idx, float *dst, bool add) {
-    if (idx < 0) return;
-    (void)hipEventRecord(ctx->tev[idx + 1], ctx->stream);
-    ctx->tlog.push_back({idx, dst, add});
-}
-static void t_flush(nnd_ctx *ctx) {
-    if (ctx->tlog.empty()) { ctx->tev_used = 0; return; }
-    (void)nnd_sync_spin(ctx);
-    for (const nnd_tlog &t : ctx->tlog) {
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ctx->tev[t.ev], ctx->tev[t.ev + 1]);
-        if (t.add) *t.dst += ms; else *t.dst = ms;
-    }
-    ctx->tlog.clear();
-    ctx->tev_used = 0;
 }
 
 static int after_data(nnd_ctx *ctx) {
@@ -667,18 +670,8 @@ extern "C" int32_t nnd_pairwise_gram(nnd_handle_t ctx, const int32_t *rows_a, in
     return 0;
 }
 
-// ---- row-sharded multi-GPU build; host orchestration: pynndescent_amd/sharded.py ----
-extern "C" int32_t nnd_set_owned_range(nnd_handle_t ctx, int64_t lo, int64_t hi) {
-    ENTER(ctx);
-    if (lo < 0 || hi > ctx->n || lo > hi) { ctx->set_error("nnd_set_owned_range: bad range [%lld, %lld)", (long long)lo, (long long)hi); return 1; }
-    ctx->own_lo = lo;
-    ctx->own_hi = hi;
-    return 0;
-}
-extern "C" int32_t nnd_row_stride(nnd_handle_t ctx) { return ctx ? ctx->ks : 0; }
-
 // Run on the caller's HIP stream (e.g. torch's current stream) instead of the handle's own: the library's kernels and the
-// caller's collectives are then ordered by the stream itself, no host synchronisation between them.  NULL: back to own.
+// caller's work are then ordered by the stream itself, no host synchronisation between them.  NULL: back to own.
 extern "C" int32_t nnd_set_stream(nnd_handle_t ctx, void *hip_stream) {
     ENTER(ctx);
     API_HIP(hipStreamSynchronize(ctx->stream));
@@ -693,116 +686,6 @@ extern "C" int32_t nnd_set_stream(nnd_handle_t ctx, void *hip_stream) {
     return 0;
 }
 
-// bounds_host[r] = first row of rank r, bounds_host[n_ranks] = n.  Sets the owned range to this handle's slice.
-extern "C" int32_t nnd_set_shard_bounds(nnd_handle_t ctx, const int64_t *bounds_host, int32_t n_ranks, int32_t rank) {
-    ENTER(ctx);
-    if (!bounds_host || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks) { ctx->set_error("nnd_set_shard_bounds: need 1 <= n_ranks <= 64 and 0 <= rank < n_ranks"); return 1; }
-    if (bounds_host[0] != 0 || bounds_host[n_ranks] != ctx->n) { ctx->set_error("nnd_set_shard_bounds: bounds must run from 0 to n"); return 1; }
-    for (int r = 0; r < n_ranks; r++)
-        if (bounds_host[r] > bounds_host[r + 1]) { ctx->set_error("nnd_set_shard_bounds: bounds must not decrease"); return 1; }
-    if (!ctx->shard_bounds) API_HIP(hipMalloc((void **)&ctx->shard_bounds, sizeof(int64_t) * 65));
-    if (!ctx->shard_cursors) API_HIP(hipMalloc((void **)&ctx->shard_cursors, sizeof(long long) * 66));
-    API_HIP(hipMemcpyAsync(ctx->shard_bounds, bounds_host, sizeof(int64_t) * (size_t)(n_ranks + 1), hipMemcpyHostToDevice, ctx->stream));
-    API_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->n_ranks = n_ranks;
-    ctx->own_lo = bounds_host[rank];
-    ctx->own_hi = bounds_host[rank + 1];
-    return 0;
-}
-
-// One sampling pass of a sharded build in two halves around the offer exchange (stream-ordered, no host sync):
-//   begin : local new edges + records for targets owned elsewhere into G regions of `cap` records; counts_dev[G]
-//   finish: records received from the other ranks, local old edges, selection (new_build_candidates, utils.py:221-320)
-extern "C" int32_t nnd_sample_begin(nnd_handle_t ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, int64_t *counts_dev) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    static float sink;
-    const int t_ = t_begin(ctx);
-    if (nnd_launch_sample_begin(ctx, cap, targets_dev, keys_dev, (long long *)counts_dev)) return 1;
-    t_end(ctx, t_, ctx->iter < 64 ? &ctx->stats.ms_sample[ctx->iter] : &sink, false);
-    return 0;
-}
-extern "C" int32_t nnd_sample_finish(nnd_handle_t ctx, const int32_t *targets_dev, const uint64_t *keys_dev, int64_t count) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    static float sink;
-    const int t_ = t_begin(ctx);
-    if (nnd_launch_sample_finish(ctx, targets_dev, keys_dev, count)) return 1;
-    t_end(ctx, t_, ctx->iter < 64 ? &ctx->stats.ms_sample[ctx->iter] : &sink, true);
-    return 0;
-}
-// proposals for vertices owned elsewhere -> G regions of `cap` (key, target) records; counts_dev[G] (may exceed cap:
-// the vertices behind the limit keep their proposals for the next iteration); stream-ordered, no host sync
-extern "C" int32_t nnd_proposal_export(nnd_handle_t ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, int64_t *counts_dev) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    return nnd_launch_proposal_export_regions(ctx, cap, targets_dev, keys_dev, (long long *)counts_dev);
-}
-// stream-ordered variants of the exchange steps (no host wait): thresholds in / out, received proposals
-extern "C" int32_t nnd_export_thresholds_async(nnd_handle_t ctx, int64_t lo, int64_t hi, float *th_dst_dev) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    API_HIP(hipMemcpyAsync(th_dst_dev, ctx->th + lo, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
-    return 0;
-}
-extern "C" int32_t nnd_import_thresholds_async(nnd_handle_t ctx, int64_t lo, int64_t hi, const float *th_src_dev) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    API_HIP(hipMemcpyAsync(ctx->th + lo, th_src_dev, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
-    return 0;
-}
-extern "C" int32_t nnd_import_proposals_async(nnd_handle_t ctx, const uint64_t *keys_dev, const int32_t *targets_dev, int64_t count) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    return nnd_launch_import_proposals(ctx, keys_dev, targets_dev, count);
-}
-
-extern "C" int32_t nnd_export_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, uint32_t *e_dst_dev, float *d_dst_dev) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    size_t cnt = (size_t)(hi - lo) * ctx->ks;
-    API_HIP(hipMemcpyAsync(e_dst_dev, ctx->knn_e + lo * ctx->ks, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-    if (d_dst_dev)
-        API_HIP(hipMemcpyAsync(d_dst_dev, ctx->knn_d + lo * ctx->ks, sizeof(float) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-    API_HIP(nnd_sync_spin(ctx));
-    return 0;
-}
-extern "C" int32_t nnd_import_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, const uint32_t *e_src_dev, const float *d_src_dev) {
-    if (ctx) ctx->all_new = false;  // imported rows may carry cleared flags
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    size_t cnt = (size_t)(hi - lo) * ctx->ks;
-    API_HIP(hipMemcpyAsync(ctx->knn_e + lo * ctx->ks, e_src_dev, sizeof(uint32_t) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-    if (d_src_dev) {  // full rows; d_src_dev == NULL: neighbour words only (thresholds come through nnd_import_thresholds)
-        API_HIP(hipMemcpyAsync(ctx->knn_d + lo * ctx->ks, d_src_dev, sizeof(float) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-        if (nnd_launch_refresh_th(ctx, lo, hi)) return 1;
-    }
-    API_HIP(nnd_sync_spin(ctx));
-    return 0;
-}
-// per-row worst distances (thresholds): 4 bytes per row instead of the 4*ks-byte distance rows
-extern "C" int32_t nnd_export_thresholds(nnd_handle_t ctx, int64_t lo, int64_t hi, float *th_dst_dev) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    API_HIP(hipMemcpyAsync(th_dst_dev, ctx->th + lo, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
-    API_HIP(nnd_sync_spin(ctx));
-    return 0;
-}
-extern "C" int32_t nnd_import_thresholds(nnd_handle_t ctx, int64_t lo, int64_t hi, const float *th_src_dev) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    API_HIP(hipMemcpyAsync(ctx->th + lo, th_src_dev, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, ctx->stream));
-    API_HIP(nnd_sync_spin(ctx));
-    return 0;
-}
-extern "C" int32_t nnd_merge_graph_rows(nnd_handle_t ctx, int64_t lo, int64_t hi, const uint32_t *e_src_dev, const float *d_src_dev) {
-    if (ctx) ctx->all_new = false;  // imported rows may carry cleared flags
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    if (nnd_launch_merge_graph_rows(ctx, lo, hi, e_src_dev, d_src_dev)) return 1;
-    API_HIP(nnd_sync_spin(ctx));
-    return 0;
-}
 extern "C" int32_t nnd_descent_sample(nnd_handle_t ctx) {
     ENTER(ctx);
     if (need_graph(ctx)) return 1;
@@ -820,50 +703,6 @@ extern "C" int32_t nnd_descent_join(nnd_handle_t ctx) {
     const int t_ = t_begin(ctx);
     if (nnd_launch_join(ctx, ctx->own_lo, ctx->own_hi)) return 1;
     t_end(ctx, t_, ctx->iter < 64 ? &ctx->stats.ms_join[ctx->iter] : &sink, false);
-    return 0;
-}
-extern "C" int32_t nnd_proposal_counts(nnd_handle_t ctx, int32_t *cnt_dev) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    if (nnd_launch_proposal_counts(ctx, cnt_dev)) return 1;
-    API_HIP(nnd_sync_spin(ctx));
-    return 0;
-}
-extern "C" int32_t nnd_export_proposals(nnd_handle_t ctx, const int64_t *offsets_dev, uint64_t *keys_out_dev, int32_t *targets_out_dev) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    if (nnd_launch_export_proposals(ctx, offsets_dev, keys_out_dev, targets_out_dev)) return 1;
-    API_HIP(nnd_sync_spin(ctx));
-    return 0;
-}
-extern "C" int32_t nnd_import_proposals(nnd_handle_t ctx, const uint64_t *keys_dev, const int32_t *targets_dev, int64_t count) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    if (nnd_launch_import_proposals(ctx, keys_dev, targets_dev, count)) return 1;
-    API_HIP(nnd_sync_spin(ctx));
-    return 0;
-}
-extern "C" int32_t nnd_descent_merge(nnd_handle_t ctx, int64_t *c_local) {
-    ENTER(ctx);
-    if (need_graph(ctx)) return 1;
-    const int it = ctx->iter;
-    static float sink;
-    const int t_ = t_begin(ctx);
-    if (nnd_launch_merge(ctx)) return 1;
-    t_end(ctx, t_, it < 64 ? &ctx->stats.ms_merge[it] : &sink, false);
-    if (nnd_read_counters(ctx)) return 1;
-    t_flush(ctx);
-    if (it < 64) {
-        ctx->stats.join_pairs[it] = ctx->h_counters[CNT_PAIRS];
-        ctx->stats.join_rows[it] = ctx->h_counters[CNT_ROWS];
-        ctx->stats.join_active[it] = ctx->h_counters[CNT_ACTIVE];
-        ctx->stats.proposals[it] = ctx->h_counters[CNT_PROPOSALS];
-        ctx->stats.updates[it] = ctx->h_counters[CNT_ACCEPT];
-        ctx->stats.join_mfma[it] = ctx->h_counters[CNT_MFMA];
-    }
-    if (c_local) *c_local = ctx->h_counters[CNT_ACCEPT];
-    ctx->iter++;
-    ctx->stats.n_iters_run = ctx->iter;
     return 0;
 }
 

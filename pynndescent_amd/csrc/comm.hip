@@ -1,0 +1,398 @@
+// comm.hip -- the three transports of comm.h.
+#include "comm.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is opened with dlopen (load_rccl)
+#include <string.h>
+
+#include <string>
+
+static thread_local char g_cerr[512] = {0};
+static void cgerr(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_cerr, sizeof(g_cerr), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *nnd_comm_last_error(nnd_comm_t c) { return c ? c->err : g_cerr; }
+
+// ------------------------------------------------------------------------------------------------ RCCL (dlopen)
+struct rccl_api {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static rccl_api g_rccl;
+static std::mutex g_rccl_mu;
+
+static const rccl_api *load_rccl(std::string &why) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return &g_rccl;
+    // a process that already carries an RCCL (torch ships one) must use THAT copy: one RCCL per process
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *lib = nullptr;
+    for (const char *nm : names) {
+        lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+        if (lib) break;
+    }
+    for (const char *nm : names) {
+        if (lib) break;
+        lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!lib) {
+        why = std::string("librccl.so could not be opened: ") + (dlerror() ? dlerror() : "not found");
+        return nullptr;
+    }
+#define RCCL_SYM(field, name)                                                  \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(lib, name);                   \
+    if (!g_rccl.field) { why = std::string("librccl has no symbol ") + name; return nullptr; }
+    RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+    RCCL_SYM(CommInitRank, "ncclCommInitRank")
+    RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    RCCL_SYM(GroupStart, "ncclGroupStart")
+    RCCL_SYM(GroupEnd, "ncclGroupEnd")
+    RCCL_SYM(Send, "ncclSend")
+    RCCL_SYM(Recv, "ncclRecv")
+    RCCL_SYM(AllGather, "ncclAllGather")
+    RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+    g_rccl.lib = lib;
+    return &g_rccl;
+}
+
+#define C_HIP(expr)                                                                                  \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            c->set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                                \
+        }                                                                                            \
+    } while (0)
+#define C_NCCL(expr)                                                                                         \
+    do {                                                                                                     \
+        ncclResult_t _r = (expr);                                                                            \
+        if (_r != ncclSuccess) {                                                                             \
+            c->set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__);     \
+            return 1;                                                                                        \
+        }                                                                                                    \
+    } while (0)
+
+static int comm_common_init(nnd_comm_s *c) {
+    C_HIP(hipHostMalloc((void **)&c->h_counts, sizeof(long long) * (size_t)(NND_MAX_RANKS + 1) * (NND_MAX_RANKS + 8), hipHostMallocDefault));
+    C_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+    return 0;
+}
+
+extern "C" int32_t nnd_comm_unique_id(void *id_out) {
+    static_assert(NND_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id travels as an opaque byte block");
+    if (!id_out) { cgerr("nnd_comm_unique_id: null argument"); return 1; }
+    std::string why;
+    const rccl_api *api = load_rccl(why);
+    if (!api) { cgerr("nnd_comm_unique_id: %s", why.c_str()); return 1; }
+    ncclUniqueId id;
+    const ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) { cgerr("ncclGetUniqueId failed: %s", api->GetErrorString(r)); return 1; }
+    memcpy(id_out, &id, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+extern "C" int32_t nnd_comm_create_rccl(nnd_comm_t *out, const void *id_bytes, int32_t world, int32_t rank, int32_t device) {
+    if (!out || !id_bytes || world < 1 || world > NND_MAX_RANKS || rank < 0 || rank >= world) { cgerr("nnd_comm_create_rccl: bad arguments"); return 1; }
+    *out = nullptr;
+    std::string why;
+    if (!load_rccl(why)) { cgerr("nnd_comm_create_rccl: %s", why.c_str()); return 1; }
+    if (hipSetDevice(device) != hipSuccess) { cgerr("nnd_comm_create_rccl: hipSetDevice(%d) failed", device); return 1; }
+    nnd_comm_s *c = new nnd_comm_s();
+    c->kind = NND_COMM_RCCL;
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = g_rccl.CommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess || comm_common_init(c) ||
+        hipMalloc((void **)&c->counts_all_dev, sizeof(long long) * (size_t)world * (NND_MAX_RANKS + 8)) != hipSuccess) {
+        cgerr("nnd_comm_create_rccl: %s", r != ncclSuccess ? g_rccl.GetErrorString(r) : (c->err[0] ? c->err : "allocation failed"));
+        if (comm) (void)g_rccl.CommDestroy(comm);
+        delete c;
+        return 1;
+    }
+    c->nccl = comm;
+    *out = c;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ LOCAL
+int nnd_local_group::barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (aborted) return 1;
+    const uint64_t gen = generation;
+    if (++arrived == world) {
+        arrived = 0;
+        generation++;
+        cv.notify_all();
+        return 0;
+    }
+    cv.wait(lk, [&] { return generation != gen || aborted; });
+    return aborted ? 1 : 0;
+}
+void nnd_local_group::abort() {
+    std::lock_guard<std::mutex> lk(mu);
+    aborted = true;
+    cv.notify_all();
+}
+
+extern "C" int32_t nnd_comm_create_local(nnd_comm_t *out, int32_t world, const int32_t *devices) {
+    if (!out || world < 1 || world > NND_MAX_RANKS) { cgerr("nnd_comm_create_local: need 1 <= world <= %d", NND_MAX_RANKS); return 1; }
+    nnd_local_group *g = new nnd_local_group();
+    g->world = world;
+    g->refs = world;
+    for (int r = 0; r < world; r++) out[r] = nullptr;
+    for (int r = 0; r < world; r++) {
+        nnd_comm_s *c = new nnd_comm_s();
+        c->kind = NND_COMM_LOCAL;
+        c->world = world;
+        c->rank = r;
+        c->device = devices ? devices[r] : 0;
+        c->grp = g;
+        out[r] = c;
+        bool bad = hipSetDevice(c->device) != hipSuccess || comm_common_init(c);
+        if (!bad) bad = hipEventCreateWithFlags(&g->posts[r].ready, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&g->posts[r].done, hipEventDisableTiming) != hipSuccess;
+        g->posts[r].device = c->device;
+        if (bad) {
+            cgerr("nnd_comm_create_local: rank %d on device %d: %s", r, c->device, c->err[0] ? c->err : "event creation failed");
+            for (int q = 0; q <= r; q++) { (void)nnd_comm_destroy(out[q]); out[q] = nullptr; }
+            g->refs -= world - (r + 1);
+            if (g->refs <= 0) delete g;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+extern "C" int32_t nnd_comm_local_set_serial(nnd_comm_t c, int32_t on) {
+    if (!c || c->kind != NND_COMM_LOCAL) { cgerr("nnd_comm_local_set_serial: not a local communicator"); return 1; }
+    c->grp->serial = on != 0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ HOST
+extern "C" int32_t nnd_comm_create_host(nnd_comm_t *out, int32_t world, int32_t rank, int32_t device, nnd_host_exchange_fn fn, void *user) {
+    if (!out || !fn || world < 1 || world > NND_MAX_RANKS || rank < 0 || rank >= world) { cgerr("nnd_comm_create_host: bad arguments"); return 1; }
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) { cgerr("nnd_comm_create_host: hipSetDevice(%d) failed", device); return 1; }
+    nnd_comm_s *c = new nnd_comm_s();
+    c->kind = NND_COMM_HOST;
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    c->fn = fn;
+    c->user = user;
+    if (comm_common_init(c)) {
+        cgerr("nnd_comm_create_host: %s", c->err);
+        delete c;
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" int32_t nnd_comm_destroy(nnd_comm_t c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->kind == NND_COMM_RCCL && c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->nccl);
+    if (c->counts_all_dev) (void)hipFree(c->counts_all_dev);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->h_send) (void)hipHostFree(c->h_send);
+    if (c->h_recv) (void)hipHostFree(c->h_recv);
+    if (c->ev) (void)hipEventDestroy(c->ev);
+    if (c->kind == NND_COMM_LOCAL && c->grp) {
+        nnd_local_group *g = c->grp;
+        if (g->posts[c->rank].ready) (void)hipEventDestroy(g->posts[c->rank].ready);
+        if (g->posts[c->rank].done) (void)hipEventDestroy(g->posts[c->rank].done);
+        g->posts[c->rank].ready = g->posts[c->rank].done = nullptr;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            last = --g->refs == 0;
+        }
+        if (last) delete g;
+    }
+    delete c;
+    return 0;
+}
+
+extern "C" int32_t nnd_comm_abort(nnd_comm_t c) {  // a rank failed: wake the others up instead of leaving them in a barrier
+    if (c && c->kind == NND_COMM_LOCAL && c->grp) c->grp->abort();
+    return 0;
+}
+
+static int spin_on(nnd_comm_s *c, hipStream_t stream) {
+    C_HIP(hipEventRecord(c->ev, stream));
+    hipError_t e;
+    while ((e = hipEventQuery(c->ev)) == hipErrorNotReady) {
+    }
+    C_HIP(e);
+    return 0;
+}
+
+static int host_stage_grow(nnd_comm_s *c, unsigned char **buf, size_t *cap, size_t need) {
+    if (need <= *cap) return 0;
+    if (*buf) C_HIP(hipHostFree(*buf));
+    *buf = nullptr;
+    *cap = need + need / 4 + 4096;
+    C_HIP(hipHostMalloc((void **)buf, *cap, hipHostMallocDefault));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ operations
+int comm_gather_counts(nnd_comm_s *c, hipStream_t stream, const long long *counts_dev, int nv, long long *matrix_host) {
+    const int G = c->world;
+    if (nv > NND_MAX_RANKS + 8) { c->set_error("comm_gather_counts: vector too long"); return 1; }
+    if (c->kind == NND_COMM_RCCL) {
+        if (G > 1) {
+            C_NCCL(g_rccl.AllGather(counts_dev, c->counts_all_dev, (size_t)nv, ncclInt64, (ncclComm_t)c->nccl, stream));
+            C_HIP(hipMemcpyAsync(c->h_counts, c->counts_all_dev, sizeof(long long) * (size_t)G * nv, hipMemcpyDeviceToHost, stream));
+        } else {
+            C_HIP(hipMemcpyAsync(c->h_counts, counts_dev, sizeof(long long) * (size_t)nv, hipMemcpyDeviceToHost, stream));
+        }
+        if (spin_on(c, stream)) return 1;
+        memcpy(matrix_host, c->h_counts, sizeof(long long) * (size_t)G * nv);
+        return 0;
+    }
+    // LOCAL / HOST: every rank brings its own vector to the host first
+    C_HIP(hipMemcpyAsync(c->h_counts, counts_dev, sizeof(long long) * (size_t)nv, hipMemcpyDeviceToHost, stream));
+    if (spin_on(c, stream)) return 1;
+    if (c->kind == NND_COMM_LOCAL) {
+        nnd_local_group *g = c->grp;
+        g->posts[c->rank].counts_host = c->h_counts;
+        if (g->barrier()) { c->set_error("local group aborted (another rank failed)"); return 1; }
+        for (int r = 0; r < G; r++) memcpy(matrix_host + (size_t)r * nv, g->posts[r].counts_host, sizeof(long long) * (size_t)nv);
+        if (g->barrier()) { c->set_error("local group aborted (another rank failed)"); return 1; }  // vectors may be overwritten now
+        return 0;
+    }
+    // HOST: an all-gather through the callback (send the same nv words to everyone)
+    int64_t soff[NND_MAX_RANKS], sb[NND_MAX_RANKS], roff[NND_MAX_RANKS], rb[NND_MAX_RANKS];
+    for (int r = 0; r < G; r++) {
+        soff[r] = 0;
+        sb[r] = (int64_t)sizeof(long long) * nv;
+        roff[r] = (int64_t)sizeof(long long) * nv * r;
+        rb[r] = sb[r];
+    }
+    if (c->fn(c->user, c->h_counts, soff, sb, matrix_host, roff, rb) != 0) { c->set_error("host exchange callback failed (counts)"); return 1; }
+    return 0;
+}
+
+int comm_alltoallv(nnd_comm_s *c, hipStream_t stream, int narr, void *const *send_bases, void *const *recv_bases, const int *elem_bytes,
+                   const size_t *soff, const size_t *scnt, const size_t *roff, const size_t *rcnt) {
+    const int G = c->world, me = c->rank;
+    for (int d = 0; d < G; d++)
+        if (d != me)
+            for (int a = 0; a < narr; a++) c->bytes_sent += (int64_t)scnt[d] * elem_bytes[a];
+    // own segment: a device copy on this rank's stream (nothing to do for an in-place all-gather)
+    auto self_copy = [&]() -> int {
+        for (int a = 0; a < narr; a++) {
+            const unsigned char *src = (const unsigned char *)send_bases[a] + soff[me] * elem_bytes[a];
+            unsigned char *dst = (unsigned char *)recv_bases[a] + roff[me] * elem_bytes[a];
+            if (scnt[me] && src != dst) C_HIP(hipMemcpyAsync(dst, src, scnt[me] * elem_bytes[a], hipMemcpyDeviceToDevice, stream));
+        }
+        return 0;
+    };
+    if (c->kind == NND_COMM_RCCL) {
+        if (self_copy()) return 1;
+        if (G == 1) return 0;
+        C_NCCL(g_rccl.GroupStart());
+        for (int p = 0; p < G; p++) {
+            if (p == me) continue;
+            for (int a = 0; a < narr; a++) {
+                if (scnt[p]) C_NCCL(g_rccl.Send((const unsigned char *)send_bases[a] + soff[p] * elem_bytes[a], scnt[p] * elem_bytes[a], ncclUint8, p, (ncclComm_t)c->nccl, stream));
+                if (rcnt[p]) C_NCCL(g_rccl.Recv((unsigned char *)recv_bases[a] + roff[p] * elem_bytes[a], rcnt[p] * elem_bytes[a], ncclUint8, p, (ncclComm_t)c->nccl, stream));
+            }
+        }
+        C_NCCL(g_rccl.GroupEnd());
+        return 0;
+    }
+    if (c->kind == NND_COMM_LOCAL) {
+        nnd_local_group *g = c->grp;
+        nnd_local_post &mine = g->posts[me];
+        mine.send_bases = send_bases;
+        mine.soff = soff;
+        mine.scnt = scnt;
+        C_HIP(hipEventRecord(mine.ready, stream));  // everything this rank sends has been produced before this point
+        if (g->barrier()) { c->set_error("local group aborted (another rank failed)"); return 1; }
+        for (int s = 0; s < G; s++) {
+            const nnd_local_post &ps = g->posts[s];
+            if (ps.scnt[me] != rcnt[s]) { c->set_error("comm_alltoallv: rank %d sends %zu elements to rank %d, which expects %zu", s, ps.scnt[me], me, rcnt[s]); g->abort(); return 1; }
+            if (!rcnt[s]) continue;
+            if (s != me) C_HIP(hipStreamWaitEvent(stream, ps.ready, 0));
+            for (int a = 0; a < narr; a++) {
+                const unsigned char *src = (const unsigned char *)ps.send_bases[a] + ps.soff[me] * elem_bytes[a];
+                unsigned char *dst = (unsigned char *)recv_bases[a] + roff[s] * elem_bytes[a];
+                if (src == dst) continue;
+                if (ps.device == c->device) C_HIP(hipMemcpyAsync(dst, src, rcnt[s] * elem_bytes[a], hipMemcpyDeviceToDevice, stream));
+                else C_HIP(hipMemcpyPeerAsync(dst, c->device, src, ps.device, rcnt[s] * elem_bytes[a], stream));
+            }
+        }
+        C_HIP(hipEventRecord(mine.done, stream));  // this rank has read what it needed from everybody
+        if (g->barrier()) { c->set_error("local group aborted (another rank failed)"); return 1; }
+        // a sender must not overwrite its buffers before every reader is done with them
+        for (int d = 0; d < G; d++)
+            if (d != me && scnt[d]) C_HIP(hipStreamWaitEvent(stream, g->posts[d].done, 0));
+        // the posted pointers (soff / scnt live on the caller's stack) must stay valid until every rank has read them
+        if (g->barrier()) { c->set_error("local group aborted (another rank failed)"); return 1; }
+        return 0;
+    }
+    // HOST: stage through pinned memory, one callback per array
+    for (int a = 0; a < narr; a++) {
+        int64_t so[NND_MAX_RANKS], sb[NND_MAX_RANKS], ro[NND_MAX_RANKS], rb[NND_MAX_RANKS];
+        size_t stot = 0, rtot = 0;
+        for (int r = 0; r < G; r++) {
+            so[r] = (int64_t)stot;
+            sb[r] = (int64_t)(scnt[r] * elem_bytes[a]);
+            stot += scnt[r] * elem_bytes[a];
+            ro[r] = (int64_t)rtot;
+            rb[r] = (int64_t)(rcnt[r] * elem_bytes[a]);
+            rtot += rcnt[r] * elem_bytes[a];
+        }
+        if (host_stage_grow(c, &c->h_send, &c->h_send_cap, stot) || host_stage_grow(c, &c->h_recv, &c->h_recv_cap, rtot)) return 1;
+        for (int r = 0; r < G; r++)
+            if (sb[r]) C_HIP(hipMemcpyAsync(c->h_send + so[r], (const unsigned char *)send_bases[a] + soff[r] * elem_bytes[a], (size_t)sb[r], hipMemcpyDeviceToHost, stream));
+        C_HIP(hipStreamSynchronize(stream));
+        if (c->fn(c->user, c->h_send, so, sb, c->h_recv, ro, rb) != 0) { c->set_error("host exchange callback failed"); return 1; }
+        for (int r = 0; r < G; r++)
+            if (rb[r]) C_HIP(hipMemcpyAsync((unsigned char *)recv_bases[a] + roff[r] * elem_bytes[a], c->h_recv + ro[r], (size_t)rb[r], hipMemcpyHostToDevice, stream));
+        C_HIP(hipStreamSynchronize(stream));  // the staging buffer is reused by the next array
+    }
+    return 0;
+}
+
+int comm_barrier(nnd_comm_s *c) {
+    if (c->kind == NND_COMM_LOCAL) {
+        if (c->grp->barrier()) { c->set_error("local group aborted (another rank failed)"); return 1; }
+        return 0;
+    }
+    if (c->kind == NND_COMM_HOST) {
+        int64_t z[NND_MAX_RANKS] = {0};
+        if (c->fn(c->user, c->h_counts, z, z, c->h_counts, z, z) != 0) { c->set_error("host exchange callback failed (barrier)"); return 1; }
+    }
+    return 0;  // RCCL: the collectives order the ranks; nothing to do
+}
+
+void comm_compute_begin(nnd_comm_s *c) {
+    if (c->kind == NND_COMM_LOCAL && c->grp->serial) c->grp->gpu_token.lock();
+}
+void comm_compute_end(nnd_comm_s *c, hipStream_t stream) {
+    if (c->kind == NND_COMM_LOCAL && c->grp->serial) {
+        (void)hipStreamSynchronize(stream);
+        c->grp->gpu_token.unlock();
+    }
+}

@@ -273,47 +273,6 @@ int nnd_launch_clear_new_flags(nnd_ctx *ctx) {
 // and folded into the owner's slots.  This is the cross-process form of the reference's ownership
 // test in apply_graph_update_array (utils.py:721-731).
 
-// records pending for every vertex this handle does NOT own (0 for owned or clean rows)
-__global__ __launch_bounds__(256) void k_proposal_counts(const uint64_t *__restrict__ pbuf, const uint8_t *__restrict__ pdirty,
-                                                         int pcap, int64_t n, int64_t own_lo, int64_t own_hi,
-                                                         int32_t *__restrict__ cnt) {
-    const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t v = (int64_t)blockIdx.x * 4 + w;
-    if (v >= n) return;
-    int c = 0;
-    if ((v < own_lo || v >= own_hi) && pdirty[v]) {
-        for (int s = lane; s < pcap; s += 64) c += pbuf[v * pcap + s] != NND_EMPTY_KEY;
-        c = nnd_wave_sum_i32(c);
-    }
-    if (lane == 0) cnt[v] = c;
-}
-
-// write the records of vertex v at offsets[v] (exclusive scan of the counts), re-arm the slots
-__global__ __launch_bounds__(256) void k_export_proposals(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
-                                                          int64_t n, int64_t own_lo, int64_t own_hi,
-                                                          const int64_t *__restrict__ offsets, uint64_t *__restrict__ keys,
-                                                          int32_t *__restrict__ targets) {
-    const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t v = (int64_t)blockIdx.x * 4 + w;
-    if (v >= n) return;
-    if ((v >= own_lo && v < own_hi) || !pdirty[v]) return;
-    int64_t off = offsets[v];
-    for (int s0 = 0; s0 < pcap; s0 += 64) {
-        const int s = s0 + lane;
-        uint64_t key = s < pcap ? pbuf[v * pcap + s] : NND_EMPTY_KEY;
-        const bool on = key != NND_EMPTY_KEY;
-        const unsigned long long m = __ballot(on);
-        if (on) {
-            const int64_t o = off + nnd_prefix_popc(m);
-            keys[o] = key;
-            targets[o] = (int32_t)v;
-            pbuf[v * pcap + s] = NND_EMPTY_KEY;
-        }
-        off += __popcll(m);
-    }
-    if (lane == 0) pdirty[v] = 0;
-}
-
 // fold received records into this handle's slots (same hashed-slot atomicMin as the join)
 __global__ void k_import_proposals(const uint64_t *__restrict__ keys, const int32_t *__restrict__ targets, int64_t count,
                                    uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed) {
@@ -435,18 +394,6 @@ int nnd_launch_proposal_export_regions(nnd_ctx *ctx, int64_t cap, int32_t *targe
     return 0;
 }
 
-int nnd_launch_proposal_counts(nnd_ctx *ctx, int32_t *cnt_dev) {
-    hipLaunchKernelGGL(k_proposal_counts, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->pbuf, ctx->pdirty,
-                       ctx->pcap, ctx->n, ctx->own_lo, ctx->own_hi, cnt_dev);
-    NND_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-int nnd_launch_export_proposals(nnd_ctx *ctx, const int64_t *offsets_dev, uint64_t *keys_out, int32_t *targets_out) {
-    hipLaunchKernelGGL(k_export_proposals, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->pbuf, ctx->pdirty,
-                       ctx->pcap, ctx->n, ctx->own_lo, ctx->own_hi, offsets_dev, keys_out, targets_out);
-    NND_HIP_CHECK(hipGetLastError());
-    return 0;
-}
 int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_t *targets, int64_t count) {
     if (count <= 0) return 0;
     // same slot hash as the join of the iteration that produced the records (iter was not advanced yet)
@@ -465,15 +412,3 @@ int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint
     return 0;
 }
 
-// th[v] = worst distance of row v, for rows whose k-lists were overwritten wholesale (imported rows)
-__global__ void k_refresh_th(const float *__restrict__ knn_d, int ks, int k, int64_t lo, int64_t hi, float *__restrict__ th) {
-    const int64_t v = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < hi) th[v] = knn_d[v * ks + (k - 1)];
-}
-int nnd_launch_refresh_th(nnd_ctx *ctx, int64_t lo, int64_t hi) {
-    if (hi <= lo) return 0;
-    hipLaunchKernelGGL(k_refresh_th, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_d, ctx->ks, ctx->k,
-                       lo, hi, ctx->th);
-    NND_HIP_CHECK(hipGetLastError());
-    return 0;
-}

@@ -380,7 +380,7 @@ __global__ void k_offer_import(const int32_t *__restrict__ targets, const uint64
 int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, long long *counts_dev) {
     if (ctx->n_ranks < 1 || !ctx->shard_bounds) { ctx->set_error("nnd_sample_begin: call nnd_set_shard_bounds first"); return 1; }
     const uint32_t it_seed = sample_seed(ctx);
-    NND_HIP_CHECK(hipMemsetAsync(ctx->active, 0, (size_t)ctx->n, ctx->stream));
+    NND_HIP_CHECK(hipMemsetAsync(ctx->active + ctx->slim_row0(), 0, (size_t)ctx->slim_rows(), ctx->stream));
     NND_HIP_CHECK(hipMemsetAsync(ctx->shard_cursors, 0, sizeof(long long) * 66, ctx->stream));
     launch_reverse_pass(ctx, 0, it_seed);
     if (ctx->n_ranks > 1) {

@@ -1,0 +1,602 @@
+// shard.hip -- one rank of the row-sharded multi-GPU build, and nnd_build_multi (one host thread per GPU).
+//
+// The reference is single-process; what it offers as a sharding rule is owner-computes over contiguous vertex ranges
+// (apply_graph_update_array utils.py:709-731, new_build_candidates utils.py:259-306, init_rp_tree
+// pynndescent_.py:154-185).  Here that rule crosses GPUs (include/pynnd_amd.h for the scheme).
+// Everything a rank does is queued on ONE HIP stream -- kernels of the single-GPU build (state.h launchers) and the
+// exchanges of comm.h -- and the host waits only for the record counts that size the next exchange (twice per
+// iteration).  The update counts of all ranks ride on the first of those waits, so the stop rule costs no collective of
+// its own: the decision for iteration i is taken after the (speculative, harmless) first half of iteration i + 1's
+// sampling has been queued.
+#include <string.h>
+
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "comm.h"
+#include "common.h"
+#include "state.h"
+
+struct nnd_shard_s {
+    nnd_comm_s *comm = nullptr;
+    nnd_ctx *h = nullptr;
+    nnd_params gp{};  // global parameters
+    int world = 1, rank = 0, k = 0, ks = 0, t0 = 0, t1 = 0;
+    int64_t n_total = 0, lo = 0, hi = 0, max_range = 0;
+    int64_t bounds[NND_MAX_RANKS + 1] = {0};
+    // device buffers
+    float *x_full = nullptr;                     // (n_total, d) replicated point set (world > 1)
+    uint32_t *recv_e = nullptr;                  // (world - 1 sources) x (n_own, ks) partial k-list rows
+    float *recv_d = nullptr;
+    int32_t *off_t = nullptr, *prop_t = nullptr;  // record regions, one per destination rank
+    uint64_t *off_k = nullptr, *prop_k = nullptr;
+    int64_t cap_o = 0, cap_p = 0;
+    int32_t *in_t = nullptr;                     // received records (grow-only)
+    uint64_t *in_k = nullptr;
+    int64_t in_cap = 0;
+    long long *cvec = nullptr;                   // (world + 4) count vector handed to comm_gather_counts
+    nnd_shard_info info{};
+    char err[512] = {0};
+    void set_error(const char *fmt, ...) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(err, sizeof(err), fmt, ap);
+        va_end(ap);
+    }
+};
+
+static thread_local char g_serr2[512] = {0};
+extern "C" const char *nnd_shard_last_error(nnd_shard_t s) { return s ? s->err : g_serr2; }
+
+#define S_HIP(expr)                                                                                 \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            s->set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                               \
+        }                                                                                           \
+    } while (0)
+#define S_CTX(expr)                                          \
+    do {                                                     \
+        if ((expr) != 0) {                                   \
+            s->set_error("%s: %s", #expr, s->h->err);        \
+            return 1;                                        \
+        }                                                    \
+    } while (0)
+#define S_COMM(expr)                                         \
+    do {                                                     \
+        if ((expr) != 0) {                                   \
+            s->set_error("%s: %s", #expr, s->comm->err);     \
+            return 1;                                        \
+        }                                                    \
+    } while (0)
+
+// [0, G) record counts per destination | G: this rank's update count of the finished iteration | G+1: dropped | G+2: deferred
+__global__ void k_pack_counts(const long long *__restrict__ cursors, const long long *__restrict__ counters_sum, int G, int with_c,
+                              long long *__restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < G) out[i] = cursors[i];
+    if (i == G) out[G] = with_c ? counters_sum[CNT_ACCEPT] : 0;
+    if (i == G + 1) out[G + 1] = cursors[64];
+    if (i == G + 2) out[G + 2] = cursors[65];
+}
+__global__ void k_counters_reduce_async(const long long *__restrict__ counters, long long *__restrict__ out) {
+    // one value per counter (same as prep.hip k_counters_reduce, kept device-side: no read-back)
+    __shared__ long long red[256];
+    for (int c = 0; c < CNT_COUNT; c++) {
+        long long v = 0;
+        for (int i = threadIdx.x; i < NND_CNT_STRIPES; i += 256) v += counters[(size_t)i * CNT_COUNT + c];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[c] = red[0];
+        __syncthreads();
+    }
+}
+
+static void shard_free(nnd_shard_s *s) {
+    if (s->h) (void)hipSetDevice(s->h->p.device);
+    void *ptrs[] = {s->x_full, s->recv_e, s->recv_d, s->off_t, s->off_k, s->prop_t, s->prop_k, s->in_t, s->in_k, s->cvec};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (s->h) (void)nnd_destroy(s->h);
+    delete s;
+}
+
+extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, nnd_comm_t comm, const int64_t *shard_sizes) {
+    auto fail = [&](const char *msg) {
+        snprintf(g_serr2, sizeof(g_serr2), "nnd_shard_create: %s", msg);
+        return 1;
+    };
+    if (!out || !params || !comm || !shard_sizes) return fail("null argument");
+    *out = nullptr;
+    const int G = comm->world, rank = comm->rank;
+    nnd_shard_s *s = new nnd_shard_s();
+    s->comm = comm;
+    s->gp = *params;
+    s->world = G;
+    s->rank = rank;
+    int64_t acc = 0;
+    for (int r = 0; r < G; r++) {
+        if (shard_sizes[r] < 0) { delete s; return fail("negative shard size"); }
+        s->bounds[r] = acc;
+        acc += shard_sizes[r];
+        if (shard_sizes[r] > s->max_range) s->max_range = shard_sizes[r];
+    }
+    s->bounds[G] = acc;
+    if (acc != params->n) { delete s; return fail("the shard sizes must add up to params->n (the GLOBAL point count)"); }
+    s->n_total = acc;
+    s->lo = s->bounds[rank];
+    s->hi = s->bounds[rank + 1];
+    // forest split by tree: contiguous runs (ranks beyond n_trees get none; every tree is built exactly once)
+    s->t0 = (int)((int64_t)params->n_trees * rank / G);
+    s->t1 = (int)((int64_t)params->n_trees * (rank + 1) / G);
+    nnd_params p = *params;
+    p.n_trees = s->t1 - s->t0;
+    p.device = comm->device;
+    // every rank draws its own trees: the per-tree state is derived from the global one and the first tree's number
+    p.tree_rng[1] = (int64_t)((uint64_t)p.tree_rng[1] + 0x9E3779B97F4A7C15ull * (uint64_t)(s->t0 + 1));
+    if (nnd_create_impl(&s->h, &p, s->bounds, G, rank)) {
+        snprintf(g_serr2, sizeof(g_serr2), "nnd_shard_create: %s", nnd_last_global_error());
+        delete s;
+        return 1;
+    }
+    s->k = s->h->k;
+    s->ks = s->h->ks;
+    const int64_t n_own = s->hi - s->lo;
+    bool ok = hipSetDevice(p.device) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s->cvec, sizeof(long long) * (size_t)(G + 4)) == hipSuccess;
+    if (ok && G > 1) {
+        // offers: at most every owned edge goes to ONE other rank; proposals: 32 of a row's 64 slots may travel per
+        // iteration (what does not fit stays and travels next time: counted in nnd_shard_info.deferred)
+        s->cap_o = n_own * s->k > 0 ? n_own * s->k : 1;
+        s->cap_p = s->max_range * 32 > 64 ? s->max_range * 32 : 64;
+        ok = ok && hipMalloc((void **)&s->x_full, sizeof(float) * (size_t)s->n_total * params->dim) == hipSuccess;
+        if (params->n_trees > 0) {
+            const size_t rows = (size_t)(G - 1) * (size_t)(n_own > 0 ? n_own : 1) * s->ks;
+            ok = ok && hipMalloc((void **)&s->recv_e, sizeof(uint32_t) * rows) == hipSuccess;
+            ok = ok && hipMalloc((void **)&s->recv_d, sizeof(float) * rows) == hipSuccess;
+        }
+        ok = ok && hipMalloc((void **)&s->off_t, sizeof(int32_t) * (size_t)G * s->cap_o) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s->off_k, sizeof(uint64_t) * (size_t)G * s->cap_o) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s->prop_t, sizeof(int32_t) * (size_t)G * s->cap_p) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s->prop_k, sizeof(uint64_t) * (size_t)G * s->cap_p) == hipSuccess;
+        s->in_cap = n_own * s->k + 1024;  // a typical iteration receives about as many offers as it sends; grows on demand
+        ok = ok && hipMalloc((void **)&s->in_t, sizeof(int32_t) * (size_t)s->in_cap) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s->in_k, sizeof(uint64_t) * (size_t)s->in_cap) == hipSuccess;
+    }
+    if (!ok) {
+        snprintf(g_serr2, sizeof(g_serr2), "nnd_shard_create: out of device memory (rank %d of %d, %lld owned rows of %lld)", rank, G,
+                 (long long)n_own, (long long)s->n_total);
+        shard_free(s);
+        return 1;
+    }
+    s->info.n_total = s->n_total;
+    s->info.own_lo = s->lo;
+    s->info.own_hi = s->hi;
+    s->info.world = G;
+    s->info.rank = rank;
+    s->info.local_trees = s->t1 - s->t0;
+    *out = s;
+    return 0;
+}
+
+extern "C" int32_t nnd_shard_destroy(nnd_shard_t s) {
+    if (s) shard_free(s);
+    return 0;
+}
+extern "C" int32_t nnd_shard_get_info(nnd_shard_t s, nnd_shard_info *out) {
+    if (!s || !out) return 1;
+    *out = s->info;
+    return 0;
+}
+extern "C" int32_t nnd_shard_get_stats(nnd_shard_t s, nnd_stats *out) {
+    if (!s || !out) return 1;
+    *out = s->h->stats;
+    return 0;
+}
+
+// compute sections: in LOCAL serial mode (tools/rank_critical_path.py) each is timed with the GPU to itself
+struct section_timer {
+    nnd_shard_s *s;
+    std::chrono::steady_clock::time_point t;
+    bool serial;
+    explicit section_timer(nnd_shard_s *s_) : s(s_) {
+        serial = s->comm->kind == NND_COMM_LOCAL && s->comm->grp->serial;
+        comm_compute_begin(s->comm);
+        t = std::chrono::steady_clock::now();
+    }
+    void end() {
+        comm_compute_end(s->comm, s->h->stream);  // serial mode: drains the stream, then releases the GPU
+        if (serial && s->info.n_sections < 256) {
+            const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count();
+            s->info.section_ms[s->info.n_sections] = ms;
+            s->info.section_bytes[s->info.n_sections] = 0;
+            s->info.n_sections++;
+        }
+    }
+};
+static void note_bytes(nnd_shard_s *s, int64_t before) {  // payload of the exchange that followed the last section
+    if (s->info.n_sections > 0 && s->info.n_sections <= 256) s->info.section_bytes[s->info.n_sections - 1] += s->comm->bytes_sent - before;
+}
+
+static int grow_inbox(nnd_shard_s *s, int64_t need) {
+    if (need <= s->in_cap) return 0;
+    S_HIP(hipStreamSynchronize(s->h->stream));
+    if (s->in_t) S_HIP(hipFree(s->in_t));
+    if (s->in_k) S_HIP(hipFree(s->in_k));
+    s->in_t = nullptr;
+    s->in_k = nullptr;
+    s->in_cap = need + need / 4;
+    S_HIP(hipMalloc((void **)&s->in_t, sizeof(int32_t) * (size_t)s->in_cap));
+    S_HIP(hipMalloc((void **)&s->in_k, sizeof(uint64_t) * (size_t)s->in_cap));
+    return 0;
+}
+
+// all-to-all-v of the per-destination record regions [d * cap, d * cap + cnt[d]) of (targets, keys); the records of the
+// OTHER ranks land back to back in (in_t, in_k).  matrix: the gathered count vectors (row = sender), nv words per row;
+// caps[r]: region capacity of sender r (a cursor beyond it means records that were not written: dropped / deferred).
+static int exchange_records(nnd_shard_s *s, int32_t *reg_t, uint64_t *reg_k, const int64_t *caps, const long long *matrix, int nv,
+                            int64_t *n_in_out, int64_t *n_sent_out) {
+    const int G = s->world, me = s->rank;
+    size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
+    int64_t n_in = 0, n_sent = 0;
+    for (int r = 0; r < G; r++) {
+        long long sc = matrix[(size_t)me * nv + r], rc = matrix[(size_t)r * nv + me];
+        if (sc > caps[me]) sc = caps[me];
+        if (rc > caps[r]) rc = caps[r];
+        if (r == me) sc = rc = 0;  // own records were applied locally
+        soff[r] = (size_t)r * (size_t)caps[me];
+        scnt[r] = (size_t)sc;
+        roff[r] = (size_t)n_in;
+        rcnt[r] = (size_t)rc;
+        n_in += rc;
+        n_sent += sc;
+    }
+    if (grow_inbox(s, n_in)) return 1;
+    void *sb[2] = {reg_t, reg_k}, *rb[2] = {s->in_t, s->in_k};
+    const int eb[2] = {4, 8};
+    S_COMM(comm_alltoallv(s->comm, s->h->stream, 2, sb, rb, eb, soff, scnt, roff, rcnt));
+    *n_in_out = n_in;
+    *n_sent_out = n_sent;
+    return 0;
+}
+
+static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream, int32_t *out_idx_dev, float *out_dist_dev) {
+    nnd_ctx *h = s->h;
+    nnd_comm_s *c = s->comm;
+    const int G = s->world, me = s->rank, nv = G + 3;
+    const int64_t n_own = s->hi - s->lo;
+    S_HIP(hipSetDevice(h->p.device));
+    hipStream_t st = h->stream;
+    const auto wall0 = std::chrono::steady_clock::now();
+    c->bytes_sent = 0;
+    s->info.iters = 0;
+    s->info.n_sections = 0;
+    s->info.dropped_offers = 0;
+    memset(s->info.c, 0, sizeof(s->info.c));
+    memset(s->info.offer_records, 0, sizeof(s->info.offer_records));
+    memset(s->info.proposal_records, 0, sizeof(s->info.proposal_records));
+    memset(s->info.deferred, 0, sizeof(s->info.deferred));
+    memset(&h->stats, 0, sizeof(h->stats));
+    if (x_stream && (hipStream_t)x_stream != st) {  // the caller's rows were produced on another stream
+        S_HIP(hipEventRecord(h->ev0, (hipStream_t)x_stream));
+        S_HIP(hipStreamWaitEvent(st, h->ev0, 0));
+    }
+    hipEvent_t e0 = h->ev0, e1 = h->ev1;
+
+    // ---- replicate the point set once (all-gather over xGMI): candidate vectors never travel again ----
+    const float *x_use = x_local_dev;
+    if (G > 1) {
+        size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
+        for (int r = 0; r < G; r++) {
+            soff[r] = 0;
+            scnt[r] = (size_t)n_own * h->d;
+            roff[r] = (size_t)s->bounds[r] * h->d;
+            rcnt[r] = (size_t)(s->bounds[r + 1] - s->bounds[r]) * h->d;
+        }
+        void *sb[1] = {(void *)x_local_dev}, *rb[1] = {s->x_full};
+        const int eb[1] = {4};
+        const int64_t b0 = c->bytes_sent;
+        S_HIP(hipEventRecord(e0, st));
+        S_COMM(comm_alltoallv(c, st, 1, sb, rb, eb, soff, scnt, roff, rcnt));
+        S_HIP(hipEventRecord(e1, st));
+        S_HIP(hipStreamSynchronize(st));
+        (void)hipEventElapsedTime(&s->info.ms_allgather, e0, e1);
+        (void)b0;
+        x_use = s->x_full;
+    }
+    // ---- prep (all rows: 5 ms at 10 M points, cheaper than shipping the prepared copies over xGMI), reset ----
+    {
+        section_timer sec(s);
+        h->x_orig = x_use;
+        h->x_owned = false;
+        const int tp = t_begin(h);
+        S_CTX(nnd_launch_prep(h));
+        S_CTX(nnd_launch_reset_graph(h));
+        t_end(h, tp, &h->stats.ms_prep, false);
+        // ---- forest split by tree: this rank seeds ALL rows from its own trees ----
+        if (h->p.n_trees > 0) {
+            const int tf = t_begin(h);
+            S_CTX(nnd_launch_forest(h));
+            t_end(h, tf, &h->stats.ms_forest, false);
+            const int tl = t_begin(h);
+            S_CTX(nnd_launch_leaf_init(h));
+            t_end(h, tl, &h->stats.ms_leaf_init, false);
+        }
+        sec.end();
+    }
+    // ---- partial k-list rows -> their owners (all-to-all-v of row blocks), merged there ----
+    if (G > 1 && s->gp.n_trees > 0) {
+        const int64_t b0 = c->bytes_sent;
+        auto trees_of = [&](int r) { return (int)((int64_t)s->gp.n_trees * (r + 1) / G) - (int)((int64_t)s->gp.n_trees * r / G); };
+        size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
+        size_t at = 0;
+        for (int r = 0; r < G; r++) {
+            const size_t rows_r = (size_t)(s->bounds[r + 1] - s->bounds[r]);
+            soff[r] = (size_t)s->bounds[r] * s->ks;
+            scnt[r] = (r != me && h->p.n_trees > 0) ? rows_r * s->ks : 0;  // a rank without trees has nothing to offer
+            roff[r] = at;
+            rcnt[r] = (r != me && trees_of(r) > 0) ? (size_t)n_own * s->ks : 0;
+            at += rcnt[r];
+        }
+        void *sb[2] = {h->knn_e, h->knn_d}, *rb[2] = {s->recv_e, s->recv_d};
+        const int eb[2] = {4, 4};
+        S_HIP(hipEventRecord(e0, st));
+        S_COMM(comm_alltoallv(c, st, 2, sb, rb, eb, soff, scnt, roff, rcnt));
+        S_HIP(hipEventRecord(e1, st));
+        note_bytes(s, b0);
+        section_timer sec(s);
+        // (merged entries carry the "new" flag like everything else before the first sampling pass: all_new stays set)
+        for (int r = 0; r < G; r++)
+            if (rcnt[r]) S_CTX(nnd_launch_merge_graph_rows(h, s->lo, s->hi, s->recv_e + roff[r], s->recv_d + roff[r]));
+        const int tr = t_begin(h);
+        S_CTX(nnd_launch_random_init(h));  // owned rows that are still not full (pynndescent_.py:188-203)
+        t_end(h, tr, &h->stats.ms_random_init, false);
+        sec.end();
+    } else {
+        section_timer sec(s);
+        const int tr = t_begin(h);
+        S_CTX(nnd_launch_random_init(h));
+        t_end(h, tr, &h->stats.ms_random_init, false);
+        sec.end();
+    }
+
+    // ---- NN-descent (pynndescent_.py:296-320), every rank scanning only ITS rows ----
+    std::vector<long long> matrix((size_t)G * nv);
+    int64_t caps_o[NND_MAX_RANKS], caps_p[NND_MAX_RANKS];
+    for (int r = 0; r < G; r++) {
+        const int64_t rows_r = s->bounds[r + 1] - s->bounds[r];
+        caps_o[r] = rows_r * s->k > 0 ? rows_r * s->k : 1;  // = nnd_shard_create's cap_o of rank r
+        caps_p[r] = s->cap_p;
+    }
+    // per-iteration kernel counters: reduced on the device after the merge, copied to a pinned block, read after the
+    // next host wait (no read-back of their own)
+    auto harvest = [&](int it_done) {
+        if (it_done < 0 || it_done >= 64) return;
+        h->stats.join_pairs[it_done] = h->h_pin[CNT_PAIRS];
+        h->stats.join_rows[it_done] = h->h_pin[CNT_ROWS];
+        h->stats.join_active[it_done] = h->h_pin[CNT_ACTIVE];
+        h->stats.proposals[it_done] = h->h_pin[CNT_PROPOSALS];
+        h->stats.join_mfma[it_done] = h->h_pin[CNT_MFMA];
+    };
+    static float sink;
+    const double stop_at = (double)s->gp.delta * s->k * (double)s->n_total;
+    bool stopped = false;
+    for (int it = 0; it < s->gp.n_iters; it++) {
+        float *ms_s = it < 64 ? &h->stats.ms_sample[it] : &sink, *ms_j = it < 64 ? &h->stats.ms_join[it] : &sink,
+              *ms_m = it < 64 ? &h->stats.ms_merge[it] : &sink;
+        // (1) thresholds of the remote rows, 4 bytes per row: all the join needs of a remote candidate (a stale threshold
+        //     only admits extra proposals); in place -- this rank's slice of th is where the others read it from
+        if (G > 1) {
+            size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
+            for (int r = 0; r < G; r++) {
+                soff[r] = (size_t)s->lo;
+                scnt[r] = (size_t)n_own;
+                roff[r] = (size_t)s->bounds[r];
+                rcnt[r] = (size_t)(s->bounds[r + 1] - s->bounds[r]);
+            }
+            void *sb[1] = {h->th}, *rb[1] = {h->th};
+            const int eb[1] = {4};
+            const int64_t b0 = c->bytes_sent;
+            S_COMM(comm_alltoallv(c, st, 1, sb, rb, eb, soff, scnt, roff, rcnt));
+            note_bytes(s, b0);
+        }
+        // (2) sampling, first half: own new edges; offers to targets owned elsewhere become records
+        {
+            section_timer sec(s);
+            const int ts = t_begin(h);
+            S_CTX(nnd_launch_sample_begin(h, s->cap_o > 0 ? s->cap_o : 1, s->off_t, s->off_k, s->cvec));
+            t_end(h, ts, ms_s, false);
+            hipLaunchKernelGGL(k_pack_counts, dim3(1), dim3(128), 0, st, h->shard_cursors, h->counters_sum, G, it > 0 ? 1 : 0, s->cvec);
+            sec.end();
+        }
+        S_COMM(comm_gather_counts(c, st, s->cvec, nv, matrix.data()));  // host wait: record counts (+ last iteration's c)
+        t_flush(h);
+        if (it > 0) {  // the stop rule of the iteration that just finished (pynndescent_.py:317), on the GLOBAL count
+            harvest(it - 1);
+            long long ctot = 0;
+            for (int r = 0; r < G; r++) ctot += matrix[(size_t)r * nv + G];
+            if (it - 1 < 64) s->info.c[it - 1] = ctot;
+            if (it - 1 < 64) h->stats.updates[it - 1] = matrix[(size_t)me * nv + G];
+            if ((double)ctot <= stop_at) {
+                stopped = true;
+                break;  // what sample_begin queued is harmless: reverse-offer slots are re-armed by the next build's reset
+            }
+        }
+        s->info.dropped_offers += matrix[(size_t)me * nv + G + 1];
+        int64_t n_in = 0, n_sent = 0;
+        if (G > 1) {
+            const int64_t b0 = c->bytes_sent;
+            if (exchange_records(s, s->off_t, s->off_k, caps_o, matrix.data(), nv, &n_in, &n_sent)) return 1;
+            note_bytes(s, b0);
+        }
+        if (it < 64) s->info.offer_records[it] = n_sent;
+        {
+            section_timer sec(s);
+            const int ts = t_begin(h);
+            S_CTX(nnd_launch_sample_finish(h, s->in_t, s->in_k, n_in));
+            t_end(h, ts, ms_s, true);
+            // (3) local join of the owned vertices
+            S_CTX(nnd_zero_counters(h));
+            const int tj = t_begin(h);
+            S_CTX(nnd_launch_join(h, s->lo, s->hi));
+            t_end(h, tj, ms_j, false);
+            // (4) proposals for vertices owned elsewhere -> their owners' regions
+            if (G > 1) {
+                S_CTX(nnd_launch_proposal_export_regions(h, s->cap_p, s->prop_t, s->prop_k, s->cvec));
+                hipLaunchKernelGGL(k_pack_counts, dim3(1), dim3(128), 0, st, h->shard_cursors, h->counters_sum, G, 0, s->cvec);
+            }
+            sec.end();
+        }
+        n_in = 0;
+        if (G > 1) {
+            S_COMM(comm_gather_counts(c, st, s->cvec, nv, matrix.data()));  // host wait: proposal record counts
+            if (it < 64) s->info.deferred[it] = matrix[(size_t)me * nv + G + 2];
+            // a region holds the rows that fit entirely: cursor minus what was deferred behind it may exceed cap only by
+            // deferred rows, whose slots inside the region are marked invalid (target -1) -- ship min(cursor, cap)
+            const int64_t b0 = c->bytes_sent;
+            if (exchange_records(s, s->prop_t, s->prop_k, caps_p, matrix.data(), nv, &n_in, &n_sent)) return 1;
+            note_bytes(s, b0);
+            if (it < 64) s->info.proposal_records[it] = n_sent;
+        }
+        {
+            section_timer sec(s);
+            if (n_in) S_CTX(nnd_launch_import_proposals(h, s->in_k, s->in_t, n_in));
+            // (5) owner-side merge; its update count stays on the device and rides on the next count exchange
+            const int tm = t_begin(h);
+            S_CTX(nnd_launch_merge(h));
+            t_end(h, tm, ms_m, false);
+            hipLaunchKernelGGL(k_counters_reduce_async, dim3(1), dim3(256), 0, st, h->counters, h->counters_sum);
+            S_HIP(hipMemcpyAsync(h->h_pin, h->counters_sum, sizeof(long long) * CNT_COUNT, hipMemcpyDeviceToHost, st));
+            sec.end();
+        }
+        h->iter++;
+        h->stats.n_iters_run = h->iter;
+        s->info.iters = it + 1;
+    }
+    if (!stopped) {  // n_iters reached: the last iteration's count is still on the device (statistics only)
+        hipLaunchKernelGGL(k_pack_counts, dim3(1), dim3(128), 0, st, h->shard_cursors, h->counters_sum, G, 1, s->cvec);
+        S_COMM(comm_gather_counts(c, st, s->cvec, nv, matrix.data()));
+        long long ctot = 0;
+        for (int r = 0; r < G; r++) ctot += matrix[(size_t)r * nv + G];
+        const int it = s->info.iters - 1;
+        harvest(it);
+        if (it >= 0 && it < 64) {
+            s->info.c[it] = ctot;
+            h->stats.updates[it] = matrix[(size_t)me * nv + G];
+        }
+    }
+    {
+        section_timer sec(s);
+        const int tf = t_begin(h);
+        S_CTX(nnd_launch_finalize(h, out_idx_dev, out_dist_dev));
+        t_end(h, tf, &h->stats.ms_finalize, false);
+        t_flush(h);
+        sec.end();
+    }
+    S_HIP(hipStreamSynchronize(st));
+    s->info.ms_klist_exchange = 0.0f;
+    if (G > 1 && s->gp.n_trees > 0) (void)hipEventElapsedTime(&s->info.ms_klist_exchange, e0, e1);
+    s->info.bytes_sent = c->bytes_sent;
+    s->info.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (s->info.dropped_offers) {
+        s->set_error("sharded build: %lld reverse-offer records did not fit their region (cap %lld): results would be degraded", (long long)s->info.dropped_offers, (long long)s->cap_o);
+        return 1;
+    }
+    return 0;
+}
+
+extern "C" int32_t nnd_shard_build(nnd_shard_t s, const float *x_local_dev, void *x_stream, int32_t *out_idx_dev, float *out_dist_dev) {
+    if (!s) { snprintf(g_serr2, sizeof(g_serr2), "nnd_shard_build: null shard"); return 1; }
+    if (!x_local_dev || !out_idx_dev || !out_dist_dev) { s->set_error("nnd_shard_build: null buffer"); return 1; }
+    const int rc = shard_build(s, x_local_dev, x_stream, out_idx_dev, out_dist_dev);
+    if (rc) (void)nnd_comm_abort(s->comm);  // LOCAL: do not leave the other ranks waiting in a barrier
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nnd_build over several GPUs of this node: host buffers in, host buffers out, one host thread per GPU.
+extern "C" int32_t nnd_build_multi(const nnd_params *params, const float *x, int32_t n_devices, const int32_t *devices, int32_t *out_idx,
+                                   float *out_dist, nnd_stats *stats, nnd_shard_info *info_rank0, char *err, int32_t errlen) {
+    auto fail = [&](const std::string &msg) {
+        if (err && errlen > 0) { strncpy(err, msg.c_str(), (size_t)errlen - 1); err[errlen - 1] = 0; }
+        return 1;
+    };
+    if (!params || !x || !out_idx || !out_dist) return fail("nnd_build_multi: null argument");
+    if (n_devices < 1 || n_devices > NND_MAX_RANKS) return fail("nnd_build_multi: n_devices must be in 1..64");
+    const int G = n_devices;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("nnd_build_multi: no HIP device visible (this library has no CPU path)");
+    std::vector<int32_t> dev(G);
+    bool distinct = true;
+    for (int r = 0; r < G; r++) {
+        dev[r] = devices ? devices[r] : r;
+        if (dev[r] < 0 || dev[r] >= ndev) return fail("nnd_build_multi: device " + std::to_string(dev[r]) + " out of range (" + std::to_string(ndev) + " visible)");
+        for (int q = 0; q < r; q++) distinct = distinct && dev[q] != dev[r];
+    }
+    std::vector<int64_t> sizes(G);
+    std::vector<int64_t> lo(G + 1);
+    for (int r = 0; r <= G; r++) lo[r] = params->n * r / G;
+    for (int r = 0; r < G; r++) sizes[r] = lo[r + 1] - lo[r];
+    // communicators: RCCL between distinct GPUs, the LOCAL transport when ranks share one
+    std::vector<nnd_comm_t> comms(G, nullptr);
+    unsigned char id[NND_COMM_ID_BYTES];
+    const bool use_rccl = distinct && G > 1;
+    if (use_rccl) {
+        if (nnd_comm_unique_id(id)) return fail(std::string("nnd_build_multi: ") + nnd_comm_last_error(nullptr));
+    } else {
+        if (nnd_comm_create_local(comms.data(), G, dev.data())) return fail(std::string("nnd_build_multi: ") + nnd_comm_last_error(nullptr));
+    }
+    std::vector<std::string> errs(G);
+    std::vector<int> rcs(G, 0);
+    std::vector<nnd_stats> st(G);
+    std::vector<nnd_shard_info> inf(G);
+    auto run = [&](int r) {
+        auto bail = [&](const std::string &m) {
+            errs[r] = m;
+            rcs[r] = 1;
+            if (comms[r]) (void)nnd_comm_abort(comms[r]);
+        };
+        if (hipSetDevice(dev[r]) != hipSuccess) return bail("hipSetDevice failed");
+        if (use_rccl && nnd_comm_create_rccl(&comms[r], id, G, r, dev[r])) return bail(nnd_comm_last_error(nullptr));
+        nnd_params p = *params;
+        p.device = dev[r];
+        nnd_shard_t sh = nullptr;
+        if (nnd_shard_create(&sh, &p, comms[r], sizes.data())) return bail(nnd_shard_last_error(nullptr));
+        const size_t nl = (size_t)sizes[r];
+        float *dx = nullptr;
+        int32_t *di = nullptr;
+        float *dd = nullptr;
+        bool ok = hipMalloc((void **)&dx, sizeof(float) * (nl ? nl : 1) * p.dim) == hipSuccess &&
+                  hipMalloc((void **)&di, sizeof(int32_t) * (nl ? nl : 1) * p.n_neighbors) == hipSuccess &&
+                  hipMalloc((void **)&dd, sizeof(float) * (nl ? nl : 1) * p.n_neighbors) == hipSuccess;
+        if (ok && nl) ok = hipMemcpy(dx, x + (size_t)lo[r] * p.dim, sizeof(float) * nl * p.dim, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) bail("allocation / H2D of the shard failed");
+        else if (nnd_shard_build(sh, dx, nullptr, di, dd)) bail(nnd_shard_last_error(sh));
+        else if (nl && (hipMemcpy(out_idx + (size_t)lo[r] * p.n_neighbors, di, sizeof(int32_t) * nl * p.n_neighbors, hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(out_dist + (size_t)lo[r] * p.n_neighbors, dd, sizeof(float) * nl * p.n_neighbors, hipMemcpyDeviceToHost) != hipSuccess))
+            bail("D2H of the result failed");
+        (void)nnd_shard_get_stats(sh, &st[r]);
+        (void)nnd_shard_get_info(sh, &inf[r]);
+        if (dx) (void)hipFree(dx);
+        if (di) (void)hipFree(di);
+        if (dd) (void)hipFree(dd);
+        (void)nnd_shard_destroy(sh);
+    };
+    std::vector<std::thread> th;
+    for (int r = 0; r < G; r++) th.emplace_back(run, r);
+    for (auto &t : th) t.join();
+    for (int r = 0; r < G; r++)
+        if (comms[r]) (void)nnd_comm_destroy(comms[r]);
+    for (int r = 0; r < G; r++)
+        if (rcs[r]) return fail("nnd_build_multi: rank " + std::to_string(r) + ": " + errs[r]);
+    if (stats) *stats = st[0];
+    if (info_rank0) *info_rank0 = inf[0];
+    return 0;
+}

@@ -55,6 +55,12 @@ struct nnd_handle_s {
     int64_t *shard_bounds = nullptr;      // device (n_ranks + 1): first row of every rank, then n
     long long *shard_cursors = nullptr;   // device (66): per-destination record cursors, [64] dropped, [65] deferred
     bool stream_owned = true;             // false after nnd_set_stream: the caller's stream is borrowed
+    // A shard created by nnd_create_impl with bounds allocates the per-OWNED-row tables (cand, rbuf, active) for its own
+    // rows only; the pointers above are biased by -own_lo rows so that kernels keep indexing by global vertex id.
+    bool slim = false;
+    void *slim_alloc[3] = {nullptr, nullptr, nullptr};  // the allocations behind cand / rbuf / active (always; biased or not)
+    int64_t slim_rows() const { return slim ? own_hi - own_lo : n; }  // rows those three tables hold
+    int64_t slim_row0() const { return slim ? own_lo : 0; }            // first of them
     uint32_t seed = 0, tree_seed = 0;
 
     // data
@@ -142,6 +148,8 @@ struct nnd_handle_s {
 };
 typedef nnd_handle_s nnd_ctx;
 
+// capi.hip: nnd_create with the shard geometry known up front (bounds == nullptr: a plain handle)
+int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bounds_host, int n_ranks, int rank);
 // ---- implemented in the kernel translation units; each returns 0 / sets ctx->err ----
 int nnd_launch_prep(nnd_ctx *ctx);
 int nnd_launch_reset_graph(nnd_ctx *ctx);
@@ -161,11 +169,8 @@ int nnd_launch_merge(nnd_ctx *ctx);
 int nnd_launch_finalize(nnd_ctx *ctx, int32_t *out_idx_dev, float *out_dist_dev);
 int nnd_launch_pairwise(nnd_ctx *ctx, const int32_t *rows_a_dev, int na, const int32_t *rows_b_dev, int nb,
                         float *out_dev);
-int nnd_launch_proposal_counts(nnd_ctx *ctx, int32_t *cnt_dev);
-int nnd_launch_export_proposals(nnd_ctx *ctx, const int64_t *offsets_dev, uint64_t *keys_out, int32_t *targets_out);
 int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_t *targets, int64_t count);
 int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
-int nnd_launch_refresh_th(nnd_ctx *ctx, int64_t lo, int64_t hi);
 int nnd_launch_clear_new_flags(nnd_ctx *ctx);
 int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev, const nnd_prune_opts *opts,
                               const int32_t *degree_dev);
@@ -207,3 +212,34 @@ static inline hipError_t nnd_sync_spin(nnd_ctx *ctx) {
     }
     return e;
 }
+
+// Stage timers are DEFERRED: begin/end events are recorded on the stream and read back in one go (t_flush) where the
+// host waits anyway, so timing a stage never drains the GPU pipeline between stages.
+static inline int t_begin(nnd_ctx *ctx) {
+    const int idx = ctx->tev_used;
+    while ((int)ctx->tev.size() < idx + 2) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return -1;  // callers skip the timer
+        ctx->tev.push_back(e);
+    }
+    (void)hipEventRecord(ctx->tev[idx], ctx->stream);
+    ctx->tev_used += 2;
+    return idx;
+}
+static inline void t_end(nnd_ctx *ctx, int idx, float *dst, bool add) {
+    if (idx < 0) return;
+    (void)hipEventRecord(ctx->tev[idx + 1], ctx->stream);
+    ctx->tlog.push_back({idx, dst, add});
+}
+static inline void t_flush(nnd_ctx *ctx) {
+    if (ctx->tlog.empty()) { ctx->tev_used = 0; return; }
+    (void)nnd_sync_spin(ctx);
+    for (const nnd_tlog &t : ctx->tlog) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ctx->tev[t.ev], ctx->tev[t.ev + 1]);
+        if (t.add) *t.dst += ms; else *t.dst = ms;
+    }
+    ctx->tlog.clear();
+    ctx->tev_used = 0;
+}
+

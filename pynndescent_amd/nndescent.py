@@ -101,7 +101,14 @@ class NNDescent:
         parallel_batch_queries=False,
         verbose=False,
         device=0,
+        n_devices=1,
+        devices=None,
     ):
+        """``device``: HIP ordinal of the GPU that builds the index.  ``n_devices`` > 1: the build is row-sharded over that
+        many GPUs of this node (``nnd_build_multi``: one host thread per GPU inside the library, RCCL over xGMI; the
+        reference's analogue is ``n_jobs``, pynndescent_.py:1141-1143); ``devices`` lists their ordinals (default
+        0..n_devices-1; a list that repeats an ordinal puts several ranks on one GPU).  Everything after the build
+        (``prepare``, ``query``, ``update``) runs on ``device``."""
         if n_trees is None:
             n_trees = max(3, min(12, int(round(2.0 * np.log10(data.shape[0])))))  # pynndescent_.py:1009-1010
         if n_iters is None:
@@ -134,6 +141,10 @@ class NNDescent:
         self.parallel_batch_queries = parallel_batch_queries
         self.verbose = verbose
         self.device = device
+        self.n_devices = int(n_devices)
+        self.devices = None if devices is None else [int(v) for v in devices]
+        if self.n_devices < 1 or (self.devices is not None and len(self.devices) != self.n_devices):
+            raise ValueError("n_devices must be >= 1 and match len(devices)")
 
         if callable(metric) or metric not in _METRIC_CODES:
             if callable(metric) or metric in _KNOWN_REFERENCE_METRICS:
@@ -206,6 +217,41 @@ class NNDescent:
             if init_dist is not None and init_graph.shape != np.asarray(init_dist).shape:
                 raise ValueError("The shapes of init graph and init distances do not match!")  # pynndescent_.py:1236
 
+        if self.n_devices > 1 and init_graph is None:
+            self._build_multi(data, metric, n_trees, eff_trees, eff_leaf_size, effective_max_candidates, n_iters, delta,
+                              max_rptree_depth, tree_states, verbose)
+        else:
+            self._build_single(data, metric, n_trees, eff_trees, eff_leaf_size, effective_max_candidates, n_iters, delta,
+                               max_rptree_depth, tree_states, init_graph, init_dist, verbose, device)
+
+        if np.any(self._neighbor_graph[0] < 0):  # pynndescent_.py:1262-1267
+            warn(
+                "Failed to correctly find n_neighbors for some samples."
+                " Results may be less than ideal. Try re-running with"
+                " different parameters."
+            )
+
+    def _build_multi(self, data, metric, n_trees, eff_trees, eff_leaf_size, effective_max_candidates, n_iters, delta,
+                     max_rptree_depth, tree_states, verbose):
+        """Row-sharded build over several GPUs, one call into the library (include/pynnd_amd.h nnd_build_multi)."""
+        from . import sharded
+
+        if verbose:
+            print(ts(), "NN descent for", str(n_iters), "iterations on", self.n_devices, "GPUs")
+        idx, dst, st, info = sharded.build_multi(
+            data, self.n_devices, self.devices, metric, self.n_neighbors, eff_trees, eff_leaf_size, effective_max_candidates,
+            n_iters, delta, max_rptree_depth=max_rptree_depth, rng_state=self.rng_state, tree_state=tree_states[0])
+        self._rp_forest = _DeviceForestSentinel(n_trees, st["n_leaves"], eff_leaf_size) if self.tree_init else None
+        self._neighbor_graph = (idx, dst)
+        self._build_stats = st
+        self._shard_info = info
+        if verbose:
+            for it, c in enumerate(info["c"]):
+                print("\t", it + 1, " / ", n_iters, " c =", c)
+
+    def _build_single(self, data, metric, n_trees, eff_trees, eff_leaf_size, effective_max_candidates, n_iters, delta,
+                      max_rptree_depth, tree_states, init_graph, init_dist, verbose, device):
+        n, n_neighbors = data.shape[0], self.n_neighbors
         builder = _capi.Builder(
             n, data.shape[1], _METRIC_CODES[metric], n_neighbors, eff_trees, eff_leaf_size, max_rptree_depth,
             effective_max_candidates, n_iters, delta, self.rng_state, tree_states[0], device=device,
@@ -239,13 +285,6 @@ class NNDescent:
             self._build_stats = builder.stats()
         finally:
             builder.close()
-
-        if np.any(self._neighbor_graph[0] < 0):  # pynndescent_.py:1262-1267
-            warn(
-                "Failed to correctly find n_neighbors for some samples."
-                " Results may be less than ideal. Try re-running with"
-                " different parameters."
-            )
 
     @property
     def neighbor_graph(self):
@@ -546,8 +585,11 @@ class NNDescent:
                     break
             self._neighbor_graph = builder.finalize()
             self._build_stats = builder.stats()
+        except StopIteration:
+            pass
         finally:
-            builder.close()
+            if builder is not None:
+                builder.close()
         self._raw_data = raw
         if hasattr(self, "_search_graph"):  # pynndescent_.py:2538-2553: the derived structures are rebuilt
             for name in ("_search_graph", "_search_forest", "_vertex_order", "_searcher"):

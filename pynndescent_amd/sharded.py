@@ -1,31 +1,25 @@
-"""Row-sharded multi-GPU index build: one process (or thread) per GPU, exchanges over RCCL.
+"""Row-sharded multi-GPU index build: host plumbing around the C-side shard builder (csrc/shard.hip).
 
-The reference is single-process; what it offers as a sharding rule is owner-computes over contiguous
-vertex ranges (``apply_graph_update_array`` utils.py:709-731, ``new_build_candidates`` utils.py:259-306,
-``init_rp_tree`` pynndescent_.py:154-185).  Here the same rule crosses GPUs:
+The reference is single-process; what it offers as a sharding rule is owner-computes over contiguous vertex ranges
+(``apply_graph_update_array`` utils.py:709-731, ``new_build_candidates`` utils.py:259-306, ``init_rp_tree``
+pynndescent_.py:154-185) and ``n_jobs`` (pynndescent_.py:1141-1143).  The whole per-rank build -- point-set all-gather,
+forest split by tree, k-list row exchange, and per NN-descent iteration the threshold all-gather, the reverse-offer and
+proposal all-to-all-v, the update count for the stop rule -- runs INSIDE ``libpynnd_amd.so`` on one HIP stream, with the
+exchanges issued from the C side (``ncclGroupStart`` / ``ncclSend`` / ``ncclRecv`` / ``ncclGroupEnd`` over xGMI; scheme in
+``include/pynnd_amd.h``).  What is left here:
 
-* rank r owns rows ``[lo_r, hi_r)`` of the k-lists; the point set is replicated once (all-gather), so
-  candidate vectors never travel again;
-* the RP forest is split by TREE: rank r builds ``n_trees/G`` trees over all points, seeds the k-lists
-  of every point from its own leaves, and the partial lists are shipped to the owners
-  (all-to-all-v of k-list row blocks) and merged there;
-* per NN-descent iteration every rank scans only ITS OWN rows:
-  (1) **threshold all-gather**, 4 bytes per row: the worst distance of every remote row, all the join needs of a
-      remote candidate (a stale threshold only admits extra proposals);
-  (2) **reverse-offer all-to-all-v** (exchange X2): an edge ``v -> u`` whose target ``u`` lives on another rank becomes a
-      12-byte record ``(u | class, priority | v)`` for u's owner, which folds it into its slot banks exactly like a
-      local offer -- the cross-process form of the ownership test ``utils.py:266-273``;
-  (3) local join of the owned vertices; a proposal for a remote target skips the membership test (the owner
-      dedups in its merge, ``utils.py:489-492``);
-  (4) **proposal all-to-all-v** of ``(target, dist | source)`` records, owner-side merge (``utils.py:721-731``);
-  (5) **all-reduce** of the update count for the stop rule (pynndescent_.py:317).
+* ``make_comm``        -- create the rank's communicator: **RCCL** when ``torch.distributed`` runs the ``nccl`` backend
+                          (the 128-byte unique id is the only thing that travels through torch); **HOST** staging with
+                          a gloo callback otherwise (two processes sharing one GPU in the tests);
+* ``LocalGroup``       -- G ranks as threads of this process on one or several GPUs (LOCAL transport: device copies);
+* ``ShardedBuilder``   -- the rank's persistent state (``nnd_shard_t``), ``build(x_local)``;
+* ``build_multi``      -- the one-call form, ``nnd_build_multi``: host arrays in and out, one host thread per GPU inside
+                          the library -- what ``NNDescent(..., n_devices=G)`` calls.
 
-The device-side halves are C-ABI entry points of ``include/pynnd_amd.h``; they are stream-ordered and the handle runs
-on this module's torch stream (``nnd_set_stream``), so kernels and collectives need no host synchronisation between
-them: the host waits only where it needs a number (record counts, the update count).  This module is host plumbing
-(torch tensors as device buffers, ``torch.distributed`` -- backend "nccl" is RCCL on ROCm).
-``ThreadComm`` runs the same code with G ranks as threads of one process on one GPU (tests).
+``TorchDistComm`` / ``ThreadComm`` are small host-side transports (all-gather-v, all-to-all-v, all-reduce on tensors);
+the HOST callback is built on the former, and bench.py uses it for the timing reductions.
 """
+import ctypes as C
 import threading
 
 import numpy as np
@@ -35,7 +29,7 @@ from . import _capi
 
 
 # ------------------------------------------------------------------------------------------------
-# partitioning helpers (pure python / torch; covered by the gloo CPU tests)
+# partitioning helpers (pure python; the C side uses the same formulas)
 
 def shard_ranges(n_total, world):
     """Contiguous, near-equal row ranges: rank r owns [n*r//G, n*(r+1)//G)."""
@@ -55,10 +49,10 @@ def segment_bounds(offsets_ext, ranges):
 
 
 # ------------------------------------------------------------------------------------------------
-# communicators
+# host-side transports on tensors
 
 class TorchDistComm:
-    """torch.distributed transport (backend nccl == RCCL over xGMI on ROCm; gloo on CPU for tests)."""
+    """torch.distributed transport on tensors (gloo on CPU; nccl == RCCL on ROCm)."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -116,7 +110,7 @@ class TorchDistComm:
                     ops.append(self.dist.irecv(recv[peer], peer, group=self.group))
             for op in ops:
                 op.wait()
-        else:  # nccl (= RCCL): one all_to_all_single with split sizes, the canonical all-to-all-v
+        else:  # nccl (= RCCL): one all_to_all_single with split sizes
             inp = torch.cat([t.reshape((t.shape[0],) + tail) for t in send], dim=0).contiguous()
             out = torch.empty((sum(rc),) + tail, dtype=send[0].dtype, device=dev)
             self.dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
@@ -140,7 +134,7 @@ class TorchDistComm:
 
 
 class ThreadComm:
-    """G ranks as threads of one process (one GPU): same call pattern, exchange through shared lists."""
+    """G ranks as threads of one process: the same tensor contract, exchange through shared lists (tests)."""
 
     class _Shared:
         def __init__(self, world):
@@ -159,8 +153,6 @@ class ThreadComm:
         return [cls(sh, r) for r in range(world)]
 
     def _exchange(self, obj, take):
-        """Every rank posts ``obj``; ``take(all_posted)`` copies what this rank needs.  The ranks run on different
-        streams of one GPU: a rank's writes are complete before it posts, its copies before the buffers are released."""
         if torch.cuda.is_available():
             torch.cuda.current_stream().synchronize()
         self.s.slots[self.rank] = obj
@@ -186,200 +178,248 @@ class ThreadComm:
 
 
 # ------------------------------------------------------------------------------------------------
+# communicators of the C-side shard builder
 
-def _sync():
-    if torch.cuda.is_available():
-        torch.cuda.current_stream().synchronize()
+class Comm:
+    """Owns one ``nnd_comm_t``."""
+
+    def __init__(self, handle, world, rank, keep=None):
+        self.lib = _capi.load_library()
+        self._h = handle
+        self.world = world
+        self.rank = rank
+        self._keep = keep  # callback objects the C side holds pointers to
+
+    def set_serial(self, on=True):
+        if self.lib.nnd_comm_local_set_serial(self._h, 1 if on else 0) != 0:
+            raise _capi.NNDError(self.lib.nnd_comm_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.nnd_comm_destroy(self._h)
+            self._h = _capi._H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LocalGroup:
+    """``world`` ranks as threads of this process (LOCAL transport); ``devices[r]`` = HIP ordinal of rank r (default: all
+    on device 0 -- several ranks sharing one GPU, which is how the tests run on a one-GPU box)."""
+
+    def __init__(self, world, devices=None):
+        lib = _capi.load_library()
+        arr = (_capi._H * world)()
+        dev = None
+        if devices is not None:
+            dev = np.ascontiguousarray(devices, np.int32)
+            assert dev.shape == (world,)
+        if lib.nnd_comm_create_local(arr, world, _capi._ptr(dev)) != 0:
+            raise _capi.NNDError(lib.nnd_comm_last_error(None).decode())
+        self.comms = [Comm(_capi._H(arr[r]), world, r) for r in range(world)]
+        self.devices = [0] * world if devices is None else [int(v) for v in devices]
+
+    def __getitem__(self, r):
+        return self.comms[r]
+
+    def close(self):
+        for c in self.comms:
+            c.close()
+
+
+def _host_callback(tcomm):
+    """nnd_host_exchange_fn on top of a TorchDistComm over gloo: an all-to-all-v of byte segments of host buffers."""
+    world, rank, dist = tcomm.world, tcomm.rank, tcomm.dist
+
+    def exchange(_user, send, send_off, send_bytes, recv, recv_off, recv_bytes):
+        try:
+            ops, keep = [], []
+            for peer in range(world):
+                sb, rb = int(send_bytes[peer]), int(recv_bytes[peer])
+                if peer == rank:
+                    if sb:
+                        C.memmove(recv + int(recv_off[peer]), send + int(send_off[peer]), sb)
+                    continue
+                if sb:
+                    buf = (C.c_uint8 * sb).from_address(send + int(send_off[peer]))
+                    t = torch.frombuffer(buf, dtype=torch.uint8)
+                    keep.append(t)
+                    ops.append(dist.isend(t, peer, group=tcomm.group))
+                if rb:
+                    buf = (C.c_uint8 * rb).from_address(recv + int(recv_off[peer]))
+                    t = torch.frombuffer(buf, dtype=torch.uint8)
+                    keep.append(t)
+                    ops.append(dist.irecv(t, peer, group=tcomm.group))
+            for op in ops:
+                op.wait()
+            if not any(int(send_bytes[p]) or int(recv_bytes[p]) for p in range(world)):
+                dist.barrier(group=tcomm.group)  # the zero-byte call is the transport's barrier
+            return 0
+        except Exception as exc:  # pragma: no cover
+            print("pynndescent_amd host exchange failed:", repr(exc))
+            return 1
+
+    return _capi.HOST_EXCHANGE_FN(exchange)
+
+
+def make_comm(device_index, group=None):
+    """The rank's communicator under ``torch.distributed``: RCCL when the process group runs the nccl backend (the
+    unique id is broadcast through torch, the data path never touches it again); HOST staging over gloo otherwise."""
+    import torch.distributed as dist
+
+    lib = _capi.load_library()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    h = _capi._H()
+    if dist.get_backend(group) == "nccl":
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            if lib.nnd_comm_unique_id(buf) != 0:
+                raise _capi.NNDError(lib.nnd_comm_last_error(None).decode())
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        ident = ident.to(torch.device("cuda", device_index))
+        dist.broadcast(ident, 0, group=group)
+        raw = bytes(ident.cpu().tolist())
+        if lib.nnd_comm_create_rccl(C.byref(h), raw, world, rank, int(device_index)) != 0:
+            raise _capi.NNDError(lib.nnd_comm_last_error(None).decode())
+        return Comm(h, world, rank)
+    cb = _host_callback(TorchDistComm(group))
+    if lib.nnd_comm_create_host(C.byref(h), world, rank, int(device_index), C.cast(cb, C.c_void_p), None) != 0:
+        raise _capi.NNDError(lib.nnd_comm_last_error(None).decode())
+    return Comm(h, world, rank, keep=cb)
+
+
+# ------------------------------------------------------------------------------------------------
+
+def _global_params(n_total, dim, metric, n_neighbors, n_trees, leaf_size, max_candidates, n_iters, delta, seed,
+                   max_rptree_depth, device):
+    """nnd_params of the GLOBAL build with the reference's derived defaults (pynndescent_.py:1009-1012, 1135-1138;
+    rp_trees.py:2845) and its RandomState draw order (identical on every rank)."""
+    k = int(n_neighbors)
+    n_iters = max(5, int(round(np.log2(n_total)))) if n_iters is None else int(n_iters)
+    leaf_size = max(60, min(256, 5 * k)) if leaf_size is None else int(leaf_size)
+    mc = min(60, k) if max_candidates is None else int(max_candidates)
+    rs = np.random.RandomState(seed)
+    lim = np.iinfo(np.int32)
+    rng_state = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
+    _search = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
+    tree_states = rs.randint(lim.min + 1, lim.max - 1, size=(max(int(n_trees), 1), 3)).astype(np.int64)
+    metric_code = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN,
+                   "cosine": _capi.NND_METRIC_ALT_COSINE}[metric]
+    p = _capi.NNDParams()
+    p.n, p.dim, p.metric, p.n_neighbors, p.n_trees, p.leaf_size = int(n_total), int(dim), metric_code, k, int(n_trees), leaf_size
+    p.max_depth, p.max_candidates, p.n_iters, p.delta = int(max_rptree_depth), mc, n_iters, float(delta)
+    p.device, p.join_blocks = int(device), 1
+    for i in range(3):
+        p.rng_state[i], p.tree_rng[i] = int(rng_state[i]), int(tree_states[0][i])
+    return p
 
 
 class ShardedBuilder:
     """Persistent state of one rank (HBM allocations survive across builds; bench.py times ``build``)."""
 
-    PROPOSAL_SLOTS_SHIPPED = 24  # region capacity per destination row (of 64 slots); what does not fit travels next iteration
-
     def __init__(self, comm, shard_sizes, dim, metric="euclidean", n_neighbors=15, n_trees=8, leaf_size=None,
                  max_candidates=None, n_iters=None, delta=0.001, seed=0, max_rptree_depth=200, device_index=None):
+        self.lib = _capi.load_library()
         self.comm = comm
-        rank, world = comm.rank, comm.world
-        sizes = [int(v) for v in shard_sizes]
-        assert len(sizes) == world
-        self.n_total = sum(sizes)
-        bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        self.bounds = bounds
-        self.ranges = [(int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
-        self.lo, self.hi = self.ranges[rank]
-        self.k = int(n_neighbors)
-        self.d = int(dim)
-        self.delta = float(delta)
-        self.n_trees = int(n_trees)
-        # the reference's derived defaults, on the GLOBAL n (pynndescent_.py:1009-1012, 1135-1138; rp_trees.py:2845)
-        self.n_iters = max(5, int(round(np.log2(self.n_total)))) if n_iters is None else int(n_iters)
-        leaf_size = max(60, min(256, 5 * self.k)) if leaf_size is None else int(leaf_size)
-        mc = min(60, self.k) if max_candidates is None else int(max_candidates)
-        rs = np.random.RandomState(seed)  # identical draws on every rank
-        lim = np.iinfo(np.int32)
-        rng_state = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
-        _search = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
-        tree_states = rs.randint(lim.min + 1, lim.max - 1, size=(max(self.n_trees, 1), 3)).astype(np.int64)
-        t0, t1 = tree_ranges(self.n_trees, world)[rank]
-        self.local_trees = t1 - t0
+        sizes = np.ascontiguousarray([int(v) for v in shard_sizes], np.int64)
+        assert sizes.shape == (comm.world,)
+        self.n_total = int(sizes.sum())
+        bounds = np.concatenate([[0], np.cumsum(sizes)])
+        self.lo, self.hi = int(bounds[comm.rank]), int(bounds[comm.rank + 1])
+        self.k, self.d = int(n_neighbors), int(dim)
         if device_index is None:
             device_index = torch.cuda.current_device()
         self.dev = torch.device("cuda", device_index)
-        metric_code = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN,
-                       "cosine": _capi.NND_METRIC_ALT_COSINE}[metric]
-        self.b = _capi.Builder(self.n_total, self.d, metric_code, self.k, self.local_trees, leaf_size, max_rptree_depth, mc,
-                               self.n_iters, delta, rng_state, tree_states[min(t0, max(self.n_trees, 1) - 1)],
-                               device=device_index)
-        # the handle runs on THIS builder's torch stream: its kernels and the collectives are ordered by the stream
-        with torch.cuda.device(self.dev):
-            self.stream = torch.cuda.Stream(device=self.dev)
-        self.b.set_stream(self.stream.cuda_stream)
-        self.b.set_shard_bounds(bounds, rank)
-        self.ks = self.b.row_stride()
-        dev = self.dev
+        self.params = _global_params(self.n_total, dim, metric, n_neighbors, n_trees, leaf_size, max_candidates, n_iters, delta,
+                                     seed, max_rptree_depth, device_index)
+        self._h = _capi._H()
+        if self.lib.nnd_shard_create(C.byref(self._h), C.byref(self.params), comm._h, _capi._ptr(sizes)) != 0:
+            raise _capi.NNDError(self.lib.nnd_shard_last_error(None).decode())
         n_own = self.hi - self.lo
-        self.own_th = torch.empty((n_own,), dtype=torch.float32, device=dev)
-        self.out_idx = torch.empty((n_own, self.k), dtype=torch.int32, device=dev)
-        self.out_dist = torch.empty((n_own, self.k), dtype=torch.float32, device=dev)
-        # record regions, one per destination rank: reverse offers (at most every owned edge goes to one rank) and proposals
-        self.cap_o = max(1, n_own * self.k)
-        self.cap_p = max(64, max(z - a for a, z in self.ranges) * self.PROPOSAL_SLOTS_SHIPPED)
-        self.off_t = torch.empty((world * self.cap_o,), dtype=torch.int32, device=dev)
-        self.off_k = torch.empty((world * self.cap_o,), dtype=torch.int64, device=dev)
-        self.prop_t = torch.empty((world * self.cap_p,), dtype=torch.int32, device=dev)
-        self.prop_k = torch.empty((world * self.cap_p,), dtype=torch.int64, device=dev)
-        self.counts = torch.zeros((world,), dtype=torch.int64, device=dev)
-        self._empty_t = torch.empty((0,), dtype=torch.int32, device=dev)
-        self._empty_k = torch.empty((0,), dtype=torch.int64, device=dev)
+        self.out_idx = torch.empty((n_own, self.k), dtype=torch.int32, device=self.dev)
+        self.out_dist = torch.empty((n_own, self.k), dtype=torch.float32, device=self.dev)
 
     def close(self):
-        self.b.close()
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.nnd_shard_destroy(self._h)
+            self._h = _capi._H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def build(self, x_local, verbose=False):
-        """One complete sharded build.  Returns (idx (n_local,k) GLOBAL ids, alt-space dist, info)."""
-        with torch.cuda.device(self.dev):
-            self.stream.wait_stream(torch.cuda.current_stream(self.dev))  # x_local was produced on the caller's stream
-            with torch.cuda.stream(self.stream):
-                out = self._build(x_local, verbose)
-                self.stream.synchronize()
-        return out
-
-    def _exchange_records(self, buf_t, buf_k, cap, counts):
-        """all-to-all-v of the per-destination regions [d*cap, d*cap + counts[d]); returns the records received from the
-        OTHER ranks as (targets, keys, n)."""
-        comm, rank = self.comm, self.comm.rank
-        send_t = [buf_t[d * cap: d * cap + counts[d]] for d in range(comm.world)]
-        send_k = [buf_k[d * cap: d * cap + counts[d]] for d in range(comm.world)]
-        recv_t, rc = comm.all_to_all_v(send_t, return_counts=True)
-        recv_k = comm.all_to_all_v(send_k, rcounts=rc)
-        parts_t = [t for i, t in enumerate(recv_t) if i != rank and t.numel()]
-        parts_k = [t for i, t in enumerate(recv_k) if i != rank and t.numel()]
-        if not parts_t:
-            return self._empty_t, self._empty_k, 0
-        rt = torch.cat(parts_t) if len(parts_t) > 1 else parts_t[0].contiguous()
-        rk = torch.cat(parts_k) if len(parts_k) > 1 else parts_k[0].contiguous()
-        return rt, rk, int(rt.numel())
-
-    def _build(self, x_local, verbose):
-        comm, b, dev, ks, k = self.comm, self.b, self.dev, self.ks, self.k
-        rank, world = comm.rank, comm.world
-        lo, hi, ranges, n_total = self.lo, self.hi, self.ranges, self.n_total
-        info = {"n_total": n_total, "range": (lo, hi), "local_trees": self.local_trees, "iters": 0, "c": [],
-                "exchanged_records": [], "offer_records": [], "proposal_records": []}
-        # ---- replicate the point set once (all-gather over xGMI): candidate vectors never travel again ----
-        if world > 1:
-            x_full = torch.cat(comm.all_gather_v(x_local.contiguous()), dim=0).contiguous()
-        else:
-            x_full = x_local.contiguous()
-        assert x_full.shape == (n_total, self.d)
-        b.set_data_device(x_full.data_ptr(), keepalive=x_full)  # prep kernel + k-list reset (stream-ordered)
-
-        # ---- forest split by tree: every rank seeds ALL rows from its own trees, owners merge the partial lists ----
-        if self.local_trees > 0:
-            b.make_forest()
-            b.init_from_leaves()
-        if self.n_trees > 0 and world > 1:
-            send_e, send_d = [], []
-            for (a, z) in ranges:
-                e = torch.empty(((z - a) * ks,), dtype=torch.int32, device=dev)
-                dd = torch.empty(((z - a) * ks,), dtype=torch.float32, device=dev)
-                b.export_graph_rows(a, z, e.data_ptr(), dd.data_ptr())
-                send_e.append(e)
-                send_d.append(dd)
-            recv_e, rc = comm.all_to_all_v(send_e, return_counts=True)
-            recv_d = comm.all_to_all_v(send_d, rcounts=rc)
-            for src in range(world):
-                if src != rank and recv_e[src].numel():
-                    b.merge_graph_rows(lo, hi, recv_e[src].data_ptr(), recv_d[src].data_ptr())
-            del send_e, send_d, recv_e, recv_d
-        b.init_random()  # owned rows that are still not full (pynndescent_.py:188-203)
-
-        keep = None
-        for it in range(self.n_iters):
-            n_off = n_prop = 0
-            # (1) thresholds of the remote rows: 4 bytes per row
-            if world > 1:
-                b.export_thresholds_async(lo, hi, self.own_th.data_ptr())
-                all_t = comm.all_gather_v(self.own_th)
-                for src, (a, z) in enumerate(ranges):
-                    if src != rank and z > a:
-                        b.import_thresholds_async(a, z, all_t[src].data_ptr())
-            # (2) sampling: own rows only; offers to remote targets travel as records
-            b.sample_begin(self.cap_o, self.off_t.data_ptr(), self.off_k.data_ptr(), self.counts.data_ptr())
-            if world > 1:
-                cnt = [int(c) for c in self.counts.tolist()]  # host wait: the record counts
-                assert max(cnt) <= self.cap_o
-                rt, rk, n_in = self._exchange_records(self.off_t, self.off_k, self.cap_o, cnt)
-                n_off = sum(cnt)
-            else:
-                rt, rk, n_in = self._empty_t, self._empty_k, 0
-            b.sample_finish(rt.data_ptr(), rk.data_ptr(), n_in)
-            # (3) local join of the owned vertices
-            b.descent_join()
-            # (4) proposals for vertices owned elsewhere -> owners
-            if world > 1:
-                b.proposal_export(self.cap_p, self.prop_t.data_ptr(), self.prop_k.data_ptr(), self.counts.data_ptr())
-                cnt = [min(int(c), self.cap_p) for c in self.counts.tolist()]  # host wait
-                pt, pk, n_in = self._exchange_records(self.prop_t, self.prop_k, self.cap_p, cnt)
-                if n_in:
-                    b.import_proposals_async(pk.data_ptr(), pt.data_ptr(), n_in)
-                n_prop = sum(cnt)
-                keep = (all_t, rt, rk, pt, pk)  # alive until the merge below has drained the stream
-            # (5) owner-side merge (reads the counters: host wait), global update count for the stop rule (pynndescent_.py:317)
-            c = comm.all_reduce_sum(b.descent_merge()) if world > 1 else b.descent_merge()
-            keep = None
-            info["c"].append(c)
-            info["offer_records"].append(n_off)
-            info["proposal_records"].append(n_prop)
-            info["exchanged_records"].append(n_off + n_prop)
-            info["iters"] = it + 1
-            if verbose and rank == 0:
-                print("\t", it + 1, " / ", self.n_iters, " c =", c)
-            if c <= self.delta * k * n_total:
-                break
-        del keep
-        b.finalize_device(self.out_idx.data_ptr(), self.out_dist.data_ptr())
-        b.synchronize()
-        info["stats"] = b.stats()
+        """One complete sharded build of this rank's rows.  x_local: float32 (n_local, d) tensor on this rank's GPU.
+        Returns (idx (n_local, k) GLOBAL ids, alt-space dist, info dict); the tensors stay resident on the GPU."""
+        assert x_local.is_cuda and x_local.dtype == torch.float32 and x_local.is_contiguous()
+        assert tuple(x_local.shape) == (self.hi - self.lo, self.d)
+        xs = torch.cuda.current_stream(self.dev).cuda_stream  # the stream that produced x_local: the build waits for it
+        rc = self.lib.nnd_shard_build(self._h, C.c_void_p(x_local.data_ptr()), C.c_void_p(xs) if xs else None,
+                                      C.c_void_p(self.out_idx.data_ptr()), C.c_void_p(self.out_dist.data_ptr()))
+        if rc != 0:
+            raise _capi.NNDError(self.lib.nnd_shard_last_error(self._h).decode())
+        info = self.info()
+        info["stats"] = self.stats()
+        if verbose and self.comm.rank == 0:
+            for it, c in enumerate(info["c"]):
+                print("\t", it + 1, " / ", int(self.params.n_iters), " c =", c)
         return self.out_idx, self.out_dist, info
 
+    def info(self):
+        inf = _capi.NNDShardInfo()
+        self.lib.nnd_shard_get_info(self._h, C.byref(inf))
+        return inf.as_dict()
 
-def sharded_build(comm, x_local, metric="euclidean", n_neighbors=15, n_trees=8, leaf_size=None, max_candidates=None,
-                  n_iters=None, delta=0.001, seed=0, max_rptree_depth=200, device_index=None, verbose=False):
-    """Convenience wrapper: allocate, build the rows this rank owns, release.
+    def stats(self):
+        st = _capi.NNDStats()
+        self.lib.nnd_shard_get_stats(self._h, C.byref(st))
+        return st.as_dict()
 
-    x_local: torch float32 (n_local, d) tensor on this rank's GPU (its shard of the point set).
-    Returns (idx int32 (n_local, k) with GLOBAL neighbour ids, alt-space dist float32 (n_local, k), info dict);
-    the tensors stay resident on the GPU."""
-    n = torch.tensor([x_local.shape[0]], dtype=torch.int64, device=x_local.device)
-    sizes = [int(t.item()) for t in comm.all_gather_v(n)]
+
+def sharded_build(comm, x_local, shard_sizes, metric="euclidean", n_neighbors=15, n_trees=8, leaf_size=None,
+                  max_candidates=None, n_iters=None, delta=0.001, seed=0, max_rptree_depth=200, device_index=None,
+                  verbose=False):
+    """Convenience wrapper: allocate, build the rows this rank owns, release.  Returns (idx int32 (n_local, k) with
+    GLOBAL neighbour ids, alt-space dist float32 (n_local, k), info dict); the tensors stay resident on the GPU."""
     if device_index is None:
         device_index = x_local.device.index if x_local.device.index is not None else torch.cuda.current_device()
-    sb = ShardedBuilder(comm, sizes, x_local.shape[1], metric, n_neighbors, n_trees, leaf_size, max_candidates, n_iters,
+    sb = ShardedBuilder(comm, shard_sizes, x_local.shape[1], metric, n_neighbors, n_trees, leaf_size, max_candidates, n_iters,
                         delta, seed, max_rptree_depth, device_index)
     try:
         idx, dist, info = sb.build(x_local, verbose=verbose)
         return idx.clone(), dist.clone(), info
     finally:
         sb.close()
+
+
+def build_multi(x, n_devices, devices=None, metric="euclidean", n_neighbors=15, n_trees=8, leaf_size=None, max_candidates=None,
+                n_iters=None, delta=0.001, seed=0, max_rptree_depth=200, rng_state=None, tree_state=None):
+    """``nnd_build_multi``: the whole build over ``n_devices`` GPUs of this node in ONE call -- host array in, host arrays
+    out, one host thread per GPU inside the library, RCCL between distinct GPUs (LOCAL copies when ``devices`` repeats an
+    ordinal).  Returns (idx int32 (n, k), alt-space dist float32 (n, k), stats of rank 0, shard info of rank 0)."""
+    lib = _capi.load_library()
+    x = np.ascontiguousarray(x, np.float32)
+    n, d = x.shape
+    p = _global_params(n, d, metric, n_neighbors, n_trees, leaf_size, max_candidates, n_iters, delta, seed, max_rptree_depth, 0)
+    if rng_state is not None:
+        for i in range(3):
+            p.rng_state[i] = int(rng_state[i])
+    if tree_state is not None:
+        for i in range(3):
+            p.tree_rng[i] = int(tree_state[i])
+    dev = None if devices is None else np.ascontiguousarray(devices, np.int32)
+    idx = np.empty((n, int(n_neighbors)), np.int32)
+    dist = np.empty((n, int(n_neighbors)), np.float32)
+    st, inf = _capi.NNDStats(), _capi.NNDShardInfo()
+    err = C.create_string_buffer(1024)
+    rc = lib.nnd_build_multi(C.byref(p), _capi._ptr(x), int(n_devices), _capi._ptr(dev), _capi._ptr(idx), _capi._ptr(dist),
+                             C.byref(st), C.byref(inf), err, 1024)
+    if rc != 0:
+        raise _capi.NNDError(err.value.decode())
+    return idx, dist, st.as_dict(), inf.as_dict()

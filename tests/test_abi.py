@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), "libpynnd_amd.so does not export %s" % name
     assert sorted(_capi.EXPORTED_SYMBOLS) == declared
-    assert lib.nnd_abi_version() == 2
+    assert lib.nnd_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_a_device():
@@ -35,6 +35,30 @@ def test_no_cpu_fallback_without_a_device():
         pytest.skip("a GPU is present")
     with pytest.raises(_capi.NNDError, match="no HIP device|gfx950"):
         _capi.Builder(100, 8, 0, 10, 2, 60, 200, 10, 5, 0.001, [1, 2, 3], [4, 5, 6])
+
+
+def test_multi_gpu_entry_point_fails_loudly_without_a_device():
+    """nnd_build_multi (the n_devices form of the drop-in call) has no CPU path either."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from pynndescent_amd import _capi
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _capi.load_library()
+    p = _capi.NNDParams()
+    p.n, p.dim, p.metric, p.n_neighbors, p.n_trees, p.leaf_size = 64, 4, 0, 5, 1, 60
+    p.max_depth, p.max_candidates, p.n_iters, p.delta = 200, 5, 3, 0.001
+    x = np.zeros((64, 4), np.float32)
+    idx = np.empty((64, 5), np.int32)
+    dist = np.empty((64, 5), np.float32)
+    err = C.create_string_buffer(512)
+    rc = lib.nnd_build_multi(C.byref(p), x.ctypes.data_as(C.c_void_p), 2, None, idx.ctypes.data_as(C.c_void_p),
+                             dist.ctypes.data_as(C.c_void_p), None, None, err, 512)
+    assert rc != 0 and b"no HIP device" in err.value
 
 
 def test_product_code_never_imports_the_oracle():

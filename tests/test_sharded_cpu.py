@@ -1,5 +1,5 @@
-"""Host side of the row-sharded build, on CPU: partition helpers and the torch.distributed transport
-(gloo, world_size 2) that carries the k-list all-gather and the proposal all-to-all-v."""
+"""Host side of the row-sharded build, on CPU: partition helpers, the torch.distributed tensor transport (gloo,
+world_size 2) and the byte-level exchange callback the library's HOST transport calls (csrc/comm.hip)."""
 import os
 import socket
 
@@ -56,6 +56,21 @@ def _worker(rank, world, port, out):
             n = (rank + src) % 3
             want = torch.arange(src * 100 + rank * 10, src * 100 + rank * 10 + n, dtype=torch.int64)
             ok = ok and torch.equal(recv[src], want)
+        # the HOST transport's callback (nnd_host_exchange_fn): all-to-all-v of byte segments of host buffers, the way
+        # csrc/comm.hip calls it -- segments of different lengths, an empty one, and the zero-byte call (barrier)
+        import ctypes as C
+
+        cb = sharded._host_callback(comm)
+        lens = [[3, 5], [0, 7]]  # lens[src][dst] bytes
+        sb = np.concatenate([np.full(lens[rank][dst], 10 * rank + dst, np.uint8) for dst in range(world)])
+        rb = np.zeros(sum(lens[src][rank] for src in range(world)), np.uint8)
+        i64 = lambda v: (C.c_int64 * world)(*v)  # noqa: E731
+        so = np.concatenate([[0], np.cumsum(lens[rank])[:-1]])
+        ro = np.concatenate([[0], np.cumsum([lens[src][rank] for src in range(world)])[:-1]])
+        rc_ = cb(None, sb.ctypes.data, i64(so), i64(lens[rank]), rb.ctypes.data, i64(ro), i64([lens[src][rank] for src in range(world)]))
+        want = np.concatenate([np.full(lens[src][rank], 10 * src + rank, np.uint8) for src in range(world)])
+        ok = ok and rc_ == 0 and np.array_equal(rb, want)
+        ok = ok and cb(None, sb.ctypes.data, i64([0] * world), i64([0] * world), rb.ctypes.data, i64([0] * world), i64([0] * world)) == 0
         # update-count all-reduce (stop rule, pynndescent_.py:317)
         ok = ok and comm.all_reduce_sum(5 + rank) == sum(5 + r for r in range(world))
         comm.barrier()

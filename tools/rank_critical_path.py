@@ -1,0 +1,114 @@
+"""Per-rank critical path of the row-sharded build, measured on ONE GPU.
+
+G ranks run as threads of this process on the same GPU (LOCAL transport) in SERIAL mode: between two exchanges only one
+rank's compute section runs at a time, with the GPU to itself, and is timed (nnd_shard_info.section_ms).  On G real GPUs
+the sections of different ranks run concurrently, so the build's critical path is
+
+    sum over sections of max over ranks (section time)  +  the exchanges,
+
+the exchanges priced from the payload bytes every rank sent (nnd_shard_info.section_bytes) at an xGMI rate: 7 links per
+GPU, --link-gbs effective GB/s each (default 45: what RCCL send/recv groups reach on a ~64 GB/s link), plus --latency-us
+per exchange.  Prints one JSON line.
+
+    python tools/rank_critical_path.py --world 8 --n 10000000 --trees 12
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import exact_knn_sample, recall_at, sift_like  # noqa: E402
+from pynndescent_amd import _capi, sharded  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--k", type=int, default=15)
+    ap.add_argument("--trees", type=int, default=12)
+    ap.add_argument("--link-gbs", type=float, default=45.0)
+    ap.add_argument("--latency-us", type=float, default=40.0)
+    ap.add_argument("--builds", type=int, default=2, help="the last build is reported (the first one pays allocations)")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    G, n = args.world, args.n
+    x = sift_like(n, args.dim, seed=1, device=dev, sample_seed=7)
+    torch.cuda.synchronize()
+    ranges = sharded.shard_ranges(n, G)
+    sizes = [b - a for a, b in ranges]
+    grp = sharded.LocalGroup(G)
+    grp[0].set_serial(True)
+    infos, outs, err = [None] * G, [None] * G, []
+
+    def run(r):
+        sb = None
+        try:
+            torch.cuda.set_device(0)
+            sb = sharded.ShardedBuilder(grp[r], sizes, args.dim, "euclidean", args.k, args.trees, seed=9, device_index=0)
+            lo, hi = ranges[r]
+            xl = x[lo:hi].contiguous()
+            for _ in range(args.builds):
+                idx, dist, info = sb.build(xl)
+            infos[r] = info
+            outs[r] = idx.clone()
+        except Exception as e:
+            err.append("rank %d: %r" % (r, e))
+            _capi.load_library().nnd_comm_abort(grp[r]._h)
+        finally:
+            if sb is not None:
+                sb.close()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    grp.close()
+    if err:
+        sys.exit("\n".join(err))
+    ns = min(len(i["section_ms"]) for i in infos)
+    sec = np.array([i["section_ms"][:ns] for i in infos])      # (G, sections)
+    byt = np.array([i["section_bytes"][:ns] for i in infos])   # payload sent after each section
+    compute_cp = float(sec.max(0).sum())
+    egress = 7.0 * args.link_gbs * 1e9
+    n_exch = int((byt.max(0) > 0).sum())
+    exch_ms = float((byt.max(0) / egress).sum() * 1e3 + n_exch * args.latency_us * 1e-3)
+    # the two bulk exchanges that are not attached to a section: the point-set all-gather precedes the first section
+    allgather_bytes = (n - max(sizes)) * args.dim * 4  # received per rank; ring / direct: each link carries 1/7 of it
+    allgather_ms = allgather_bytes / egress * 1e3
+    idx = torch.cat(outs)
+    rows = torch.from_numpy(np.random.RandomState(0).choice(n, 2000, replace=False)).to(dev)
+    rec = recall_at(exact_knn_sample(x, rows, 10), idx[rows], 10)
+    st0 = infos[0]["stats"]
+    out = {
+        "what": "per-rank critical path of the sharded build, thread-ranks in serial mode on one MI355X",
+        "world": G, "n": n, "dim": args.dim, "k": args.k, "n_trees": args.trees, "iters": infos[0]["iters"],
+        "recall_at_10": round(rec, 4),
+        "compute_critical_path_ms": round(compute_cp, 2),
+        "compute_sum_all_ranks_ms": round(float(sec.sum()), 2),
+        "per_rank_compute_ms": [round(float(v), 2) for v in sec.sum(1)],
+        "sections_max_ms": [round(float(v), 2) for v in sec.max(0)],
+        "sections_min_ms": [round(float(v), 2) for v in sec.min(0)],
+        "exchange_bytes_max_per_rank": [int(v) for v in byt.max(0)],
+        "modelled_exchange_ms": round(exch_ms, 2),
+        "modelled_allgather_ms": round(allgather_ms, 2),
+        "model": "7 xGMI links x %.0f GB/s effective per GPU, %.0f us per exchange" % (args.link_gbs, args.latency_us),
+        "critical_path_ms": round(compute_cp + exch_ms + allgather_ms, 2),
+        "rank0_stage_ms": {"prep": round(st0["ms_prep"], 2), "forest": round(st0["ms_forest"], 2), "leaf_init": round(st0["ms_leaf_init"], 2),
+                           "join": round(sum(st0["ms_join"]), 2), "sample": round(sum(st0["ms_sample"]), 2),
+                           "merge": round(sum(st0["ms_merge"]), 2), "finalize": round(st0["ms_finalize"], 2)},
+        "deferred_proposals": [sum(i["deferred"]) for i in infos],
+        "local_trees": [i["local_trees"] for i in infos],
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
