@@ -392,7 +392,7 @@ void comm_compute_begin(nnd_comm_s *c) {
 }
 void comm_compute_end(nnd_comm_s *c, hipStream_t stream) {
     if (c->kind == NND_COMM_LOCAL && c->grp->serial) {
-        (void)hipStreamSynchronize(stream);
+        (void)spin_on(c, stream);  // polled: a blocking wait wakes up ~1 ms late and would be charged to the section
         c->grp->gpu_token.unlock();
     }
 }

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
     auto load_cand = [&](int64_t g) __attribute__((always_inline)) -> int {
         const int row = lane < RV ? lane : 0;
         const bool ok = lane < RV && g < n_v;
-        const int64_t v = ok ? (order ? (int64_t)order[v_begin + g] : v_begin + g) : 0;
+        const int64_t gg = ok ? g : 0;  // idle lanes read the launch's first vertex: on a shard the table holds the owned rows only
+        const int64_t v = order ? (int64_t)order[v_begin + gg] : v_begin + gg;
         const int c = cand[v * RV + row];
         return ok ? c : -1;
     };
@@ -370,6 +371,18 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
     }
 }
 
+// visiting order of a launch over [v_begin, v_end): the whole-set spatial order, or -- on a shard -- the owned vertices in
+// the order shard.hip derived from the rank's first tree (positions [v_begin - own_lo, v_end - own_lo) of that list)
+static const int32_t *join_order(const nnd_ctx *ctx, int64_t &v_begin, int64_t &v_end) {
+    const int32_t *order = nnd_vertex_order(ctx);
+    if (!order && ctx->own_order && v_begin >= ctx->own_lo && v_end <= ctx->own_hi) {
+        order = ctx->own_order;
+        v_begin -= ctx->own_lo;
+        v_end -= ctx->own_lo;
+    }
+    return order;
+}
+
 template <int DC, int KS16>
 static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     constexpr int RV = 32, kls = KS16 * 16 + 4;
@@ -399,8 +412,9 @@ static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     if (grid > 8) grid &= ~7u;  // whole multiples of the XCD count: every XCD walks its own slice of the order
     uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
     ctx->pbuf_clean = false;
+    const int32_t *order = join_order(ctx, v_begin, v_end);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
-                       nnd_vertex_order(ctx), v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed,
+                       order, v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed,
                        ctx->counters, nnd_list_lo(ctx), nnd_list_hi(ctx));
     NND_HIP_CHECK(hipGetLastError());
     return 0;
@@ -470,7 +484,8 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
     // candidate ids of vertex g: slot lane + 64*u of [new(MCP) | old(MCP)]
     auto load_cand = [&](int64_t g, int (&c)[RPL]) __attribute__((always_inline)) {
         const bool ok = g < n_v;
-        const int64_t v = ok ? (order ? (int64_t)order[v_begin + g] : v_begin + g) : 0;
+        const int64_t gg = ok ? g : 0;  // idle lanes read the launch's first vertex: on a shard the table holds the owned rows only
+        const int64_t v = order ? (int64_t)order[v_begin + gg] : v_begin + gg;
 #pragma unroll
         for (int u = 0; u < RPL; u++) {
             const int cc = cand[v * RV + lane + 64 * u];
@@ -724,8 +739,9 @@ static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     if (grid > 8) grid &= ~7u;
     uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
     ctx->pbuf_clean = false;
+    const int32_t *order = join_order(ctx, v_begin, v_end);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
-                       nnd_vertex_order(ctx), v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty,
+                       order, v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty,
                        ctx->pcap, slot_seed, ctx->counters, nnd_list_lo(ctx), nnd_list_hi(ctx));
     NND_HIP_CHECK(hipGetLastError());
     return 0;

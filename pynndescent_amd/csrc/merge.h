@@ -211,13 +211,10 @@ __device__ __forceinline__ int nnd_merge_row(int64_t v, int k, int ks, uint32_t 
 __device__ __forceinline__ int nnd_dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); }
 __device__ __forceinline__ int nnd_dpp_row_ror1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false); }
 
+// core: the row's entries (e, d) are updated IN the registers, nothing is stored (chained merges: k_merge_graph_rows_q)
 template <int NBLK, typename CandFn>
-__device__ __forceinline__ int nnd_merge_rows_q16(bool row_on, uint32_t *__restrict__ row_e, float *__restrict__ row_d,
-                                                  float *__restrict__ th_slot, uint32_t e, float d, int k, int ncand,
-                                                  CandFn cand) {
+__device__ __forceinline__ int nnd_merge_rows_q16_regs(bool row_on, uint32_t &e, float &d, int k, int ncand, CandFn cand) {
     const int lane = nnd_lane(), j = lane & 15, gbase = lane & 48;
-    const uint32_t e_in = e;
-    const float d_in = d;
     uint32_t klo = e & NND_IDX_MASK, khi = __float_as_uint(d);  // key = khi:klo; empty slots: 0x7FFFFFFF / +inf bits
     if (e == NND_EMPTY_E) { klo = 0xFFFFFFFFu; khi = 0xFFFFFFFFu; }
     uint32_t flag = e == NND_EMPTY_E ? 0u : (e & NND_NEW_BIT);
@@ -275,12 +272,24 @@ __device__ __forceinline__ int nnd_merge_rows_q16(bool row_on, uint32_t *__restr
     }
     if (pushed == 0) return 0;
     const bool empty = (klo & khi) == 0xFFFFFFFFu;
-    const uint32_t e_out = empty ? NND_EMPTY_E : (klo | flag);
-    const float d_out = empty ? INFINITY : __uint_as_float(khi);
-    if (row_on && j < k && (e_out != e_in || d_out != d_in)) {
-        row_e[j] = e_out;
-        row_d[j] = d_out;
-        if (j == k - 1) *th_slot = d_out;  // new worst distance of the row
+    e = empty ? NND_EMPTY_E : (klo | flag);
+    d = empty ? INFINITY : __uint_as_float(khi);
+    return pushed;
+}
+
+template <int NBLK, typename CandFn>
+__device__ __forceinline__ int nnd_merge_rows_q16(bool row_on, uint32_t *__restrict__ row_e, float *__restrict__ row_d,
+                                                  float *__restrict__ th_slot, uint32_t e, float d, int k, int ncand,
+                                                  CandFn cand) {
+    const int j = nnd_lane() & 15;
+    const uint32_t e_in = e;
+    const float d_in = d;
+    const int pushed = nnd_merge_rows_q16_regs<NBLK>(row_on, e, d, k, ncand, cand);
+    if (pushed == 0) return 0;
+    if (row_on && j < k && (e != e_in || d != d_in)) {
+        row_e[j] = e;
+        row_d[j] = d;
+        if (j == k - 1) *th_slot = d;  // new worst distance of the row
     }
     return pushed;
 }

@@ -304,80 +304,120 @@ __global__ __launch_bounds__(256) void k_merge_graph_rows(int64_t lo, int64_t hi
     });
 }
 
-// One launch instead of counts -> host scan -> export: 128 consecutive vertices per workgroup; the records of a vertex go
-// to the region of its owner (regions of `cap` records, one global atomic per workgroup and destination).  A vertex whose
-// records do not fit any more keeps them (slots and dirty flag untouched): they travel with the next iteration's --
-// proposals are suggestions with exact distances, a late one is as valid as a fresh one.
+// Proposals for vertices owned elsewhere -> records in their owners' regions (regions of `cap` records per destination).
+// A workgroup takes 128 consecutive rows, 32 per wave.  A wave reads the dirty flags of its rows with one load, then the
+// 64 slots of every dirty row that is not ours ONCE, into registers (lane = slot; <= 32 rows x 2 VGPRs), counting them
+// with ballots.  Space is reserved hierarchically: a wave adds the total of each run of rows with one destination to the
+// workgroup's LDS counter of that destination (rows ascend and owners are contiguous ranges: one run, rarely two), one
+// GLOBAL atomic per workgroup and destination follows -- the cursors are 8 hot addresses, a global atomic per wave
+// serialised the launch (measured: 8 ms) -- and the records are written straight from the registers.  A row whose
+// records would cross the end of the region keeps them (slots and dirty flag untouched; the part of the reservation that
+// lies inside the region is marked as holes, target -1): they travel with the next iteration's -- proposals are
+// suggestions with exact distances, a late one is as valid as a fresh one.  (The first version walked the rows twice --
+// count, serial scan by one thread, write -- and read every dirty row's 512 bytes both times.)
 __global__ __launch_bounds__(256) void k_proposal_export_regions(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
                                                                  int64_t n, int64_t own_lo, int64_t own_hi,
                                                                  const int64_t *__restrict__ bounds, int n_ranks, int64_t cap,
                                                                  long long *__restrict__ cursors, int32_t *__restrict__ targets,
                                                                  uint64_t *__restrict__ keys, long long *__restrict__ deferred) {
-    __shared__ int rcnt[128], rdest[128];
-    __shared__ long long roff[128];
+    constexpr int R = 32, MAXRUN = 3;
+    __shared__ int wg_cnt[64];
+    __shared__ long long wg_base[64];
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * 128;
-    for (int r = 0; r < 32; r++) {
-        const int li = w * 32 + r;
-        const int64_t v = row0 + li;
-        int c = 0;
-        if (v < n && (v < own_lo || v >= own_hi) && pdirty[v]) {  // wave-uniform
-            const uint64_t key = lane < pcap ? pbuf[v * pcap + lane] : NND_EMPTY_KEY;
-            c = __popcll(__ballot(key != NND_EMPTY_KEY));
-        }
-        if (lane == 0) rcnt[li] = c;
-    }
+    if (threadIdx.x < 64) wg_cnt[threadIdx.x] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {  // rows ascend, owners are contiguous ranges: a few groups per workgroup
+    const int64_t base = ((int64_t)blockIdx.x * 4 + w) * R;
+    const int64_t v_l = base + lane;
+    const unsigned m = base < n ? (unsigned)__ballot(lane < R && v_l < n && (v_l < own_lo || v_l >= own_hi) && pdirty[v_l < n ? v_l : 0] != 0) : 0u;
+    uint64_t key[R];
+    int c[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        key[i] = NND_EMPTY_KEY;
+        if ((m >> i) & 1u) key[i] = lane < pcap ? pbuf[(base + i) * pcap + lane] : NND_EMPTY_KEY;  // wave-uniform branch
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) c[i] = ((m >> i) & 1u) ? __popcll(__ballot(key[i] != NND_EMPTY_KEY)) : 0;
+    // runs of dirty rows with one destination (wave-uniform bookkeeping)
+    int run_d[MAXRUN], run_first[MAXRUN], run_tot[MAXRUN], run_off[MAXRUN];
+    int n_run = 0;
+    int off[R];
+    {
         int d = -1;
-        int i0 = 0;
-        long long acc = 0;
-        auto flush = [&](int i1) {
-            if (d < 0 || acc == 0) return;
-            const long long b = (long long)atomicAdd((unsigned long long *)&cursors[d], (unsigned long long)acc);
-            for (int i = i0; i < i1; i++)
-                if (rcnt[i] > 0) {
-                    roff[i] += b;
-                    if (roff[i] + rcnt[i] > cap) rcnt[i] = -rcnt[i];  // does not fit: deferred
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            off[i] = 0;
+            if (!((m >> i) & 1u)) continue;
+            const int64_t v = base + i;
+            if (d < 0 || v >= bounds[d + 1]) {  // a new run starts at this row
+                d = d < 0 ? nnd_owner_of(bounds, n_ranks, v) : d + 1;
+                while (v >= bounds[d + 1]) d++;
+                if (n_run < MAXRUN) {
+                    run_d[n_run] = d;
+                    run_first[n_run] = i;
+                    run_tot[n_run] = 0;
                 }
-        };
-        for (int i = 0; i < 128; i++) {
-            if (rcnt[i] == 0) continue;
-            const int64_t v = row0 + i;
-            if (d < 0 || v >= bounds[d + 1]) {
-                flush(i);
-                d = nnd_owner_of(bounds, n_ranks, v);
-                i0 = i;
-                acc = 0;
+                n_run++;
             }
-            rdest[i] = d;
-            roff[i] = acc;
-            acc += rcnt[i];
+            const int r = n_run - 1 < MAXRUN ? n_run - 1 : MAXRUN - 1;  // (more runs than slots: ranks of < 11 rows -- the last slot is re-used with direct global atomics below)
+            off[i] = run_tot[r];
+            run_tot[r] += c[i];
         }
-        flush(128);
+    }
+    const bool simple = n_run <= MAXRUN;
+    if (simple) {
+#pragma unroll
+        for (int r = 0; r < MAXRUN; r++) {
+            run_off[r] = 0;
+            if (r < n_run && run_tot[r] > 0) {
+                int o = 0;
+                if (lane == 0) o = atomicAdd(&wg_cnt[run_d[r]], run_tot[r]);
+                run_off[r] = __builtin_amdgcn_readfirstlane(o);
+            }
+        }
     }
     __syncthreads();
-    for (int r = 0; r < 32; r++) {
-        const int li = w * 32 + r;
-        const int c = rcnt[li];
-        if (c == 0) continue;  // wave-uniform
-        const int64_t v = row0 + li;
-        if (c < 0) {  // deferred; the part of its reservation that lies inside the region is marked invalid (target -1)
-            if (lane == 0) atomicAdd((unsigned long long *)deferred, (unsigned long long)(-c));
-            if (roff[li] < cap && roff[li] + lane < cap && lane < -c) targets[(int64_t)rdest[li] * cap + roff[li] + lane] = -1;
+    if (threadIdx.x < n_ranks && wg_cnt[threadIdx.x] > 0)
+        wg_base[threadIdx.x] = (long long)atomicAdd((unsigned long long *)&cursors[threadIdx.x], (unsigned long long)wg_cnt[threadIdx.x]);
+    __syncthreads();
+    if (!m) return;
+    long long n_deferred = 0;
+    if (!simple) {  // degenerate geometry (ranks of a few rows): the whole wave defers -- nothing is lost, see above
+#pragma unroll
+        for (int i = 0; i < R; i++) n_deferred += c[i];
+        if (lane == 0 && n_deferred) atomicAdd((unsigned long long *)deferred, (unsigned long long)n_deferred);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        if (!((m >> i) & 1u)) continue;  // wave-uniform
+        const int64_t v = base + i;
+        if (c[i] == 0) {  // dirty without a live slot: just clear the flag
+            if (lane == 0) pdirty[v] = 0;
             continue;
         }
-        const uint64_t key = lane < pcap ? pbuf[v * pcap + lane] : NND_EMPTY_KEY;
-        const bool on = key != NND_EMPTY_KEY;
-        const unsigned long long m = __ballot(on);
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < MAXRUN; q++)
+            if (q < n_run && i >= run_first[q]) r = q;
+        const int d = run_d[r];
+        const long long at = wg_base[d] + run_off[r] + off[i];
+        const bool on = key[i] != NND_EMPTY_KEY;
+        const int pre = nnd_prefix_popc(__ballot(on));
+        if (at + c[i] > cap) {  // does not fit: deferred; what lies inside the region becomes holes
+            n_deferred += c[i];
+            if (on && at + pre < cap) targets[(int64_t)d * cap + at + pre] = -1;
+            continue;
+        }
         if (on) {
-            const int64_t idx = (int64_t)rdest[li] * cap + roff[li] + nnd_prefix_popc(m);
-            keys[idx] = key;
+            const int64_t idx = (int64_t)d * cap + at + pre;
+            keys[idx] = key[i];
             targets[idx] = (int32_t)v;
             pbuf[v * pcap + lane] = NND_EMPTY_KEY;
         }
         if (lane == 0) pdirty[v] = 0;
     }
+    if (lane == 0 && n_deferred) atomicAdd((unsigned long long *)deferred, (unsigned long long)n_deferred);
 }
 
 int nnd_launch_proposal_export_regions(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, long long *counts_dev) {
@@ -404,10 +444,52 @@ int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
-int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src) {
-    if (hi <= lo) return 0;
-    hipLaunchKernelGGL(k_merge_graph_rows, dim3((unsigned)((hi - lo + 3) / 4)), dim3(256), 0, ctx->stream, lo, hi, ctx->k, ctx->ks,
-                       e_src, d_src, ctx->knn_e, ctx->knn_d, ctx->th);
+// k <= 16: all sources in ONE launch, four rows per wave (quarter-wave merges chained in registers): a row is loaded and
+// stored once instead of once per source.  e_src / d_src: n_src blocks of (hi - lo, ks) rows, `stride` words apart.
+__global__ __launch_bounds__(256) void k_merge_graph_rows_q(int64_t lo, int64_t hi, int k, int ks, int n_src, int64_t stride,
+                                                            const uint32_t *__restrict__ e_src, const float *__restrict__ d_src,
+                                                            uint32_t *__restrict__ knn_e, float *__restrict__ knn_d, float *__restrict__ th) {
+    const int lane = nnd_lane(), w = threadIdx.x >> 6, j = lane & 15, grp = lane >> 4;
+    const int64_t v = lo + ((int64_t)blockIdx.x * 4 + w) * 4 + grp;
+    const bool on = v < hi;
+    const int64_t vv = on ? v : lo;
+    uint32_t e = (on && j < k) ? knn_e[vv * ks + j] : NND_EMPTY_E;
+    float d = (on && j < k) ? knn_d[vv * ks + j] : INFINITY;
+    const uint32_t e_in = e;
+    const float d_in = d;
+    uint32_t se = e_src[(vv - lo) * ks + j];
+    float sd = d_src[(vv - lo) * ks + j];
+    for (int s = 0; s < n_src; s++) {
+        const uint32_t ce = se;
+        const float cd = sd;
+        if (s + 1 < n_src) {  // the next source's row is in flight during this merge
+            se = e_src[(int64_t)(s + 1) * stride + (vv - lo) * ks + j];
+            sd = d_src[(int64_t)(s + 1) * stride + (vv - lo) * ks + j];
+        }
+        nnd_merge_rows_q16_regs<1>(on, e, d, k, k, [&](int c, uint32_t &id, float &dc) {
+            id = ce & NND_IDX_MASK;
+            dc = cd;
+            return ce != NND_EMPTY_E;
+        });
+    }
+    if (on && j < k && (e != e_in || d != d_in)) {
+        knn_e[v * ks + j] = e;
+        knn_d[v * ks + j] = d;
+        if (j == k - 1) th[v] = d;
+    }
+}
+
+// n_src source blocks of (hi - lo, ks) rows each, `stride` words apart (stride = 0 with n_src = 1: one block)
+int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src, int n_src, int64_t stride) {
+    if (hi <= lo || n_src <= 0) return 0;
+    if (ctx->k <= 16) {
+        hipLaunchKernelGGL(k_merge_graph_rows_q, dim3((unsigned)((hi - lo + 15) / 16)), dim3(256), 0, ctx->stream, lo, hi, ctx->k, ctx->ks,
+                           n_src, stride, e_src, d_src, ctx->knn_e, ctx->knn_d, ctx->th);
+    } else {
+        for (int s = 0; s < n_src; s++)
+            hipLaunchKernelGGL(k_merge_graph_rows, dim3((unsigned)((hi - lo + 3) / 4)), dim3(256), 0, ctx->stream, lo, hi, ctx->k, ctx->ks,
+                               e_src + (int64_t)s * stride, d_src + (int64_t)s * stride, ctx->knn_e, ctx->knn_d, ctx->th);
+    }
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -345,7 +345,19 @@ __global__ __launch_bounds__(256) void k_offer_export(const uint32_t *__restrict
             if ((int64_t)u < own_lo || (int64_t)u >= own_hi) dest = nnd_owner_of(bounds, n_ranks, (int64_t)u);
         }
     }
-    if (dest >= 0) my = atomicAdd(&cnt[dest], 1);
+    {  // one LDS atomic per wave and destination (not per record: 256 threads on <= 8 counters serialise)
+        unsigned long long todo = __ballot(dest >= 0);
+        while (todo) {  // wave-uniform
+            const int lead = __builtin_ctzll(todo);
+            const int dd = __builtin_amdgcn_readlane(dest, lead);
+            const unsigned long long md = __ballot(dest == dd);
+            int b = 0;
+            if ((tid & 63) == lead) b = atomicAdd(&cnt[dd], __popcll(md));
+            b = __builtin_amdgcn_readlane(b, lead);
+            if (dest == dd) my = b + nnd_prefix_popc(md);
+            todo &= ~md;
+        }
+    }
     __syncthreads();
     if (tid < n_ranks && cnt[tid] > 0) base[tid] = (long long)atomicAdd((unsigned long long *)&cursors[tid], (unsigned long long)cnt[tid]);
     __syncthreads();

@@ -37,6 +37,8 @@ struct nnd_shard_s {
     uint64_t *in_k = nullptr;
     int64_t in_cap = 0;
     long long *cvec = nullptr;                   // (world + 4) count vector handed to comm_gather_counts
+    int32_t *own_order = nullptr;                // (n_own) owned vertices in the first local tree's leaf order
+    int *order_cursor = nullptr;
     nnd_shard_info info{};
     char err[512] = {0};
     void set_error(const char *fmt, ...) {
@@ -99,9 +101,50 @@ __global__ void k_counters_reduce_async(const long long *__restrict__ counters, 
     }
 }
 
+// The owned vertices in the order they have in the first local tree's leaf sequence: vertices that are close in space are
+// joined at the same time (their candidate rows, neighbour lists and proposal slots share L2 lines).  A workgroup
+// compacts a run of 4096 positions; runs land in the order their workgroups reserve space -- coherence inside a run is
+// what matters, and the join's results do not depend on the visiting order (proposals are atomicMin'ed).
+__global__ __launch_bounds__(256) void k_compact_owned(const int32_t *__restrict__ perm, int64_t n, int64_t lo, int64_t hi,
+                                                       int32_t *__restrict__ out, int *__restrict__ cursor) {
+    __shared__ int wcnt[4], wbase[4];
+    __shared__ int blk_base;
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t p0 = (int64_t)blockIdx.x * 4096;
+    int cnt = 0;
+    for (int it = 0; it < 16; it++) {
+        const int64_t p = p0 + it * 256 + threadIdx.x;
+        const int v = p < n ? perm[p] : -1;
+        cnt += __popcll(__ballot(v >= lo && v < hi));
+    }
+    if (lane == 0) wcnt[w] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        blk_base = tot ? atomicAdd(cursor, tot) : 0;
+    }
+    __syncthreads();
+    // second pass in the same order: iteration-major, wave-minor
+    int at = blk_base;
+    for (int it = 0; it < 16; it++) {
+        const int64_t p = p0 + it * 256 + threadIdx.x;
+        const int v = p < n ? perm[p] : -1;
+        const bool on = v >= lo && v < hi;
+        const unsigned long long m = __ballot(on);
+        if (lane == 0) wbase[w] = __popcll(m);
+        __syncthreads();
+        int before = 0;
+        for (int q = 0; q < w; q++) before += wbase[q];
+        const int tot = wbase[0] + wbase[1] + wbase[2] + wbase[3];
+        if (on) out[at + before + nnd_prefix_popc(m)] = v;
+        at += tot;
+        __syncthreads();
+    }
+}
+
 static void shard_free(nnd_shard_s *s) {
     if (s->h) (void)hipSetDevice(s->h->p.device);
-    void *ptrs[] = {s->x_full, s->recv_e, s->recv_d, s->off_t, s->off_k, s->prop_t, s->prop_k, s->in_t, s->in_k, s->cvec};
+    void *ptrs[] = {s->x_full, s->recv_e, s->recv_d, s->off_t, s->off_k, s->prop_t, s->prop_k, s->in_t, s->in_k, s->cvec, s->own_order, s->order_cursor};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h) (void)nnd_destroy(s->h);
@@ -151,6 +194,10 @@ extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, 
     const int64_t n_own = s->hi - s->lo;
     bool ok = hipSetDevice(p.device) == hipSuccess;
     ok = ok && hipMalloc((void **)&s->cvec, sizeof(long long) * (size_t)(G + 4)) == hipSuccess;
+    if (ok && G > 1 && p.n_trees > 0) {
+        ok = ok && hipMalloc((void **)&s->own_order, sizeof(int32_t) * (size_t)(n_own > 0 ? n_own : 1)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s->order_cursor, sizeof(int)) == hipSuccess;
+    }
     if (ok && G > 1) {
         // offers: at most every owned edge goes to ONE other rank; proposals: 32 of a row's 64 slots may travel per
         // iteration (what does not fit stays and travels next time: counted in nnd_shard_info.deferred)
@@ -328,6 +375,12 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
             const int tl = t_begin(h);
             S_CTX(nnd_launch_leaf_init(h));
             t_end(h, tl, &h->stats.ms_leaf_init, false);
+            if (s->own_order && n_own > 0) {  // the first local tree's leaf order, restricted to the owned vertices
+                S_HIP(hipMemsetAsync(s->order_cursor, 0, sizeof(int), st));
+                hipLaunchKernelGGL(k_compact_owned, dim3((unsigned)((h->n + 4095) / 4096)), dim3(256), 0, st, h->perm[h->cur], h->n, s->lo, s->hi,
+                                   s->own_order, s->order_cursor);
+                h->own_order = s->own_order;
+            }
         }
         sec.end();
     }
@@ -353,8 +406,9 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         note_bytes(s, b0);
         section_timer sec(s);
         // (merged entries carry the "new" flag like everything else before the first sampling pass: all_new stays set)
-        for (int r = 0; r < G; r++)
-            if (rcnt[r]) S_CTX(nnd_launch_merge_graph_rows(h, s->lo, s->hi, s->recv_e + roff[r], s->recv_d + roff[r]));
+        int n_src = 0;  // the sources' blocks lie back to back: (n_own, ks) rows each
+        for (int r = 0; r < G; r++) n_src += rcnt[r] ? 1 : 0;
+        S_CTX(nnd_launch_merge_graph_rows(h, s->lo, s->hi, s->recv_e, s->recv_d, n_src, (int64_t)n_own * s->ks));
         const int tr = t_begin(h);
         S_CTX(nnd_launch_random_init(h));  // owned rows that are still not full (pynndescent_.py:188-203)
         t_end(h, tr, &h->stats.ms_random_init, false);

@@ -57,6 +57,7 @@ struct nnd_handle_s {
     bool stream_owned = true;             // false after nnd_set_stream: the caller's stream is borrowed
     // A shard created by nnd_create_impl with bounds allocates the per-OWNED-row tables (cand, rbuf, active) for its own
     // rows only; the pointers above are biased by -own_lo rows so that kernels keep indexing by global vertex id.
+    const int32_t *own_order = nullptr;   // shard: the owned vertices in a spatially coherent order (shard.hip), or nullptr
     bool slim = false;
     void *slim_alloc[3] = {nullptr, nullptr, nullptr};  // the allocations behind cand / rbuf / active (always; biased or not)
     int64_t slim_rows() const { return slim ? own_hi - own_lo : n; }  // rows those three tables hold
@@ -170,7 +171,7 @@ int nnd_launch_finalize(nnd_ctx *ctx, int32_t *out_idx_dev, float *out_dist_dev)
 int nnd_launch_pairwise(nnd_ctx *ctx, const int32_t *rows_a_dev, int na, const int32_t *rows_b_dev, int nb,
                         float *out_dev);
 int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_t *targets, int64_t count);
-int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src);
+int nnd_launch_merge_graph_rows(nnd_ctx *ctx, int64_t lo, int64_t hi, const uint32_t *e_src, const float *d_src, int n_src, int64_t stride);
 int nnd_launch_clear_new_flags(nnd_ctx *ctx);
 int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev, const nnd_prune_opts *opts,
                               const int32_t *degree_dev);
