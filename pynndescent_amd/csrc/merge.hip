@@ -413,8 +413,8 @@ __global__ __launch_bounds__(256) void k_proposal_export_regions(uint64_t *__res
             const int64_t idx = (int64_t)d * cap + at + pre;
             keys[idx] = key[i];
             targets[idx] = (int32_t)v;
-            pbuf[v * pcap + lane] = NND_EMPTY_KEY;
         }
+        if (lane < pcap) pbuf[v * pcap + lane] = NND_EMPTY_KEY;  // the whole row: full 128-byte lines, no read-modify-write
         if (lane == 0) pdirty[v] = 0;
     }
     if (lane == 0 && n_deferred) atomicAdd((unsigned long long *)deferred, (unsigned long long)n_deferred);

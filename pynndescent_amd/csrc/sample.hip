@@ -321,8 +321,12 @@ int nnd_launch_sample(nnd_ctx *ctx) {
 // u's owner, the host ships the regions (all-to-all-v over RCCL), and the owner folds what it receives into its slot
 // banks with the same atomicMin as a local offer.  This is the cross-process form of the ownership test of
 // new_build_candidates (utils.py:266-273): every rank scans only ITS rows instead of all n * k edges.
-// same thread layout as k_sample_reverse; records are grouped per destination inside the workgroup (LDS atomics), one
-// global atomic per workgroup and destination reserves their slots in the destination's region
+// Thread layout of k_sample_reverse (x = slot, y = row), OFFER_IT row groups per workgroup: a thread keeps its OFFER_IT
+// edges in registers, records are counted per destination inside the workgroup (one LDS atomic per wave, pass and
+// destination), ONE global atomic per workgroup and destination reserves their slots in the destination's region -- the
+// cursors are <= 64 hot addresses: a reservation per 16 rows (the first version) spent the launch serialising on them
+// (0.95 ms per launch at 1.25 M owned rows) -- and the records are written from the registers.
+#define OFFER_IT 16
 __global__ __launch_bounds__(256) void k_offer_export(const uint32_t *__restrict__ knn_e, int64_t row_lo, int64_t row_hi, int k, int ks,
                                                       uint32_t it_seed, const int64_t *__restrict__ bounds, int n_ranks,
                                                       int64_t own_lo, int64_t own_hi, int64_t cap, long long *__restrict__ cursors,
@@ -333,44 +337,54 @@ __global__ __launch_bounds__(256) void k_offer_export(const uint32_t *__restrict
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     if (tid < 64) cnt[tid] = 0;
     __syncthreads();
-    const int64_t g = row_lo + (int64_t)blockIdx.x * blockDim.y + threadIdx.y;
     const int j = threadIdx.x;
-    int dest = -1, my = 0;
-    uint32_t u = 0, cls = 0;
-    if (g < row_hi && j < k) {
-        const uint32_t e = knn_e[g * ks + j];
-        if (e != NND_EMPTY_E) {
-            u = e & NND_IDX_MASK;
-            cls = e >> 31;
-            if ((int64_t)u < own_lo || (int64_t)u >= own_hi) dest = nnd_owner_of(bounds, n_ranks, (int64_t)u);
-        }
+    uint32_t ev[OFFER_IT];
+    int dest[OFFER_IT], my[OFFER_IT];
+#pragma unroll
+    for (int it = 0; it < OFFER_IT; it++) {
+        const int64_t g = row_lo + ((int64_t)blockIdx.x * OFFER_IT + it) * blockDim.y + threadIdx.y;
+        ev[it] = NND_EMPTY_E;
+        if (g < row_hi && j < k) ev[it] = knn_e[g * ks + j];
     }
-    {  // one LDS atomic per wave and destination (not per record: 256 threads on <= 8 counters serialise)
-        unsigned long long todo = __ballot(dest >= 0);
-        while (todo) {  // wave-uniform
+#pragma unroll
+    for (int it = 0; it < OFFER_IT; it++) {
+        dest[it] = -1;
+        my[it] = 0;
+        if (ev[it] != NND_EMPTY_E) {
+            const int64_t u = (int64_t)(ev[it] & NND_IDX_MASK);
+            if (u < own_lo || u >= own_hi) dest[it] = nnd_owner_of(bounds, n_ranks, u);
+        }
+        unsigned long long todo = __ballot(dest[it] >= 0);
+        while (todo) {  // wave-uniform: one LDS atomic per destination present in the wave
             const int lead = __builtin_ctzll(todo);
-            const int dd = __builtin_amdgcn_readlane(dest, lead);
-            const unsigned long long md = __ballot(dest == dd);
+            const int dd = __builtin_amdgcn_readlane(dest[it], lead);
+            const unsigned long long md = __ballot(dest[it] == dd);
             int b = 0;
             if ((tid & 63) == lead) b = atomicAdd(&cnt[dd], __popcll(md));
             b = __builtin_amdgcn_readlane(b, lead);
-            if (dest == dd) my = b + nnd_prefix_popc(md);
+            if (dest[it] == dd) my[it] = b + nnd_prefix_popc(md);
             todo &= ~md;
         }
     }
     __syncthreads();
     if (tid < n_ranks && cnt[tid] > 0) base[tid] = (long long)atomicAdd((unsigned long long *)&cursors[tid], (unsigned long long)cnt[tid]);
     __syncthreads();
-    if (dest >= 0) {
-        const long long at = base[dest] + my;
+    int n_drop = 0;
+#pragma unroll
+    for (int it = 0; it < OFFER_IT; it++) {
+        if (dest[it] < 0) continue;
+        const int64_t g = row_lo + ((int64_t)blockIdx.x * OFFER_IT + it) * blockDim.y + threadIdx.y;
+        const uint32_t u = ev[it] & NND_IDX_MASK, cls = ev[it] >> 31;
+        const long long at = base[dest[it]] + my[it];
         if (at < cap) {
-            const int64_t idx = (int64_t)dest * cap + at;
+            const int64_t idx = (int64_t)dest[it] * cap + at;
             targets[idx] = (int32_t)(u | (cls << 31));
             keys[idx] = ((uint64_t)nnd_hash3(it_seed, (uint32_t)g, u) << 32) | (uint64_t)(uint32_t)g;
         } else {
-            atomicAdd((unsigned long long *)dropped, 1ull);  // cannot happen with cap = owned rows * k
+            n_drop++;  // cannot happen with cap = owned rows * k
         }
     }
+    if (n_drop) atomicAdd((unsigned long long *)dropped, (unsigned long long)n_drop);
 }
 
 __global__ void k_offer_import(const int32_t *__restrict__ targets, const uint64_t *__restrict__ keys, int64_t count, uint32_t want_cls,
@@ -399,7 +413,7 @@ int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uin
         int ksp = 16;
         while (ksp < ctx->ks) ksp <<= 1;
         const int rows = 256 / ksp;
-        const unsigned grid = (unsigned)((ctx->own_hi - ctx->own_lo + rows - 1) / rows);
+        const unsigned grid = (unsigned)((ctx->own_hi - ctx->own_lo + (int64_t)rows * OFFER_IT - 1) / ((int64_t)rows * OFFER_IT));
         if (grid > 0)
             hipLaunchKernelGGL(k_offer_export, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->knn_e, ctx->own_lo, ctx->own_hi, ctx->k,
                                ctx->ks, it_seed, ctx->shard_bounds, ctx->n_ranks, ctx->own_lo, ctx->own_hi, cap, ctx->shard_cursors,
