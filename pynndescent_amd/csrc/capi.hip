@@ -67,7 +67,7 @@ static void free_all(nnd_ctx *ctx) {
     };
     if (ctx->x_owned) F((void *)ctx->x_orig);
     for (void *&a : ctx->slim_alloc) { F(a); a = nullptr; }  // cand / rbuf / active (the working pointers may be biased)
-    F(ctx->xp); F(ctx->nrm); F(ctx->nr2); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->pbuf);
+    F(ctx->xp); F(ctx->nrm); F(ctx->nr2); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->pbuf_r);
     F(ctx->pdirty);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
@@ -184,7 +184,11 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
             ctx->cand = a_cand - (size_t)ctx->own_lo * (ctx->slim ? 1 : 0) * 2 * ctx->mcp;
             ctx->rbuf = a_rbuf - (size_t)ctx->own_lo * (ctx->slim ? 1 : 0) * 2 * ctx->rcap;
             ctx->active = a_active - (size_t)ctx->own_lo * (ctx->slim ? 1 : 0);
-            if ((rc = dalloc(ctx, &ctx->pbuf, n * ctx->pcap))) break;
+            uint64_t *a_pbuf = nullptr;
+            if ((rc = dalloc(ctx, &a_pbuf, rows * ctx->pcap))) break;
+            ctx->slim_alloc[3] = a_pbuf;
+            ctx->pbuf = a_pbuf - (size_t)ctx->own_lo * (ctx->slim ? 1 : 0) * ctx->pcap;
+            if (ctx->slim && (rc = dalloc(ctx, &ctx->pbuf_r, n * ctx->pcap_r))) break;
             if ((rc = dalloc(ctx, &ctx->pdirty, n))) break;
             if (hipMemset(ctx->pdirty, 0, n) != hipSuccess) { ctx->set_error("hipMemset failed"); rc = 1; break; }
             if (ctx->n_ranks > 0) {

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
                                                          int64_t v_end, int k, int ks, const uint32_t *__restrict__ knn_e,
                                                          const float *__restrict__ th, uint64_t *__restrict__ pbuf,
                                                          uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed,
-                                                         long long *__restrict__ counters, int64_t own_lo, int64_t own_hi) {
+                                                         long long *__restrict__ counters, int64_t own_lo, int64_t own_hi,
+                                                         uint64_t *__restrict__ pbuf_r, int pcap_r, int64_t rt_lo, int64_t rt_hi) {
     constexpr int MCP = 16, RV = 32;          // rows per vertex: [new(16) | old(16)]
     constexpr int NT = DC / 16;               // 16-byte chunks per lane, row and K block
     constexpr int KQ = KS16 * 4;              // uint4 chunks per neighbour-list row
@@ -89,6 +90,14 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
     uint32_t *cflag = cslot + RV;                       // RV: 1 when a proposal was stored for the row (-> pdirty)
     uint32_t *klist = cflag + RV;                       // RV * kls
     const int kq = ks >> 2;
+    // [own_lo, own_hi): the rows whose CURRENT neighbour lists this handle holds (membership tests); [rt_lo, rt_hi): the
+    // rows it owns.  Proposal slot of target t: a shard keeps proposals for vertices owned ELSEWHERE in a narrow table
+    // (pcap_r slots per row: a rank sends a remote row a few proposals per iteration, and the export streams that table)
+    auto prop_slot = [&](int t, uint32_t slot) __attribute__((always_inline)) -> unsigned long long * {
+        if (pbuf_r && ((int64_t)t < rt_lo || (int64_t)t >= rt_hi))
+            return (unsigned long long *)&pbuf_r[(int64_t)t * pcap_r + (slot & (uint32_t)(pcap_r - 1))];
+        return (unsigned long long *)&pbuf[(int64_t)t * pcap + slot];
+    };
     const int r16 = lane & 15, gq = lane >> 4;
     // Vertices are visited in `order` (the first tree's leaf order when there is a forest): vertices that are close
     // in space run at the same time, and their candidate sets overlap heavily, so most row / neighbour-list gathers
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
                         if ((en.x & 1024u) && !klist_has<KS16>(klist + a * kls, (uint32_t)qid)) {  // p <- q
 #ifndef NND_JOIN_NOATOMIC  // timing experiments only
                             {
-                                unsigned long long *slot = (unsigned long long *)&pbuf[(int64_t)pid * pcap + cslot[b]];
+                                unsigned long long *slot = prop_slot(pid, cslot[b]);
                                 const unsigned long long key = (unsigned long long)nnd_make_key(d, (uint32_t)qid);
                                 atomicMin(slot, key);
                             }
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
                         if ((en.x & 2048u) && !klist_has<KS16>(klist + b * kls, (uint32_t)pid)) {  // q <- p
 #ifndef NND_JOIN_NOATOMIC
                             {
-                                unsigned long long *slot = (unsigned long long *)&pbuf[(int64_t)qid * pcap + cslot[a]];
+                                unsigned long long *slot = prop_slot(qid, cslot[a]);
                                 const unsigned long long key = (unsigned long long)nnd_make_key(d, (uint32_t)pid);
                                 atomicMin(slot, key);
                             }
@@ -415,7 +424,7 @@ static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     const int32_t *order = join_order(ctx, v_begin, v_end);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
                        order, v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed,
-                       ctx->counters, nnd_list_lo(ctx), nnd_list_hi(ctx));
+                       ctx->counters, nnd_list_lo(ctx), nnd_list_hi(ctx), ctx->pbuf_r, ctx->pcap_r, ctx->own_lo, ctx->own_hi);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -448,7 +457,8 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
                                                                        const uint32_t *__restrict__ knn_e,
                                                                        const float *__restrict__ th, uint64_t *__restrict__ pbuf,
                                                                        uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed,
-                                                                       long long *__restrict__ counters, int64_t own_lo, int64_t own_hi) {
+                                                                       long long *__restrict__ counters, int64_t own_lo, int64_t own_hi,
+                                                                       uint64_t *__restrict__ pbuf_r, int pcap_r, int64_t rt_lo, int64_t rt_hi) {
     constexpr int NA = MCP / 16, NB = 2 * NA, RV = 2 * MCP;
     constexpr int NT = DC / 16;                       // 16-byte chunks per lane, row and K block
     constexpr int RPL = RV / 64;                      // candidate slots per lane (1 or 2)
@@ -467,6 +477,14 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
     uint32_t *cslot = (uint32_t *)(cth + RV);           // RV
     uint32_t *cflag = cslot + RV;                       // RV
     const int kq = ks >> 2;
+    // [own_lo, own_hi): the rows whose CURRENT neighbour lists this handle holds (membership tests); [rt_lo, rt_hi): the
+    // rows it owns.  Proposal slot of target t: a shard keeps proposals for vertices owned ELSEWHERE in a narrow table
+    // (pcap_r slots per row: a rank sends a remote row a few proposals per iteration, and the export streams that table)
+    auto prop_slot = [&](int t, uint32_t slot) __attribute__((always_inline)) -> unsigned long long * {
+        if (pbuf_r && ((int64_t)t < rt_lo || (int64_t)t >= rt_hi))
+            return (unsigned long long *)&pbuf_r[(int64_t)t * pcap_r + (slot & (uint32_t)(pcap_r - 1))];
+        return (unsigned long long *)&pbuf[(int64_t)t * pcap + slot];
+    };
     const int r16 = lane & 15, gq = lane >> 4;
     int64_t n_v = v_end - v_begin;
     int64_t g, stride;
@@ -578,14 +596,12 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
                 const float d = __uint_as_float(en.y);
                 const int pid = cid[a], qid = cid[b];
                 if ((en.x & (1u << 13)) && !list_has(pid, (uint32_t)qid)) {  // p <- q
-                    atomicMin((unsigned long long *)&pbuf[(int64_t)pid * pcap + cslot[b]],
-                              (unsigned long long)nnd_make_key(d, (uint32_t)qid));
+                    atomicMin(prop_slot(pid, cslot[b]), (unsigned long long)nnd_make_key(d, (uint32_t)qid));
                     cflag[a] = 1;
                     tot_prop++;
                 }
                 if ((en.x & (1u << 14)) && !list_has(qid, (uint32_t)pid)) {  // q <- p
-                    atomicMin((unsigned long long *)&pbuf[(int64_t)qid * pcap + cslot[a]],
-                              (unsigned long long)nnd_make_key(d, (uint32_t)pid));
+                    atomicMin(prop_slot(qid, cslot[a]), (unsigned long long)nnd_make_key(d, (uint32_t)pid));
                     cflag[b] = 1;
                     tot_prop++;
                 }
@@ -742,7 +758,7 @@ static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     const int32_t *order = join_order(ctx, v_begin, v_end);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
                        order, v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty,
-                       ctx->pcap, slot_seed, ctx->counters, nnd_list_lo(ctx), nnd_list_hi(ctx));
+                       ctx->pcap, slot_seed, ctx->counters, nnd_list_lo(ctx), nnd_list_hi(ctx), ctx->pbuf_r, ctx->pcap_r, ctx->own_lo, ctx->own_hi);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -243,6 +243,7 @@ int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float
         ctx->set_error("init graph width %d exceeds %d", width, ctx->pcap < 64 ? ctx->pcap : 64);
         return 1;
     }
+    if (ctx->slim) { ctx->set_error("init graphs are not supported on a shard of a row-sharded build"); return 1; }
     ctx->pbuf_clean = false;
     hipLaunchKernelGGL(k_graph_init, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, ctx->dp,
                        ctx->nrm, ctx->p.metric, ctx->n, idx_dev, dist_dev, width, ctx->pbuf, ctx->pdirty, ctx->pcap);
@@ -275,13 +276,27 @@ int nnd_launch_clear_new_flags(nnd_ctx *ctx) {
 
 // fold received records into this handle's slots (same hashed-slot atomicMin as the join)
 __global__ void k_import_proposals(const uint64_t *__restrict__ keys, const int32_t *__restrict__ targets, int64_t count,
-                                   uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed) {
+                                   uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed,
+                                   const uint32_t *__restrict__ knn_e, const float *__restrict__ th, int ks) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint64_t key = keys[i];
     const int64_t t = targets[i];
     if (t < 0) return;  // hole left by a deferred vertex (k_proposal_export_regions)
-    const uint32_t s = nnd_hash2(slot_seed, nnd_key_idx(key)) & (uint32_t)(pcap - 1);
+    // The sender could not test the proposal against the target's neighbour list (it lives here): do it now, BEFORE the
+    // record competes for a slot -- most records are "already present" (utils.py:489-492), and those are by construction
+    // NEAR the target: left in, they win the slots (atomicMin keeps the nearer key) and push the genuine candidates out.
+    // The threshold may have tightened since the sender read it, too (utils.py:484).
+    const uint32_t src = nnd_key_idx(key);
+    if (!(nnd_key_dist(key) < th[t])) return;
+    const u32x4 *row = (const u32x4 *)(knn_e + t * ks);
+    bool present = false;
+    for (int c = 0; c < (ks >> 2); c++) {
+        const u32x4 wv = row[c] & NND_IDX_MASK;
+        present |= (wv.x == src) | (wv.y == src) | (wv.z == src) | (wv.w == src);
+    }
+    if (present) return;
+    const uint32_t s = nnd_hash2(slot_seed, src) & (uint32_t)(pcap - 1);
     atomicMin((unsigned long long *)&pbuf[t * pcap + s], (unsigned long long)key);
     pdirty[t] = 1;
 }
@@ -305,40 +320,45 @@ __global__ __launch_bounds__(256) void k_merge_graph_rows(int64_t lo, int64_t hi
 }
 
 // Proposals for vertices owned elsewhere -> records in their owners' regions (regions of `cap` records per destination).
-// A workgroup takes 128 consecutive rows, 32 per wave.  A wave reads the dirty flags of its rows with one load, then the
-// 64 slots of every dirty row that is not ours ONCE, into registers (lane = slot; <= 32 rows x 2 VGPRs), counting them
-// with ballots.  Space is reserved hierarchically: a wave adds the total of each run of rows with one destination to the
-// workgroup's LDS counter of that destination (rows ascend and owners are contiguous ranges: one run, rarely two), one
-// GLOBAL atomic per workgroup and destination follows -- the cursors are 8 hot addresses, a global atomic per wave
-// serialised the launch (measured: 8 ms) -- and the records are written straight from the registers.  A row whose
-// records would cross the end of the region keeps them (slots and dirty flag untouched; the part of the reservation that
-// lies inside the region is marked as holes, target -1): they travel with the next iteration's -- proposals are
-// suggestions with exact distances, a late one is as valid as a fresh one.  (The first version walked the rows twice --
-// count, serial scan by one thread, write -- and read every dirty row's 512 bytes both times.)
-__global__ __launch_bounds__(256) void k_proposal_export_regions(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap,
+// They sit in the shard's NARROW table pbuf_r (PR = 16 slots per row: a rank sends a remote row a few proposals per
+// iteration; the wide 64-slot rows of the first version made this export stream 1 KB per dirty row -- 1.8 ms per launch
+// at 10 M points, most of what the exchange cost a rank).  A workgroup takes 128 consecutive rows, 32 per wave; a wave
+// reads the dirty flags of its rows with one load and then its rows four at a time (lane = row-in-step * 16 + slot),
+// ONCE, into registers, counting with ballots.  Space is reserved hierarchically: the wave adds the total of each run of
+// rows with one destination to the workgroup's LDS counter of that destination (rows ascend, owners are contiguous
+// ranges: one run, rarely two), ONE global atomic per workgroup and destination follows -- the cursors are <= 64 hot
+// addresses; a global atomic per wave serialised the launch (measured: 8 ms) -- and the records are written straight
+// from the registers.  A row whose records would cross the end of the region keeps them (slots and dirty flag
+// untouched; the part of the reservation inside the region becomes holes, target -1): they travel with the next
+// iteration's -- proposals are suggestions with exact distances, a late one is as valid as a fresh one.
+template <int PR>
+__global__ __launch_bounds__(256) void k_proposal_export_regions(uint64_t *__restrict__ pbuf_r, uint8_t *__restrict__ pdirty,
                                                                  int64_t n, int64_t own_lo, int64_t own_hi,
                                                                  const int64_t *__restrict__ bounds, int n_ranks, int64_t cap,
                                                                  long long *__restrict__ cursors, int32_t *__restrict__ targets,
                                                                  uint64_t *__restrict__ keys, long long *__restrict__ deferred) {
-    constexpr int R = 32, MAXRUN = 3;
+    constexpr int R = 32, RPS = 64 / PR, STEPS = R / RPS, MAXRUN = 3;  // RPS rows per step: lane = row-in-step * PR + slot
+    constexpr unsigned GM = PR == 32 ? 0xFFFFFFFFu : 0xFFFFu, SM = (1u << RPS) - 1u;
     __shared__ int wg_cnt[64];
     __shared__ long long wg_base[64];
-    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int lane = nnd_lane(), w = threadIdx.x >> 6, grp = lane / PR, sl = lane % PR;
     if (threadIdx.x < 64) wg_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = ((int64_t)blockIdx.x * 4 + w) * R;
     const int64_t v_l = base + lane;
     const unsigned m = base < n ? (unsigned)__ballot(lane < R && v_l < n && (v_l < own_lo || v_l >= own_hi) && pdirty[v_l < n ? v_l : 0] != 0) : 0u;
-    uint64_t key[R];
-    int c[R];
+    uint64_t key[STEPS];
+    unsigned long long bal[STEPS];
 #pragma unroll
-    for (int i = 0; i < R; i++) {
-        key[i] = NND_EMPTY_KEY;
-        if ((m >> i) & 1u) key[i] = lane < pcap ? pbuf[(base + i) * pcap + lane] : NND_EMPTY_KEY;  // wave-uniform branch
+    for (int st = 0; st < STEPS; st++) {
+        key[st] = NND_EMPTY_KEY;
+        if ((m >> (RPS * st)) & SM) {  // wave-uniform: some row of this step is dirty
+            const int i = RPS * st + grp;
+            if ((m >> i) & 1u) key[st] = pbuf_r[(base + i) * PR + sl];
+        }
+        bal[st] = __ballot(key[st] != NND_EMPTY_KEY);
     }
-#pragma unroll
-    for (int i = 0; i < R; i++) c[i] = ((m >> i) & 1u) ? __popcll(__ballot(key[i] != NND_EMPTY_KEY)) : 0;
-    // runs of dirty rows with one destination (wave-uniform bookkeeping)
+    // runs of dirty rows with one destination (wave-uniform bookkeeping); c = live slots of a row
     int run_d[MAXRUN], run_first[MAXRUN], run_tot[MAXRUN], run_off[MAXRUN];
     int n_run = 0;
     int off[R];
@@ -348,6 +368,7 @@ __global__ __launch_bounds__(256) void k_proposal_export_regions(uint64_t *__res
         for (int i = 0; i < R; i++) {
             off[i] = 0;
             if (!((m >> i) & 1u)) continue;
+            const int c = __popc((unsigned)(bal[i / RPS] >> (PR * (i % RPS))) & GM);
             const int64_t v = base + i;
             if (d < 0 || v >= bounds[d + 1]) {  // a new run starts at this row
                 d = d < 0 ? nnd_owner_of(bounds, n_ranks, v) : d + 1;
@@ -359,9 +380,9 @@ __global__ __launch_bounds__(256) void k_proposal_export_regions(uint64_t *__res
                 }
                 n_run++;
             }
-            const int r = n_run - 1 < MAXRUN ? n_run - 1 : MAXRUN - 1;  // (more runs than slots: ranks of < 11 rows -- the last slot is re-used with direct global atomics below)
+            const int r = n_run - 1 < MAXRUN ? n_run - 1 : MAXRUN - 1;  // (more runs than slots: ranks of < 11 rows; the whole wave defers below)
             off[i] = run_tot[r];
-            run_tot[r] += c[i];
+            run_tot[r] += c;
         }
     }
     const bool simple = n_run <= MAXRUN;
@@ -384,52 +405,76 @@ __global__ __launch_bounds__(256) void k_proposal_export_regions(uint64_t *__res
     long long n_deferred = 0;
     if (!simple) {  // degenerate geometry (ranks of a few rows): the whole wave defers -- nothing is lost, see above
 #pragma unroll
-        for (int i = 0; i < R; i++) n_deferred += c[i];
+        for (int st = 0; st < STEPS; st++) n_deferred += __popcll(bal[st]);
         if (lane == 0 && n_deferred) atomicAdd((unsigned long long *)deferred, (unsigned long long)n_deferred);
         return;
     }
 #pragma unroll
-    for (int i = 0; i < R; i++) {
-        if (!((m >> i) & 1u)) continue;  // wave-uniform
-        const int64_t v = base + i;
-        if (c[i] == 0) {  // dirty without a live slot: just clear the flag
-            if (lane == 0) pdirty[v] = 0;
-            continue;
+    for (int st = 0; st < STEPS; st++) {
+        if (!((m >> (RPS * st)) & SM)) continue;  // wave-uniform
+        // this lane's row of the step: i = RPS * st + grp (its bookkeeping values are picked from the uniform arrays)
+        int my_off = 0, my_run = 0;
+#pragma unroll
+        for (int g = 0; g < RPS; g++) {
+            const int i = RPS * st + g;
+            int r = 0;
+#pragma unroll
+            for (int q = 1; q < MAXRUN; q++)
+                if (q < n_run && i >= run_first[q]) r = q;
+            if (grp == g) {
+                my_off = off[i];
+                my_run = r;
+            }
         }
-        int r = 0;
+        const int i = RPS * st + grp;
+        const bool dirty = (m >> i) & 1u;
+        const int64_t v = base + i;
+        const unsigned gb = (unsigned)(bal[st] >> (PR * grp)) & GM;  // live slots of my row
+        const int c = __popc(gb);
+        int d = run_d[0];
+        int roff = run_off[0];
 #pragma unroll
         for (int q = 1; q < MAXRUN; q++)
-            if (q < n_run && i >= run_first[q]) r = q;
-        const int d = run_d[r];
-        const long long at = wg_base[d] + run_off[r] + off[i];
-        const bool on = key[i] != NND_EMPTY_KEY;
-        const int pre = nnd_prefix_popc(__ballot(on));
-        if (at + c[i] > cap) {  // does not fit: deferred; what lies inside the region becomes holes
-            n_deferred += c[i];
-            if (on && at + pre < cap) targets[(int64_t)d * cap + at + pre] = -1;
-            continue;
+            if (my_run == q) { d = run_d[q]; roff = run_off[q]; }
+        const bool on = key[st] != NND_EMPTY_KEY;
+        const int pre = __popc(gb & (sl ? (0xFFFFFFFFu >> (32 - sl)) : 0u));
+        if (dirty) {
+            const long long at = wg_base[d] + roff + my_off;
+            if (c > 0 && at + c > cap) {  // does not fit: deferred; what lies inside the region becomes holes
+                if (sl == 0) n_deferred += c;
+                if (on && at + pre < cap) targets[(int64_t)d * cap + at + pre] = -1;
+            } else {
+                if (on) {
+                    const int64_t idx = (int64_t)d * cap + at + pre;
+                    keys[idx] = key[st];
+                    targets[idx] = (int32_t)v;
+                }
+                pbuf_r[v * PR + sl] = NND_EMPTY_KEY;  // the whole row: a full 128-byte line
+                if (sl == 0) pdirty[v] = 0;
+            }
         }
-        if (on) {
-            const int64_t idx = (int64_t)d * cap + at + pre;
-            keys[idx] = key[i];
-            targets[idx] = (int32_t)v;
-        }
-        if (lane < pcap) pbuf[v * pcap + lane] = NND_EMPTY_KEY;  // the whole row: full 128-byte lines, no read-modify-write
-        if (lane == 0) pdirty[v] = 0;
     }
+    n_deferred = nnd_wave_sum_i32((int)n_deferred);
     if (lane == 0 && n_deferred) atomicAdd((unsigned long long *)deferred, (unsigned long long)n_deferred);
 }
 
 int nnd_launch_proposal_export_regions(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, long long *counts_dev) {
-    if (ctx->n_ranks < 1 || !ctx->shard_bounds) { ctx->set_error("nnd_proposal_export: call nnd_set_shard_bounds first"); return 1; }
-    if (ctx->pcap > 64) { ctx->set_error("nnd_proposal_export expects at most 64 proposal slots per row"); return 1; }
+    if (ctx->n_ranks < 1 || !ctx->shard_bounds) { ctx->set_error("nnd_proposal_export: the handle is not a shard"); return 1; }
     NND_HIP_CHECK(hipMemsetAsync(ctx->shard_cursors, 0, sizeof(long long) * 66, ctx->stream));
-    hipLaunchKernelGGL(k_proposal_export_regions, dim3((unsigned)((ctx->n + 127) / 128)), dim3(256), 0, ctx->stream, ctx->pbuf, ctx->pdirty,
-                       ctx->pcap, ctx->n, ctx->own_lo, ctx->own_hi, ctx->shard_bounds, ctx->n_ranks, cap, ctx->shard_cursors, targets_dev,
-                       keys_dev, ctx->shard_cursors + 65);
-    NND_HIP_CHECK(hipGetLastError());
-    // a region holds min(cursor, cap) records ... the kernel only writes rows that fit entirely, so the count of WRITTEN
-    // records of a region is cursor minus what was deferred behind it; the host gets the exact per-region numbers:
+    if (ctx->pbuf_r) {
+        if (ctx->pcap_r != 16 && ctx->pcap_r != 32) { ctx->set_error("nnd_proposal_export expects 16 or 32 remote proposal slots per row"); return 1; }
+        if (ctx->pcap_r == 16)
+            hipLaunchKernelGGL(k_proposal_export_regions<16>, dim3((unsigned)((ctx->n + 127) / 128)), dim3(256), 0, ctx->stream, ctx->pbuf_r, ctx->pdirty,
+                               ctx->n, ctx->own_lo, ctx->own_hi, ctx->shard_bounds, ctx->n_ranks, cap, ctx->shard_cursors, targets_dev,
+                               keys_dev, ctx->shard_cursors + 65);
+        else
+            hipLaunchKernelGGL(k_proposal_export_regions<32>, dim3((unsigned)((ctx->n + 127) / 128)), dim3(256), 0, ctx->stream, ctx->pbuf_r, ctx->pdirty,
+                               ctx->n, ctx->own_lo, ctx->own_hi, ctx->shard_bounds, ctx->n_ranks, cap, ctx->shard_cursors, targets_dev,
+                               keys_dev, ctx->shard_cursors + 65);
+        NND_HIP_CHECK(hipGetLastError());
+    }
+    // a region holds the rows that fit entirely: the host ships min(cursor, cap) records per region (deferred rows' slots
+    // inside the region are holes)
     NND_HIP_CHECK(hipMemcpyAsync(counts_dev, ctx->shard_cursors, sizeof(long long) * (size_t)ctx->n_ranks, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
@@ -440,7 +485,7 @@ int nnd_launch_import_proposals(nnd_ctx *ctx, const uint64_t *keys, const int32_
     uint32_t slot_seed = nnd_hash2(ctx->seed ^ 0x2545F491u, (uint32_t)ctx->iter);
     ctx->pbuf_clean = false;
     hipLaunchKernelGGL(k_import_proposals, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, keys, targets, count,
-                       ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed);
+                       ctx->pbuf, ctx->pdirty, ctx->pcap, slot_seed, ctx->knn_e, ctx->th, ctx->ks);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

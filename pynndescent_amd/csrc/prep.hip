@@ -144,7 +144,10 @@ int nnd_launch_reset_graph(nnd_ctx *ctx) {
                        ctx->knn_d, total, ctx->th, ctx->n);
     // k_merge and k_sample_select re-arm every slot they consume, so after a complete single-GPU iteration both slot
     // tables are EMPTY again; the flags are cleared by every kernel launch that writes slots
-    if (!ctx->pbuf_clean) NND_HIP_CHECK(hipMemsetAsync(ctx->pbuf, 0xFF, sizeof(uint64_t) * (size_t)ctx->n * ctx->pcap, ctx->stream));
+    if (!ctx->pbuf_clean) {
+        NND_HIP_CHECK(hipMemsetAsync(ctx->pbuf + (size_t)ctx->slim_row0() * ctx->pcap, 0xFF, sizeof(uint64_t) * (size_t)ctx->slim_rows() * ctx->pcap, ctx->stream));
+        if (ctx->pbuf_r) NND_HIP_CHECK(hipMemsetAsync(ctx->pbuf_r, 0xFF, sizeof(uint64_t) * (size_t)ctx->n * ctx->pcap_r, ctx->stream));
+    }
     if (!ctx->rbuf_clean)
         NND_HIP_CHECK(hipMemsetAsync(ctx->rbuf + (size_t)ctx->slim_row0() * 2 * ctx->rcap, 0xFF, sizeof(uint64_t) * (size_t)ctx->slim_rows() * 2 * ctx->rcap, ctx->stream));
     ctx->pbuf_clean = ctx->rbuf_clean = true;

@@ -57,9 +57,10 @@ struct nnd_handle_s {
     bool stream_owned = true;             // false after nnd_set_stream: the caller's stream is borrowed
     // A shard created by nnd_create_impl with bounds allocates the per-OWNED-row tables (cand, rbuf, active) for its own
     // rows only; the pointers above are biased by -own_lo rows so that kernels keep indexing by global vertex id.
+    bool lists_replicated = false;        // shard: the neighbour ids of ALL rows are refreshed before every join (shard.hip): remote targets are tested too
     const int32_t *own_order = nullptr;   // shard: the owned vertices in a spatially coherent order (shard.hip), or nullptr
     bool slim = false;
-    void *slim_alloc[3] = {nullptr, nullptr, nullptr};  // the allocations behind cand / rbuf / active (always; biased or not)
+    void *slim_alloc[4] = {nullptr, nullptr, nullptr, nullptr};  // the allocations behind cand / rbuf / active / pbuf (always; biased or not)
     int64_t slim_rows() const { return slim ? own_hi - own_lo : n; }  // rows those three tables hold
     int64_t slim_row0() const { return slim ? own_lo : 0; }            // first of them
     uint32_t seed = 0, tree_seed = 0;
@@ -81,7 +82,9 @@ struct nnd_handle_s {
     // candidates / proposals
     int32_t *cand = nullptr;  // (n, 2*mcp): [new | old], -1 padded
     uint64_t *rbuf = nullptr; // (n, 2, rcap) reverse offers (priority<<32 | source), hashed slots
-    uint64_t *pbuf = nullptr; // (n, pcap) proposals (dist_bits<<32 | source), hashed slots
+    uint64_t *pbuf = nullptr; // (n, pcap) proposals (dist_bits<<32 | source), hashed slots; a shard holds its OWNED rows only (biased)
+    uint64_t *pbuf_r = nullptr; // shard: (n, pcap_r) proposals for vertices owned elsewhere, exported every iteration (merge.hip)
+    int pcap_r = 32;
     uint8_t *pdirty = nullptr; // (n) 1 when the row has pending proposals
     uint8_t *active = nullptr; // (n) 1 when the vertex will hold >= 1 new candidate this iteration
 
@@ -196,12 +199,11 @@ static inline const int32_t *nnd_vertex_order(const nnd_ctx *ctx) {
     return ctx->perm[ctx->cur];
 }
 
-// Rows whose CURRENT neighbour lists this handle holds (the join's membership test reads them): only the owned slice on
-// a shard of a row-sharded build (nnd_set_shard_bounds: remote rows are never imported, their owners dedup in the merge,
-// utils.py:489-492); every row otherwise -- including handles driven through nnd_set_owned_range + nnd_import_graph_rows,
-// which do import the remote rows.
-static inline int64_t nnd_list_lo(const nnd_ctx *ctx) { return ctx->n_ranks > 1 ? ctx->own_lo : 0; }
-static inline int64_t nnd_list_hi(const nnd_ctx *ctx) { return ctx->n_ranks > 1 ? ctx->own_hi : ctx->n; }
+// Rows whose CURRENT neighbour lists this handle holds (the join's membership test reads them): every row on a plain
+// handle and on a shard whose builder all-gathers the neighbour ids before every join (lists_replicated); only the owned
+// slice otherwise (the owners then dedup at import / in the merge, utils.py:489-492).
+static inline int64_t nnd_list_lo(const nnd_ctx *ctx) { return (ctx->n_ranks > 1 && !ctx->lists_replicated) ? ctx->own_lo : 0; }
+static inline int64_t nnd_list_hi(const nnd_ctx *ctx) { return (ctx->n_ranks > 1 && !ctx->lists_replicated) ? ctx->own_hi : ctx->n; }
 
 // Wait for everything queued on the handle's stream by polling an event: the per-level read-backs of the forest build
 // are latency critical (the GPU idles until the host has the segment count), and a blocking wait wakes up late.
