@@ -137,6 +137,8 @@ _SIGNATURES = [
     ("nnd_destroy", C.c_int32, [_H]),
     ("nnd_set_data_host", C.c_int32, [_H, C.c_void_p]),
     ("nnd_set_data_device", C.c_int32, [_H, C.c_void_p]),
+    ("nnd_data_nonfinite", C.c_int32, [_H, C.POINTER(C.c_int32)]),
+    ("nnd_release_pending", C.c_int32, []),
     ("nnd_make_forest", C.c_int32, [_H]),
     ("nnd_leaf_array_shape", C.c_int32, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     ("nnd_get_leaf_array", C.c_int32, [_H, C.c_void_p]),
@@ -267,6 +269,12 @@ class Builder:
         x = np.ascontiguousarray(x, dtype=np.float32)
         assert x.shape == (self.n, self.dim)
         self._check(self.lib.nnd_set_data_host(self._h, _ptr(x)))
+
+    def data_nonfinite(self):
+        """True when the point set handed in held a NaN or an infinity (flag raised by the prep kernel)."""
+        out = C.c_int32()
+        self._check(self.lib.nnd_data_nonfinite(self._h, C.byref(out)))
+        return bool(out.value)
 
     def set_data_device(self, dev_ptr, keepalive=None):
         """dev_ptr: integer address of a float32 (n, dim) C-contiguous device buffer (e.g. tensor.data_ptr()).

@@ -3,7 +3,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -31,9 +33,14 @@ extern "C" const char *nnd_last_error(nnd_handle_t h) { return h ? h->err : g_er
         }                                                                                            \
     } while (0)
 
+void nnd_release_parked();
 template <typename T>
 static int dalloc(nnd_ctx *ctx, T **p, size_t count) {
-    API_HIP(hipMalloc((void **)p, sizeof(T) * (count ? count : 1)));
+    if (hipMalloc((void **)p, sizeof(T) * (count ? count : 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        nnd_release_parked();  // a parked handle (nnd_destroy) may hold what is missing
+        API_HIP(hipMalloc((void **)p, sizeof(T) * (count ? count : 1)));
+    }
     // debugging aid: fresh hipMalloc pages are usually zero, recycled ones are not -- NND_POISON=<byte> fills every buffer with
     // that byte (try 165: negative ints / tiny floats, and 1 or 127: positive ints) before the build initialises it
     static const int poison = [] { const char *e = getenv("NND_POISON"); return e ? atoi(e) : 0; }();  // the fill byte
@@ -68,7 +75,7 @@ static void free_all(nnd_ctx *ctx) {
     if (ctx->x_owned) F((void *)ctx->x_orig);
     for (void *&a : ctx->slim_alloc) { F(a); a = nullptr; }  // cand / rbuf / active (the working pointers may be biased)
     F(ctx->xp); F(ctx->nrm); F(ctx->nr2); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->pbuf_r);
-    F(ctx->pdirty);
+    F(ctx->pdirty); F(ctx->out_idx); F(ctx->out_dist);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
     F(ctx->xs); F(ctx->xsh); F(ctx->nr2s); F(ctx->node_hf); F(ctx->node_hh); F(ctx->node_child); F(ctx->node_pack); F(ctx->s_leaf_depth);
@@ -87,6 +94,7 @@ static void free_all(nnd_ctx *ctx) {
     if (ctx->stream && ctx->stream_owned) (void)hipStreamDestroy(ctx->stream);
 }
 
+static nnd_ctx *take_parked(const nnd_params *p);
 extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) { return nnd_create_impl(out, p, nullptr, 0, 0); }
 
 int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bounds_host, int n_ranks, int rank) {
@@ -94,7 +102,7 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
     *out = nullptr;
     if (p->n < 1 || p->dim < 1) { gerr("nnd_create: need n >= 1 and dim >= 1 (got n=%lld dim=%d)", (long long)p->n, p->dim); return 1; }
     if (p->metric != NND_METRIC_SQEUCLIDEAN && p->metric != NND_METRIC_ALT_COSINE) { gerr("nnd_create: unknown metric %d", p->metric); return 1; }
-    if (p->n_neighbors < 1 || p->n_neighbors > 64) { gerr("nnd_create: n_neighbors must be in 1..64 (got %d)", p->n_neighbors); return 1; }
+    if (p->n_neighbors < 1 || p->n_neighbors > 128) { gerr("nnd_create: n_neighbors must be in 1..128 (got %d)", p->n_neighbors); return 1; }
     if (p->max_candidates < 1 || p->max_candidates > 64) { gerr("nnd_create: max_candidates must be in 1..64 (got %d)", p->max_candidates); return 1; }
     if (p->n_trees < 0 || p->leaf_size < 1) { gerr("nnd_create: bad n_trees/leaf_size"); return 1; }
     if (p->n >= (int64_t)0x7FFFFFF0) { gerr("nnd_create: n too large for int32 ids"); return 1; }
@@ -109,6 +117,13 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
     if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) { gerr("nnd_create: hipGetDeviceProperties failed"); return 1; }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { gerr("nnd_create: device %d is %s; this build targets gfx950 (MI355X) only", p->device, prop.gcnArchName); return 1; }
     if (hipSetDevice(p->device) != hipSuccess) { gerr("nnd_create: hipSetDevice failed"); return 1; }
+    if (!bounds_host) {
+        if (nnd_ctx *parked = take_parked(p)) {
+            *out = parked;
+            return 0;
+        }
+        nnd_release_parked();  // a parked handle of another geometry: its memory is wanted now
+    }
 
     nnd_ctx *ctx = new nnd_ctx();
     ctx->p = *p;
@@ -134,6 +149,7 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
     ctx->ks = (p->n_neighbors + 15) & ~15;
     ctx->mc = p->max_candidates;
     ctx->mcp = p->max_candidates <= 16 ? 16 : (p->max_candidates <= 32 ? 32 : 64);
+    if (ctx->ks > 64 && ctx->mcp < 32) ctx->mcp = 32;  // wide rows: the join that reads neighbour lists from global memory (join.hip k_local_join_w)
     // reverse-offer slots per (vertex, class): at least max_candidates rounded up to a power of two, so that a vertex
     // can fill its list from reverse offers alone, as the reference's max_candidates-deep heaps can (utils.py:277-306)
     ctx->rcap = p->max_candidates <= 32 ? 32 : 64;
@@ -268,12 +284,90 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
     return 0;
 }
 
-extern "C" int32_t nnd_destroy(nnd_handle_t ctx) {
-    if (!ctx) return 0;
+// Creating and releasing a handle's HBM costs ~10 ms at 1 M points (every hipFree synchronises the device and unmaps;
+// doing it on a background thread only moved the cost into the next call's hipMalloc).  nnd_destroy therefore PARKS one
+// plain handle instead of freeing it, and nnd_create re-arms the parked handle when the geometry matches (same device,
+// n, dim, metric, k, trees, leaf size, candidates, flags): repeated builds -- NNDescent(...) in a loop, nnd_build -- pay
+// neither.  The parked handle holds its memory until a different geometry arrives, nnd_release_pending() is called, or
+// the process ends; an allocation that fails while a handle is parked releases it and tries once more.
+static std::mutex g_park_mu;
+static nnd_ctx *g_parked = nullptr;
+
+static void destroy_now(nnd_ctx *ctx) {
     (void)hipSetDevice(ctx->p.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_all(ctx);
     delete ctx;
+}
+void nnd_release_parked() {
+    nnd_ctx *old = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        old = g_parked;
+        g_parked = nullptr;
+    }
+    if (old) destroy_now(old);
+}
+static bool same_geometry(const nnd_params &a, const nnd_params &b) {
+    return a.n == b.n && a.dim == b.dim && a.metric == b.metric && a.n_neighbors == b.n_neighbors && a.n_trees == b.n_trees &&
+           a.leaf_size == b.leaf_size && a.max_candidates == b.max_candidates && a.device == b.device && a.flags == b.flags;
+}
+// a parked handle of this geometry, re-armed for a new build (seeds, counters, per-build flags), or nullptr
+static nnd_ctx *take_parked(const nnd_params *p) {
+    nnd_ctx *ctx = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        if (g_parked && same_geometry(g_parked->p, *p)) {
+            ctx = g_parked;
+            g_parked = nullptr;
+        }
+    }
+    if (!ctx) return nullptr;
+    (void)hipSetDevice(p->device);
+    ctx->p = *p;
+    if (ctx->p.join_blocks < 1) ctx->p.join_blocks = 1;
+    ctx->seed = nnd_mix32((uint32_t)p->rng_state[0] ^ nnd_mix32((uint32_t)p->rng_state[1] + 0x9E3779B9u) ^ nnd_mix32((uint32_t)p->rng_state[2] + 0x7F4A7C15u));
+    ctx->tree_seed = nnd_mix32((uint32_t)p->tree_rng[0] ^ nnd_mix32((uint32_t)p->tree_rng[1] + 0x9E3779B9u) ^ nnd_mix32((uint32_t)p->tree_rng[2] + 0x7F4A7C15u));
+    ctx->iter = 0;
+    ctx->stats = nnd_stats{};
+    ctx->err[0] = 0;
+    ctx->forest_built = false;
+    ctx->h_leaf_valid = false;
+    ctx->n_leaves = 0;
+    ctx->max_leaf = 0;
+    ctx->own_order = nullptr;
+    ctx->lists_replicated = false;
+    nnd_hub_tree_free(ctx);
+    if (!ctx->stream_owned) {  // a borrowed stream must not outlive its lender
+        ctx->stream = nullptr;
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { destroy_now(ctx); return nullptr; }
+        ctx->stream_owned = true;
+    }
+    if (!ctx->x_owned) ctx->x_orig = nullptr;  // a borrowed point set is gone; an owned copy's buffer is reused by nnd_set_data_host
+    ctx->x_valid = false;
+    ctx->tlog.clear();
+    ctx->tev_used = 0;
+    return ctx;
+}
+
+extern "C" int32_t nnd_destroy(nnd_handle_t ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->p.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    nnd_ctx *old = nullptr;
+    if (ctx->n_ranks == 0) {  // plain handles only: a shard's tables are sized by its slice
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        old = g_parked;
+        g_parked = ctx;
+    } else {
+        old = ctx;
+    }
+    if (old) destroy_now(old);
+    return 0;
+}
+// release the parked handle's device memory now
+extern "C" int32_t nnd_release_pending(void) {
+    nnd_release_parked();
     return 0;
 }
 
@@ -282,7 +376,7 @@ extern "C" int32_t nnd_destroy(nnd_handle_t ctx) {
     API_HIP(hipSetDevice(ctx->p.device));
 
 static int need_data(nnd_ctx *ctx) {
-    if (!ctx->x_orig) { ctx->set_error("no data set (call nnd_set_data_host/device first)"); return 1; }
+    if (!ctx->x_orig || !ctx->x_valid) { ctx->set_error("no data set (call nnd_set_data_host/device first)"); return 1; }
     return 0;
 }
 // build entry points: the handle must hold the graph state (not an auxiliary NND_FLAG_NO_GRAPH handle)
@@ -304,12 +398,14 @@ static int after_data(nnd_ctx *ctx) {
 extern "C" int32_t nnd_set_data_host(nnd_handle_t ctx, const float *x) {
     ENTER(ctx);
     if (!x) { ctx->set_error("nnd_set_data_host: null data"); return 1; }
-    if (ctx->x_owned && ctx->x_orig) { API_HIP(hipFree((void *)ctx->x_orig)); }
-    float *dx = nullptr;
-    API_HIP(hipMalloc((void **)&dx, sizeof(float) * (size_t)ctx->n * ctx->d));
-    ctx->x_orig = dx;
-    ctx->x_owned = true;
-    API_HIP(hipMemcpyAsync(dx, x, sizeof(float) * (size_t)ctx->n * ctx->d, hipMemcpyHostToDevice, ctx->stream));
+    if (!(ctx->x_owned && ctx->x_orig)) {  // the handle's own copy of the rows: allocated once, reused by later calls
+        float *dx = nullptr;
+        API_HIP(hipMalloc((void **)&dx, sizeof(float) * (size_t)ctx->n * ctx->d));
+        ctx->x_orig = dx;
+        ctx->x_owned = true;
+    }
+    API_HIP(hipMemcpyAsync((void *)ctx->x_orig, x, sizeof(float) * (size_t)ctx->n * ctx->d, hipMemcpyHostToDevice, ctx->stream));
+    ctx->x_valid = true;
     return after_data(ctx);
 }
 
@@ -319,7 +415,19 @@ extern "C" int32_t nnd_set_data_device(nnd_handle_t ctx, const float *x_dev) {
     if (ctx->x_owned && ctx->x_orig) { API_HIP(hipFree((void *)ctx->x_orig)); }
     ctx->x_orig = x_dev;
     ctx->x_owned = false;
+    ctx->x_valid = true;
     return after_data(ctx);
+}
+
+// 1 when the point set handed to nnd_set_data_* held a NaN or an infinity (seen by the prep kernel): the reference rejects
+// such input in check_array (pynndescent_.py:1054); the host mirror raises the same error from this flag
+extern "C" int32_t nnd_data_nonfinite(nnd_handle_t ctx, int32_t *out) {
+    ENTER(ctx);
+    if (need_data(ctx)) return 1;
+    if (ctx->p.flags & NND_FLAG_NO_PREP) { *out = 0; return 0; }
+    API_HIP(nnd_sync_spin(ctx));
+    *out = ctx->h_pin[63] != 0 ? 1 : 0;
+    return 0;
 }
 
 extern "C" int32_t nnd_make_forest(nnd_handle_t ctx) {
@@ -406,7 +514,7 @@ extern "C" int32_t nnd_init_from_graph(nnd_handle_t ctx, const int32_t *init_idx
     ENTER(ctx);
     if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
-    if (!init_idx || width < 1) { ctx->set_error("nnd_init_from_graph: bad arguments"); return 1; }
+    if (!init_idx || width < 1 || width > 128) { ctx->set_error("nnd_init_from_graph: width must be in 1..128"); return 1; }
     size_t cnt = (size_t)ctx->n * width;
     nnd_scratch tmp;
     int32_t *di = tmp.get<int32_t>(ctx, cnt);
@@ -524,19 +632,71 @@ extern "C" int32_t nnd_finalize_device(nnd_handle_t ctx, int32_t *out_idx_dev, f
     return 0;
 }
 
+// Device -> pageable host memory.  The runtime stages such a copy through pinned buffers with a single-threaded memcpy
+// (~9 GB/s: 13 ms for the 114 MB graph of a 1 M-point index).  Here: two pinned 32 MB buffers (allocated once per
+// process), the DMA of chunk c + 1 in flight while chunk c is copied out of its buffer by four host threads.
+static std::mutex g_stage_mu;
+static char *g_stage[2] = {nullptr, nullptr};
+static hipEvent_t g_stage_ev[2] = {nullptr, nullptr};
+static int d2h_parallel(nnd_ctx *ctx, void *dst, const void *src, size_t bytes, int parts) {
+    constexpr size_t STAGE = (size_t)32 << 20;
+    if (bytes < (size_t)(4u << 20)) {
+        API_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    for (int b = 0; b < 2; b++) {
+        if (!g_stage[b]) API_HIP(hipHostMalloc((void **)&g_stage[b], STAGE, hipHostMallocDefault));
+        if (!g_stage_ev[b]) API_HIP(hipEventCreateWithFlags(&g_stage_ev[b], hipEventDisableTiming));
+    }
+    const size_t nchunks = (bytes + STAGE - 1) / STAGE;
+    for (size_t c = 0; c <= nchunks; c++) {
+        if (c < nchunks) {
+            const size_t o = c * STAGE, len = bytes - o < STAGE ? bytes - o : STAGE;
+            API_HIP(hipMemcpyAsync(g_stage[c & 1], (const char *)src + o, len, hipMemcpyDeviceToHost, ctx->stream));
+            API_HIP(hipEventRecord(g_stage_ev[c & 1], ctx->stream));
+        }
+        if (c >= 1) {
+            const size_t o = (c - 1) * STAGE, len = bytes - o < STAGE ? bytes - o : STAGE;
+            API_HIP(hipEventSynchronize(g_stage_ev[(c - 1) & 1]));
+            const char *from = g_stage[(c - 1) & 1];
+            char *to = (char *)dst + o;
+            std::vector<std::thread> th;
+            const size_t piece = ((len + parts - 1) / parts + 4095) & ~(size_t)4095;
+            for (int t = 1; t < parts; t++) {
+                const size_t po = (size_t)t * piece;
+                if (po >= len) break;
+                const size_t pl = len - po < piece ? len - po : piece;
+                th.emplace_back([=] { memcpy(to + po, from + po, pl); });
+            }
+            memcpy(to, from, len < piece ? len : piece);
+            for (auto &t : th) t.join();
+        }
+    }
+    return 0;
+}
+
+// grow-only device buffers for the finished graph of the host-buffer entry points (no hipMalloc / hipFree per call)
+static int out_buffers(nnd_ctx *ctx, size_t cnt) {
+    if (cnt <= ctx->out_cap) return 0;
+    if (ctx->out_idx) { API_HIP(hipFree(ctx->out_idx)); ctx->out_idx = nullptr; }
+    if (ctx->out_dist) { API_HIP(hipFree(ctx->out_dist)); ctx->out_dist = nullptr; }
+    ctx->out_cap = 0;
+    API_HIP(hipMalloc((void **)&ctx->out_idx, sizeof(int32_t) * cnt));
+    API_HIP(hipMalloc((void **)&ctx->out_dist, sizeof(float) * cnt));
+    ctx->out_cap = cnt;
+    return 0;
+}
+
 extern "C" int32_t nnd_finalize_host(nnd_handle_t ctx, int32_t *out_idx, float *out_dist) {
     ENTER(ctx);
     if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
     size_t cnt = (size_t)(ctx->own_hi - ctx->own_lo) * ctx->k;  // owned rows only
-    nnd_scratch tmp;
-    int32_t *di = tmp.get<int32_t>(ctx, cnt);
-    float *dd = tmp.get<float>(ctx, cnt);
-    if (!di || !dd) return 1;
-    if (nnd_finalize_device(ctx, di, dd)) return 1;
-    API_HIP(hipMemcpyAsync(out_idx, di, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-    API_HIP(hipMemcpyAsync(out_dist, dd, sizeof(float) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-    API_HIP(nnd_sync_spin(ctx));
+    if (out_buffers(ctx, cnt)) return 1;
+    if (nnd_finalize_device(ctx, ctx->out_idx, ctx->out_dist)) return 1;  // (ends with a flush: the stream has drained)
+    if (d2h_parallel(ctx, out_idx, ctx->out_idx, sizeof(int32_t) * cnt, 4)) return 1;
+    if (d2h_parallel(ctx, out_dist, ctx->out_dist, sizeof(float) * cnt, 4)) return 1;
     return 0;
 }
 
@@ -583,23 +743,10 @@ extern "C" int32_t nnd_build(const nnd_params *params, const float *x, const int
             if (!rc) rc = nnd_descent(h);
             if (!rc) rc = nnd_finalize_host(h, out_idx, out_dist);
         } else {
-            size_t cnt = (size_t)h->n * h->k;
-            int32_t *di = nullptr;
-            float *dd = nullptr;
-            if (hipMalloc((void **)&di, sizeof(int32_t) * cnt) != hipSuccess || hipMalloc((void **)&dd, sizeof(float) * cnt) != hipSuccess) {
-                h->set_error("hipMalloc of the output buffers failed");
-                rc = 1;
-            }
-            if (!rc) rc = nnd_build_device(h, di, dd);
-            if (!rc) {
-                if (hipMemcpy(out_idx, di, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost) != hipSuccess ||
-                    hipMemcpy(out_dist, dd, sizeof(float) * cnt, hipMemcpyDeviceToHost) != hipSuccess) {
-                    h->set_error("copy of the result to the host failed");
-                    rc = 1;
-                }
-            }
-            if (di) (void)hipFree(di);
-            if (dd) (void)hipFree(dd);
+            if (!rc) rc = out_buffers(h, (size_t)h->n * h->k);
+            if (!rc) rc = nnd_build_device(h, h->out_idx, h->out_dist);
+            if (!rc) rc = d2h_parallel(h, out_idx, h->out_idx, sizeof(int32_t) * (size_t)h->n * h->k, 4);
+            if (!rc) rc = d2h_parallel(h, out_dist, h->out_dist, sizeof(float) * (size_t)h->n * h->k, 4);
         }
     }
     if (stats) *stats = h->stats;

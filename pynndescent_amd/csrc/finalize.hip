@@ -119,8 +119,73 @@ __global__ __launch_bounds__(256, METRIC == 0 ? 6 : 4) void k_finalize(const flo
     }
 }
 
+// 64 < k <= 128: one wave per row, ids / exact distances through LDS, four neighbours at a time (16 lanes each), ranks by
+// counting over the LDS copy.  Same arithmetic as k_finalize (float64 accumulation of the reference's formulas).
+__global__ __launch_bounds__(256) void k_finalize_wide(const float *__restrict__ x, int d, int64_t lo, int64_t n, int k, int ks, int metric,
+                                                       const uint32_t *__restrict__ knn_e, int32_t *__restrict__ out_idx,
+                                                       float *__restrict__ out_dist) {
+    __shared__ uint32_t sid[4][128];
+    __shared__ float sdist[4][128];
+    const int lane = nnd_lane(), w = threadIdx.x >> 6, grp = lane >> 4, l16 = lane & 15;
+    const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;
+    if (v >= n) return;
+    for (int j = lane; j < k; j += 64) sid[w][j] = knn_e[v * ks + j];
+    nnd_wave_lds_sync();
+    const float *xv = x + v * d;
+    for (int j0 = 0; j0 < k; j0 += 4) {
+        const int j = j0 + grp;
+        const uint32_t ej = j < k ? sid[w][j] : NND_EMPTY_E;
+        const bool on = ej != NND_EMPTY_E;
+        const float *xu = x + (int64_t)(on ? (ej & NND_IDX_MASK) : 0) * d;
+        double s = 0.0, dot = 0.0, nx = 0.0, ny = 0.0;
+        for (int t = l16; t < d; t += 16) {
+            const double a0 = xv[t], b0 = xu[t];
+            if (metric == 0) s += (a0 - b0) * (a0 - b0);
+            else {
+                dot += a0 * b0;
+                nx += a0 * a0;
+                ny += b0 * b0;
+            }
+        }
+        float val;
+        if (metric == 0) {
+            val = (float)fin_group16_sum_f64(s);
+        } else {
+            const double dt = fin_group16_sum_f64(dot), ax = fin_group16_sum_f64(nx), ay = fin_group16_sum_f64(ny);
+            if (ax == 0.0 && ay == 0.0) val = 0.0f;
+            else if (ax == 0.0 || ay == 0.0 || dt <= 0.0) val = NND_FLT_MAX;
+            else {
+                const double r = log2(sqrt(ax * ay) / dt);
+                val = r > 0.0 ? (float)r : 0.0f;
+            }
+        }
+        if (!on) val = INFINITY;
+        if (l16 == 0 && j < k) sdist[w][j] = val;
+    }
+    nnd_wave_lds_sync();
+    for (int j = lane; j < k; j += 64) {
+        const uint32_t e = sid[w][j];
+        const uint32_t myidx = e == NND_EMPTY_E ? NND_IDX_MASK : (e & NND_IDX_MASK);
+        const uint64_t mykey = ((uint64_t)__float_as_uint(sdist[w][j]) << 32) | myidx;
+        int r = 0;
+        for (int q = 0; q < k; q++) {
+            const uint32_t eq = sid[w][q];
+            const uint64_t kq = ((uint64_t)__float_as_uint(sdist[w][q]) << 32) | (eq == NND_EMPTY_E ? NND_IDX_MASK : (eq & NND_IDX_MASK));
+            r += (kq < mykey || (kq == mykey && q < j)) ? 1 : 0;
+        }
+        out_idx[(v - lo) * k + r] = e == NND_EMPTY_E ? -1 : (int32_t)(e & NND_IDX_MASK);
+        out_dist[(v - lo) * k + r] = sdist[w][j];
+    }
+}
+
 int nnd_launch_finalize(nnd_ctx *ctx, int32_t *out_idx_dev, float *out_dist_dev) {
     unsigned grid = (unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4);
+    if (ctx->k > 64) {
+        hipLaunchKernelGGL(k_finalize_wide, dim3(grid), dim3(256), 0, ctx->stream, ctx->x_orig, ctx->d, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks,
+                           ctx->p.metric, ctx->knn_e, out_idx_dev, out_dist_dev);
+        NND_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     grid = (grid + 7u) & ~7u;  // whole multiples of the XCD count
     if (ctx->p.metric == 0)
         hipLaunchKernelGGL(k_finalize<0>, dim3(grid), dim3(256), 0, ctx->stream, ctx->x_orig, ctx->d, ctx->own_lo, ctx->own_hi,

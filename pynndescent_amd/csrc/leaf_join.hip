@@ -358,6 +358,167 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : (QW && NT <= 5 
     }
 }
 
+// Leaves of more than 96 points (k = 30, the reference's default, gives leaf_size 150).  The one-workgroup-per-leaf kernel
+// above then keeps 16 rows of the distance block per wave, needs 82 KB of LDS (ONE workgroup of 8 waves per CU) and deals
+// whole tile rows to its waves (10 tile rows over 8 waves: two waves merge 32 rows while six merge 16): 3.4 ms per tree at
+// 1 M points, 7 x the k = 15 cost.  Here a workgroup of NW waves takes a BLOCK OF 8 * NW ROWS of a leaf: all m rows of
+// the leaf are staged (they are the block's candidates), the block x m distance rows are computed (tiles dealt
+// round-robin) and each wave merges 8 rows.  41 KB of LDS at 160 points: three workgroups per CU, every wave with the
+// same share of the merges; the leaf's Gram block is computed twice (no symmetry across workgroups) and its rows are
+// staged once per block (the reason for 64-row blocks: 32-row blocks staged every leaf five times).  Rows of one leaf
+// are owned by exactly one workgroup: no atomics.
+template <int NT, int NW = 8, bool WIDE = false>
+__global__ __launch_bounds__(NW * 64, 2) void k_leaf_join_rb(const float *__restrict__ xp, int dp, const float *__restrict__ nrm, int metric,
+                                                         const int32_t *__restrict__ perm, const int32_t *__restrict__ wl_start,
+                                                         const int32_t *__restrict__ wl_len, int64_t leaf0, int64_t n_leaves, int k, int ks,
+                                                         uint32_t *__restrict__ knn_e, float *__restrict__ knn_d, float *__restrict__ th,
+                                                         long long *__restrict__ counters) {
+    constexpr int DC = 64, MP = NT * 16, RB = NW * 8, TRB = RB / 16, DSTRIDE = MP + 1;  // 8 rows merged per wave
+    constexpr int TPW = (TRB * NT + NW - 1) / NW;                     // tiles per wave: TRB tile rows x NT tile columns
+    constexpr int NLD = (MP * (DC / 4) + NW * 64 - 1) / (NW * 64);    // 16-byte row chunks per thread and K block
+    constexpr int BIG = MP * DC > RB * DSTRIDE ? MP * DC : RB * DSTRIDE;
+    __shared__ __attribute__((aligned(16))) float big[BIG];           // row tile, then the 32 x m distance block
+    __shared__ int32_t ids[MP];
+    __shared__ float nrs[MP];
+    __shared__ uint64_t wide_scr[WIDE ? NW : 1][WIDE ? NND_WIDE_SCRATCH_WORDS : 1];  // 64 < k <= 128: rows merged through LDS
+    const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
+    const int64_t leaf = leaf0 + blockIdx.x;
+    if (leaf >= n_leaves) return;
+    const int start = wl_start[leaf], m = wl_len[leaf];
+    const int r0 = blockIdx.y * RB;  // first row of this workgroup's block
+    if (m < 2 || r0 >= m) return;
+    const int nt = (m + 15) >> 4, mp = nt << 4;
+    for (int r = tid; r < MP; r += NW * 64) {
+        const int id = r < m ? perm[start + r] : -1;
+        ids[r] = id;
+        nrs[r] = nrm[id >= 0 ? id : 0];
+    }
+    __syncthreads();
+    f32x4 acc[TPW];
+    int tI[TPW], tJ[TPW];
+    bool tOn[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; q++) {
+        acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int t = w + q * NW;                // row-major over (TRB, nt)
+        const int I = t / nt, J = t - I * nt;    // wave-uniform
+        tOn[q] = t < TRB * nt && (r0 >> 4) + I < nt;
+        tI[q] = tOn[q] ? (r0 >> 4) + I : 0;
+        tJ[q] = tOn[q] ? J : 0;
+    }
+    float *Xs = big;
+    const int r16 = lane & 15, g = lane >> 4;
+    for (int c0 = 0; c0 < dp; c0 += DC) {
+        const int cw = (dp - c0) < DC ? (dp - c0) : DC;
+        const int nch = cw >> 2, total = mp * nch, nsh = cw == 64 ? 4 : 3;
+        f32x4 rv[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int idx = tid + q * NW * 64, idc = idx < total ? idx : 0;
+            const int r = idc >> nsh, ch = idc & (nch - 1);
+            const int id = ids[r];
+            rv[q] = *(const f32x4 *)(xp + (int64_t)(id >= 0 ? id : 0) * dp + c0 + 4 * ch);
+        }
+        if (c0 > 0) __syncthreads();  // the previous block's operand reads are done
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int idx = tid + q * NW * 64;
+            if (idx < total) {
+                const int r = idx >> nsh, ch = idx & (nch - 1);
+                *(f32x4 *)&Xs[nnd_swz<DC>(r, ch)] = rv[q];
+            }
+        }
+        __syncthreads();
+        for (int t = 0; t < (cw >> 4); t++) {
+            const int c = 4 * t + g;
+            float4 a[TPW], b[TPW];
+#pragma unroll
+            for (int q = 0; q < TPW; q++) {
+                a[q] = *(const float4 *)&Xs[nnd_swz<DC>(tI[q] * 16 + r16, c)];
+                b[q] = *(const float4 *)&Xs[nnd_swz<DC>(tJ[q] * 16 + r16, c)];
+            }
+#pragma unroll
+            for (int q = 0; q < TPW; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b[q].x, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < TPW; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, b[q].y, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < TPW; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, b[q].z, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < TPW; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, b[q].w, acc[q], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // Xs is overwritten by the distance block
+    float *Dm = big;  // RB x DSTRIDE: row il = global leaf row r0 + il
+#pragma unroll
+    for (int q = 0; q < TPW; q++) {
+        if (!tOn[q]) continue;
+        const int j = tJ[q] * 16 + r16;
+        const float nj = nrs[j];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int il = tI[q] * 16 - r0 + 4 * g + r;
+            Dm[il * DSTRIDE + j] = nnd_gram_to_dist(metric, acc[q][r], nrs[r0 + il], nj);
+        }
+    }
+    __syncthreads();
+    int accepted = 0;
+    const int lk = lane < k ? lane : 0;
+    const int row_first = r0 + w * (RB / NW), row_end = (row_first + RB / NW) < m ? (row_first + RB / NW) : m;
+    uint32_t e_nx = NND_EMPTY_E;
+    float d_nx = INFINITY;
+    if (row_first < row_end) {
+        e_nx = knn_e[(int64_t)ids[row_first] * ks + lk];
+        d_nx = knn_d[(int64_t)ids[row_first] * ks + lk];
+    }
+    if constexpr (WIDE) {
+        for (int i = row_first; i < row_end; i++) {
+            const float *Drow = Dm + (i - r0) * DSTRIDE;
+            const int64_t v = ids[i];
+            accepted += nnd_merge_row_lds<(MP + 63) / 64>(wide_scr[w], knn_e + v * ks, knn_d + v * ks, th + v, k, m,
+                                                         [&](int c, uint32_t &id, float &dc) {
+                                                             id = (uint32_t)ids[c];
+                                                             dc = Drow[c];
+                                                             return c != i;  // pynndescent_.py:97: p != q
+                                                         });
+            nnd_wave_lds_sync();
+        }
+    } else
+    for (int i = row_first; i < row_end; i++) {  // rolling prefetch: the next row's k-list is in flight during this merge
+        const float *Drow = Dm + (i - r0) * DSTRIDE;
+        const int64_t v = ids[i];
+        const uint32_t e0 = lane < k ? e_nx : NND_EMPTY_E;
+        const float d0 = lane < k ? d_nx : INFINITY;
+        if (i + 1 < row_end) {
+            const int64_t vn = ids[i + 1];
+            e_nx = knn_e[vn * ks + lk];
+            d_nx = knn_d[vn * ks + lk];
+        }
+        auto cf = [&](int c, uint32_t &id, float &dc) {
+            id = (uint32_t)ids[c];
+            dc = Drow[c];
+            return c != i;  // pynndescent_.py:97: p != q
+        };
+        if (m <= 64) accepted += nnd_merge_row_regs<1>(knn_e + v * ks, knn_d + v * ks, th + v, e0, d0, k, m, cf);
+        else if (MP > 128 && m <= 128) accepted += nnd_merge_row_regs<2>(knn_e + v * ks, knn_d + v * ks, th + v, e0, d0, k, m, cf);
+        else accepted += nnd_merge_row_regs<(MP + 63) / 64>(knn_e + v * ks, knn_d + v * ks, th + v, e0, d0, k, m, cf);
+    }
+    __syncthreads();
+    int *wacc = (int *)nrs;  // nrs is dead
+    if (lane == 0) wacc[w] = accepted;
+    __syncthreads();
+    if (tid == 0) {
+        long long a = 0;
+        for (int q = 0; q < NW; q++) a += wacc[q];
+        nnd_count(counters, CNT_ACCEPT, a);
+        if (blockIdx.y == 0) {  // per-leaf statistics once
+            nnd_count(counters, CNT_PAIRS, (long long)m * (m - 1) / 2);
+            nnd_count(counters, CNT_ROWS, m);
+        }
+        const int trows = (r0 >> 4) + TRB <= nt ? TRB : nt - (r0 >> 4);
+        nnd_count(counters, CNT_MFMA, (long long)trows * nt * (dp >> 2));
+    }
+}
+
 // Work list: leaves longer than 256 points (possible only when max_depth cuts the recursion short,
 // rp_trees.py:2188) are cut into runs of <= 256 consecutive positions for seeding purposes.
 static constexpr int LEAF_MAX = 256;
@@ -376,7 +537,14 @@ static int run_leaf_rounds(nnd_ctx *ctx, const int32_t *perm, const int32_t *d_w
 #define LEAF_ARGS ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, perm, d_ws, d_wl, tb[t], tb[t + 1], ctx->k, ctx->ks, \
                   ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters
         const bool qw = ctx->k <= 16;
-        if (maxlen <= 64 && qw)
+        if (ctx->k > NND_MAX_K) {  // wide rows: the row-block kernel with LDS merges, whatever the leaf size
+            if (maxlen <= 128)
+                hipLaunchKernelGGL((k_leaf_join_rb<8, 8, true>), dim3((unsigned)cnt, 2), dim3(512), 0, ctx->stream, LEAF_ARGS);
+            else if (maxlen <= 160)
+                hipLaunchKernelGGL((k_leaf_join_rb<10, 8, true>), dim3((unsigned)cnt, 3), dim3(512), 0, ctx->stream, LEAF_ARGS);
+            else
+                hipLaunchKernelGGL((k_leaf_join_rb<16, 8, true>), dim3((unsigned)cnt, 4), dim3(512), 0, ctx->stream, LEAF_ARGS);
+        } else if (maxlen <= 64 && qw)
             hipLaunchKernelGGL((k_leaf_join<4, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 64)
             hipLaunchKernelGGL((k_leaf_join<4, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
@@ -392,12 +560,12 @@ static int run_leaf_rounds(nnd_ctx *ctx, const int32_t *perm, const int32_t *d_w
             hipLaunchKernelGGL((k_leaf_join<6, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 96)
             hipLaunchKernelGGL((k_leaf_join<6, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
-        else if (maxlen <= 128)
-            hipLaunchKernelGGL((k_leaf_join<8, 4, 64>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
-        else if (maxlen <= 160)  // k = 30 (leaf_size 150): 10 x 10 tiles instead of 16 x 16
-            hipLaunchKernelGGL((k_leaf_join<10, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 128)  // larger leaves: a workgroup per block of 32 rows (k_leaf_join_rb)
+            hipLaunchKernelGGL((k_leaf_join_rb<8, 8>), dim3((unsigned)cnt, 2), dim3(512), 0, ctx->stream, LEAF_ARGS);
+        else if (maxlen <= 160)  // k = 30 (leaf_size 150)
+            hipLaunchKernelGGL((k_leaf_join_rb<10, 8>), dim3((unsigned)cnt, 3), dim3(512), 0, ctx->stream, LEAF_ARGS);
         else
-            hipLaunchKernelGGL((k_leaf_join<16, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+            hipLaunchKernelGGL((k_leaf_join_rb<16, 8>), dim3((unsigned)cnt, 4), dim3(512), 0, ctx->stream, LEAF_ARGS);
 #undef LEAF_ARGS
     }
     NND_HIP_CHECK(hipGetLastError());

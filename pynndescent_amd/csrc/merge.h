@@ -293,3 +293,99 @@ __device__ __forceinline__ int nnd_merge_rows_q16(bool row_on, uint32_t *__restr
     }
     return pushed;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Wide rows, 64 < k <= 128 (the reference has no bound on n_neighbors, utils.py:130-158): the row does not fit one entry
+// per lane, so it is merged through LDS -- same result as nnd_merge_row_regs (the k smallest keys of row U {candidates
+// that beat the row's worst distance as it was at the start and are not in the row}), same return value, by the same
+// rank counting; the loops read LDS broadcasts instead of v_readlane.  `scr`: NND_WIDE_SCRATCH_WORDS 64-bit words of
+// LDS private to this wave.  The row is read from and written to global memory here (every row is merged at most once
+// per launch by its callers).  Not tuned: k > 64 builds instead of raising; the k <= 64 paths are the fast ones.
+#define NND_WIDE_K 128
+#define NND_WIDE_MAXC 256
+#define NND_WIDE_SCRATCH_WORDS (NND_WIDE_K + NND_WIDE_MAXC)
+template <int NCHUNK, typename CandFn>
+__device__ __forceinline__ int nnd_merge_row_lds(uint64_t *scr, uint32_t *__restrict__ row_e, float *__restrict__ row_d,
+                                                 float *__restrict__ th_slot, int k, int ncand, CandFn cand) {
+    static_assert(NCHUNK * 64 <= NND_WIDE_MAXC, "candidate scratch");
+    const int lane = nnd_lane();
+    uint64_t *rkey = scr;               // [k] the row's keys (dist_bits << 32 | idx | flag kept apart below)
+    uint64_t *ckey = scr + NND_WIDE_K;  // [nv] surviving candidates' keys, compacted
+    uint32_t me[2];
+    float md[2];
+    int nlist = 0;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int j = lane + 64 * u;
+        me[u] = j < k ? row_e[j] : NND_EMPTY_E;
+        md[u] = j < k ? row_d[j] : INFINITY;
+        if (j < k) rkey[j] = me[u] == NND_EMPTY_E ? NND_EMPTY_KEY : nnd_make_key(md[u], me[u]);
+        nlist += __popcll(__ballot(me[u] != NND_EMPTY_E));
+    }
+    nnd_wave_lds_sync();
+    const float th = nlist >= k ? nnd_key_dist(rkey[k - 1]) : INFINITY;  // strict, utils.py:484
+    // filter + dedupe (utils.py:489-492), then compact the survivors' keys
+    uint64_t mykey[NCHUNK];
+    int nv = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ch++) {
+        const int c = ch * 64 + lane;
+        uint32_t id = 0;
+        float dc = 0.0f;
+        bool ok = false;
+        if (ch * 64 < ncand) {  // wave-uniform
+            ok = (c < ncand) && cand(c, id, dc) && (dc < th);
+            if (__ballot(ok))
+                for (int j = 0; j < nlist; j++) ok = ok && (nnd_key_idx(rkey[j]) != id);
+        }
+        mykey[ch] = ok ? nnd_make_key(dc, id) : NND_EMPTY_KEY;
+        const unsigned long long m = __ballot(ok);
+        if (ok) ckey[nv + nnd_prefix_popc(m)] = mykey[ch];
+        nv += __popcll(m);
+    }
+    if (nv == 0) return 0;
+    nnd_wave_lds_sync();
+    // list entries: new position = old position + #{candidates before it}
+    int shift[2] = {0, 0};
+    for (int c = 0; c < nv; c++) {
+        const uint64_t kc = ckey[c];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint64_t rk = me[u] == NND_EMPTY_E ? NND_EMPTY_KEY : nnd_make_key(md[u], me[u]);
+            shift[u] += kc < rk ? 1 : 0;
+        }
+    }
+    // candidates: rank = #{list entries before it} + #{candidates before it}
+    int rank[NCHUNK];
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ch++) rank[ch] = 0;
+    for (int j = 0; j < nlist; j++) {
+        const uint64_t lj = rkey[j];
+#pragma unroll
+        for (int ch = 0; ch < NCHUNK; ch++) rank[ch] += lj < mykey[ch] ? 1 : 0;
+    }
+    for (int c = 0; c < nv; c++) {
+        const uint64_t kc = ckey[c];
+#pragma unroll
+        for (int ch = 0; ch < NCHUNK; ch++) rank[ch] += kc < mykey[ch] ? 1 : 0;
+    }
+    nnd_wave_lds_sync();  // every lane has read what it needs from the LDS copies (the caller may reuse them)
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int j = lane + 64 * u;
+        if (j < nlist && shift[u] > 0 && j + shift[u] < k) {
+            row_e[j + shift[u]] = me[u];
+            row_d[j + shift[u]] = md[u];
+            if (j + shift[u] == k - 1) *th_slot = md[u];
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ch++) {
+        if (mykey[ch] != NND_EMPTY_KEY && rank[ch] < k) {
+            row_e[rank[ch]] = nnd_key_idx(mykey[ch]) | NND_NEW_BIT;
+            row_d[rank[ch]] = nnd_key_dist(mykey[ch]);
+            if (rank[ch] == k - 1) *th_slot = nnd_key_dist(mykey[ch]);
+        }
+    }
+    return nv;
+}

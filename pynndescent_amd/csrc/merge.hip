@@ -149,10 +149,45 @@ __global__ __launch_bounds__(256) void k_merge_q(uint64_t *__restrict__ pbuf, ui
     }
 }
 
+// 64 < k <= 128: the same walk over the dirty rows, one at a time, merged through LDS (merge.h nnd_merge_row_lds)
+__global__ __launch_bounds__(256) void k_merge_wide(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap, int64_t lo, int64_t n,
+                                                    int k, int ks, uint32_t *__restrict__ knn_e, float *__restrict__ knn_d,
+                                                    float *__restrict__ th, long long *__restrict__ counters) {
+    __shared__ uint64_t scr[4][NND_WIDE_SCRATCH_WORDS];
+    __shared__ int wacc[4];
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t base = lo + ((int64_t)blockIdx.x * 4 + w) * 64;
+    int acc = 0;
+    unsigned long long m = 0;
+    if (base < n) m = __ballot(base + lane < n && pdirty[base + lane < n ? base + lane : lo] != 0);
+    while (m) {
+        const int64_t v = base + __builtin_ctzll(m);
+        m &= m - 1;
+        const uint64_t mykey = lane < pcap ? pbuf[v * pcap + lane] : NND_EMPTY_KEY;
+        acc += nnd_merge_row_lds<1>(scr[w], knn_e + v * ks, knn_d + v * ks, th + v, k, pcap, [&](int c, uint32_t &id, float &dc) {
+            id = nnd_key_idx(mykey);
+            dc = nnd_key_dist(mykey);
+            return mykey != NND_EMPTY_KEY;
+        });
+        if (lane < pcap && mykey != NND_EMPTY_KEY) pbuf[v * pcap + lane] = NND_EMPTY_KEY;
+        if (lane == 0) pdirty[v] = 0;
+        nnd_wave_lds_sync();
+    }
+    if (lane == 0) wacc[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long a = (long long)wacc[0] + wacc[1] + wacc[2] + wacc[3];
+        if (a) nnd_count(counters, CNT_ACCEPT, a);
+    }
+}
+
 int nnd_launch_merge(nnd_ctx *ctx) {
     if (ctx->pcap > 64) { ctx->set_error("k_merge expects at most 64 proposal slots per row"); return 1; }
     const dim3 grid((unsigned)((ctx->own_hi - ctx->own_lo + 255) / 256));
-    if (ctx->k <= 16 && ctx->pcap == 64)
+    if (ctx->k > NND_MAX_K)
+        hipLaunchKernelGGL(k_merge_wide, grid, dim3(256), 0, ctx->stream, ctx->pbuf, ctx->pdirty, ctx->pcap, ctx->own_lo, ctx->own_hi, ctx->k,
+                           ctx->ks, ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters);
+    else if (ctx->k <= 16 && ctx->pcap == 64)
         hipLaunchKernelGGL(k_merge_q, grid, dim3(256), 0, ctx->stream, ctx->pbuf, ctx->pdirty, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks,
                            ctx->knn_e, ctx->knn_d, ctx->th, ctx->counters);
     else
@@ -185,10 +220,14 @@ __global__ __launch_bounds__(256) void k_random_init(const float *__restrict__ x
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
     const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;
     if (v >= hi) return;
-    uint32_t e = lane < k ? knn_e[v * ks + lane] : NND_EMPTY_E;
-    int filled = __popcll(__ballot(lane < k && e != NND_EMPTY_E));
+    int filled = 0;
+    for (int j0 = 0; j0 < k; j0 += 64) {  // (k <= 128: up to two entries per lane)
+        const uint32_t e = j0 + lane < k ? knn_e[v * ks + j0 + lane] : NND_EMPTY_E;
+        filled += __popcll(__ballot(e != NND_EMPTY_E));
+    }
     int todo = k - filled;  // pynndescent_.py:196
     if (todo <= 0) return;
+    if (todo > 64) todo = 64;  // one pass offers at most 64 picks (the proposal slots); wide rows take a second pass
     uint32_t pick = (uint32_t)(nnd_hash3(seed, (uint32_t)v, (uint32_t)lane) % (uint64_t)n);  // pynndescent_.py:197
     bool mine = lane < todo;
     for (int j = 0; j < todo; j++) {  // the same id drawn twice is pushed once (utils.py:489-492)
@@ -206,49 +245,55 @@ __global__ __launch_bounds__(256) void k_random_init(const float *__restrict__ x
 }
 
 int nnd_launch_random_init(nnd_ctx *ctx) {
-    ctx->pbuf_clean = false;
-    hipLaunchKernelGGL(k_random_init, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp,
-                       ctx->dp, ctx->nrm, ctx->p.metric, ctx->n, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e, ctx->seed ^ 0x3C6EF372u, ctx->pbuf,
-                       ctx->pdirty, ctx->pcap);
-    NND_HIP_CHECK(hipGetLastError());
-    return nnd_launch_merge(ctx);
+    for (int pass = 0; pass < (ctx->k + 63) / 64; pass++) {
+        ctx->pbuf_clean = false;
+        hipLaunchKernelGGL(k_random_init, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp,
+                           ctx->dp, ctx->nrm, ctx->p.metric, ctx->n, ctx->own_lo, ctx->own_hi, ctx->k, ctx->ks, ctx->knn_e,
+                           ctx->seed ^ 0x3C6EF372u ^ (uint32_t)(pass * 0x9E3779B9u), ctx->pbuf, ctx->pdirty, ctx->pcap);
+        NND_HIP_CHECK(hipGetLastError());
+        if (nnd_launch_merge(ctx)) return 1;
+    }
+    return 0;
 }
 
 // utils.py:836-860: every valid (i, j=graph[i][c]) is pushed with distance metric(x_i, x_j) or the given one
 __global__ __launch_bounds__(256) void k_graph_init(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
                                                     int metric, int64_t n, const int32_t *__restrict__ gidx,
-                                                    const float *__restrict__ gdist, int width,
+                                                    const float *__restrict__ gdist, int width, int col0, int wchunk,
                                                     uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap) {
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
     const int64_t v = (int64_t)blockIdx.x * 4 + w;
     if (v >= n) return;
-    int32_t id = lane < width ? gidx[v * width + lane] : -1;
+    // columns [col0, col0 + wchunk) of the row (wchunk <= 64 = the proposal slots; wider graphs come in several launches,
+    // an id repeated across launches is dropped by the merge, utils.py:489-492)
+    int32_t id = lane < wchunk ? gidx[v * width + col0 + lane] : -1;
     bool mine = id >= 0 && (int64_t)id < n;
-    for (int j = 0; j < width; j++) {
+    for (int j = 0; j < wchunk; j++) {
         int32_t other = __shfl(id, j, 64);
         if (j < lane && other == id) mine = false;
     }
-    for (int j = 0; j < width; j++) {
+    for (int j = 0; j < wchunk; j++) {
         int32_t q = __shfl(id, j, 64);
         bool on = __shfl((int)mine, j, 64);
         if (!on) continue;
-        float d = gdist ? nnd_clamp_dist(gdist[v * width + j]) : row_dist(xp, dp, nrm, metric, v, (int64_t)q);
+        float d = gdist ? nnd_clamp_dist(gdist[v * width + col0 + j]) : row_dist(xp, dp, nrm, metric, v, (int64_t)q);
         if (lane == 0) pbuf[v * pcap + j] = nnd_make_key(d, (uint32_t)q);
     }
     if (lane == 0) pdirty[v] = 1;
 }
 
 int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float *dist_dev, int width) {
-    if (width > ctx->pcap || width > 64) {
-        ctx->set_error("init graph width %d exceeds %d", width, ctx->pcap < 64 ? ctx->pcap : 64);
-        return 1;
-    }
+    if (ctx->pcap < 64) { ctx->set_error("init graphs need 64 proposal slots per row"); return 1; }
     if (ctx->slim) { ctx->set_error("init graphs are not supported on a shard of a row-sharded build"); return 1; }
-    ctx->pbuf_clean = false;
-    hipLaunchKernelGGL(k_graph_init, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, ctx->dp,
-                       ctx->nrm, ctx->p.metric, ctx->n, idx_dev, dist_dev, width, ctx->pbuf, ctx->pdirty, ctx->pcap);
-    NND_HIP_CHECK(hipGetLastError());
-    return nnd_launch_merge(ctx);
+    for (int col0 = 0; col0 < width; col0 += 64) {
+        const int wchunk = width - col0 < 64 ? width - col0 : 64;
+        ctx->pbuf_clean = false;
+        hipLaunchKernelGGL(k_graph_init, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, ctx->dp,
+                           ctx->nrm, ctx->p.metric, ctx->n, idx_dev, dist_dev, width, col0, wchunk, ctx->pbuf, ctx->pdirty, ctx->pcap);
+        NND_HIP_CHECK(hipGetLastError());
+        if (nnd_launch_merge(ctx)) return 1;
+    }
+    return 0;
 }
 
 // every entry of the owned rows becomes "old" (init_from_neighbor_graph pushes with flag 0, pynndescent_.py:213)
@@ -311,12 +356,18 @@ __global__ __launch_bounds__(256) void k_merge_graph_rows(int64_t lo, int64_t hi
     if (v >= hi) return;
     const uint32_t *es = e_src + (v - lo) * ks;
     const float *ds = d_src + (v - lo) * ks;
-    nnd_merge_row<1>(v, k, ks, knn_e, knn_d, th, k, [&](int c, uint32_t &id, float &dc) {
+    auto cf = [&](int c, uint32_t &id, float &dc) {
         const uint32_t e = es[c];
         id = e & NND_IDX_MASK;
         dc = ds[c];
         return e != NND_EMPTY_E;
-    });
+    };
+    if (k > NND_MAX_K) {
+        __shared__ uint64_t scr[4][NND_WIDE_SCRATCH_WORDS];
+        nnd_merge_row_lds<2>(scr[w], knn_e + v * ks, knn_d + v * ks, th + v, k, k, cf);
+    } else {
+        nnd_merge_row<1>(v, k, ks, knn_e, knn_d, th, k, cf);
+    }
 }
 
 // Proposals for vertices owned elsewhere -> records in their owners' regions (regions of `cap` records per destination).

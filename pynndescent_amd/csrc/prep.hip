@@ -45,16 +45,19 @@ __global__ __launch_bounds__(256) void k_colsum_final(const double *__restrict__
 __global__ __launch_bounds__(256) void k_prep_rows(const float *__restrict__ x, int64_t n, int d, int dp, int metric,
                                                    const float *__restrict__ mean, float *__restrict__ xp,
                                                    float *__restrict__ nrm, uint16_t *__restrict__ xh,
-                                                   float2 *__restrict__ nr2) {
+                                                   float2 *__restrict__ nr2, long long *__restrict__ nonfinite) {
     int lane = nnd_lane();
     int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n) return;
     const float *src = x + row * d;
     float *dst = xp + row * dp;
+    bool bad = false;  // a NaN / inf in the input: the host raises what check_array raises in the reference (pynndescent_.py:1054)
     if (metric == 0) {
         float s = 0.0f, r2 = 0.0f;
         for (int j = lane; j < dp; j += 64) {
-            float v = j < d ? src[j] - mean[j] : 0.0f;
+            const float raw = j < d ? src[j] : 0.0f;
+            bad |= !isfinite(raw);
+            float v = j < d ? raw - mean[j] : 0.0f;
             dst[j] = v;
             if (xh) {
                 const uint16_t b = nnd_f32_to_bf16(v);
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(256) void k_prep_rows(const float *__restrict__ x, 
         float s = 0.0f;
         for (int j = lane; j < d; j += 64) {
             float v = src[j];
+            bad |= !isfinite(v);
             s += v * v;
         }
         s = nnd_wave_sum_f32(s);
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(256) void k_prep_rows(const float *__restrict__ x, 
             if (xh) nr2[row] = make_float2(s > 0.0f ? 1.0f : 0.0f, sqrtf(r2) * 1.000001f);
         }
     }
+    if (__ballot(bad) && lane == 0) atomicOr((unsigned long long *)nonfinite, 1ull);
 }
 
 int nnd_launch_prep(nnd_ctx *ctx) {
@@ -120,9 +125,12 @@ int nnd_launch_prep(nnd_ctx *ctx) {
         NND_HIP_CHECK(hipMemsetAsync(ctx->mean, 0, sizeof(float) * dp, ctx->stream));
     }
     int64_t blocks = (n + 3) / 4;
+    long long *flag = ctx->counters_sum + CNT_SCRATCH;  // a spare word of the reduced-counter block
+    NND_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(long long), ctx->stream));
     hipLaunchKernelGGL(k_prep_rows, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->x_orig, n, d, dp,
-                       ctx->p.metric, ctx->mean, ctx->xp, ctx->nrm, ctx->xh, ctx->nr2);
+                       ctx->p.metric, ctx->mean, ctx->xp, ctx->nrm, ctx->xh, ctx->nr2, flag);
     NND_HIP_CHECK(hipGetLastError());
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 63, flag, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));  // read by nnd_data_nonfinite
     return 0;
 }
 

@@ -163,6 +163,97 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
     if (valid && cls == 1u && my_rank < mc) knn_e[v * ks + lane] = u;
 }
 
+// 64 < k <= 128: the same selection with up to two forward edges per lane (the reference has no bound on n_neighbors).
+// Items of a class: <= k forward + rcap reverse offers; ranks by counting over the LDS copy; the rank of every forward
+// new edge goes through LDS (rank_new) to the lane that holds the edge, which clears its flag when it was sampled.
+__global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
+                                                            int mcp, uint32_t it_seed, uint64_t *__restrict__ rbuf, int rcap,
+                                                            int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
+                                                            const uint8_t *__restrict__ active) {
+    constexpr int MAXI = 128 + 64;
+    __shared__ uint64_t skey[4][2][MAXI];
+    __shared__ int srank[4][128];  // rank among the new offers of forward item i (class new)
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t v = own_lo + (int64_t)blockIdx.x * 4 + w;
+    if (v >= own_hi) return;
+    if (!active[v]) {
+        for (int j = lane; j < mcp; j += 64) cand[v * 2 * mcp + j] = -1;
+        return;
+    }
+    uint64_t(*key)[MAXI] = skey[w];
+    uint32_t e[2];
+    int item[2];  // index of my forward edge among its class's items, or -1
+    int cnt[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int j = lane + 64 * u;
+        e[u] = j < k ? knn_e[v * ks + j] : NND_EMPTY_E;
+        item[u] = -1;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const bool mine = e[u] != NND_EMPTY_E && (e[u] >> 31) == (uint32_t)c;
+            const unsigned long long m = __ballot(mine);
+            if (mine) {
+                const uint32_t tgt = e[u] & NND_IDX_MASK;
+                item[u] = cnt[c] + nnd_prefix_popc(m);
+                key[c][item[u]] = ((uint64_t)nnd_hash3(it_seed, (uint32_t)v, tgt) << 32) | tgt;
+            }
+            cnt[c] += __popcll(m);
+        }
+    }
+    nnd_wave_lds_sync();
+    const int nfwd[2] = {cnt[0], cnt[1]};
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        uint64_t *slots = rbuf + (v * 2 + c) * rcap;
+        for (int s0 = 0; s0 < rcap; s0 += 64) {
+            const int sidx = s0 + lane;
+            uint64_t rk = NND_EMPTY_KEY;
+            if (sidx < rcap) {
+                rk = slots[sidx];
+                if (rk != NND_EMPTY_KEY) slots[sidx] = NND_EMPTY_KEY;  // re-arm for the next iteration
+            }
+            bool ok = rk != NND_EMPTY_KEY;
+            if (__ballot(ok)) {  // utils.py:427-430: an id already in the list is not pushed again
+                const uint32_t src = (uint32_t)rk;
+                for (int j = 0; j < nfwd[c]; j++) ok = ok && ((uint32_t)key[c][j] != src);
+            }
+            const unsigned long long m = __ballot(ok);
+            if (ok) key[c][cnt[c] + nnd_prefix_popc(m)] = rk;
+            cnt[c] += __popcll(m);
+        }
+    }
+    nnd_wave_lds_sync();
+    int32_t *out = cand + v * 2 * mcp;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int M = cnt[c];
+        int32_t *dst = out + (c == 1 ? 0 : mcp);  // layout [new | old]
+        for (int i0 = 0; i0 < M; i0 += 64) {
+            const int i = i0 + lane;
+            if (i < M) {
+                const uint64_t kk = key[c][i];
+                int r = 0;
+                for (int j = 0; j < M; j++) r += (key[c][j] < kk) ? 1 : 0;
+                if (r < mc) dst[r] = (int32_t)(uint32_t)kk;
+                if (c == 1 && i < nfwd[1]) srank[w][i] = r;
+            }
+        }
+        const int filled = M < mc ? M : mc;
+        for (int j = filled + lane; j < mcp; j += 64) dst[j] = -1;
+    }
+    nnd_wave_lds_sync();
+    // flag reset (utils.py:311-318): a forward new edge that was sampled becomes old
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int j = lane + 64 * u;
+        if (e[u] != NND_EMPTY_E && (e[u] >> 31) == 1u && item[u] >= 0 && srank[w][item[u]] < mc) knn_e[v * ks + j] = e[u] & NND_IDX_MASK;
+    }
+}
+
 // k <= 32 with 32 reverse slots per class (max_candidates <= 32, the BASELINE regime): TWO vertices per wave, 32 lanes
 // each.  k_sample_select keeps ~30 of 64 lanes busy and is bound by instruction issue; here the loops (duplicate screen
 // over the forward ids, rank count over the items) run for both vertices at once.  Lane j of a half holds forward edge
@@ -285,6 +376,13 @@ static void launch_reverse_pass(nnd_ctx *ctx, int pass, uint32_t it_seed) {
 static uint32_t sample_seed(const nnd_ctx *ctx) { return nnd_hash2(ctx->seed ^ 0x9E3779B9u, (uint32_t)ctx->iter + 1u); }
 
 static void launch_select(nnd_ctx *ctx, uint32_t it_seed) {
+    if (ctx->k > 64) {
+        hipLaunchKernelGGL(k_sample_select_wide, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream,
+                           ctx->knn_e, ctx->n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand, ctx->own_lo,
+                           ctx->own_hi, ctx->active);
+        if (ctx->n_ranks <= 1) ctx->rbuf_clean = true;
+        return;
+    }
     const char *force_old = getenv("NND_SELECT_WAVE");  // A/B and the parity test: the one-wave-per-vertex kernel
     if (ctx->k <= 32 && ctx->rcap == 32 && ctx->mc <= 32 && !(force_old && atoi(force_old) != 0)) {
         hipLaunchKernelGGL(k_sample_select_h, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 7) / 8)), dim3(256), 0, ctx->stream,

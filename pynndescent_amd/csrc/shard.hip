@@ -159,6 +159,7 @@ extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, 
     };
     if (!out || !params || !comm || !shard_sizes) return fail("null argument");
     *out = nullptr;
+    (void)nnd_release_pending();  // handles destroyed earlier may still hold HBM this shard needs
     const int G = comm->world, rank = comm->rank;
     nnd_shard_s *s = new nnd_shard_s();
     s->comm = comm;
@@ -365,6 +366,7 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         section_timer sec(s);
         h->x_orig = x_use;
         h->x_owned = false;
+        h->x_valid = true;
         const int tp = t_begin(h);
         S_CTX(nnd_launch_prep(h));
         S_CTX(nnd_launch_reset_graph(h));

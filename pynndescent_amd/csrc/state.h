@@ -68,6 +68,7 @@ struct nnd_handle_s {
     // data
     const float *x_orig = nullptr; // (n,d) original rows (device); owned iff x_owned
     bool x_owned = false;
+    bool x_valid = false;          // x_orig holds the rows of a nnd_set_data_* call made on THIS use of the handle
     float *xp = nullptr;   // (n,dp) prepared rows: centred (euclid) or L2-normalised (cosine), zero padded
     float *nrm = nullptr;  // (n) |x-mu|^2 (euclid) or 1/0 non-zero flag (cosine)
     float2 *nr2 = nullptr;                    // (n) (nrm, |x - bf16(x)|) per row: what the forest's margin kernels read (rpforest.hip rp_band)
@@ -136,6 +137,9 @@ struct nnd_handle_s {
     bool all_new = false;  // every edge of the graph still carries the "new" flag (true from reset until the first sampling pass)
     bool pbuf_clean = false, rbuf_clean = false;  // every proposal / reverse-offer slot is EMPTY (their consumers re-arm what they read): nnd_launch_reset_graph then skips the 2 x 512 MB memsets
 
+    int32_t *out_idx = nullptr;           // finished graph of the host-buffer entry points (grow-only; capi.hip out_buffers)
+    float *out_dist = nullptr;
+    size_t out_cap = 0;
     nnd_hub_result *hub = nullptr;
 
     long long *counters = nullptr;      // device NND_CNT_STRIPES x CNT_COUNT (stripe 0 doubles as scratch for single-block kernels)

@@ -9,8 +9,8 @@ if the HIP library or a gfx950 device is missing, construction raises.
 
 Also on the GPU: ``update`` (warm start, pynndescent_.py:2381-2553), ``build_search_graph`` (the pruning
 pass of ``_init_search_graph``, all diversify methods), ``prepare`` (hub search tree + reordering) and
-``query``.  Out of scope: sparse input, metrics other than euclidean / l2 / cosine, ``n_neighbors`` or
-``max_candidates`` above 64.  Those raise ``NotImplementedError`` naming the reference entry point to use
+``query``.  Out of scope: sparse input, metrics other than euclidean / l2 / cosine, ``n_neighbors`` above 128 or
+``max_candidates`` above 64 (``prepare`` / ``query``: ``n_neighbors`` above 64).  Those raise ``NotImplementedError`` naming the reference entry point to use
 instead; ``pynndescent_amd.make_index`` hands such inputs to ``pynndescent.NNDescent`` when it is importable.
 """
 import time
@@ -164,7 +164,10 @@ class NNDescent:
             pass
 
         _check_supported_sizes(n_neighbors, max_candidates, init_graph)
-        data = check_array(data, dtype=np.float32, order="C")  # pynndescent_.py:1054
+        # pynndescent_.py:1054 check_array(data, dtype=np.float32, order="C") -- minus its single-core scan for NaN / inf
+        # (24 ms at 1 M x 128): the prep kernel looks at every value anyway and raises a flag; _raise_if_nonfinite then
+        # lets sklearn produce the reference's own error
+        data = _check_array_no_scan(data)
         self._input_dtype = np.float32
         self._raw_data = data
 
@@ -234,8 +237,11 @@ class NNDescent:
     def _build_multi(self, data, metric, n_trees, eff_trees, eff_leaf_size, effective_max_candidates, n_iters, delta,
                      max_rptree_depth, tree_states, verbose):
         """Row-sharded build over several GPUs, one call into the library (include/pynnd_amd.h nnd_build_multi)."""
+        from sklearn.utils import assert_all_finite
+
         from . import sharded
 
+        assert_all_finite(data)  # check_array's scan (pynndescent_.py:1054): the one-call multi-GPU build has no flag to read
         if verbose:
             print(ts(), "NN descent for", str(n_iters), "iterations on", self.n_devices, "GPUs")
         idx, dst, st, info = sharded.build_multi(
@@ -258,6 +264,7 @@ class NNDescent:
         )
         try:
             builder.set_data_host(data)
+            _raise_if_nonfinite(builder, data)
             if self.tree_init:
                 builder.make_forest()
                 st = builder.stats()
@@ -658,20 +665,37 @@ def nn_descent(data, n_neighbors, rng_state, max_candidates=50, dist="squared_eu
     return idx, dst
 
 
+def _check_array_no_scan(data):
+    try:
+        return check_array(data, dtype=np.float32, order="C", ensure_all_finite=False)
+    except TypeError:  # scikit-learn < 1.6
+        return check_array(data, dtype=np.float32, order="C", force_all_finite=False)
+
+
+def _raise_if_nonfinite(builder, data):
+    """The ValueError check_array raises in the reference for NaN / inf input (pynndescent_.py:1054), from the device flag."""
+    if builder.data_nonfinite():
+        from sklearn.utils import assert_all_finite
+
+        assert_all_finite(data)  # raises "Input contains NaN." / "... infinity or a value too large ..."
+        raise ValueError("Input contains NaN or infinity.")  # (unreachable unless the two scans disagree)
+
+
 def _check_supported_sizes(n_neighbors, max_candidates, init_graph):
-    """The GPU k-lists / candidate lists hold at most 64 entries (one wave); the reference has no such bound
-    (pynndescent_.py:976-982), so the limit is reported up front and by name."""
-    if int(n_neighbors) > 64 or (max_candidates is not None and int(max_candidates) > 64):
+    """The GPU k-lists hold at most 128 entries (two per lane of a wave; rows above 64 take the LDS-merge kernels) and the
+    candidate lists at most 64; the reference has no such bounds (pynndescent_.py:976-982), so the limits are reported up
+    front and by name."""
+    if int(n_neighbors) > 128 or (max_candidates is not None and int(max_candidates) > 64):
         raise NotImplementedError(
-            "pynndescent_amd supports n_neighbors <= 64 and max_candidates <= 64 (got n_neighbors=%s, max_candidates=%s); "
+            "pynndescent_amd supports n_neighbors <= 128 and max_candidates <= 64 (got n_neighbors=%s, max_candidates=%s); "
             "use pynndescent.NNDescent (or pynndescent_amd.make_index) for wider graphs" % (n_neighbors, max_candidates))
-    if init_graph is not None and np.ndim(init_graph) == 2 and np.shape(init_graph)[1] > 64:
-        raise NotImplementedError("pynndescent_amd supports init_graph with at most 64 columns (got %d); use "
+    if init_graph is not None and np.ndim(init_graph) == 2 and np.shape(init_graph)[1] > 128:
+        raise NotImplementedError("pynndescent_amd supports init_graph with at most 128 columns (got %d); use "
                                   "pynndescent.NNDescent" % np.shape(init_graph)[1])
 
 
 def make_index(data, *args, **kwargs):
-    """``NNDescent(data, ...)`` on the GPU when the input is in scope (dense data, euclidean / l2 / cosine, k <= 64);
+    """``NNDescent(data, ...)`` on the GPU when the input is in scope (dense data, euclidean / l2 / cosine, k <= 128);
     otherwise -- and only then -- the reference ``pynndescent.NNDescent`` on the CPU when that package is importable
     (SURVEY.md section 8b), with a warning.  A missing HIP library or GPU is never papered over: that still raises."""
     device = kwargs.pop("device", 0)

@@ -7,6 +7,7 @@ import pytest
 
 from oracle import oracle as O
 from pynndescent_amd import NNDescent
+from tests.gpu_util import check_graph_invariants
 from tests.util_data import clustered, nn_data_like
 
 pytestmark = pytest.mark.gpu
@@ -331,8 +332,8 @@ def test_search_graph_non_default_modes_vs_reference_fixture(tag, metric, method
 
 def test_unsupported_sizes_are_reported_up_front():
     x = clustered(500, 8, 4, 5, seed=1)
-    with pytest.raises(NotImplementedError, match="n_neighbors <= 64"):
-        NNDescent(x, n_neighbors=100)
+    with pytest.raises(NotImplementedError, match="n_neighbors <= 128"):
+        NNDescent(x, n_neighbors=200)
     with pytest.raises(NotImplementedError, match="max_candidates <= 64"):
         NNDescent(x, n_neighbors=10, max_candidates=80)
     with pytest.raises(NotImplementedError, match="manhattan"):
@@ -370,3 +371,28 @@ def test_nn_descent_function_with_reference_leaf_array(metric, dist):
     hi, hd, hf = O.init_rp_tree(x, k, metric, la)
     gi2, _ = pynndescent_amd.nn_descent(x, k, rng_state, max_candidates=k, dist=dist, n_iters=n_iters, init_graph=(hi, hd, hf))
     assert abs(O.recall(ti, gi2) - ro) <= 0.005
+
+
+@pytest.mark.parametrize("metric,k,n_trees", [("euclidean", 100, 4), ("cosine", 80, 3), ("euclidean", 128, 2)])
+def test_wide_rows_up_to_128_neighbours(metric, k, n_trees):
+    """The reference has no bound on n_neighbors (utils.py:130-158); rows above 64 entries take the LDS-merge kernels
+    (merge.h nnd_merge_row_lds): same invariants, same parity bar against the reference algorithm (oracle)."""
+    n, d = 12000, 24
+    x = clustered(n, d, 6, 40, seed=k)
+    index = NNDescent(x, metric, n_neighbors=k, n_trees=n_trees, random_state=3)
+    idx, dist = index._neighbor_graph
+    assert idx.shape == (n, k) and (idx >= 0).all()
+    check_graph_invariants(x, metric, idx, dist, tol=2e-4, name="wide")
+    oi, od = O.build_index(x, metric, n_neighbors=k, n_trees=n_trees, random_state=3, n_threads=8, kind="fast")
+    rows = np.arange(0, n, 7)
+    ti, _ = O.brute_force_knn(x, k, metric, rows=rows, kind="fast")
+    rg, ro = O.recall(ti, idx[rows]), O.recall(ti, oi[rows])
+    print("k=%d %s: recall@k GPU %.4f oracle %.4f, %d iterations" % (k, metric, rg, ro, index._build_stats["n_iters_run"]))
+    assert abs(rg - ro) <= 0.005
+    # an init graph as wide as the rows, and the update() warm start
+    index2 = NNDescent(x, metric, n_neighbors=k, init_graph=idx, init_dist=dist, random_state=3, n_iters=2)
+    assert O.recall(ti, index2._neighbor_graph[0][rows]) >= rg - 0.005
+    with pytest.raises(NotImplementedError, match="at most 64"):
+        index.prepare()
+    with pytest.raises(NotImplementedError, match="n_neighbors <= 128"):
+        NNDescent(x, metric, n_neighbors=129)

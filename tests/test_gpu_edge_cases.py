@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from pynndescent_amd import NNDescent
+from tests.util_data import clustered
 
 pytestmark = pytest.mark.gpu
 
@@ -38,3 +39,17 @@ def test_degenerate_shapes(n, d, k, kw):
     # max_candidates) may miss it, exactly as in the reference
     if "max_candidates" not in kw and kw.get("metric") != "cosine":
         assert np.all(idx[:, 0] == np.arange(n))
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf])
+def test_nonfinite_input_raises_like_check_array(bad):
+    """The reference rejects NaN / inf input in check_array (pynndescent_.py:1054); here the prep kernel raises a flag while it
+    reads the rows and the host lets sklearn phrase the same ValueError -- no single-core scan on the good path."""
+    x = clustered(3000, 20, 5, 10, seed=2)
+    x[1234, 7] = bad
+    with pytest.raises(ValueError, match="NaN|infinity"):
+        NNDescent(x, "euclidean", n_neighbors=10, random_state=1)
+    with pytest.raises(ValueError, match="NaN|infinity"):
+        NNDescent(x, "cosine", n_neighbors=10, random_state=1)
+    x[1234, 7] = 0.5
+    NNDescent(x, "euclidean", n_neighbors=10, random_state=1)
