@@ -73,6 +73,9 @@ typedef struct nnd_params {
  * NND_FLAG_NO_PREP additionally skips the prepared (padded, centred / normalised) copy of the rows: hub tree only. */
 #define NND_FLAG_NO_GRAPH 1
 #define NND_FLAG_NO_PREP 2
+/* test hook: candidate selection by the one-wave-per-vertex kernel where the two-vertices-per-wave kernel would run
+ * (tests/test_gpu_kernels.py proves the two produce identical lists) */
+#define NND_FLAG_TEST_SELECT_WAVE 4
 
 /* Run-time statistics for measurement (bench.py roofline). */
 typedef struct nnd_stats {

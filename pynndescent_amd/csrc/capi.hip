@@ -43,7 +43,7 @@ static int dalloc(nnd_ctx *ctx, T **p, size_t count) {
     }
     // debugging aid: fresh hipMalloc pages are usually zero, recycled ones are not -- NND_POISON=<byte> fills every buffer with
     // that byte (try 165: negative ints / tiny floats, and 1 or 127: positive ints) before the build initialises it
-    static const int poison = [] { const char *e = getenv("NND_POISON"); return e ? atoi(e) : 0; }();  // the fill byte
+    static const int poison = [] { const char *e = nnd_knob("NND_POISON"); return e ? atoi(e) : 0; }();  // the fill byte
     if (poison) API_HIP(hipMemset(*p, poison & 0xFF, sizeof(T) * (count ? count : 1)));
     return 0;
 }
@@ -153,12 +153,12 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
     // reverse-offer slots per (vertex, class): at least max_candidates rounded up to a power of two, so that a vertex
     // can fill its list from reverse offers alone, as the reference's max_candidates-deep heaps can (utils.py:277-306)
     ctx->rcap = p->max_candidates <= 32 ? 32 : 64;
-    if (const char *rc_env = getenv("NND_RCAP")) {  // experiments: reverse-offer slots per (vertex, class), a power of two
+    if (const char *rc_env = nnd_knob("NND_RCAP")) {  // experiments: reverse-offer slots per (vertex, class), a power of two
         const int r = atoi(rc_env);
         if (r == 16 || r == 32 || r == 64) ctx->rcap = r;
     }
     ctx->pcap = 64;  // one candidate per lane in k_merge (merge.h NCHUNK = 1)
-    if (const char *pc_env = getenv("NND_PCAP")) {  // experiments: proposal slots per vertex, a power of two <= 64
+    if (const char *pc_env = nnd_knob("NND_PCAP")) {  // experiments: proposal slots per vertex, a power of two <= 64
         const int r = atoi(pc_env);
         if (r == 16 || r == 32 || r == 64) ctx->pcap = r;
     }
@@ -224,14 +224,14 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
             // Routing pass (rpforest.hip): the top of the trees is built from every 8th point when the set is large
             // enough for that sample to resolve cells of a few hundred points, and rows fit the route kernel's registers.
             // NND_FOREST_WHOLE=1 forces the whole-set level-synchronous build (A/B measurements).
-            const char *whole = getenv("NND_FOREST_WHOLE");
+            const char *whole = nnd_knob("NND_FOREST_WHOLE");
             if (graph && p->n >= 131072 && ctx->dp <= 256 && !(whole && whole[0] == '1')) {
-                const char *ss = getenv("NND_SAMPLE_STRIDE");
+                const char *ss = nnd_knob("NND_SAMPLE_STRIDE");
                 ctx->s_stride = ss ? atoi(ss) : 8;
                 if (ctx->s_stride < 2) ctx->s_stride = 2;
                 ctx->s_m = p->n / ctx->s_stride;
-                const char *cl = getenv("NND_CELL_LEAF");
-                const char *es = getenv("NND_EARLY_STOP");
+                const char *cl = nnd_knob("NND_CELL_LEAF");
+                const char *es = nnd_knob("NND_EARLY_STOP");
                 ctx->early_stop = es ? atoi(es) : 0;
                 ctx->cell_leaf = cl ? atoi(cl) : 48;  // x stride: cells of <= ~450 points, ~215 on average (one wave per cell)
                 if (ctx->cell_leaf < 8) ctx->cell_leaf = 8;

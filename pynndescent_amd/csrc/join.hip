@@ -409,7 +409,7 @@ static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
         int occ = 0;
         NND_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, 256, smem));
         wg_per_cu = occ < 1 ? 1 : occ;
-        if (const char *cap = getenv("NND_J16_WGCAP")) {  // experiments: fewer resident workgroups per CU
+        if (const char *cap = nnd_knob("NND_J16_WGCAP")) {  // experiments: fewer resident workgroups per CU
             const int c = atoi(cap);
             if (c >= 1 && c < wg_per_cu) wg_per_cu = c;
         }

@@ -1419,7 +1419,7 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
             return 1;
         }
         if (v.record && node_base + S > ctx->node_cap) {
-            if (getenv("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+            if (nnd_knob("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
             return 2;
         }
         if (v.record) v.level_base.push_back(node_base);
@@ -1490,7 +1490,7 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
         NND_HIP_CHECK(nnd_sync_spin(ctx));
         const long long nfin = ctx->h_pin[34];
         if (nfin > ctx->max_segs || node_base + nfin + 1 >= ctx->node_cap) {
-            if (getenv("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+            if (nnd_knob("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
             return 2;
         }
         if (nfin > 0) {
@@ -1515,7 +1515,7 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
             NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 38, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             NND_HIP_CHECK(nnd_sync_spin(ctx));
             if (((const int *)(ctx->h_pin + 38))[1]) {  // node tables exhausted
-                if (getenv("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+                if (nnd_knob("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
                 return 2;
             }
         }
@@ -1580,7 +1580,7 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
                        dp, M, ctx->s_stride, ctx->tree_seed, ctx->xs, ctx->xsh, ctx->nr2s);
     // sample subtrees of <= 512 members leave the level-synchronous passes for the (one-wave) recording finisher;
     // 2048 (+ a workgroup class) means 4 fewer levels but a slower finisher: 6.9-7.2 ms vs 6.6 ms per forest at 1 M points
-    static const int rec_fin = [] { const char *e = getenv("NND_REC_FIN"); const int r = e ? atoi(e) : FIN_SMALL; return r <= FIN_SMALL ? FIN_SMALL : FIN_MAX; }();
+    static const int rec_fin = [] { const char *e = nnd_knob("NND_REC_FIN"); const int r = e ? atoi(e) : FIN_SMALL; return r <= FIN_SMALL ? FIN_SMALL : FIN_MAX; }();
     forest_view v{ctx->xs, ctx->xsh, ctx->nr2s, M, Ps, ctx->cell_leaf, rec_fin, true};
     int rc = forest_levels(ctx, v);
     if (rc) return rc;
@@ -1590,7 +1590,7 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     NND_HIP_CHECK(nnd_sync_spin(ctx));
     const int32_t n_cells = *(const int32_t *)(ctx->h_pin + 35);
     if (n_cells > ctx->cell_cap || n_cells + P / (ctx->p.leaf_size + 1) > ctx->max_segs) {
-        if (getenv("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+        if (nnd_knob("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
         return 2;
     }
     hipLaunchKernelGGL(k_cell_depths, dim3((unsigned)((Ps + 255) / 256)), dim3(256), 0, ctx->stream, ctx->leaf_flag, ctx->scan_out,
@@ -1605,7 +1605,7 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     int rrc = 2;
     // one tree per XCD (k_route_xcd) measured no faster than all trees per point (2.8-3.2 ms vs 2.8 ms at 1 M points):
     // the walk is bound by its dependent record fetches and rechecks, not by where the records are cached.  Opt-in.
-    static const bool route_xcd = [] { const char *e = getenv("NND_ROUTE_XCD"); return e && atoi(e) != 0; }();
+    static const bool route_xcd = [] { const char *e = nnd_knob("NND_ROUTE_XCD"); return e && atoi(e) != 0; }();
     if (route_xcd && T % 8 == 0 && dp % 32 == 0 && dp <= 256) {  // every XCD gets the same number of trees
         switch (dp / 32) {
             case 1: rrc = launch_route_xcd<1, 4>(ctx, ctx->scan_out); break;
@@ -1653,7 +1653,7 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     NND_HIP_CHECK(nnd_sync_spin(ctx));
     const long long n_big = ctx->h_pin[36], n_small = ctx->h_pin[37];
     if (n_big > ctx->max_segs) {
-        if (getenv("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+        if (nnd_knob("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
         return 2;
     }
     if (launch_finishers(ctx, ctx->perm[0], ctx->perm[1], big_start, big_len, big_depth, 0, n_big, n_small)) return 1;
@@ -1680,7 +1680,7 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     unsigned gridP = (unsigned)((P + 255) / 256);
     int levels = 0, rc = 2;
     if (ctx->s_m > 0) rc = forest_by_routing(ctx, &levels);
-    if (getenv("NND_FOREST_DEBUG"))
+    if (nnd_knob("NND_FOREST_DEBUG"))
         fprintf(stderr, "forest: n=%lld T=%d s_m=%lld routing rc=%d levels=%d node_cap=%lld cell_cap=%lld max_segs=%lld\n", (long long)n, T,
                 (long long)ctx->s_m, rc, levels, (long long)ctx->node_cap, (long long)ctx->cell_cap, (long long)ctx->max_segs);
     if (rc == 1) return 1;

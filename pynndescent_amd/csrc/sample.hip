@@ -383,8 +383,8 @@ static void launch_select(nnd_ctx *ctx, uint32_t it_seed) {
         if (ctx->n_ranks <= 1) ctx->rbuf_clean = true;
         return;
     }
-    const char *force_old = getenv("NND_SELECT_WAVE");  // A/B and the parity test: the one-wave-per-vertex kernel
-    if (ctx->k <= 32 && ctx->rcap == 32 && ctx->mc <= 32 && !(force_old && atoi(force_old) != 0)) {
+    const bool force_old = (ctx->p.flags & NND_FLAG_TEST_SELECT_WAVE) != 0;  // parity test: the one-wave-per-vertex kernel
+    if (ctx->k <= 32 && ctx->rcap == 32 && ctx->mc <= 32 && !force_old) {
         hipLaunchKernelGGL(k_sample_select_h, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 7) / 8)), dim3(256), 0, ctx->stream,
                            ctx->knn_e, ctx->n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->cand, ctx->own_lo,
                            ctx->own_hi, ctx->active);

@@ -10,6 +10,19 @@
 
 #include "../../include/pynnd_amd.h"
 
+// Experiment / debugging knobs (NND_* environment variables: table sizes, kernel variants, NND_POISON, NND_FOREST_DEBUG)
+// exist only in a library built with `make KNOBS=1` (-DNND_EXPERIMENT_KNOBS): the product library reads no environment
+// variable -- an environment leftover must not be able to change what a build computes.
+#include <stdlib.h>
+static inline const char *nnd_knob(const char *name) {
+#ifdef NND_EXPERIMENT_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // device-side counters (one int64 each), reset per phase
 enum {
     CNT_ACCEPT = 0,   // k-list insertions (c of pynndescent_.py:317)

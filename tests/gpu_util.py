@@ -23,14 +23,14 @@ def alt_dist_matrix(x, rows_a, rows_b, metric):
 
 
 def make_builder(x, metric="euclidean", k=15, n_trees=8, leaf_size=None, mc=None, n_iters=None, delta=0.001,
-                 seed=1, max_depth=200, join_blocks=1):
+                 seed=1, max_depth=200, join_blocks=1, flags=0):
     n, d = x.shape
     rng_state, _, tree_states = O.draw_rng_states(seed, max(n_trees, 1))
     ls = O.default_leaf_size(k) if leaf_size is None else leaf_size
     mc = min(60, k) if mc is None else mc
     n_iters = O.default_n_iters(n) if n_iters is None else n_iters
     b = _capi.Builder(n, d, O.METRICS[metric], k, n_trees, ls, max_depth, mc, n_iters, delta, rng_state,
-                      tree_states[0], join_blocks=join_blocks)
+                      tree_states[0], join_blocks=join_blocks, flags=flags)
     b.set_data_host(x)
     return b
 

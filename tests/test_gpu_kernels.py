@@ -291,13 +291,14 @@ def test_repeated_builds_on_one_handle_are_identical():
 
 
 @pytest.mark.parametrize("k,mc", [(15, 15), (10, 10), (30, 30), (20, 12)])
-def test_half_wave_select_equals_wave_select(k, mc, monkeypatch):
+def test_half_wave_select_equals_wave_select(k, mc):
     """k_sample_select_h (two vertices per wave) must produce exactly the lists and flag resets of k_sample_select."""
     x = clustered(6000, 24, 6, 25, seed=13)
     outs = []
-    for force in ("0", "1"):
-        monkeypatch.setenv("NND_SELECT_WAVE", force)
-        b = make_builder(x, "euclidean", k=k, n_trees=3, mc=mc)
+    from pynndescent_amd import _capi
+
+    for flags in (0, _capi.NND_FLAG_TEST_SELECT_WAVE):
+        b = make_builder(x, "euclidean", k=k, n_trees=3, mc=mc, flags=flags)
         b.make_forest()
         b.init_from_leaves()
         b.init_random()
