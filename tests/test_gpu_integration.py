@@ -52,6 +52,26 @@ def test_integration_md_stub_verbatim(metric):
         np.testing.assert_allclose(dist, ((xi[:, None, :] - xi[idx]) ** 2).sum(-1), rtol=1e-5, atol=1e-6)
 
 
+def test_integration_md_stub_two_devices():
+    """The stub's n_devices argument (the GPU analogue of n_jobs, pynndescent_.py:1141-1143): nnd_build_multi, two ranks --
+    both on this box's one GPU (devices=[0, 0]: the library's LOCAL transport; distinct ordinals would talk over RCCL)."""
+    gpu_nn_descent = _integration_stub()
+    x = clustered(40000, 48, 10, 64, seed=3)
+    k, n_trees, seed = 15, 8, 11
+    rng_state, _, tree_states = O.draw_rng_states(seed, n_trees)
+    args = (x, k, rng_state, tree_states, min(60, k), "euclidean", O.default_n_iters(x.shape[0]), 0.001, n_trees, O.default_leaf_size(k), 200)
+    idx2, dist2 = gpu_nn_descent(*args, n_devices=2, devices=[0, 0])
+    idx1, _ = gpu_nn_descent(*args)
+    assert idx2.shape == (40000, k) and (idx2 >= 0).all() and np.all(np.diff(dist2, axis=1) >= 0)
+    rows = np.arange(0, 40000, 8)
+    ti, _ = O.brute_force_knn(x, 10, "euclidean", rows=rows, kind="fast")
+    r2, r1 = O.recall(ti, idx2[rows]), O.recall(ti, idx1[rows])
+    print("INTEGRATION.md stub: recall@10 with n_devices=2 %.4f, one device %.4f" % (r2, r1))
+    assert abs(r2 - r1) <= 0.005
+    xi = x[rows].astype(np.float64)
+    np.testing.assert_allclose(dist2[rows], ((xi[:, None, :] - x[idx2[rows]].astype(np.float64)) ** 2).sum(-1), rtol=1e-5, atol=1e-6)
+
+
 def test_integration_md_stub_init_graph_and_error():
     gpu_nn_descent = _integration_stub()
     x = clustered(3000, 16, 5, 20, seed=5)

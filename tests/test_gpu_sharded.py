@@ -158,3 +158,27 @@ def test_sharded_at_scale_matches_single_gpu(world, n, n_trees):
     assert abs(r_sh - r_1) <= 0.005
     # deferral is a valve, not the normal path: under 2 % of the proposal records
     assert sum(deferred) <= 0.02 * max(sum(sent), 1)
+
+
+def test_rccl_communicator_world_of_one():
+    """The RCCL transport on this one-GPU box: librccl is opened (dlopen), ncclGetUniqueId / ncclCommInitRank succeed and a
+    shard built over that communicator equals what the LOCAL transport gives for one rank.  (Two RCCL ranks cannot share a
+    GPU -- "Duplicate GPU detected" -- so the send / recv groups themselves run only on a multi-GPU node.)"""
+    import ctypes as C
+
+    lib = _capi.load_library()
+    ident = (C.c_uint8 * 128)()
+    assert lib.nnd_comm_unique_id(ident) == 0, lib.nnd_comm_last_error(None)
+    h = _capi._H()
+    assert lib.nnd_comm_create_rccl(C.byref(h), bytes(ident), 1, 0, 0) == 0, lib.nnd_comm_last_error(None)
+    comm = sharded.Comm(h, 1, 0)
+    x = clustered(20000, 32, 8, 40, seed=31)
+    xd = torch.from_numpy(x).cuda()
+    sb = sharded.ShardedBuilder(comm, [20000], 32, "euclidean", 15, 8, seed=5, device_index=0)
+    idx, dist, info = sb.build(xd)
+    idx = idx.cpu().numpy()
+    sb.close()
+    comm.close()
+    idx_l, _, _ = _run_local(xd, 1, "euclidean", 15, n_trees=8, seed=5)
+    np.testing.assert_array_equal(idx, idx_l.cpu().numpy())  # same code, same seeds: the transport must not matter
+    assert info["world"] == 1 and info["dropped_offers"] == 0
