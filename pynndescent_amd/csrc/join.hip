@@ -54,7 +54,7 @@ __device__ __forceinline__ bool klist_has(const uint32_t *kl, uint32_t id) {
 #ifndef NND_J16_WAVES
 #define NND_J16_WAVES 3
 #endif
-template <int DC, int KS16>
+template <int DC, int KS16, bool SHARD>
 __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
                                                          int metric, const int32_t *__restrict__ cand,
                                                          const int32_t *__restrict__ order, int64_t v_begin,
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, NND_J16_WAVES) void k_local_join16(const float
     // rows it owns.  Proposal slot of target t: a shard keeps proposals for vertices owned ELSEWHERE in a narrow table
     // (pcap_r slots per row: a rank sends a remote row a few proposals per iteration, and the export streams that table)
     auto prop_slot = [&](int t, uint32_t slot) __attribute__((always_inline)) -> unsigned long long * {
-        if (pbuf_r && ((int64_t)t < rt_lo || (int64_t)t >= rt_hi))
+        if (SHARD && ((int64_t)t < rt_lo || (int64_t)t >= rt_hi))  // (SHARD = false: the plain build carries none of this)
             return (unsigned long long *)&pbuf_r[(int64_t)t * pcap_r + (slot & (uint32_t)(pcap_r - 1))];
         return (unsigned long long *)&pbuf[(int64_t)t * pcap + slot];
     };
@@ -392,12 +392,12 @@ static const int32_t *join_order(const nnd_ctx *ctx, int64_t &v_begin, int64_t &
     return order;
 }
 
-template <int DC, int KS16>
+template <int DC, int KS16, bool SHARD>
 static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     constexpr int RV = 32, kls = KS16 * 16 + 4;
     constexpr int WAVE_BYTES = NND_J16_QCAP * 8 + 2 * RV * 4 + 4 * 4 + 5 * RV * 4 + RV * kls * 4 + 8;  // = the kernel's
     size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
-    auto kern = k_local_join16<DC, KS16>;
+    auto kern = k_local_join16<DC, KS16, SHARD>;
     // function attributes and occupancy are per DEVICE: cached per device ordinal, not per process
     static int wg_per_cu_dev[64] = {0}, n_cu_dev[64] = {0};
     int &wg_per_cu = wg_per_cu_dev[ctx->p.device & 63], &n_cu = n_cu_dev[ctx->p.device & 63];
@@ -431,9 +431,14 @@ static int launch_join16_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
 
 template <int DC>
 static int launch_join16_ks(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
-    if (ctx->ks <= 16) return launch_join16_t<DC, 1>(ctx, v_begin, v_end);
-    if (ctx->ks <= 32) return launch_join16_t<DC, 2>(ctx, v_begin, v_end);
-    return launch_join16_t<DC, 4>(ctx, v_begin, v_end);
+    if (ctx->pbuf_r) {  // a shard of a row-sharded build: proposals for rows owned elsewhere go to the narrow table
+        if (ctx->ks <= 16) return launch_join16_t<DC, 1, true>(ctx, v_begin, v_end);
+        if (ctx->ks <= 32) return launch_join16_t<DC, 2, true>(ctx, v_begin, v_end);
+        return launch_join16_t<DC, 4, true>(ctx, v_begin, v_end);
+    }
+    if (ctx->ks <= 16) return launch_join16_t<DC, 1, false>(ctx, v_begin, v_end);
+    if (ctx->ks <= 32) return launch_join16_t<DC, 2, false>(ctx, v_begin, v_end);
+    return launch_join16_t<DC, 4, false>(ctx, v_begin, v_end);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -448,7 +453,7 @@ static int launch_join16_ks(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
 #ifndef NND_JW_DCW
 #define NND_JW_DCW 32
 #endif
-template <int MCP, int DC>
+template <int MCP, int DC, bool SHARD>
 __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_join_w(const float *__restrict__ xp, int dp,
                                                                        const float *__restrict__ nrm, int metric,
                                                                        const int32_t *__restrict__ cand,
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
     // rows it owns.  Proposal slot of target t: a shard keeps proposals for vertices owned ELSEWHERE in a narrow table
     // (pcap_r slots per row: a rank sends a remote row a few proposals per iteration, and the export streams that table)
     auto prop_slot = [&](int t, uint32_t slot) __attribute__((always_inline)) -> unsigned long long * {
-        if (pbuf_r && ((int64_t)t < rt_lo || (int64_t)t >= rt_hi))
+        if (SHARD && ((int64_t)t < rt_lo || (int64_t)t >= rt_hi))  // (SHARD = false: the plain build carries none of this)
             return (unsigned long long *)&pbuf_r[(int64_t)t * pcap_r + (slot & (uint32_t)(pcap_r - 1))];
         return (unsigned long long *)&pbuf[(int64_t)t * pcap + slot];
     };
@@ -730,12 +735,12 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
     }
 }
 
-template <int MCP, int DC>
-static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
+template <int MCP, int DC, bool SHARD>
+static int launch_join_w_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     constexpr int RV = 2 * MCP;
     constexpr int WAVE_BYTES = 512 * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + 8;
     size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
-    auto kern = k_local_join_w<MCP, DC>;
+    auto kern = k_local_join_w<MCP, DC, SHARD>;
     // function attributes and occupancy are per DEVICE: cached per device ordinal, not per process
     static int wg_per_cu_dev[64] = {0}, n_cu_dev[64] = {0};
     int &wg_per_cu = wg_per_cu_dev[ctx->p.device & 63], &n_cu = n_cu_dev[ctx->p.device & 63];
@@ -761,6 +766,11 @@ static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
                        ctx->pcap, slot_seed, ctx->counters, nnd_list_lo(ctx), nnd_list_hi(ctx), ctx->pbuf_r, ctx->pcap_r, ctx->own_lo, ctx->own_hi);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+template <int MCP, int DC>
+static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
+    return ctx->pbuf_r ? launch_join_w_t<MCP, DC, true>(ctx, v_begin, v_end) : launch_join_w_t<MCP, DC, false>(ctx, v_begin, v_end);
 }
 
 int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
