@@ -522,7 +522,7 @@ def main():
                        "rows sharded over %d GPUs (one global index of %d points): point set all-gathered once, forest split "
                        "by tree, per iteration threshold all-gather + reverse-offer all-to-all-v + proposal all-to-all-v, the "
                        "update counts riding on the record-count exchange; ncclSend/ncclRecv groups issued by libpynnd_amd.so "
-                       "on the build's stream (%s transport)" % (world, n_total, "gloo HOST-staged debug" if share_gpu else "RCCL"),
+                       "on the build's stream (%s transport)" % (world, n_total, {"rccl": "RCCL", "host": "HOST-staged over gloo (debug / fallback)"}.get(comm.transport, comm.transport)),
                        "join_blocks": args.join_blocks},
             "recall_at_10": round(rec_all, 4),
             "recall_at_10_strict_first10": round(rec_strict, 4),

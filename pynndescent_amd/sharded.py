@@ -189,6 +189,7 @@ class Comm:
         self.world = world
         self.rank = rank
         self._keep = keep  # callback objects the C side holds pointers to
+        self.transport = "local"
 
     def set_serial(self, on=True):
         if self.lib.nnd_comm_local_set_serial(self._h, 1 if on else 0) != 0:
@@ -265,31 +266,56 @@ def _host_callback(tcomm):
     return _capi.HOST_EXCHANGE_FN(exchange)
 
 
-def make_comm(device_index, group=None):
+def make_comm(device_index, group=None, allow_host_fallback=True):
     """The rank's communicator under ``torch.distributed``: RCCL when the process group runs the nccl backend (the
-    unique id is broadcast through torch, the data path never touches it again); HOST staging over gloo otherwise."""
+    unique id is broadcast through torch, the data path never touches it again); HOST staging over gloo otherwise.
+    If the RCCL communicator cannot be created on some rank (all ranks agree on that through one all-reduce) and
+    ``allow_host_fallback`` is set, every rank falls back to the HOST transport over a gloo group -- loudly: a slow
+    exchange is better than no index, and ``Comm.transport`` says which one is in use."""
     import torch.distributed as dist
 
     lib = _capi.load_library()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     h = _capi._H()
     if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", device_index)
         ident = torch.zeros(128, dtype=torch.uint8)
+        ok = 1
         if rank == 0:
             buf = (C.c_uint8 * 128)()
             if lib.nnd_comm_unique_id(buf) != 0:
-                raise _capi.NNDError(lib.nnd_comm_last_error(None).decode())
+                ok = 0
             ident = torch.tensor(list(buf), dtype=torch.uint8)
-        ident = ident.to(torch.device("cuda", device_index))
+        ident = ident.to(dev)
         dist.broadcast(ident, 0, group=group)
         raw = bytes(ident.cpu().tolist())
-        if lib.nnd_comm_create_rccl(C.byref(h), raw, world, rank, int(device_index)) != 0:
-            raise _capi.NNDError(lib.nnd_comm_last_error(None).decode())
-        return Comm(h, world, rank)
-    cb = _host_callback(TorchDistComm(group))
+        why = ""
+        if ok and lib.nnd_comm_create_rccl(C.byref(h), raw, world, rank, int(device_index)) != 0:
+            ok, why = 0, lib.nnd_comm_last_error(None).decode()
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 1:
+            c = Comm(h, world, rank)
+            c.transport = "rccl"
+            return c
+        if h.value:
+            lib.nnd_comm_destroy(h)
+            h = _capi._H()
+        if not allow_host_fallback:
+            raise _capi.NNDError("RCCL communicator could not be created on every rank: %s" % (why or "another rank failed"))
+        import warnings
+
+        warnings.warn("pynndescent_amd: RCCL communicator unavailable (%s); exchanging through the HOST transport over gloo -- "
+                      "correct but slow" % (why or "another rank failed"))
+        hg = dist.new_group(backend="gloo")
+        cb = _host_callback(TorchDistComm(hg))
+    else:
+        cb = _host_callback(TorchDistComm(group))
     if lib.nnd_comm_create_host(C.byref(h), world, rank, int(device_index), C.cast(cb, C.c_void_p), None) != 0:
         raise _capi.NNDError(lib.nnd_comm_last_error(None).decode())
-    return Comm(h, world, rank, keep=cb)
+    c = Comm(h, world, rank, keep=cb)
+    c.transport = "host"
+    return c
 
 
 # ------------------------------------------------------------------------------------------------
