@@ -170,9 +170,8 @@ extern "C" int32_t nnd_comm_create_local(nnd_comm_t *out, int32_t world, const i
         g->posts[r].device = c->device;
         if (bad) {
             cgerr("nnd_comm_create_local: rank %d on device %d: %s", r, c->device, c->err[0] ? c->err : "event creation failed");
+            g->refs = r + 1;  // the communicators that exist: the last nnd_comm_destroy below releases the group
             for (int q = 0; q <= r; q++) { (void)nnd_comm_destroy(out[q]); out[q] = nullptr; }
-            g->refs -= world - (r + 1);
-            if (g->refs <= 0) delete g;
             return 1;
         }
     }

@@ -254,7 +254,10 @@ extern "C" int32_t nnd_shard_get_stats(nnd_shard_t s, nnd_stats *out) {
 struct section_timer {
     nnd_shard_s *s;
     std::chrono::steady_clock::time_point t;
-    bool serial;
+    bool serial, open = true;
+    ~section_timer() {  // an error return inside the section must not keep the serial-mode token
+        if (open) comm_compute_end(s->comm, s->h->stream);
+    }
     explicit section_timer(nnd_shard_s *s_) : s(s_) {
         serial = s->comm->kind == NND_COMM_LOCAL && s->comm->grp->serial;
         comm_compute_begin(s->comm);
@@ -262,6 +265,7 @@ struct section_timer {
         t = std::chrono::steady_clock::now();
     }
     void end() {
+        open = false;
         comm_compute_end(s->comm, s->h->stream);  // serial mode: drains the stream, then releases the GPU
         if (serial && s->info.n_sections < 256) {
             const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count();
