@@ -188,7 +188,7 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
             if ((rc = dalloc(ctx, &ctx->th, n))) break;
             const size_t rows = ctx->slim ? (size_t)(ctx->own_hi - ctx->own_lo) : n;  // per-OWNED-row tables
             int32_t *a_cand = nullptr;
-            uint64_t *a_rbuf = nullptr;
+            uint32_t *a_rbuf = nullptr;
             uint8_t *a_active = nullptr;
             if ((rc = dalloc(ctx, &a_cand, rows * 2 * ctx->mcp))) break;
             ctx->slim_alloc[0] = a_cand;

@@ -9,6 +9,7 @@
 #define NND_NEW_BIT 0x80000000u           // "new" flag packed into bit 31 of the neighbour word (utils.py:155 flags)
 #define NND_IDX_MASK 0x7FFFFFFFu
 #define NND_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define NND_EMPTY_SLOT 0xFFFFFFFFu  // an unarmed reverse-offer slot (sample.hip)
 #define NND_FLT_MAX 3.402823466e+38f
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -22,6 +23,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __host__ __device__ __forceinline__ uint32_t nnd_mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU;
     x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+// nnd_mix32 is a bijection of the 32-bit words; this is its inverse (each xorshift and each odd multiplier undone in turn)
+__host__ __device__ __forceinline__ uint32_t nnd_unmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x43021123U;
+    x ^= (x >> 15) ^ (x >> 30); x *= 0x1d69e2a5U;
     x ^= x >> 16;
     return x;
 }

@@ -157,7 +157,7 @@ int nnd_launch_reset_graph(nnd_ctx *ctx) {
         if (ctx->pbuf_r) NND_HIP_CHECK(hipMemsetAsync(ctx->pbuf_r, 0xFF, sizeof(uint64_t) * (size_t)ctx->n * ctx->pcap_r, ctx->stream));
     }
     if (!ctx->rbuf_clean)
-        NND_HIP_CHECK(hipMemsetAsync(ctx->rbuf + (size_t)ctx->slim_row0() * 2 * ctx->rcap, 0xFF, sizeof(uint64_t) * (size_t)ctx->slim_rows() * 2 * ctx->rcap, ctx->stream));
+        NND_HIP_CHECK(hipMemsetAsync(ctx->rbuf + (size_t)ctx->slim_row0() * 2 * ctx->rcap, 0xFF, sizeof(uint32_t) * (size_t)ctx->slim_rows() * 2 * ctx->rcap, ctx->stream));
     ctx->pbuf_clean = ctx->rbuf_clean = true;
     NND_HIP_CHECK(hipGetLastError());
     ctx->iter = 0;

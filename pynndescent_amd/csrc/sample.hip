@@ -10,16 +10,27 @@
 // The reference makes every thread scan all n*k edges and push into the heaps of the vertices it
 // owns.  Here:
 //   k_sample_reverse : one thread per edge scatters the reverse offer into a bank of RCAP hashed
-//                      slots per (target, class) with a 64-bit atomicMin on (priority<<32 | source)
-//                      -- order independent, so the sample is deterministic for a given seed;
+//                      slots per (target, class) with a 32-bit atomicMin on the offer's priority
+//                      -- order independent, so the sample is deterministic for a given seed.  The
+//                      priority of the offer v -> u is mix32(v ^ salt(u)): mix32 is a bijection, so
+//                      the 4-byte slot IS the source (v = unmix32(slot) ^ salt(u)) and its order is
+//                      a fresh pseudo-random order of the sources for every target and iteration;
 //   k_sample_select  : one wave per vertex gathers its k forward offers and its reverse slots,
 //                      drops reverse offers that duplicate a forward id, ranks by priority and
 //                      writes the max_candidates smallest of each class, clears the flags of the
 //                      sampled forward-new edges and re-arms the reverse slots.
-// Priorities are hash(seed, iteration, v, u): forward and reverse offers of one edge share the
-// priority, as they do in the reference when one thread owns both endpoints (utils.py:275-291).
+// Forward priorities are hash(seed, iteration, v, u); both kinds are uniform 32-bit words, ranked together.
+// (Until round 3 a slot held priority << 32 | source, 8 bytes: the table was the largest stream of the phase.)
 #include "common.h"
 #include "state.h"
+
+// per-target, per-iteration salt of the reverse priorities
+__device__ __forceinline__ uint32_t nnd_offer_salt(uint32_t it_seed, uint32_t u) { return nnd_hash2(it_seed ^ 0x3C6EF372u, u); }
+__device__ __forceinline__ uint32_t nnd_offer_prio(uint32_t it_seed, uint32_t v, uint32_t u) { return nnd_mix32(v ^ nnd_offer_salt(it_seed, u)); }
+// slot word of vertex u's bank -> the 64-bit item key (priority << 32 | source) the selection ranks
+__device__ __forceinline__ uint64_t nnd_offer_key(uint32_t slot_word, uint32_t salt_u) {
+    return ((uint64_t)slot_word << 32) | (uint64_t)(nnd_unmix32(slot_word) ^ salt_u);
+}
 
 // Two passes over the edges.  pass 0: NEW edges -- reverse offer into the target's "new" slots, and both endpoints are
 // marked active (they will hold at least one new candidate).  pass 1: OLD edges -- offered only to ACTIVE targets: a
@@ -29,7 +40,7 @@
 // no division per edge.  Rows are visited in `order` (spatially coherent, one contiguous eighth per XCD): the targets
 // of a window of rows are each other's neighbours, so the offers of a window land in a few slot banks that stay in L2.
 __global__ __launch_bounds__(256) void k_sample_reverse(const uint32_t *__restrict__ knn_e, int64_t row_lo, int64_t n, int k, int ks, uint32_t it_seed,
-                                                        uint64_t *__restrict__ rbuf, int rcap, int64_t own_lo, int64_t own_hi, int pass,
+                                                        uint32_t *__restrict__ rbuf, int rcap, int64_t own_lo, int64_t own_hi, int pass,
                                                         uint8_t *__restrict__ active, const int32_t *__restrict__ order) {
     int64_t b = blockIdx.x;
     if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
@@ -46,10 +57,8 @@ __global__ __launch_bounds__(256) void k_sample_reverse(const uint32_t *__restri
     if ((int64_t)u < own_lo || (int64_t)u >= own_hi) return;  // owner-computes: only targets this handle owns (utils.py:270-273)
     if (pass == 0) active[u] = 1;
     else if (!active[u]) return;
-    uint32_t prio = nnd_hash3(it_seed, (uint32_t)v, u);
     uint32_t slot = nnd_hash2(it_seed ^ 0x68E31DA4u, (uint32_t)v) & (uint32_t)(rcap - 1);
-    atomicMin((unsigned long long *)&rbuf[((int64_t)u * 2 + cls) * rcap + slot],
-              ((unsigned long long)prio << 32) | (unsigned long long)(uint32_t)v);
+    atomicMin(&rbuf[((int64_t)u * 2 + cls) * rcap + slot], nnd_offer_prio(it_seed, (uint32_t)v, u));  // (a priority equal to NND_EMPTY_SLOT, 1 in 2^32, is a lost offer)
 }
 
 #define SAMPLE_MAX_ITEMS 128  // k (<=64) forward + rcap (<=64) reverse offers per class
@@ -59,7 +68,7 @@ struct sample_scratch {
 };
 
 __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
-                                                       int mcp, uint32_t it_seed, uint64_t *__restrict__ rbuf, int rcap,
+                                                       int mcp, uint32_t it_seed, uint32_t *__restrict__ rbuf, int rcap,
                                                        int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
                                                        const uint8_t *__restrict__ active) {
     __shared__ sample_scratch scr[4];
@@ -88,16 +97,18 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
     }
     nnd_wave_lds_sync();
     const int nfwd[2] = {cnt[0], cnt[1]};
+    const uint32_t salt = nnd_offer_salt(it_seed, (uint32_t)v);
     // reverse offers: when both classes' slot banks fit one wave (2 * rcap <= 64) they are fetched and screened together
     if (2 * rcap <= 64) {
         const int c = lane >= rcap ? 1 : 0;
-        uint64_t *slots = rbuf + v * 2 * rcap;  // [class 0 | class 1] are adjacent
-        uint64_t rk = NND_EMPTY_KEY;
+        uint32_t *slots = rbuf + v * 2 * rcap;  // [class 0 | class 1] are adjacent
+        uint32_t rw = NND_EMPTY_SLOT;
         if (lane < 2 * rcap) {
-            rk = slots[lane];
-            if (rk != NND_EMPTY_KEY) slots[lane] = NND_EMPTY_KEY;  // re-arm for the next iteration
+            rw = slots[lane];
+            if (rw != NND_EMPTY_SLOT) slots[lane] = NND_EMPTY_SLOT;  // re-arm for the next iteration
         }
-        bool ok = rk != NND_EMPTY_KEY;
+        bool ok = rw != NND_EMPTY_SLOT;
+        const uint64_t rk = nnd_offer_key(rw, salt);
         if (ok) {  // utils.py:427-430: an id already in the list is not pushed again
             const uint32_t src = (uint32_t)rk;
             const int nf = c ? nfwd[1] : nfwd[0];
@@ -113,15 +124,16 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
     } else {
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            uint64_t *slots = rbuf + (v * 2 + c) * rcap;
+            uint32_t *slots = rbuf + (v * 2 + c) * rcap;
             for (int s0 = 0; s0 < rcap; s0 += 64) {
                 int s = s0 + lane;
-                uint64_t rk = NND_EMPTY_KEY;
+                uint32_t rw = NND_EMPTY_SLOT;
                 if (s < rcap) {
-                    rk = slots[s];
-                    if (rk != NND_EMPTY_KEY) slots[s] = NND_EMPTY_KEY;  // re-arm for the next iteration
+                    rw = slots[s];
+                    if (rw != NND_EMPTY_SLOT) slots[s] = NND_EMPTY_SLOT;  // re-arm for the next iteration
                 }
-                bool ok = rk != NND_EMPTY_KEY;
+                bool ok = rw != NND_EMPTY_SLOT;
+                const uint64_t rk = nnd_offer_key(rw, salt);
                 if (ok) {  // utils.py:427-430: an id already in the list is not pushed again
                     uint32_t src = (uint32_t)rk;
                     for (int j = 0; j < nfwd[c]; j++) ok &= ((uint32_t)sc.key[c][j] != src);
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
 // Items of a class: <= k forward + rcap reverse offers; ranks by counting over the LDS copy; the rank of every forward
 // new edge goes through LDS (rank_new) to the lane that holds the edge, which clears its flag when it was sampled.
 __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
-                                                            int mcp, uint32_t it_seed, uint64_t *__restrict__ rbuf, int rcap,
+                                                            int mcp, uint32_t it_seed, uint32_t *__restrict__ rbuf, int rcap,
                                                             int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
                                                             const uint8_t *__restrict__ active) {
     constexpr int MAXI = 128 + 64;
@@ -206,17 +218,19 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
     }
     nnd_wave_lds_sync();
     const int nfwd[2] = {cnt[0], cnt[1]};
+    const uint32_t salt = nnd_offer_salt(it_seed, (uint32_t)v);
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-        uint64_t *slots = rbuf + (v * 2 + c) * rcap;
+        uint32_t *slots = rbuf + (v * 2 + c) * rcap;
         for (int s0 = 0; s0 < rcap; s0 += 64) {
             const int sidx = s0 + lane;
-            uint64_t rk = NND_EMPTY_KEY;
+            uint32_t rw = NND_EMPTY_SLOT;
             if (sidx < rcap) {
-                rk = slots[sidx];
-                if (rk != NND_EMPTY_KEY) slots[sidx] = NND_EMPTY_KEY;  // re-arm for the next iteration
+                rw = slots[sidx];
+                if (rw != NND_EMPTY_SLOT) slots[sidx] = NND_EMPTY_SLOT;  // re-arm for the next iteration
             }
-            bool ok = rk != NND_EMPTY_KEY;
+            bool ok = rw != NND_EMPTY_SLOT;
+            const uint64_t rk = nnd_offer_key(rw, salt);
             if (__ballot(ok)) {  // utils.py:427-430: an id already in the list is not pushed again
                 const uint32_t src = (uint32_t)rk;
                 for (int j = 0; j < nfwd[c]; j++) ok = ok && ((uint32_t)key[c][j] != src);
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
 // j, reverse slots j (old class) and 32 + j (new class), and items j and 32 + j of each class's list (<= k + 32 <= 64
 // items).  Same keys, same duplicate rule, same ranks: the candidate lists are identical to k_sample_select's.
 __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
-                                                         int mcp, uint32_t it_seed, uint64_t *__restrict__ rbuf,
+                                                         int mcp, uint32_t it_seed, uint32_t *__restrict__ rbuf,
                                                          int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
                                                          const uint8_t *__restrict__ active) {
     constexpr int RCAP = 32;
@@ -277,14 +291,16 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
 
     uint32_t e = NND_EMPTY_E;
     if (act && j < k) e = knn_e[vv * ks + j];
-    uint64_t rk0 = NND_EMPTY_KEY, rk1 = NND_EMPTY_KEY;  // reverse offers: old class, new class
-    uint64_t *slots = rbuf + vv * 2 * RCAP;              // [class 0 | class 1] are adjacent
+    uint32_t rw0 = NND_EMPTY_SLOT, rw1 = NND_EMPTY_SLOT;  // reverse offers: old class, new class
+    uint32_t *slots = rbuf + vv * 2 * RCAP;                // [class 0 | class 1] are adjacent: one 256-byte bank pair per vertex
     if (act) {
-        rk0 = slots[j];
-        rk1 = slots[RCAP + j];
-        if (rk0 != NND_EMPTY_KEY) slots[j] = NND_EMPTY_KEY;  // re-arm for the next iteration
-        if (rk1 != NND_EMPTY_KEY) slots[RCAP + j] = NND_EMPTY_KEY;
+        rw0 = slots[j];
+        rw1 = slots[RCAP + j];
+        if (rw0 != NND_EMPTY_SLOT) slots[j] = NND_EMPTY_SLOT;  // re-arm for the next iteration
+        if (rw1 != NND_EMPTY_SLOT) slots[RCAP + j] = NND_EMPTY_SLOT;
     }
+    const uint32_t salt = nnd_offer_salt(it_seed, (uint32_t)vv);
+    const uint64_t rk0 = nnd_offer_key(rw0, salt), rk1 = nnd_offer_key(rw1, salt);
     const bool valid = e != NND_EMPTY_E;
     const uint32_t u = e & NND_IDX_MASK;
     const uint32_t cls = e >> 31;
@@ -303,7 +319,7 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
     nnd_wave_lds_sync();
     const int nf0 = cnt[0], nf1 = cnt[1];
     // utils.py:427-430: an id already in the list is not pushed again (a reverse offer that repeats a forward edge)
-    bool ok0 = rk0 != NND_EMPTY_KEY, ok1 = rk1 != NND_EMPTY_KEY;
+    bool ok0 = rw0 != NND_EMPTY_SLOT, ok1 = rw1 != NND_EMPTY_SLOT;
     {
         const int a = nf0 > nf1 ? nf0 : nf1;
         const int a0 = __builtin_amdgcn_readlane(a, 0), a1 = __builtin_amdgcn_readlane(a, 32);
@@ -486,7 +502,7 @@ __global__ __launch_bounds__(256) void k_offer_export(const uint32_t *__restrict
 }
 
 __global__ void k_offer_import(const int32_t *__restrict__ targets, const uint64_t *__restrict__ keys, int64_t count, uint32_t want_cls,
-                               uint32_t it_seed, uint64_t *__restrict__ rbuf, int rcap, uint8_t *__restrict__ active,
+                               uint32_t it_seed, uint32_t *__restrict__ rbuf, int rcap, uint8_t *__restrict__ active,
                                int64_t own_lo, int64_t own_hi) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -495,9 +511,9 @@ __global__ void k_offer_import(const int32_t *__restrict__ targets, const uint64
     if (cls != want_cls || (int64_t)u < own_lo || (int64_t)u >= own_hi) return;
     if (cls == 1u) active[u] = 1;
     else if (!active[u]) return;  // no new candidate reaches u: its old list is never read
-    const uint64_t key = keys[i];
-    const uint32_t slot = nnd_hash2(it_seed ^ 0x68E31DA4u, (uint32_t)key) & (uint32_t)(rcap - 1);
-    atomicMin((unsigned long long *)&rbuf[((int64_t)u * 2 + cls) * rcap + slot], (unsigned long long)key);
+    const uint32_t v = (uint32_t)keys[i];  // the source; the priority is a function of (source, target)
+    const uint32_t slot = nnd_hash2(it_seed ^ 0x68E31DA4u, v) & (uint32_t)(rcap - 1);
+    atomicMin(&rbuf[((int64_t)u * 2 + cls) * rcap + slot], nnd_offer_prio(it_seed, v, u));
 }
 
 // first half of a sharded sampling pass: local new edges, and the records for targets owned elsewhere (both classes)

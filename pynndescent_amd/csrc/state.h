@@ -95,7 +95,7 @@ struct nnd_handle_s {
 
     // candidates / proposals
     int32_t *cand = nullptr;  // (n, 2*mcp): [new | old], -1 padded
-    uint64_t *rbuf = nullptr; // (n, 2, rcap) reverse offers (priority<<32 | source), hashed slots
+    uint32_t *rbuf = nullptr; // (n, 2, rcap) reverse offers, hashed slots: 32-bit invertible priority of the source (sample.hip)
     uint64_t *pbuf = nullptr; // (n, pcap) proposals (dist_bits<<32 | source), hashed slots; a shard holds its OWNED rows only (biased)
     uint64_t *pbuf_r = nullptr; // shard: (n, pcap_r) proposals for vertices owned elsewhere, exported every iteration (merge.hip)
     int pcap_r = 32;
