@@ -250,6 +250,10 @@ extern "C" int32_t nnd_shard_get_stats(nnd_shard_t s, nnd_stats *out) {
     return 0;
 }
 
+// the neighbour ids are all-gathered before a join only while the previous iteration changed at least this fraction of the
+// n * k list entries (see shard_build, step 2)
+#define NND_GATHER_MIN 0.02
+
 // compute sections: in LOCAL serial mode (tools/rank_critical_path.py) each is timed with the GPU to itself
 struct section_timer {
     nnd_shard_s *s;
@@ -450,31 +454,11 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
     static float sink;
     const double stop_at = (double)s->gp.delta * s->k * (double)s->n_total;
     bool stopped = false;
+    long long c_prev = 0;  // the global update count of the previous iteration
     for (int it = 0; it < s->gp.n_iters; it++) {
         float *ms_s = it < 64 ? &h->stats.ms_sample[it] : &sink, *ms_j = it < 64 ? &h->stats.ms_join[it] : &sink,
               *ms_m = it < 64 ? &h->stats.ms_merge[it] : &sink;
-        // (1) what the join needs of the rows owned elsewhere, all-gathered in place (this rank's slices are where the
-        //     others read from): the thresholds, 4 bytes per row (a stale threshold only admits extra proposals), and the
-        //     neighbour ids, 4 * ks bytes per row -- with them a proposal for a remote vertex passes the same membership
-        //     test as a local one (utils.py:489-492) BEFORE it competes for a proposal slot.  Without the ids most records
-        //     shipped were "already present"; being near their target by construction they also won the hashed slots from
-        //     the genuine candidates (recall at 8 ranks x 10 M points: 0.969 against 0.980 on one GPU).
-        if (G > 1) {
-            size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
-            for (int r = 0; r < G; r++) {
-                soff[r] = (size_t)s->lo;
-                scnt[r] = (size_t)n_own;
-                roff[r] = (size_t)s->bounds[r];
-                rcnt[r] = (size_t)(s->bounds[r + 1] - s->bounds[r]);
-            }
-            void *sb[2] = {h->th, h->knn_e}, *rb[2] = {h->th, h->knn_e};
-            const int eb[2] = {4, 4 * s->ks};
-            const int64_t b0 = c->bytes_sent;
-            S_COMM(comm_alltoallv(c, st, s->gather_lists ? 2 : 1, sb, rb, eb, soff, scnt, roff, rcnt));
-            note_bytes(s, b0);
-            h->lists_replicated = s->gather_lists;
-        }
-        // (2) sampling, first half: own new edges; offers to targets owned elsewhere become records
+        // (1) sampling, first half: own new edges; offers to targets owned elsewhere become records
         {
             section_timer sec(s);
             const int ts = t_begin(h);
@@ -489,12 +473,39 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
             harvest(it - 1);
             long long ctot = 0;
             for (int r = 0; r < G; r++) ctot += matrix[(size_t)r * nv + G];
+            c_prev = ctot;
             if (it - 1 < 64) s->info.c[it - 1] = ctot;
             if (it - 1 < 64) h->stats.updates[it - 1] = matrix[(size_t)me * nv + G];
             if ((double)ctot <= stop_at) {
                 stopped = true;
                 break;  // what sample_begin queued is harmless: reverse-offer slots are re-armed by the next build's reset
             }
+        }
+        // (2) what the join needs of the rows owned elsewhere, all-gathered in place (this rank's slices are where the
+        //     others read from): the thresholds, 4 bytes per row (a stale threshold only admits extra proposals), and the
+        //     neighbour ids, 4 * ks bytes per row -- with them a proposal for a remote vertex passes the same membership
+        //     test as a local one (utils.py:489-492) BEFORE it competes for a proposal slot.  Without the ids most records
+        //     shipped were "already present"; being near their target by construction they also won the hashed slots from
+        //     the genuine candidates (recall at 8 ranks x 10 M points: 0.969 against 0.980 on one GPU).
+        //     STALE ids are a safe filter too: an id that has left the row since was evicted by k closer ones (it cannot
+        //     come back), an id that has entered since only lets a junk record through to the owner's own test.  So once
+        //     an iteration changes under NND_GATHER_MIN of the entries (known here: the count wait above) the ids are not
+        //     gathered again -- 4 * ks of the 4 + 4 * ks bytes per row, in the iterations where few rows changed.
+        if (G > 1) {
+            const bool ids_now = s->gather_lists && (it == 0 || (double)c_prev >= NND_GATHER_MIN * (double)s->k * (double)s->n_total);
+            size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
+            for (int r = 0; r < G; r++) {
+                soff[r] = (size_t)s->lo;
+                scnt[r] = (size_t)n_own;
+                roff[r] = (size_t)s->bounds[r];
+                rcnt[r] = (size_t)(s->bounds[r + 1] - s->bounds[r]);
+            }
+            void *sb[2] = {h->th, h->knn_e}, *rb[2] = {h->th, h->knn_e};
+            const int eb[2] = {4, 4 * s->ks};
+            const int64_t b0 = c->bytes_sent;
+            S_COMM(comm_alltoallv(c, st, ids_now ? 2 : 1, sb, rb, eb, soff, scnt, roff, rcnt));
+            note_bytes(s, b0);
+            h->lists_replicated = s->gather_lists;
         }
         s->info.dropped_offers += matrix[(size_t)me * nv + G + 1];
         int64_t n_in = 0, n_sent = 0;
@@ -568,6 +579,9 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         sec.end();
     }
     S_HIP(hipStreamSynchronize(st));
+    // LOCAL: the ranks' streams wait on each other's events; nobody returns (and tears its stream / events down) while a
+    // peer's stream may still hold such a wait.  After this barrier every rank's stream has drained.
+    if (c->kind == NND_COMM_LOCAL && G > 1) S_COMM(comm_barrier(c));
     s->info.ms_klist_exchange = 0.0f;
     if (G > 1 && s->gp.n_trees > 0) (void)hipEventElapsedTime(&s->info.ms_klist_exchange, e0, e1);
     s->info.bytes_sent = c->bytes_sent;
