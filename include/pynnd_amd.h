@@ -191,10 +191,10 @@ int32_t nnd_pairwise_gram(nnd_handle_t h, const int32_t *rows_a, int32_t na, con
  * [lo_r, hi_r) of the k-lists; the point set is replicated once (all-gather over xGMI: candidate vectors never travel
  * again); the forest is split by tree (rank r builds its share of the trees over all points and seeds every row from
  * them; partial k-list rows go to their owners and are merged there); per NN-descent iteration
- *   (1) threshold all-gather, 4 bytes per row; (2) reverse-offer all-to-all-v of 12-byte records (the cross-process form
- *   of the ownership test utils.py:266-273); (3) local sampling + join of the owned vertices; (4) proposal
- *   all-to-all-v, owner-side merge (utils.py:721-731); the update counts of all ranks (stop rule, pynndescent_.py:317)
- *   ride on the record-count exchange.
+ *   (1) all-gather of the thresholds, 4 bytes per row, and -- while the lists still change much -- of the neighbour ids;
+ *   (2) reverse-offer all-to-all-v of 8-byte records (the cross-process form of the ownership test utils.py:266-273);
+ *   (3) local sampling + join of the owned vertices; (4) proposal all-to-all-v of 12-byte records, owner-side merge
+ *   (utils.py:721-731); the update counts of all ranks (stop rule, pynndescent_.py:317) ride on the record-count exchange.
  * The whole per-rank build runs inside the library (csrc/shard.hip) on one HIP stream; the exchanges are issued from
  * the C side on that stream -- ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd (RCCL) -- so kernels and collectives
  * need no host synchronisation between them; the host waits twice per iteration, for the record counts.

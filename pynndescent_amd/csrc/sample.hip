@@ -431,7 +431,7 @@ int nnd_launch_sample(nnd_ctx *ctx) {
 
 // ------------------------------------------------------------------------------------------------
 // Row-sharded build (exchange X2): a reverse offer (v -> u) whose target u is owned by another
-// rank is not applied here -- it becomes a 12-byte record (u | class << 31, priority << 32 | v) in the region of
+// rank is not applied here -- it becomes an 8-byte record (u | class << 31, v) in the region of
 // u's owner, the host ships the regions (all-to-all-v over RCCL), and the owner folds what it receives into its slot
 // banks with the same atomicMin as a local offer.  This is the cross-process form of the ownership test of
 // new_build_candidates (utils.py:266-273): every rank scans only ITS rows instead of all n * k edges.
@@ -444,7 +444,7 @@ int nnd_launch_sample(nnd_ctx *ctx) {
 __global__ __launch_bounds__(256) void k_offer_export(const uint32_t *__restrict__ knn_e, int64_t row_lo, int64_t row_hi, int k, int ks,
                                                       uint32_t it_seed, const int64_t *__restrict__ bounds, int n_ranks,
                                                       int64_t own_lo, int64_t own_hi, int64_t cap, long long *__restrict__ cursors,
-                                                      int32_t *__restrict__ targets, uint64_t *__restrict__ keys,
+                                                      int32_t *__restrict__ targets, uint32_t *__restrict__ sources,
                                                       long long *__restrict__ dropped) {
     __shared__ int cnt[64];
     __shared__ long long base[64];
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_offer_export(const uint32_t *__restrict
         if (at < cap) {
             const int64_t idx = (int64_t)dest[it] * cap + at;
             targets[idx] = (int32_t)(u | (cls << 31));
-            keys[idx] = ((uint64_t)nnd_hash3(it_seed, (uint32_t)g, u) << 32) | (uint64_t)(uint32_t)g;
+            sources[idx] = (uint32_t)g;
         } else {
             n_drop++;  // cannot happen with cap = owned rows * k
         }
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void k_offer_export(const uint32_t *__restrict
     if (n_drop) atomicAdd((unsigned long long *)dropped, (unsigned long long)n_drop);
 }
 
-__global__ void k_offer_import(const int32_t *__restrict__ targets, const uint64_t *__restrict__ keys, int64_t count, uint32_t want_cls,
+__global__ void k_offer_import(const int32_t *__restrict__ targets, const uint32_t *__restrict__ sources, int64_t count, uint32_t want_cls,
                                uint32_t it_seed, uint32_t *__restrict__ rbuf, int rcap, uint8_t *__restrict__ active,
                                int64_t own_lo, int64_t own_hi) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -511,13 +511,13 @@ __global__ void k_offer_import(const int32_t *__restrict__ targets, const uint64
     if (cls != want_cls || (int64_t)u < own_lo || (int64_t)u >= own_hi) return;
     if (cls == 1u) active[u] = 1;
     else if (!active[u]) return;  // no new candidate reaches u: its old list is never read
-    const uint32_t v = (uint32_t)keys[i];  // the source; the priority is a function of (source, target)
+    const uint32_t v = sources[i];  // the priority is a function of (source, target): it does not travel
     const uint32_t slot = nnd_hash2(it_seed ^ 0x68E31DA4u, v) & (uint32_t)(rcap - 1);
     atomicMin(&rbuf[((int64_t)u * 2 + cls) * rcap + slot], nnd_offer_prio(it_seed, v, u));
 }
 
 // first half of a sharded sampling pass: local new edges, and the records for targets owned elsewhere (both classes)
-int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, long long *counts_dev) {
+int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint32_t *sources_dev, long long *counts_dev) {
     if (ctx->n_ranks < 1 || !ctx->shard_bounds) { ctx->set_error("nnd_sample_begin: call nnd_set_shard_bounds first"); return 1; }
     const uint32_t it_seed = sample_seed(ctx);
     NND_HIP_CHECK(hipMemsetAsync(ctx->active + ctx->slim_row0(), 0, (size_t)ctx->slim_rows(), ctx->stream));
@@ -531,7 +531,7 @@ int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uin
         if (grid > 0)
             hipLaunchKernelGGL(k_offer_export, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->knn_e, ctx->own_lo, ctx->own_hi, ctx->k,
                                ctx->ks, it_seed, ctx->shard_bounds, ctx->n_ranks, ctx->own_lo, ctx->own_hi, cap, ctx->shard_cursors,
-                               targets_dev, keys_dev, ctx->shard_cursors + 64);
+                               targets_dev, sources_dev, ctx->shard_cursors + 64);
     }
     NND_HIP_CHECK(hipGetLastError());
     NND_HIP_CHECK(hipMemcpyAsync(counts_dev, ctx->shard_cursors, sizeof(long long) * (size_t)ctx->n_ranks, hipMemcpyDeviceToDevice, ctx->stream));
@@ -540,18 +540,18 @@ int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uin
 
 // second half: received records (new class first: they decide which vertices are active), local old edges, received
 // old-class records, then the per-vertex selection
-int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uint64_t *keys_dev, int64_t count) {
+int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uint32_t *sources_dev, int64_t count) {
     const uint32_t it_seed = sample_seed(ctx);
     const unsigned grid = (unsigned)((count + 255) / 256);
     if (count > 0) {
         ctx->rbuf_clean = false;
-        hipLaunchKernelGGL(k_offer_import, dim3(grid), dim3(256), 0, ctx->stream, targets_dev, keys_dev, count, 1u, it_seed, ctx->rbuf,
+        hipLaunchKernelGGL(k_offer_import, dim3(grid), dim3(256), 0, ctx->stream, targets_dev, sources_dev, count, 1u, it_seed, ctx->rbuf,
                            ctx->rcap, ctx->active, ctx->own_lo, ctx->own_hi);
     }
     if (!ctx->all_new) {
         launch_reverse_pass(ctx, 1, it_seed);
         if (count > 0)
-            hipLaunchKernelGGL(k_offer_import, dim3(grid), dim3(256), 0, ctx->stream, targets_dev, keys_dev, count, 0u, it_seed, ctx->rbuf,
+            hipLaunchKernelGGL(k_offer_import, dim3(grid), dim3(256), 0, ctx->stream, targets_dev, sources_dev, count, 0u, it_seed, ctx->rbuf,
                                ctx->rcap, ctx->active, ctx->own_lo, ctx->own_hi);
     }
     ctx->all_new = false;

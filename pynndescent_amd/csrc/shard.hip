@@ -31,7 +31,8 @@ struct nnd_shard_s {
     uint32_t *recv_e = nullptr;                  // (world - 1 sources) x (n_own, ks) partial k-list rows
     float *recv_d = nullptr;
     int32_t *off_t = nullptr, *prop_t = nullptr;  // record regions, one per destination rank
-    uint64_t *off_k = nullptr, *prop_k = nullptr;
+    uint32_t *off_k = nullptr;   // reverse-offer records: the source vertex (the target and class are in off_t)
+    uint64_t *prop_k = nullptr;  // proposal records: distance bits << 32 | candidate
     int64_t cap_o = 0, cap_p = 0;
     int32_t *in_t = nullptr;                     // received records (grow-only)
     uint64_t *in_k = nullptr;
@@ -212,7 +213,7 @@ extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, 
             ok = ok && hipMalloc((void **)&s->recv_d, sizeof(float) * rows) == hipSuccess;
         }
         ok = ok && hipMalloc((void **)&s->off_t, sizeof(int32_t) * (size_t)G * s->cap_o) == hipSuccess;
-        ok = ok && hipMalloc((void **)&s->off_k, sizeof(uint64_t) * (size_t)G * s->cap_o) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s->off_k, sizeof(uint32_t) * (size_t)G * s->cap_o) == hipSuccess;
         ok = ok && hipMalloc((void **)&s->prop_t, sizeof(int32_t) * (size_t)G * s->cap_p) == hipSuccess;
         ok = ok && hipMalloc((void **)&s->prop_k, sizeof(uint64_t) * (size_t)G * s->cap_p) == hipSuccess;
         s->in_cap = n_own * s->k + 1024;  // a typical iteration receives about as many offers as it sends; grows on demand
@@ -252,7 +253,7 @@ extern "C" int32_t nnd_shard_get_stats(nnd_shard_t s, nnd_stats *out) {
 
 // the neighbour ids are all-gathered before a join only while the previous iteration changed at least this fraction of the
 // n * k list entries (see shard_build, step 2)
-#define NND_GATHER_MIN 0.02
+#define NND_GATHER_MIN 0.05
 
 // compute sections: in LOCAL serial mode (tools/rank_critical_path.py) each is timed with the GPU to itself
 struct section_timer {
@@ -299,7 +300,7 @@ static int grow_inbox(nnd_shard_s *s, int64_t need) {
 // all-to-all-v of the per-destination record regions [d * cap, d * cap + cnt[d]) of (targets, keys); the records of the
 // OTHER ranks land back to back in (in_t, in_k).  matrix: the gathered count vectors (row = sender), nv words per row;
 // caps[r]: region capacity of sender r (a cursor beyond it means records that were not written: dropped / deferred).
-static int exchange_records(nnd_shard_s *s, int32_t *reg_t, uint64_t *reg_k, const int64_t *caps, const long long *matrix, int nv,
+static int exchange_records(nnd_shard_s *s, int32_t *reg_t, void *reg_k, int key_bytes, const int64_t *caps, const long long *matrix, int nv,
                             int64_t *n_in_out, int64_t *n_sent_out) {
     const int G = s->world, me = s->rank;
     size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
@@ -318,7 +319,7 @@ static int exchange_records(nnd_shard_s *s, int32_t *reg_t, uint64_t *reg_k, con
     }
     if (grow_inbox(s, n_in)) return 1;
     void *sb[2] = {reg_t, reg_k}, *rb[2] = {s->in_t, s->in_k};
-    const int eb[2] = {4, 8};
+    const int eb[2] = {4, key_bytes};  // the inbox's second array is sized for 8-byte keys; 4-byte ones lie packed at its front
     S_COMM(comm_alltoallv(s->comm, s->h->stream, 2, sb, rb, eb, soff, scnt, roff, rcnt));
     *n_in_out = n_in;
     *n_sent_out = n_sent;
@@ -511,14 +512,14 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         int64_t n_in = 0, n_sent = 0;
         if (G > 1) {
             const int64_t b0 = c->bytes_sent;
-            if (exchange_records(s, s->off_t, s->off_k, caps_o, matrix.data(), nv, &n_in, &n_sent)) return 1;
+            if (exchange_records(s, s->off_t, s->off_k, 4, caps_o, matrix.data(), nv, &n_in, &n_sent)) return 1;
             note_bytes(s, b0);
         }
         if (it < 64) s->info.offer_records[it] = n_sent;
         {
             section_timer sec(s);
             const int ts = t_begin(h);
-            S_CTX(nnd_launch_sample_finish(h, s->in_t, s->in_k, n_in));
+            S_CTX(nnd_launch_sample_finish(h, s->in_t, (const uint32_t *)s->in_k, n_in));
             t_end(h, ts, ms_s, true);
             // (3) local join of the owned vertices
             S_CTX(nnd_zero_counters(h));
@@ -539,7 +540,7 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
             // a region holds the rows that fit entirely: cursor minus what was deferred behind it may exceed cap only by
             // deferred rows, whose slots inside the region are marked invalid (target -1) -- ship min(cursor, cap)
             const int64_t b0 = c->bytes_sent;
-            if (exchange_records(s, s->prop_t, s->prop_k, caps_p, matrix.data(), nv, &n_in, &n_sent)) return 1;
+            if (exchange_records(s, s->prop_t, s->prop_k, 8, caps_p, matrix.data(), nv, &n_in, &n_sent)) return 1;
             note_bytes(s, b0);
             if (it < 64) s->info.proposal_records[it] = n_sent;
         }

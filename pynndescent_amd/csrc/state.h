@@ -182,8 +182,8 @@ int nnd_launch_leaf_init_array(nnd_ctx *ctx, const int32_t *leaf_host, int64_t n
 int nnd_launch_random_init(nnd_ctx *ctx);
 int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float *dist_dev, int width);
 int nnd_launch_sample(nnd_ctx *ctx);
-int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, long long *counts_dev);
-int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uint64_t *keys_dev, int64_t count);
+int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint32_t *sources_dev, long long *counts_dev);
+int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uint32_t *sources_dev, int64_t count);
 int nnd_launch_proposal_export_regions(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, long long *counts_dev);
 int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end);
 int nnd_launch_merge(nnd_ctx *ctx);
