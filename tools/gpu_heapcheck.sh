@@ -2,6 +2,7 @@
 # crash hunt: repeat the multi-rank tests, native backtrace on abort (tools/dbg/abrt_bt.c)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+[ -f tools/dbg/abrt_bt.so ] || gcc -O1 -g -shared -fPIC -o tools/dbg/abrt_bt.so tools/dbg/abrt_bt.c
 N=${1:-16}
 fails=0
 for i in $(seq 1 $N); do
