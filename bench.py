@@ -154,7 +154,7 @@ def host_inclusive(_capi, x_host, k, n_trees, leaf_size, n_iters, rng_state, tre
                     % (x_host.nbytes >> 20, (idx.nbytes + dist.nbytes) >> 20, reps)}
 
 
-def class_api(x_host, k, n_trees, device, reps=2):
+def class_api(x_host, k, n_trees, device, reps=3):
     """SURVEY.md section 8d's metric, literally: n / wall(NNDescent(x, ...) -> neighbor_graph arrays on the host), warm."""
     import pynndescent_amd
 

@@ -103,11 +103,18 @@ const char *nnd_last_error(nnd_handle_t h);
 /* Create a builder on params->device and allocate its HBM state (k-lists,
  * candidate lists, proposal buffers).  Fails if the device is not gfx950. */
 int32_t nnd_create(nnd_handle_t *out, const nnd_params *params);
-/* Returns at once: the handle's HBM is released by a background thread (every hipFree synchronises the device: ~9 ms for
- * the state of a 1 M-point build).  nnd_release_pending() waits until everything destroyed so far has been released;
- * an nnd_create that runs out of memory does that itself and retries. */
+/* nnd_destroy PARKS one plain handle instead of releasing it (every hipFree synchronises the device: ~9 ms for the state
+ * of a 1 M-point build, and as much again for the next hipMalloc): an nnd_create of the same geometry re-arms it.  A
+ * create of another geometry, an allocation that fails, or nnd_release_pending() releases the parked handle's HBM. */
 int32_t nnd_destroy(nnd_handle_t h);
 int32_t nnd_release_pending(void);
+
+/* Host-side helpers for the result arrays (NNDescent.neighbor_graph returns a COPY of the ids and the corrected
+ * distances, pynndescent_.py:2145-2158): a fresh 60 MB destination costs ~15 k first-touch page faults, which a
+ * single-threaded numpy copy / sqrt pays one after the other (18 + 14 ms at 1 M x 15).  These split the range over a few
+ * host threads.  nnd_host_sqrt_f32 is IEEE sqrtf per element: bit-identical to numpy.sqrt on float32. */
+int32_t nnd_host_copy(void *dst, const void *src, int64_t bytes);
+int32_t nnd_host_sqrt_f32(float *dst, const float *src, int64_t count);
 
 /* Point set, float32 C-contiguous (n, dim) -- NNDescent._raw_data (pynndescent_.py:1054-1057).
  * Host variant copies H2D; device variant BORROWS the pointer (it must outlive the handle's

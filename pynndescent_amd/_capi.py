@@ -140,6 +140,8 @@ _SIGNATURES = [
     ("nnd_set_data_device", C.c_int32, [_H, C.c_void_p]),
     ("nnd_data_nonfinite", C.c_int32, [_H, C.POINTER(C.c_int32)]),
     ("nnd_release_pending", C.c_int32, []),
+    ("nnd_host_copy", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("nnd_host_sqrt_f32", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
     ("nnd_make_forest", C.c_int32, [_H]),
     ("nnd_leaf_array_shape", C.c_int32, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     ("nnd_get_leaf_array", C.c_int32, [_H, C.c_void_p]),
@@ -486,3 +488,23 @@ class Searcher:
             self.close()
         except Exception:
             pass
+
+
+def host_copy(a):
+    """``a.copy()`` for a C-contiguous array, the pages of the fresh destination touched by several host threads."""
+    if not a.flags.c_contiguous or a.nbytes < (4 << 20):
+        return a.copy()
+    out = np.empty_like(a)
+    if load_library().nnd_host_copy(_ptr(out), _ptr(a), a.nbytes) != 0:
+        raise NNDError(load_library().nnd_last_global_error().decode())
+    return out
+
+
+def host_sqrt(a):
+    """``numpy.sqrt(a)`` for a C-contiguous float32 array (IEEE sqrtf per element: the same bits), several host threads."""
+    if a.dtype != np.float32 or not a.flags.c_contiguous or a.nbytes < (4 << 20):
+        return np.sqrt(a)
+    out = np.empty_like(a)
+    if load_library().nnd_host_sqrt_f32(_ptr(out), _ptr(a), a.size) != 0:
+        raise NNDError(load_library().nnd_last_global_error().decode())
+    return out

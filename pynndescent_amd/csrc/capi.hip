@@ -676,6 +676,37 @@ static int d2h_parallel(nnd_ctx *ctx, void *dst, const void *src, size_t bytes, 
     return 0;
 }
 
+// ---- host-side helpers of the drop-in class (include/pynnd_amd.h): first-touch-bound array operations over a few threads
+template <typename F>
+static void host_parallel(size_t bytes, size_t unit, F fn) {  // fn(offset_units, count_units); pieces are multiples of a page
+    const size_t total = bytes / unit;
+    int parts = bytes >= ((size_t)4 << 20) ? 8 : 1;
+    const unsigned hc = std::thread::hardware_concurrency();
+    if (hc && (unsigned)parts > hc) parts = (int)hc;
+    const size_t per = ((total + parts - 1) / parts + (4096 / unit) - 1) / (4096 / unit) * (4096 / unit);
+    std::vector<std::thread> th;
+    for (int t = 1; t < parts; t++) {
+        const size_t o = (size_t)t * per;
+        if (o >= total) break;
+        const size_t c = total - o < per ? total - o : per;
+        th.emplace_back([=] { fn(o, c); });
+    }
+    fn(0, total < per ? total : per);
+    for (auto &t : th) t.join();
+}
+extern "C" int32_t nnd_host_copy(void *dst, const void *src, int64_t bytes) {
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) { gerr("nnd_host_copy: bad arguments"); return 1; }
+    host_parallel((size_t)bytes, 1, [=](size_t o, size_t c) { memcpy((char *)dst + o, (const char *)src + o, c); });
+    return 0;
+}
+extern "C" int32_t nnd_host_sqrt_f32(float *dst, const float *src, int64_t count) {
+    if (count < 0 || (count > 0 && (!dst || !src))) { gerr("nnd_host_sqrt_f32: bad arguments"); return 1; }
+    host_parallel((size_t)count * sizeof(float), sizeof(float), [=](size_t o, size_t c) {
+        for (size_t i = o; i < o + c; i++) dst[i] = sqrtf(src[i]);
+    });
+    return 0;
+}
+
 // grow-only device buffers for the finished graph of the host-buffer entry points (no hipMalloc / hipFree per call)
 static int out_buffers(nnd_ctx *ctx, size_t cnt) {
     if (cnt <= ctx->out_cap) return 0;

@@ -52,7 +52,8 @@ def correct_alternative_cosine(d):
     return 1.0 - np.power(2.0, -np.asarray(d, dtype=np.float64))
 
 
-_DISTANCE_CORRECTIONS = {"euclidean": np.sqrt, "l2": np.sqrt, "cosine": correct_alternative_cosine}
+# (numpy.sqrt; large float32 arrays go through the library's threaded sqrtf -- the same bits, the fresh pages touched in parallel)
+_DISTANCE_CORRECTIONS = {"euclidean": _capi.host_sqrt, "l2": _capi.host_sqrt, "cosine": correct_alternative_cosine}
 
 
 class _DeviceForestSentinel:
@@ -301,7 +302,7 @@ class NNDescent:
         if self.compressed and not hasattr(self, "_neighbor_graph"):
             warn("Compressed indexes do not have neighbor graph information.")
             return None
-        return (self._neighbor_graph[0].copy(), self._distance_correction(self._neighbor_graph[1]))
+        return (_capi.host_copy(self._neighbor_graph[0]), self._distance_correction(self._neighbor_graph[1]))
 
     def build_search_graph(self):
         """The pruning pass of ``_init_search_graph`` (pynndescent_.py:1451-1611: diversify, reverse diversify,

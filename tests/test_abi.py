@@ -109,3 +109,23 @@ def test_from_graph_validates_and_mirrors_reference_attributes():
         NNDescent.from_graph(x, idx, dist, metric="no-such-metric")
     with pytest.raises(TypeError):
         NNDescent.from_graph(x, idx, dist, not_a_parameter=1)
+
+
+def test_host_copy_and_sqrt_helpers_match_numpy():
+    """nnd_host_copy / nnd_host_sqrt_f32 (the threaded first-touch helpers behind NNDescent.neighbor_graph): the same
+    bytes as ndarray.copy() and numpy.sqrt on float32; small or non-contiguous inputs take numpy's own path."""
+    import numpy as np
+
+    from pynndescent_amd import _capi
+
+    rs = np.random.RandomState(3)
+    a = rs.randint(-1, 1 << 30, size=(700_001, 3)).astype(np.int32)  # > 4 MB, not a multiple of the page size
+    b = _capi.host_copy(a)
+    assert b is not a and b.dtype == a.dtype and np.array_equal(a, b)
+    d = np.abs(rs.standard_normal((1_100_003,)).astype(np.float32)) * 1e3
+    d[:5] = [0.0, np.inf, 1e-45, 3.4e38, 2.0]
+    s = _capi.host_sqrt(d)
+    assert s.dtype == np.float32 and np.array_equal(s.view(np.uint32), np.sqrt(d).view(np.uint32))
+    small = np.arange(10, dtype=np.float32)
+    assert np.array_equal(_capi.host_sqrt(small), np.sqrt(small))
+    assert np.array_equal(_capi.host_copy(a[::2]), a[::2])
