@@ -68,6 +68,11 @@ struct nnd_scratch {
     }
 };
 
+std::recursive_mutex &nnd_lifecycle_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+
 static void free_all(nnd_ctx *ctx) {
     auto F = [](void *p) {
         if (p) (void)hipFree(p);
@@ -125,6 +130,7 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
         nnd_release_parked();  // a parked handle of another geometry: its memory is wanted now
     }
 
+    std::lock_guard<std::recursive_mutex> lifecycle(nnd_lifecycle_mutex());
     nnd_ctx *ctx = new nnd_ctx();
     ctx->p = *p;
     ctx->n = p->n;
@@ -294,6 +300,7 @@ static std::mutex g_park_mu;
 static nnd_ctx *g_parked = nullptr;
 
 static void destroy_now(nnd_ctx *ctx) {
+    std::lock_guard<std::recursive_mutex> lifecycle(nnd_lifecycle_mutex());
     (void)hipSetDevice(ctx->p.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_all(ctx);

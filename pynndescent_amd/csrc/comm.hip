@@ -7,6 +7,8 @@
 
 #include <string>
 
+std::recursive_mutex &nnd_lifecycle_mutex();  // capi.hip (state.h): creation / tear-down of handles is serialised
+
 static thread_local char g_cerr[512] = {0};
 static void cgerr(const char *fmt, ...) {
     va_list ap;
@@ -207,6 +209,7 @@ extern "C" int32_t nnd_comm_create_host(nnd_comm_t *out, int32_t world, int32_t 
 
 extern "C" int32_t nnd_comm_destroy(nnd_comm_t c) {
     if (!c) return 0;
+    std::lock_guard<std::recursive_mutex> lifecycle(nnd_lifecycle_mutex());
     (void)hipSetDevice(c->device);
     if (c->kind == NND_COMM_RCCL && c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->nccl);
     if (c->counts_all_dev) (void)hipFree(c->counts_all_dev);

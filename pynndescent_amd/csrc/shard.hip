@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void k_compact_owned(const int32_t *__restrict
 }
 
 static void shard_free(nnd_shard_s *s) {
+    std::lock_guard<std::recursive_mutex> lifecycle(nnd_lifecycle_mutex());
     if (s->h) (void)hipSetDevice(s->h->p.device);
     void *ptrs[] = {s->x_full, s->recv_e, s->recv_d, s->off_t, s->off_k, s->prop_t, s->prop_k, s->in_t, s->in_k, s->cvec, s->own_order, s->order_cursor};
     for (void *p : ptrs)
@@ -195,6 +196,7 @@ extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, 
     s->k = s->h->k;
     s->ks = s->h->ks;
     const int64_t n_own = s->hi - s->lo;
+    std::lock_guard<std::recursive_mutex> lifecycle(nnd_lifecycle_mutex());
     bool ok = hipSetDevice(p.device) == hipSuccess;
     ok = ok && hipMalloc((void **)&s->cvec, sizeof(long long) * (size_t)(G + 4)) == hipSuccess;
     if (ok && G > 1 && p.n_trees > 0) {

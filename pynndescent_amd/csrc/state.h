@@ -1,6 +1,7 @@
 // state.h -- host-side state of one builder handle (one GPU, one HIP stream) and the
 // launch entry points implemented by the kernel translation units.
 #pragma once
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -182,6 +183,11 @@ int nnd_launch_leaf_init_array(nnd_ctx *ctx, const int32_t *leaf_host, int64_t n
 int nnd_launch_random_init(nnd_ctx *ctx);
 int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float *dist_dev, int width);
 int nnd_launch_sample(nnd_ctx *ctx);
+// One process-wide lock around the creation and the tear-down of handles (hipMalloc / hipFree storms, stream and event
+// creation / destruction): ranks that live as threads of one process (LOCAL transport, nnd_build_multi) create and destroy
+// their state at the same moment; none of it is on a timed path, so it is simply serialised.
+std::recursive_mutex &nnd_lifecycle_mutex();
+
 int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint32_t *sources_dev, long long *counts_dev);
 int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uint32_t *sources_dev, int64_t count);
 int nnd_launch_proposal_export_regions(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint64_t *keys_dev, long long *counts_dev);
