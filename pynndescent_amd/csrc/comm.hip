@@ -49,7 +49,8 @@ static const rccl_api *load_rccl(std::string &why) {
         lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!lib) {
-        why = std::string("librccl.so could not be opened: ") + (dlerror() ? dlerror() : "not found");
+        const char *de = dlerror();  // (a second call would return NULL: the message is consumed)
+        why = std::string("librccl.so could not be opened: ") + (de ? de : "not found");
         return nullptr;
     }
 #define RCCL_SYM(field, name)                                                  \
