@@ -109,3 +109,35 @@ def test_thread_comm_matches_the_contract():
         assert [t.tolist() for t in g] == [[0], [1, 1], [2, 2, 2]]
         assert [t.tolist() for t in a] == [[src * 10 + r] * ((src + r) % 2) for src in range(3)]
         assert s == 6
+
+
+def test_global_params_follow_the_reference_draw_order():
+    """The sharded build's parameters (identical on every rank) use the RandomState draw order of the class
+    (pynndescent_.py:1105-1113: rng_state, search_rng_state, then make_forest's per-tree states, rp_trees.py:2850) and the
+    reference's derived defaults as the oracle restates them (leaf size, max_candidates, n_iters)."""
+    from oracle import oracle as O
+
+    p = sharded._global_params(123456, 64, "cosine", 20, 6, None, None, None, 0.001, 77, 200, 0)
+    rng_state, _, tree_states = O.draw_rng_states(77, 6)
+    assert [p.rng_state[i] for i in range(3)] == [int(v) for v in rng_state]
+    assert [p.tree_rng[i] for i in range(3)] == [int(v) for v in tree_states[0]]
+    assert p.n == 123456 and p.dim == 64 and p.n_neighbors == 20 and p.n_trees == 6
+    assert p.leaf_size == O.default_leaf_size(20) and p.max_candidates == 20
+    assert p.n_iters == O.default_n_iters(123456) and abs(p.delta - 0.001) < 1e-9
+
+
+def test_bench_load_points_formats(tmp_path):
+    """bench.py --data: .npy and TEXMEX .fvecs (int32 d, then d floats, per row) give the same float32 (n, d) array."""
+    import bench
+
+    x = np.random.RandomState(0).standard_normal((37, 12)).astype(np.float32)
+    np.save(tmp_path / "pts.npy", x.astype(np.float64))  # any dtype on disk: converted
+    rows = np.empty((37, 13), np.int32)
+    rows[:, 0] = 12
+    rows[:, 1:] = x.view(np.int32)
+    rows.tofile(tmp_path / "pts.fvecs")
+    a = bench.load_points(str(tmp_path / "pts.npy"))
+    b = bench.load_points(str(tmp_path / "pts.fvecs"))
+    assert a.dtype == b.dtype == np.float32 and a.flags.c_contiguous and b.flags.c_contiguous
+    np.testing.assert_array_equal(a, x)
+    np.testing.assert_array_equal(b, x)
