@@ -76,6 +76,10 @@ typedef struct nnd_params {
 /* test hook: candidate selection by the one-wave-per-vertex kernel where the two-vertices-per-wave kernel would run
  * (tests/test_gpu_kernels.py proves the two produce identical lists) */
 #define NND_FLAG_TEST_SELECT_WAVE 4
+/* test hook (row-sharded build): proposal regions of ONE record per destination row instead of 32, so that the deferral
+ * path (records that do not fit stay in the sender's table and travel with the next iteration's) is exercised at test
+ * sizes (tests/test_gpu_sharded.py) */
+#define NND_FLAG_TEST_SMALL_REGIONS 8
 
 /* Run-time statistics for measurement (bench.py roofline). */
 typedef struct nnd_stats {

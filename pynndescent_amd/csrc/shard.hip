@@ -208,6 +208,7 @@ extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, 
         // iteration (what does not fit stays and travels next time: counted in nnd_shard_info.deferred)
         s->cap_o = n_own * s->k > 0 ? n_own * s->k : 1;
         s->cap_p = s->max_range * 32 > 64 ? s->max_range * 32 : 64;
+        if (params->flags & NND_FLAG_TEST_SMALL_REGIONS) s->cap_p = s->max_range > 64 ? s->max_range : 64;  // test hook: forces deferrals
         ok = ok && hipMalloc((void **)&s->x_full, sizeof(float) * (size_t)s->n_total * params->dim) == hipSuccess;
         if (params->n_trees > 0) {
             const size_t rows = (size_t)(G - 1) * (size_t)(n_own > 0 ? n_own : 1) * s->ks;

@@ -348,7 +348,7 @@ class ShardedBuilder:
     """Persistent state of one rank (HBM allocations survive across builds; bench.py times ``build``)."""
 
     def __init__(self, comm, shard_sizes, dim, metric="euclidean", n_neighbors=15, n_trees=8, leaf_size=None,
-                 max_candidates=None, n_iters=None, delta=0.001, seed=0, max_rptree_depth=200, device_index=None):
+                 max_candidates=None, n_iters=None, delta=0.001, seed=0, max_rptree_depth=200, device_index=None, flags=0):
         self.lib = _capi.load_library()
         self.comm = comm
         sizes = np.ascontiguousarray([int(v) for v in shard_sizes], np.int64)
@@ -362,6 +362,7 @@ class ShardedBuilder:
         self.dev = torch.device("cuda", device_index)
         self.params = _global_params(self.n_total, dim, metric, n_neighbors, n_trees, leaf_size, max_candidates, n_iters, delta,
                                      seed, max_rptree_depth, device_index)
+        self.params.flags = int(flags)
         self._h = _capi._H()
         if self.lib.nnd_shard_create(C.byref(self._h), C.byref(self.params), comm._h, _capi._ptr(sizes)) != 0:
             raise _capi.NNDError(self.lib.nnd_shard_last_error(None).decode())

@@ -14,7 +14,7 @@ from tests.util_data import clustered
 pytestmark = pytest.mark.gpu
 
 
-def _run_local(x_dev, world, metric, k, n_trees, seed, serial=False):
+def _run_local(x_dev, world, metric, k, n_trees, seed, serial=False, flags=0):
     """x_dev: torch float32 (n, d) on cuda:0.  Returns (idx, dist) as device tensors in global row order + per-rank infos."""
     n = x_dev.shape[0]
     ranges = sharded.shard_ranges(n, world)
@@ -30,7 +30,7 @@ def _run_local(x_dev, world, metric, k, n_trees, seed, serial=False):
         try:
             torch.cuda.set_device(0)
             lo, hi = ranges[r]
-            sb = sharded.ShardedBuilder(grp[r], sizes, x_dev.shape[1], metric, k, n_trees, seed=seed, device_index=0)
+            sb = sharded.ShardedBuilder(grp[r], sizes, x_dev.shape[1], metric, k, n_trees, seed=seed, device_index=0, flags=flags)
             idx, dist, info = sb.build(x_dev[lo:hi].contiguous())
             out[r] = (idx.clone(), dist.clone(), info)
         except Exception as e:  # pragma: no cover
@@ -80,6 +80,33 @@ def test_sharded_matches_single_gpu_and_oracle(world, metric):
         assert all(i["bytes_sent"] > 0 for i in infos)
     else:
         assert infos[0]["exchanged_records"] == [0] * infos[0]["iters"]
+
+
+def test_proposal_regions_defer_what_does_not_fit():
+    """Regions of ONE proposal record per destination row (NND_FLAG_TEST_SMALL_REGIONS; the product uses 32): most of the
+    first iterations' records do not fit, stay in the sender's table and travel later.  Nothing may be lost silently (the
+    deferrals are counted), the graph stays valid, and the recall stays within 1 % of the build with full-size regions
+    (late proposals are as valid as fresh ones; the stop rule sees fewer updates per iteration, so it is not identical)."""
+    x = clustered(40_000, 32, 8, 200, seed=17)
+    xd = torch.from_numpy(x).cuda()
+    k = 15
+    idx_s, dist_s, infos_s = _run_local(xd, 3, "euclidean", k, n_trees=4, seed=5, flags=_capi.NND_FLAG_TEST_SMALL_REGIONS)
+    idx_f, _, infos_f = _run_local(xd, 3, "euclidean", k, n_trees=4, seed=5)
+    assert sum(sum(i["deferred"]) for i in infos_s) > 0, "the small regions did not overflow: the test does not test anything"
+    assert all(sum(i["deferred"]) == 0 for i in infos_f)
+    assert all(i["dropped_offers"] == 0 for i in infos_s)
+    idx = idx_s.cpu().numpy()
+    assert (idx >= 0).all()
+    for row in idx[::97]:
+        assert len(np.unique(row)) == k
+    rows = np.arange(0, 40_000, 10)
+    ti, _ = O.brute_force_knn(x, 10, "euclidean", rows=rows, kind="fast")
+    r_s, r_f = O.recall(ti, idx[rows]), O.recall(ti, idx_f.cpu().numpy()[rows])
+    print("recall@10 with 1-record regions %.4f (deferred per rank %s, iterations %d), full regions %.4f (iterations %d)" % (
+        r_s, [sum(i["deferred"]) for i in infos_s], infos_s[0]["iters"], r_f, infos_f[0]["iters"]))
+    assert r_s >= r_f - 0.01
+    truth = ((x[rows, None, :].astype(np.float64) - x[idx[rows]].astype(np.float64)) ** 2).sum(-1)
+    np.testing.assert_allclose(dist_s.cpu().numpy()[rows], truth, rtol=1e-5, atol=1e-6)
 
 
 def test_build_multi_and_class_api_two_ranks_on_one_gpu():
