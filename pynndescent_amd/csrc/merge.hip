@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void k_proposal_export_regions(uint64_t *__res
                 }
                 n_run++;
             }
-            const int r = n_run - 1 < MAXRUN ? n_run - 1 : MAXRUN - 1;  // (more runs than slots: ranks of < 11 rows; the whole wave defers below)
+            const int r = n_run - 1 < MAXRUN ? n_run - 1 : MAXRUN - 1;  // (more runs than slots: ranks of < 11 rows; per-row reservations below)
             off[i] = run_tot[r];
             run_tot[r] += c;
         }
@@ -454,9 +454,45 @@ __global__ __launch_bounds__(256) void k_proposal_export_regions(uint64_t *__res
     __syncthreads();
     if (!m) return;
     long long n_deferred = 0;
-    if (!simple) {  // degenerate geometry (ranks of a few rows): the whole wave defers -- nothing is lost, see above
+    if (!simple) {  // degenerate geometry (ranks of < 11 rows: more than MAXRUN destinations in one wave): every row
+                    // reserves its records with a global atomic of its own -- slow, and only ever a handful of rows
 #pragma unroll
-        for (int st = 0; st < STEPS; st++) n_deferred += __popcll(bal[st]);
+        for (int st = 0; st < STEPS; st++) {
+            if (!((m >> (RPS * st)) & SM)) continue;  // wave-uniform
+            const int i = RPS * st + grp;
+            const bool dirty = (m >> i) & 1u;
+            const int64_t v = base + i;
+            const unsigned gb = (unsigned)(bal[st] >> (PR * grp)) & GM;  // live slots of my row
+            const int c = __popc(gb);
+            const bool on = key[st] != NND_EMPTY_KEY;
+            const int pre = __popc(gb & (sl ? (0xFFFFFFFFu >> (32 - sl)) : 0u));
+            int d = 0, at_lo = 0, at_hi = 0;
+            if (dirty && c > 0) {  // uniform inside a row's lanes
+                d = nnd_owner_of(bounds, n_ranks, v);
+                if (sl == 0) {
+                    const unsigned long long a = atomicAdd((unsigned long long *)&cursors[d], (unsigned long long)c);
+                    at_lo = (int)(uint32_t)a;
+                    at_hi = (int)(uint32_t)(a >> 32);
+                }
+            }
+            at_lo = __shfl(at_lo, grp * PR, 64);
+            at_hi = __shfl(at_hi, grp * PR, 64);
+            const long long at = (long long)(((unsigned long long)(uint32_t)at_hi << 32) | (uint32_t)at_lo);
+            if (!dirty) continue;
+            if (c > 0 && at + c > cap) {
+                if (sl == 0) n_deferred += c;
+                if (on && at + pre < cap) targets[(int64_t)d * cap + at + pre] = -1;
+            } else {
+                if (on) {
+                    const int64_t idx = (int64_t)d * cap + at + pre;
+                    keys[idx] = key[st];
+                    targets[idx] = (int32_t)v;
+                }
+                pbuf_r[v * PR + sl] = NND_EMPTY_KEY;
+                if (sl == 0) pdirty[v] = 0;
+            }
+        }
+        n_deferred = nnd_wave_sum_i32((int)n_deferred);
         if (lane == 0 && n_deferred) atomicAdd((unsigned long long *)deferred, (unsigned long long)n_deferred);
         return;
     }

@@ -170,7 +170,7 @@ extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, 
     s->rank = rank;
     int64_t acc = 0;
     for (int r = 0; r < G; r++) {
-        if (shard_sizes[r] < 0) { delete s; return fail("negative shard size"); }
+        if (shard_sizes[r] < 1) { delete s; return fail("every rank must own at least one row (shard sizes >= 1)"); }
         s->bounds[r] = acc;
         acc += shard_sizes[r];
         if (shard_sizes[r] > s->max_range) s->max_range = shard_sizes[r];
@@ -615,7 +615,8 @@ extern "C" int32_t nnd_build_multi(const nnd_params *params, const float *x, int
     };
     if (!params || !x || !out_idx || !out_dist) return fail("nnd_build_multi: null argument");
     if (n_devices < 1 || n_devices > NND_MAX_RANKS) return fail("nnd_build_multi: n_devices must be in 1..64");
-    const int G = n_devices;
+    if (params->n < 1) return fail("nnd_build_multi: need n >= 1");
+    const int G = (int64_t)n_devices <= params->n ? n_devices : (int)params->n;  // every rank owns at least one row: the first n devices build a set of n < n_devices points
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("nnd_build_multi: no HIP device visible (this library has no CPU path)");
     std::vector<int32_t> dev(G);

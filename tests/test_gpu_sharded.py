@@ -109,6 +109,24 @@ def test_proposal_regions_defer_what_does_not_fit():
     np.testing.assert_allclose(dist_s.cpu().numpy()[rows], truth, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,world,k", [(70, 8, 5), (5, 8, 3), (1000, 8, 15), (300, 3, 30), (9, 2, 15)])
+def test_degenerate_shard_geometries(n, world, k):
+    """Ranks of a handful of rows (a wave of the proposal export then spans more than three destinations: per-row
+    reservations instead of the per-workgroup ones), fewer points than ranks (the first n devices build), n < k."""
+    x = np.random.RandomState(n).standard_normal((n, 7)).astype(np.float32)
+    idx, dist, st, info = sharded.build_multi(x, world, devices=[0] * world, metric="euclidean", n_neighbors=k, n_trees=3, seed=1)
+    assert idx.shape == dist.shape == (n, k) and info["world"] == min(world, n)
+    filled = idx >= 0
+    assert (filled.sum(1) == min(k, n)).all() and np.all(np.isinf(dist[~filled]))
+    for row, f in zip(idx, filled):
+        assert len(set(row[f].tolist())) == int(f.sum())
+    kk = min(k, n, 10)
+    ti, _ = O.brute_force_knn(x, kk, "euclidean")
+    rec = O.recall(ti, idx)
+    print("n=%d world=%d k=%d: recall@%d %.3f, deferred %d, iterations %d" % (n, world, k, kk, rec, sum(info["deferred"]), info["iters"]))
+    assert rec >= 0.99 and info["dropped_offers"] == 0
+
+
 def test_build_multi_and_class_api_two_ranks_on_one_gpu():
     """The drop-in boundary reaches the sharded build: nnd_build_multi (host arrays in / out, one host thread per rank
     inside the library) and NNDescent(..., n_devices=2).  devices=[0, 0]: both ranks on this box's one GPU."""
