@@ -2,7 +2,7 @@
 usage: PYNND_AMD_LIB=... python tools/ab_stage.py [n_trees ...]"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import bench
 from pynndescent_amd import _capi
 

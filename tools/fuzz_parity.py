@@ -4,7 +4,6 @@ tree -- whether a tiny leaf injects random edges -- moves recall by 0.1-0.3 on c
 parity), plus structural invariants.  usage: fuzz_parity.py [N] [seed]"""
 import os
 import sys
-import warnings
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
