@@ -80,6 +80,9 @@ typedef struct nnd_params {
  * path (records that do not fit stay in the sender's table and travel with the next iteration's) is exercised at test
  * sizes (tests/test_gpu_sharded.py) */
 #define NND_FLAG_TEST_SMALL_REGIONS 8
+/* test hook: the rp forest's routing pass as ONE walk per (tree, point) through global memory (the round-2 kernel)
+ * instead of the two coherent passes; the two assign every point to the same cell (tests/test_gpu_kernels.py) */
+#define NND_FLAG_TEST_ROUTE_PLAIN 16
 
 /* Run-time statistics for measurement (bench.py roofline). */
 typedef struct nnd_stats {

@@ -17,6 +17,7 @@ NND_FLAG_NO_GRAPH = 1  # auxiliary handle: no k-lists / candidate / proposal tab
 NND_FLAG_NO_PREP = 2   # ... and no prepared copy of the rows (hub tree only)
 NND_FLAG_TEST_SELECT_WAVE = 4  # test hook: the one-wave-per-vertex selection kernel
 NND_FLAG_TEST_SMALL_REGIONS = 8  # test hook (sharded build): tiny proposal regions, so that records are deferred
+NND_FLAG_TEST_ROUTE_PLAIN = 16  # test hook: the forest's routing pass as one walk per (tree, point) through global memory
 
 
 class NNDParams(C.Structure):

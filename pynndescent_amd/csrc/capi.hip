@@ -83,7 +83,7 @@ static void free_all(nnd_ctx *ctx) {
     F(ctx->pdirty); F(ctx->out_idx); F(ctx->out_dist);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
-    F(ctx->xs); F(ctx->xsh); F(ctx->nr2s); F(ctx->node_hf); F(ctx->node_hh); F(ctx->node_child); F(ctx->node_pack); F(ctx->s_leaf_depth);
+    F(ctx->xs); F(ctx->xsh); F(ctx->nr2s); F(ctx->node_hf); F(ctx->node_hh); F(ctx->node_child); F(ctx->node_pack); F(ctx->node_hfc); F(ctx->route_roots); F(ctx->route_ws); F(ctx->s_leaf_depth);
     F(ctx->cell_count); F(ctx->cell_start); F(ctx->cell_depth); F(ctx->small_list);
     F(ctx->hyper); F(ctx->hyper_h); F(ctx->leaf_start); F(ctx->leaf_len); F(ctx->wl_start); F(ctx->wl_len); F(ctx->colsum_partial); F(ctx->counters_sum);
     if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; }
@@ -186,7 +186,7 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
             if ((rc = dalloc(ctx, &ctx->nrm, n))) break;
             if (p->n_trees > 0 && (rc = dalloc(ctx, &ctx->xh, n * ctx->dp))) break;
             if (p->n_trees > 0 && (rc = dalloc(ctx, &ctx->nr2, n))) break;
-            if ((rc = dalloc(ctx, &ctx->mean, (size_t)ctx->dp))) break;
+            if ((rc = dalloc(ctx, &ctx->mean, (size_t)ctx->dp + 4))) break;  // + scale of the screening copies, 1 / scale^2, sampled max
         }
         if (graph) {
             if ((rc = dalloc(ctx, &ctx->knn_e, n * ctx->ks))) break;
@@ -252,6 +252,8 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
                 if ((rc = dalloc(ctx, &ctx->node_hh, (size_t)ctx->node_cap * ctx->dp))) break;
                 if ((rc = dalloc(ctx, &ctx->node_child, (size_t)ctx->node_cap * 2))) break;
                 if ((rc = dalloc(ctx, &ctx->node_pack, (size_t)ctx->node_cap * (2 * ctx->dp + 16)))) break;
+                if ((rc = dalloc(ctx, &ctx->node_hfc, (size_t)ctx->node_cap * (ctx->dp + 4)))) break;
+                if ((rc = dalloc(ctx, &ctx->route_roots, (size_t)4096))) break;
                 if ((rc = dalloc(ctx, &ctx->s_leaf_depth, (size_t)Ps))) break;
                 if ((rc = dalloc(ctx, &ctx->cell_count, (size_t)ctx->cell_cap))) break;
                 if ((rc = dalloc(ctx, &ctx->cell_start, (size_t)ctx->cell_cap))) break;
@@ -643,15 +645,20 @@ extern "C" int32_t nnd_finalize_device(nnd_handle_t ctx, int32_t *out_idx_dev, f
 // (~9 GB/s: 13 ms for the 114 MB graph of a 1 M-point index).  Here: two pinned 32 MB buffers (allocated once per
 // process), the DMA of chunk c + 1 in flight while chunk c is copied out of its buffer by four host threads.
 static std::mutex g_stage_mu;
-static char *g_stage[2] = {nullptr, nullptr};
-static hipEvent_t g_stage_ev[2] = {nullptr, nullptr};
+// per DEVICE: an event can only be recorded on a stream of the device it was created on (a build on device 1 after one on
+// device 0 in the same process), and the pinned buffers are registered with the device that was current at allocation
+static char *g_stage_dev[64][2] = {{nullptr, nullptr}};
+static hipEvent_t g_stage_ev_dev[64][2] = {{nullptr, nullptr}};
 static int d2h_parallel(nnd_ctx *ctx, void *dst, const void *src, size_t bytes, int parts) {
     constexpr size_t STAGE = (size_t)32 << 20;
-    if (bytes < (size_t)(4u << 20)) {
+    if (bytes < (size_t)(4u << 20) || ctx->p.device < 0 || ctx->p.device >= 64) {
         API_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
         return 0;
     }
     std::lock_guard<std::mutex> lk(g_stage_mu);
+    char **g_stage = g_stage_dev[ctx->p.device];
+    hipEvent_t *g_stage_ev = g_stage_ev_dev[ctx->p.device];
+    API_HIP(hipSetDevice(ctx->p.device));
     for (int b = 0; b < 2; b++) {
         if (!g_stage[b]) API_HIP(hipHostMalloc((void **)&g_stage[b], STAGE, hipHostMallocDefault));
         if (!g_stage_ev[b]) API_HIP(hipEventCreateWithFlags(&g_stage_ev[b], hipEventDisableTiming));

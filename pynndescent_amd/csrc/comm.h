@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <vector>
@@ -42,6 +43,8 @@ struct nnd_local_group {
     int arrived = 0;
     uint64_t generation = 0;
     bool aborted = false;
+    std::atomic<int> abort_flag{0};  // the same, readable without the lock (polled by the host waits of every rank)
+    int64_t timeout_ms = 120000;     // a rank that waits longer than this for its peers gives up (and aborts the group)
     int refs = 0;
     nnd_local_post posts[NND_MAX_RANKS];
     // serial mode (critical-path measurement on one GPU): only one rank's compute section runs at a time
@@ -54,6 +57,17 @@ struct nnd_local_group {
 struct nnd_comm_s {
     int kind = 0, world = 1, rank = 0, device = 0;
     char err[512] = {0};
+    // failure handling: every host wait of a rank (comm_wait) polls `abort_flag` -- shared by the ranks of one process
+    // (LOCAL group, the threads of nnd_build_multi); NULL for one process per GPU -- and gives up after timeout_ms.  A rank
+    // that gives up under RCCL calls ncclCommAbort on its communicator(s): the collectives queued on its streams are
+    // cancelled, the streams drain, and the build returns an error instead of blocking in a collective for ever.
+    std::atomic<int> *abort_flag = nullptr;
+    int64_t timeout_ms = 120000;
+    bool dead = false;                  // aborted: no further collective may be issued, ncclCommDestroy is skipped
+    // second channel (own RCCL communicator / LOCAL group and own stream): bulk transfers that overlap the build's stream
+    nnd_comm_s *aux = nullptr;
+    hipStream_t aux_stream = nullptr;
+    bool is_aux = false;
     // RCCL
     void *nccl = nullptr;               // ncclComm_t
     long long *counts_all_dev = nullptr;  // (world, nv) gathered count vectors
@@ -85,6 +99,14 @@ int comm_gather_counts(nnd_comm_s *c, hipStream_t stream, const long long *count
 int comm_alltoallv(nnd_comm_s *c, hipStream_t stream, int narr, void *const *send_bases, void *const *recv_bases, const int *elem_bytes,
                    const size_t *soff, const size_t *scnt, const size_t *roff, const size_t *rcnt);
 int comm_barrier(nnd_comm_s *c);
+// Wait until everything queued on `stream` has run: an event polled by the host, with the abort flag and the timeout of
+// the communicator checked while polling (hipStreamSynchronize would block for ever behind a collective whose peer died).
+// Returns 0, or 1 with c->err set (and the communicator aborted).
+int comm_wait(nnd_comm_s *c, hipStream_t stream, const char *what);
+// a peer (or this rank) failed: mark the shared flag, wake LOCAL waiters, cancel RCCL work (ncclCommAbort)
+void comm_fail(nnd_comm_s *c);
+// 1 when a rank of this process has raised the shared abort flag
+static inline int comm_aborted(const nnd_comm_s *c) { return c->dead || (c->abort_flag && c->abort_flag->load(std::memory_order_relaxed)); }
 // LOCAL serial mode: bracket a compute section (no-ops otherwise)
 void comm_compute_begin(nnd_comm_s *c);
 void comm_compute_end(nnd_comm_s *c, hipStream_t stream);

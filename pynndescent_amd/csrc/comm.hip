@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: librccl is opened with dlopen (load_rccl)
 #include <string.h>
 
+#include <chrono>
 #include <string>
 
 std::recursive_mutex &nnd_lifecycle_mutex();  // capi.hip (state.h): creation / tear-down of handles is serialised
@@ -24,6 +25,8 @@ struct rccl_api {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -59,6 +62,8 @@ static const rccl_api *load_rccl(std::string &why) {
     RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
     RCCL_SYM(CommInitRank, "ncclCommInitRank")
     RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    RCCL_SYM(CommAbort, "ncclCommAbort")
+    RCCL_SYM(GetVersion, "ncclGetVersion")
     RCCL_SYM(GroupStart, "ncclGroupStart")
     RCCL_SYM(GroupEnd, "ncclGroupEnd")
     RCCL_SYM(Send, "ncclSend")
@@ -106,12 +111,7 @@ extern "C" int32_t nnd_comm_unique_id(void *id_out) {
     return 0;
 }
 
-extern "C" int32_t nnd_comm_create_rccl(nnd_comm_t *out, const void *id_bytes, int32_t world, int32_t rank, int32_t device) {
-    if (!out || !id_bytes || world < 1 || world > NND_MAX_RANKS || rank < 0 || rank >= world) { cgerr("nnd_comm_create_rccl: bad arguments"); return 1; }
-    *out = nullptr;
-    std::string why;
-    if (!load_rccl(why)) { cgerr("nnd_comm_create_rccl: %s", why.c_str()); return 1; }
-    if (hipSetDevice(device) != hipSuccess) { cgerr("nnd_comm_create_rccl: hipSetDevice(%d) failed", device); return 1; }
+static nnd_comm_s *make_rccl(const void *id_bytes, int32_t world, int32_t rank, int32_t device) {
     nnd_comm_s *c = new nnd_comm_s();
     c->kind = NND_COMM_RCCL;
     c->world = world;
@@ -120,16 +120,52 @@ extern "C" int32_t nnd_comm_create_rccl(nnd_comm_t *out, const void *id_bytes, i
     ncclUniqueId id;
     memcpy(&id, id_bytes, NCCL_UNIQUE_ID_BYTES);
     ncclComm_t comm = nullptr;
+    // (not under the lifecycle lock: ncclCommInitRank returns only when every rank of the world has called it)
     const ncclResult_t r = g_rccl.CommInitRank(&comm, world, id, rank);
     if (r != ncclSuccess || comm_common_init(c) ||
         hipMalloc((void **)&c->counts_all_dev, sizeof(long long) * (size_t)world * (NND_MAX_RANKS + 8)) != hipSuccess) {
         cgerr("nnd_comm_create_rccl: %s", r != ncclSuccess ? g_rccl.GetErrorString(r) : (c->err[0] ? c->err : "allocation failed"));
-        if (comm) (void)g_rccl.CommDestroy(comm);
+        if (comm) (void)g_rccl.CommAbort(comm);
+        if (c->counts_all_dev) (void)hipFree(c->counts_all_dev);
+        if (c->h_counts) (void)hipHostFree(c->h_counts);
+        if (c->ev) (void)hipEventDestroy(c->ev);
         delete c;
-        return 1;
+        return nullptr;
     }
     c->nccl = comm;
+    return c;
+}
+
+extern "C" int32_t nnd_comm_create_rccl(nnd_comm_t *out, const void *id_bytes, int32_t world, int32_t rank, int32_t device) {
+    if (!out || !id_bytes || world < 1 || world > NND_MAX_RANKS || rank < 0 || rank >= world) { cgerr("nnd_comm_create_rccl: bad arguments"); return 1; }
+    *out = nullptr;
+    std::string why;
+    if (!load_rccl(why)) { cgerr("nnd_comm_create_rccl: %s", why.c_str()); return 1; }
+    if (hipSetDevice(device) != hipSuccess) { cgerr("nnd_comm_create_rccl: hipSetDevice(%d) failed", device); return 1; }
+    nnd_comm_s *c = make_rccl(id_bytes, world, rank, device);
+    if (!c) return 1;
     *out = c;
+    return 0;
+}
+
+// A second channel for the bulk transfers that overlap the build (the point-set all-gather): its own RCCL communicator
+// (a second unique id, created like the first) and its own stream, so that its send / recv kernels neither queue behind
+// nor block the collectives of the build's stream.  Collective: every rank of the world calls it, or none.
+extern "C" int32_t nnd_comm_add_channel_rccl(nnd_comm_t c, const void *id_bytes) {
+    if (!c || !id_bytes || c->kind != NND_COMM_RCCL) { cgerr("nnd_comm_add_channel_rccl: not an RCCL communicator"); return 1; }
+    if (c->aux) return 0;
+    if (hipSetDevice(c->device) != hipSuccess) { cgerr("nnd_comm_add_channel_rccl: hipSetDevice(%d) failed", c->device); return 1; }
+    nnd_comm_s *a = make_rccl(id_bytes, c->world, c->rank, c->device);
+    if (!a) return 1;
+    a->is_aux = true;
+    a->abort_flag = c->abort_flag;
+    a->timeout_ms = c->timeout_ms;
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) {
+        cgerr("nnd_comm_add_channel_rccl: hipStreamCreate failed");
+        (void)nnd_comm_destroy(a);
+        return 1;
+    }
+    c->aux = a;
     return 0;
 }
 
@@ -144,36 +180,56 @@ int nnd_local_group::barrier() {
         cv.notify_all();
         return 0;
     }
-    cv.wait(lk, [&] { return generation != gen || aborted; });
+    const bool ok = cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return generation != gen || aborted; });
+    if (!ok) {  // a peer never arrived (it returned without telling anyone, or it is stuck): nobody waits for ever
+        aborted = true;
+        abort_flag.store(1);
+        cv.notify_all();
+    }
     return aborted ? 1 : 0;
 }
 void nnd_local_group::abort() {
     std::lock_guard<std::mutex> lk(mu);
     aborted = true;
+    abort_flag.store(1);
     cv.notify_all();
+}
+
+static nnd_comm_s *make_local(nnd_local_group *g, int world, int r, int device) {
+    nnd_comm_s *c = new nnd_comm_s();
+    c->kind = NND_COMM_LOCAL;
+    c->world = world;
+    c->rank = r;
+    c->device = device;
+    c->grp = g;
+    bool bad = hipSetDevice(c->device) != hipSuccess || comm_common_init(c);
+    if (!bad) bad = hipEventCreateWithFlags(&g->posts[r].ready, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&g->posts[r].done, hipEventDisableTiming) != hipSuccess;
+    g->posts[r].device = c->device;
+    if (bad) cgerr("nnd_comm_create_local: rank %d on device %d: %s", r, c->device, c->err[0] ? c->err : "event creation failed");
+    c->dead = bad;  // (reported by the caller; the object exists so that nnd_comm_destroy can release what was created)
+    return c;
 }
 
 extern "C" int32_t nnd_comm_create_local(nnd_comm_t *out, int32_t world, const int32_t *devices) {
     if (!out || world < 1 || world > NND_MAX_RANKS) { cgerr("nnd_comm_create_local: need 1 <= world <= %d", NND_MAX_RANKS); return 1; }
-    nnd_local_group *g = new nnd_local_group();
-    g->world = world;
-    g->refs = world;
+    // two groups: the build's channel and the second channel for overlapped bulk transfers (see nnd_comm_add_channel_rccl)
+    nnd_local_group *g = new nnd_local_group(), *ga = new nnd_local_group();
+    g->world = ga->world = world;
+    g->refs = ga->refs = world;
     for (int r = 0; r < world; r++) out[r] = nullptr;
     for (int r = 0; r < world; r++) {
-        nnd_comm_s *c = new nnd_comm_s();
-        c->kind = NND_COMM_LOCAL;
-        c->world = world;
-        c->rank = r;
-        c->device = devices ? devices[r] : 0;
-        c->grp = g;
+        const int device = devices ? devices[r] : 0;
+        nnd_comm_s *c = make_local(g, world, r, device);
+        nnd_comm_s *a = make_local(ga, world, r, device);
+        a->is_aux = true;
+        c->aux = a;
+        c->abort_flag = a->abort_flag = &g->abort_flag;  // one flag for both channels
         out[r] = c;
-        bool bad = hipSetDevice(c->device) != hipSuccess || comm_common_init(c);
-        if (!bad) bad = hipEventCreateWithFlags(&g->posts[r].ready, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&g->posts[r].done, hipEventDisableTiming) != hipSuccess;
-        g->posts[r].device = c->device;
+        bool bad = c->dead || a->dead;
+        if (!bad) bad = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess;
         if (bad) {
-            cgerr("nnd_comm_create_local: rank %d on device %d: %s", r, c->device, c->err[0] ? c->err : "event creation failed");
-            g->refs = r + 1;  // the communicators that exist: the last nnd_comm_destroy below releases the group
+            g->refs = ga->refs = r + 1;  // the communicators that exist: the last nnd_comm_destroy below releases the groups
             for (int q = 0; q <= r; q++) { (void)nnd_comm_destroy(out[q]); out[q] = nullptr; }
             return 1;
         }
@@ -210,9 +266,15 @@ extern "C" int32_t nnd_comm_create_host(nnd_comm_t *out, int32_t world, int32_t 
 
 extern "C" int32_t nnd_comm_destroy(nnd_comm_t c) {
     if (!c) return 0;
+    if (c->aux) {
+        (void)nnd_comm_destroy(c->aux);
+        c->aux = nullptr;
+    }
     std::lock_guard<std::recursive_mutex> lifecycle(nnd_lifecycle_mutex());
     (void)hipSetDevice(c->device);
-    if (c->kind == NND_COMM_RCCL && c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->nccl);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    // an aborted communicator was released by ncclCommAbort already
+    if (c->kind == NND_COMM_RCCL && c->nccl && !c->dead && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->nccl);
     if (c->counts_all_dev) (void)hipFree(c->counts_all_dev);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_send) (void)hipHostFree(c->h_send);
@@ -228,21 +290,80 @@ extern "C" int32_t nnd_comm_destroy(nnd_comm_t c) {
             std::lock_guard<std::mutex> lk(g->mu);
             last = --g->refs == 0;
         }
+        // the shared abort flag lives in the MAIN group: it goes last (the aux communicator of a rank is destroyed first)
         if (last) delete g;
     }
     delete c;
     return 0;
 }
 
-extern "C" int32_t nnd_comm_abort(nnd_comm_t c) {  // a rank failed: wake the others up instead of leaving them in a barrier
-    if (c && c->kind == NND_COMM_LOCAL && c->grp) c->grp->abort();
+// This rank gives up (its own failure, a peer's raised flag, or a timeout).  Idempotent.
+void comm_fail(nnd_comm_s *c) {
+    if (c->abort_flag) c->abort_flag->store(1);
+    for (nnd_comm_s *q : {c, c->aux}) {
+        if (!q) continue;
+        if (q->kind == NND_COMM_LOCAL && q->grp) q->grp->abort();
+        if (q->kind == NND_COMM_RCCL && q->nccl && !q->dead && g_rccl.CommAbort) {
+            (void)hipSetDevice(q->device);
+            (void)g_rccl.CommAbort((ncclComm_t)q->nccl);  // cancels the collectives queued on this rank's streams
+        }
+        q->dead = true;
+    }
+}
+
+extern "C" int32_t nnd_comm_abort(nnd_comm_t c) {  // a rank failed: wake the others up instead of leaving them in a collective
+    if (c) comm_fail(c);
     return 0;
 }
 
-static int spin_on(nnd_comm_s *c, hipStream_t stream) {
+extern "C" int32_t nnd_comm_set_timeout(nnd_comm_t c, int64_t timeout_ms) {
+    if (!c || timeout_ms < 1) { cgerr("nnd_comm_set_timeout: bad arguments"); return 1; }
+    for (nnd_comm_s *q : {c, c->aux}) {
+        if (!q) continue;
+        q->timeout_ms = timeout_ms;
+        if (q->kind == NND_COMM_LOCAL && q->grp) {
+            std::lock_guard<std::mutex> lk(q->grp->mu);
+            q->grp->timeout_ms = timeout_ms;
+        }
+    }
+    return 0;
+}
+
+// out[0] transport (NND_COMM_RCCL = 1, LOCAL = 2, HOST = 3), out[1] world, out[2] ncclGetVersion() (0 unless RCCL),
+// out[3] 1 when the second channel exists
+extern "C" int32_t nnd_comm_info(nnd_comm_t c, int32_t *out) {
+    if (!c || !out) { cgerr("nnd_comm_info: null argument"); return 1; }
+    out[0] = c->kind;
+    out[1] = c->world;
+    out[2] = 0;
+    if (c->kind == NND_COMM_RCCL && g_rccl.GetVersion) {
+        int v = 0;
+        if (g_rccl.GetVersion(&v) == ncclSuccess) out[2] = v;
+    }
+    out[3] = c->aux ? 1 : 0;
+    return 0;
+}
+
+int comm_wait(nnd_comm_s *c, hipStream_t stream, const char *what) {
+    if (c->dead) { c->set_error("%s: the communicator was aborted", what); return 1; }
     C_HIP(hipEventRecord(c->ev, stream));
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e;
+    unsigned spins = 0;
     while ((e = hipEventQuery(c->ev)) == hipErrorNotReady) {
+        if (comm_aborted(c)) {
+            comm_fail(c);
+            c->set_error("%s: another rank failed (rank %d of %d gave up waiting)", what, c->rank, c->world);
+            return 1;
+        }
+        if ((++spins & 0xFFu) == 0) {
+            const int64_t ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > c->timeout_ms) {
+                comm_fail(c);
+                c->set_error("%s: rank %d of %d timed out after %lld ms waiting for its peers", what, c->rank, c->world, (long long)ms);
+                return 1;
+            }
+        }
     }
     C_HIP(e);
     return 0;
@@ -268,13 +389,13 @@ int comm_gather_counts(nnd_comm_s *c, hipStream_t stream, const long long *count
         } else {
             C_HIP(hipMemcpyAsync(c->h_counts, counts_dev, sizeof(long long) * (size_t)nv, hipMemcpyDeviceToHost, stream));
         }
-        if (spin_on(c, stream)) return 1;
+        if (comm_wait(c, stream, "count exchange")) return 1;
         memcpy(matrix_host, c->h_counts, sizeof(long long) * (size_t)G * nv);
         return 0;
     }
     // LOCAL / HOST: every rank brings its own vector to the host first
     C_HIP(hipMemcpyAsync(c->h_counts, counts_dev, sizeof(long long) * (size_t)nv, hipMemcpyDeviceToHost, stream));
-    if (spin_on(c, stream)) return 1;
+    if (comm_wait(c, stream, "count exchange")) return 1;
     if (c->kind == NND_COMM_LOCAL) {
         nnd_local_group *g = c->grp;
         g->posts[c->rank].counts_host = c->h_counts;
@@ -298,6 +419,7 @@ int comm_gather_counts(nnd_comm_s *c, hipStream_t stream, const long long *count
 int comm_alltoallv(nnd_comm_s *c, hipStream_t stream, int narr, void *const *send_bases, void *const *recv_bases, const int *elem_bytes,
                    const size_t *soff, const size_t *scnt, const size_t *roff, const size_t *rcnt) {
     const int G = c->world, me = c->rank;
+    if (comm_aborted(c)) { comm_fail(c); c->set_error("exchange: another rank failed"); return 1; }
     for (int d = 0; d < G; d++)
         if (d != me)
             for (int a = 0; a < narr; a++) c->bytes_sent += (int64_t)scnt[d] * elem_bytes[a];
@@ -385,7 +507,9 @@ int comm_barrier(nnd_comm_s *c) {
     }
     if (c->kind == NND_COMM_HOST) {
         int64_t z[NND_MAX_RANKS] = {0};
-        if (c->fn(c->user, c->h_counts, z, z, c->h_counts, z, z) != 0) { c->set_error("host exchange callback failed (barrier)"); return 1; }
+        // send == recv == NULL is the transport's barrier (a data exchange in which some rank moves no byte is NOT one:
+        // with three or more ranks the others would be in point-to-point calls while that rank sits in a barrier)
+        if (c->fn(c->user, nullptr, z, z, nullptr, z, z) != 0) { c->set_error("host exchange callback failed (barrier)"); return 1; }
     }
     return 0;  // RCCL: the collectives order the ranks; nothing to do
 }
@@ -395,7 +519,7 @@ void comm_compute_begin(nnd_comm_s *c) {
 }
 void comm_compute_end(nnd_comm_s *c, hipStream_t stream) {
     if (c->kind == NND_COMM_LOCAL && c->grp->serial) {
-        (void)spin_on(c, stream);  // polled: a blocking wait wakes up ~1 ms late and would be charged to the section
+        (void)comm_wait(c, stream, "compute section");  // polled: a blocking wait wakes up ~1 ms late and would be charged to the section
         c->grp->gpu_token.unlock();
     }
 }

@@ -87,12 +87,20 @@ __device__ __forceinline__ uint64_t nnd_make_key(float d, uint32_t idx) {
 __device__ __forceinline__ float nnd_key_dist(uint64_t key) { return __uint_as_float((uint32_t)(key >> 32)); }
 __device__ __forceinline__ uint32_t nnd_key_idx(uint64_t key) { return (uint32_t)key & NND_IDX_MASK; }
 
-// round-to-nearest-even f32 -> bf16 (finite inputs)
-__device__ __forceinline__ uint16_t nnd_f32_to_bf16(float v) {
-    uint32_t u = __float_as_uint(v);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// Screening copies of rows and hyperplanes (rp forest): IEEE half precision of (value * scale), scale a power of two chosen
+// by the prep kernel so that the data sits well inside the half range (state.h nnd_ctx::mean[dp]).  11 significant bits:
+// the rounding error -- and with it the band of margins that need the exact f32 recheck -- is 8x smaller than with the
+// bf16 copies of rounds 1-3 (2.5 % of the margins fell inside that band, and a recheck is a dependent global fetch inside
+// a divergent branch: it is priced per wave).  Subnormal results are flushed to zero HERE, so that whatever the packed
+// dot-product instruction does with subnormal inputs cannot matter: the residual norms (|x - half(x)|, stored per row and
+// per hyperplane) are computed from the value actually stored and keep the band rigorous.  Overflow gives inf, an inf
+// residual, an infinite band: such a row is always rechecked exactly.
+__device__ __forceinline__ uint16_t nnd_f32_to_h16(float v, float scale) {
+    uint16_t b = __builtin_bit_cast(uint16_t, (_Float16)(v * scale));  // round to nearest even
+    if ((b & 0x7C00u) == 0) b &= 0x8000u;
+    return b;
 }
+__device__ __forceinline__ float nnd_h16_to_f32(uint16_t b, float inv_scale) { return (float)__builtin_bit_cast(_Float16, b) * inv_scale; }
 
 __device__ __forceinline__ float nnd_clamp_dist(float d) { return d > 0.0f ? d : 0.0f; }
 

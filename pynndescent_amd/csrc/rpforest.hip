@@ -64,27 +64,31 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
                                                     const int32_t *__restrict__ seg_start,
                                                     const int32_t *__restrict__ seg_len, int n_segs, int angular,
                                                     uint32_t seed, int depth, float *__restrict__ hyper, int hs,
-                                                    uint16_t *__restrict__ hyper_h) {
+                                                    uint16_t *__restrict__ hyper_h, uint32_t pos_bias, const float *__restrict__ scal) {
+    // pos_bias: the sharded build splits the tree tops by tree over the ranks; a rank's trees sit at positions
+    // [0, T_local * n) here but draw what they would draw at their GLOBAL positions -- the forest does not depend on
+    // the number of ranks
     int lane = nnd_lane();
     int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (s >= n_segs) return;
     int a = seg_start[s], len = seg_len[s];
-    uint32_t li = nnd_hash3(seed, (uint32_t)a, (uint32_t)(2 * depth)) % (uint32_t)len;
-    uint32_t ri = nnd_hash3(seed, (uint32_t)a, (uint32_t)(2 * depth + 1)) % (uint32_t)len;
+    uint32_t li = nnd_hash3(seed, (uint32_t)a + pos_bias, (uint32_t)(2 * depth)) % (uint32_t)len;
+    uint32_t ri = nnd_hash3(seed, (uint32_t)a + pos_bias, (uint32_t)(2 * depth + 1)) % (uint32_t)len;
     if (ri == li) ri = (ri + 1) % (uint32_t)len;  // rp_trees.py:353-354
     const float *xl = xp + (int64_t)perm[a + li] * dp;
     const float *xr = xp + (int64_t)perm[a + ri] * dp;
     float *h = hyper + (int64_t)s * hs;
-    uint16_t *hb = hyper_h + (int64_t)s * dp;  // bf16 copy read by the screening pass of the margin kernels
+    uint16_t *hb = hyper_h + (int64_t)s * dp;  // half-precision copy read by the screening pass of the margin kernels
+    const float hsc = scal[0], hinv = 1.0f / hsc;
     float acc = 0.0f, sq = 0.0f, res = 0.0f;
     for (int j = lane; j < dp; j += 64) {
         float l = xl[j], r = xr[j];
         float v = l - r;
         h[j] = v;
         if (!angular) {
-            const uint16_t b = nnd_f32_to_bf16(v);
+            const uint16_t b = nnd_f32_to_h16(v, hsc);
             hb[j] = b;
-            const float e = v - __uint_as_float((uint32_t)b << 16);
+            const float e = v - nnd_h16_to_f32(b, hinv);
             res += e * e;
         }
         acc += angular ? v * v : v * (l + r);
@@ -98,9 +102,9 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
         for (int j = lane; j < dp; j += 64) {
             const float v = h[j] * inv;
             h[j] = v;
-            const uint16_t b = nnd_f32_to_bf16(v);
+            const uint16_t b = nnd_f32_to_h16(v, hsc);
             hb[j] = b;
-            const float e = v - __uint_as_float((uint32_t)b << 16);
+            const float e = v - nnd_h16_to_f32(b, hinv);
             res += e * e;
         }
         res = nnd_wave_sum_f32(res);
@@ -138,17 +142,22 @@ __global__ __launch_bounds__(256) void k_hyperplane(const float *__restrict__ xp
 // elementwise worst case assumes, and r is ~0.4 * 2^-8 of the norm on average, so the band is ~2.6x narrower than
 // RP_BAND |h||x| and as rigorous.  RP_ACC covers the f32 accumulation-order differences of both sums.
 #define RP_ACC 3e-5f
+#ifdef NND_RP_ALWAYS_EXACT  // debugging: every margin takes the exact f32 path
+#define RP_IN_BAND(m, band) ((band) >= 0.0f || (m) == (m))
+#else
+#define RP_IN_BAND(m, band) (!(fabsf(m) > (band)))
+#endif
 __device__ __forceinline__ float rp_band(float xnorm, float rx, float hnorm, float rh) {
     return rx * hnorm + (xnorm + rx) * rh + RP_ACC * hnorm * xnorm + RP_EPS;  // + RP_EPS: outside the band the exact margin is no coin flip either
 }
 // non-negative f32 -> bf16 bits, rounded UP (packed bounds stay bounds)
 __device__ __forceinline__ uint32_t rp_bf16_up(float v) { return (__float_as_uint(v) + 0xFFFFu) >> 16; }
-typedef __attribute__((ext_vector_type(2))) __bf16 rp_bf16x2;
-__device__ __forceinline__ float rp_dot8(uint4 q, uint4 p, float acc) {
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2, q.x), __builtin_bit_cast(rp_bf16x2, p.x), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2, q.y), __builtin_bit_cast(rp_bf16x2, p.y), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2, q.z), __builtin_bit_cast(rp_bf16x2, p.z), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rp_bf16x2, q.w), __builtin_bit_cast(rp_bf16x2, p.w), acc, false);
+typedef _Float16 rp_h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rp_dot8(uint4 q, uint4 p, float acc) {  // 8 half x half products, f32 accumulation (v_dot2_f32_f16)
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(rp_h16x2, q.x), __builtin_bit_cast(rp_h16x2, p.x), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(rp_h16x2, q.y), __builtin_bit_cast(rp_h16x2, p.y), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(rp_h16x2, q.z), __builtin_bit_cast(rp_h16x2, p.z), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(rp_h16x2, q.w), __builtin_bit_cast(rp_h16x2, p.w), acc, false);
     return acc;
 }
 // sum over the 4 lanes of an aligned quad (DPP quad permutes; every lane ends with the same value)
@@ -174,7 +183,7 @@ __device__ __forceinline__ uint8_t rp_side(float m, float band, const float *__r
 #ifdef NND_RP_NORECHECK  // timing experiments only
     if (band < 0.0f) m = rp_exact_quad(xf_row, h, dp, sub) + off;
 #else
-    if (!(fabsf(m) > band)) m = rp_exact_quad(xf_row, h, dp, sub) + off;  // uniform inside the quad
+    if (RP_IN_BAND(m, band)) m = rp_exact_quad(xf_row, h, dp, sub) + off;  // uniform inside the quad
 #endif
     if (fabsf(m) < RP_EPS) return (uint8_t)(nnd_hash3(seed ^ 0x5bd1e995u, key, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
     return m > 0.0f ? 0 : 1;                                                                              // rp_trees.py:386-391
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, co
                                                 const int32_t *__restrict__ perm, const int32_t *__restrict__ pos_seg,
                                                 int64_t P, const float *__restrict__ hyper, int hs,
                                                 const uint16_t *__restrict__ hyper_h, uint32_t seed, int depth,
-                                                uint8_t *__restrict__ side) {
+                                                uint8_t *__restrict__ side, uint32_t pos_bias, const float *__restrict__ scal) {
     const int sub = threadIdx.x & 3;
     const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
     const int s = g < P ? pos_seg[g] : -1;
@@ -210,9 +219,9 @@ __global__ __launch_bounds__(256) void k_margin(const float *__restrict__ xp, co
         for (int j = 0; j < 4; j++)
             if (c + 4 * j < (dp >> 3)) acc = rp_dot8(q[j], p[j], acc);
     }
-    const float m = rp_quad_sum(acc) + off;
+    const float m = rp_quad_sum(acc) * scal[1] + off;
     const float band = rp_band(metric == 0 ? sqrtf(xn) : xn, rx, hnorm, rh);
-    const uint8_t sd = rp_side(m, band, xp + pt * dp, h, off, dp, sub, seed, (uint32_t)g, depth);
+    const uint8_t sd = rp_side(m, band, xp + pt * dp, h, off, dp, sub, seed, (uint32_t)g + pos_bias, depth);
     if (sub == 0) side[g] = sd;
 }
 
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ 
                                                       int n_trees, const int32_t *__restrict__ seg_pt,
                                                       const float *__restrict__ hyper, int hs,
                                                       const uint16_t *__restrict__ hyper_h, uint32_t seed, int depth,
-                                                      uint8_t *__restrict__ side_pt) {
+                                                      uint8_t *__restrict__ side_pt, uint32_t pos_bias, const float *__restrict__ scal) {
     const int sub = threadIdx.x & 3;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
     if (i >= n) return;  // whole quad
@@ -264,10 +273,10 @@ __global__ __launch_bounds__(256) void k_margin_fused(const float *__restrict__ 
             if (sg[u] < 0) continue;  // whole quad
             const float *h = hyper + (int64_t)sg[u] * hs;
             const float off = h[dp], hnorm = h[dp + 1], rh = h[dp + 2];
-            const float m = rp_quad_sum(acc[u]) + off;
+            const float m = rp_quad_sum(acc[u]) * scal[1] + off;
             const float band = rp_band(xnorm, rx, hnorm, rh);
             const int64_t slot = (int64_t)(t0 + u) * n + i;
-            const uint8_t sd = rp_side(m, band, xp + i * dp, h, off, dp, sub, seed, (uint32_t)slot, depth);
+            const uint8_t sd = rp_side(m, band, xp + i * dp, h, off, dp, sub, seed, (uint32_t)slot + pos_bias, depth);
             if (sub == 0) side_pt[slot] = sd;
         }
     }
@@ -605,6 +614,20 @@ struct rp_record {
     int *counter, *overflow;
     int min_len, max_len;  // this launch takes the segments with min_len <= len <= max_len (two launches share one work list)
 };
+// Which tree a segment belongs to (the per-tree salt of every hash): position / n plus tree_bias when every tree holds
+// n positions; the sharded build finishes cells of ALL trees in one position space of its own, tree t at positions
+// [tree_begin[t], tree_begin[t + 1]).
+struct rp_tree_map {
+    int tree_bias = 0;
+    const int32_t *tree_begin = nullptr;
+    int n_tree_begin = 0;
+};
+__device__ __forceinline__ uint32_t rp_tree_of(const rp_tree_map &tm, int64_t a, int64_t n) {
+    if (!tm.tree_begin) return (uint32_t)(a / n) + (uint32_t)tm.tree_bias;
+    int t = 0;
+    for (int q = 1; q < tm.n_tree_begin; q++) t = a >= tm.tree_begin[q] ? q : t;
+    return (uint32_t)t;
+}
 
 // NTHR threads per workgroup, CAP = most points of a segment whose ids live in LDS.  Small cells run with ONE WAVE per
 // cell (NTHR = 64, CAP = 512: ~6 KB of LDS, the barriers are single-wave): a node of a hundred points is a chain of
@@ -621,7 +644,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
                                                          uint8_t *__restrict__ side_g, int fin_max,
                                                          int32_t *__restrict__ fin_start, int32_t *__restrict__ fin_len,
                                                          int32_t *__restrict__ fin_depth, long long *__restrict__ fin_count,
-                                                         rp_record rec = rp_record{}) {
+                                                         rp_tree_map tm, const float *__restrict__ scal, rp_record rec = rp_record{}) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     const int s = blockIdx.x;
     if (s >= n_segs) return;
@@ -639,7 +662,8 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
     int32_t *wsum = stk + FIN_STACK * 4;           // FIN_WS: per-wave partial sums / scalars (FIN_STACK entries: see the push below)
     uint64_t *wkeys = (uint64_t *)(wsum + 8);      // 8 keys (16 words): per-wave top-2 of the pivot draw
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
-    const uint32_t seedt = seed ^ ((uint32_t)((int64_t)a / n) * 0x9E3779B9u);  // per tree
+    const uint32_t seedt = seed ^ (rp_tree_of(tm, a, n) * 0x9E3779B9u);  // per tree
+    const float hsc = scal[0], hinv = 1.0f / hsc, inv_s2 = scal[1];
     if (!BIG)
         for (int i = tid; i < len; i += NTHR) ids[i] = perm[a + i];
     if (tid == 0) {
@@ -741,9 +765,9 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
         float pres = 0.0f;  // |h - bf16(h)|^2: the hyperplane's share of the screening band (rp_band)
         for (int j = tid; j < dp; j += NTHR) {
             const float v = h[j];
-            const uint16_t b = nnd_f32_to_bf16(v);
+            const uint16_t b = nnd_f32_to_h16(v, hsc);
             hb[j] = b;
-            const float e = v - __uint_as_float((uint32_t)b << 16);
+            const float e = v - nnd_h16_to_f32(b, hinv);
             pres += e * e;
         }
         pres = nnd_wave_sum_f32(pres);
@@ -804,7 +828,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
             for (int u = 0; u < 2; u++) {
                 const int i = i0 + u * GQ + grp;
                 if (i >= l) continue;  // whole quad
-                const float m = rp_quad_sum(acc[u]) + off;
+                const float m = rp_quad_sum(acc[u]) * inv_s2 + off;
                 const float band = rp_band(metric == 0 ? sqrtf(xn[u]) : xn[u], rxv[u], hnorm, rhv);
                 const uint8_t side = rp_side(m, band, xp + pt[u] * dp, h, off, dp, sub, seedt, (uint32_t)pt[u], dep);
                 if (sub == 0) sd[i] = side;
@@ -940,40 +964,70 @@ __global__ void k_fill_leaf_array(const int32_t *__restrict__ perm, const int32_
 // coin flips for |margin| < eps), the point's cell is counted with one atomicAdd whose return value is its slot in
 // the cell, and k_place writes the permutation.  Cells are finished by k_finish_subtrees, which is order independent.
 __global__ void k_gather_sample(const float *__restrict__ xp, const uint16_t *__restrict__ xh, const float2 *__restrict__ nr,
-                                int dp, int64_t m, int64_t stride, uint32_t seed, float *__restrict__ xs,
+                                int dp, int64_t j_lo, int64_t j_hi, int64_t stride, uint32_t seed, float *__restrict__ xs,
                                 uint16_t *__restrict__ xsh, float2 *__restrict__ nrs) {
+    // sample members [j_lo, j_hi) (the sharded build gathers the members among a rank's own rows, then all-gathers)
     const int sub = threadIdx.x & 15;
-    const int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
-    if (j >= m) return;
+    const int64_t j = j_lo + (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    if (j >= j_hi) return;
     const int64_t i = j * stride + (int64_t)(nnd_hash2(seed ^ 0x7F4A7C15u, (uint32_t)j) % (uint32_t)stride);
     for (int c = sub; c < (dp >> 2); c += 16) ((float4 *)(xs + j * dp))[c] = ((const float4 *)(xp + i * dp))[c];
     for (int c = sub; c < (dp >> 3); c += 16) ((uint4 *)(xsh + j * dp))[c] = ((const uint4 *)(xh + i * dp))[c];
     if (sub == 0) nrs[j] = nr[i];
 }
 
-__device__ __forceinline__ uint32_t rp_pack_bf16(float a, float b) {
-    return (uint32_t)nnd_f32_to_bf16(a) | ((uint32_t)nnd_f32_to_bf16(b) << 16);
+__device__ __forceinline__ uint32_t rp_pack_h16(float a, float b, float scale) {
+    return (uint32_t)nnd_f32_to_h16(a, scale) | ((uint32_t)nnd_f32_to_h16(b, scale) << 16);
 }
+// explicit fused multiply-adds, in this order: both routing forms must round an exact margin the same way (left to the
+// compiler's contraction one kernel got v_pk_mul + v_add, the other v_pk_fma: one decision in 30 million differed)
 __device__ __forceinline__ float rp_dot4f(float4 a, float4 b, float acc) {
-    return acc + a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    acc = __builtin_fmaf(a.x, b.x, acc);
+    acc = __builtin_fmaf(a.y, b.y, acc);
+    acc = __builtin_fmaf(a.z, b.z, acc);
+    return __builtin_fmaf(a.w, b.w, acc);
 }
 
 // Recorded nodes are packed for the walk: [dp bf16 hyperplane | f32 offset | bf16 |h| : bf16 |h - bf16(h)| (both rounded
 // up) | child 0 | child 1], one record of 2 * dp + 16 bytes per node (a walk step touches ONE contiguous record instead
-// of three tables).
+// of three tables).  The table is COMPACTED on the way: the level-synchronous passes number their nodes upwards from 0
+// ([0, n_low)), the recording finisher downwards from the end of the table ([high_lo, node_cap)); record v' of the packed
+// table is node v' (v' < n_low) or node high_lo + (v' - n_low).  Children: a node -> its packed id + node_base (the
+// sharded build concatenates the tables of all ranks); a cell -> -2 - its GLOBAL cell number, looked up through
+// cell_gid (sharded build: cells are renumbered owner-major, rpforest.hip nnd_forest_tops_pack) or cell_base + its
+// number in position order.  hf_out (optional): the f32 hyperplanes (exact rechecks) compacted the same way.
+struct rp_pack_map {
+    int64_t n_low, high_lo;     // compaction (see above)
+    int node_base, cell_base;   // rebasing
+    const int32_t *cell_gid;    // (n_cells) local cell number -> global cell number, or nullptr
+};
 __global__ void k_pack_nodes(const uint16_t *__restrict__ node_hh, const float *__restrict__ node_hf, int hs,
-                             const int32_t *__restrict__ node_child, int dp, int64_t n_nodes, unsigned char *__restrict__ pack) {
+                             const int32_t *__restrict__ node_child, const int32_t *__restrict__ leafscan, int dp, int64_t n_packed,
+                             rp_pack_map mp, unsigned char *__restrict__ pack, float *__restrict__ hf_out) {
     const int sub = threadIdx.x & 15;
-    const int64_t v = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
-    if (v >= n_nodes) return;
+    const int64_t vp = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    if (vp >= n_packed) return;
+    const int64_t v = vp < mp.n_low ? vp : mp.high_lo + (vp - mp.n_low);
     const int rec = 2 * dp + 16;
-    uint4 *dst = (uint4 *)(pack + v * rec);
+    uint4 *dst = (uint4 *)(pack + vp * rec);
     const uint4 *src = (const uint4 *)(node_hh + v * dp);
     for (int c = sub; c < (dp >> 3); c += 16) dst[c] = src[c];
+    const float *h = node_hf + v * hs;
+    if (hf_out)
+        for (int c = sub; c < (hs >> 2); c += 16) ((float4 *)(hf_out + vp * hs))[c] = ((const float4 *)h)[c];
     if (sub == 0) {
-        const float *h = node_hf + v * hs;
-        dst[dp >> 3] = make_uint4(__float_as_uint(h[dp]), (rp_bf16_up(h[dp + 1]) << 16) | rp_bf16_up(h[dp + 2]),
-                                  (uint32_t)node_child[2 * v], (uint32_t)node_child[2 * v + 1]);
+        int ch[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = node_child[2 * v + q];
+            if (c >= 0) {
+                ch[q] = (int)((int64_t)c < mp.n_low ? c : c - (mp.high_lo - mp.n_low)) + mp.node_base;
+            } else {  // <= -2: a cell, encoded as -2 - its first sample position
+                const int lc = leafscan[-2 - c];
+                ch[q] = -2 - (mp.cell_gid ? mp.cell_gid[lc] : mp.cell_base + lc);
+            }
+        }
+        dst[dp >> 3] = make_uint4(__float_as_uint(h[dp]), (rp_bf16_up(h[dp + 1]) << 16) | rp_bf16_up(h[dp + 2]), (uint32_t)ch[0], (uint32_t)ch[1]);
     }
 }
 
@@ -985,12 +1039,12 @@ __global__ void k_pack_nodes(const uint16_t *__restrict__ node_hh, const float *
 template <int NC, int TB>
 __global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, const float2 *__restrict__ nr, int metric, int dp,
                                                int64_t n, int n_trees, const unsigned char *__restrict__ node_pack,
-                                               const float *__restrict__ node_hf, int hs,
-                                               const int32_t *__restrict__ leafscan, uint32_t seed,
+                                               const float *__restrict__ node_hf, int hs, uint32_t seed,
                                                int32_t *__restrict__ cell_count, int32_t *__restrict__ cell_of,
-                                               int32_t *__restrict__ rank_of, int n_top, int l_top) {
+                                               int32_t *__restrict__ rank_of, int n_top, int l_top, const float *__restrict__ scal) {
     extern __shared__ __attribute__((aligned(16))) unsigned char top_tab[];
     const int rec = 2 * dp + 16;
+    const float hsc = scal[0], inv_s2 = scal[1];
     {
         const uint4 *src = (const uint4 *)node_pack;
         uint4 *dst = (uint4 *)top_tab;
@@ -1015,8 +1069,8 @@ __global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, con
             }
 #pragma unroll
             for (int q = 0; q < NC; q++)
-                xq[q] = make_uint4(rp_pack_bf16(xa[q].x, xa[q].y), rp_pack_bf16(xa[q].z, xa[q].w), rp_pack_bf16(xb[q].x, xb[q].y),
-                                   rp_pack_bf16(xb[q].z, xb[q].w));
+                xq[q] = make_uint4(rp_pack_h16(xa[q].x, xa[q].y, hsc), rp_pack_h16(xa[q].z, xa[q].w, hsc), rp_pack_h16(xb[q].x, xb[q].y, hsc),
+                                   rp_pack_h16(xb[q].z, xb[q].w, hsc));
         }
         const float2 nrv = nr[i];
         const float xn = nrv.x, rx = nrv.y;
@@ -1068,9 +1122,9 @@ __global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, con
                     if (node[u] < 0) continue;  // whole quad
                     const float off = __uint_as_float(meta[u].x), hnorm = __uint_as_float(meta[u].y & 0xFFFF0000u),
                                 rh = __uint_as_float(meta[u].y << 16);
-                    float m = rp_quad_sum(acc[u]) + off;
+                    float m = rp_quad_sum(acc[u]) * inv_s2 + off;
                     const float band = rp_band(xnorm, rx, hnorm, rh);
-                    if (!(fabsf(m) > band)) {  // inside the bf16 error band: the exact f32 margin decides (quad-uniform)
+                    if (RP_IN_BAND(m, band)) {  // inside the screening error band: the exact f32 margin decides (quad-uniform)
                         const float4 *h4 = (const float4 *)(node_hf + (int64_t)node[u] * hs);
                         float e = 0.0f;
 #pragma unroll
@@ -1086,9 +1140,9 @@ __global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, con
                     if (fabsf(m) < RP_EPS) side = (int)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)slot, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
                     else side = m > 0.0f ? 0 : 1;                                                                             // rp_trees.py:386-391
                     const int nxt = (int)(side ? meta[u].w : meta[u].z);
-                    if (nxt <= -2) {  // reached a cell: first sample position -2 - nxt -> cell index
+                    if (nxt <= -2) {  // reached a cell (its number is baked into the record, k_pack_nodes)
                         if (sub == 0) {
-                            const int cell = leafscan[-2 - nxt];
+                            const int cell = -2 - nxt;
                             cell_of[slot] = cell;
                             rk[u] = atomicAdd(&cell_count[cell], 1);
                         }
@@ -1107,157 +1161,464 @@ __global__ __launch_bounds__(512) void k_route(const float *__restrict__ xp, con
     }
 }
 
-// One tree per XCD.  k_route above walks every tree from every workgroup, so each XCD's L2 (4 MB) has to hold the node
-// records of ALL trees (10 MB at 1 M points, 8 trees): the deep levels miss and come over the fabric -- 10 GB of
-// fetches per build, 20 x the rows themselves.  Here the workgroups of XCD x (workgroups are dealt round-robin, so
-// that is blockIdx.x & 7) walk only trees x, x + 8, ...: one tree's records (1.3 MB) stay in that XCD's L2, and the
-// first l_top levels of the tree -- ALL its nodes at those depths, whoever recorded them -- sit in LDS in heap order
-// (slot 1 = root, children of slot s at 2s and 2s + 1), so a walk reads LDS while depth < l_top and L2 after that.
-// The price: a point's row is fetched once per tree instead of once -- but only its bf16 copy (the screening operand,
-// 2 * dp bytes); the f32 row is touched only when a margin falls inside the bf16 error band.  PB points per quad walk
-// in lock step (independent chains to cover the L2 latency).  Same arithmetic, same coins, same cells as k_route.
-#ifndef NND_RX_OCC
-#define NND_RX_OCC 4  // waves per SIMD the register budget is sized for (two 512-thread workgroups per CU)
-#endif
-#ifndef NND_RX_LDS_KB
-#define NND_RX_LDS_KB 72
-#endif
-template <int NC, int PB>
-__global__ __launch_bounds__(512, NND_RX_OCC) void k_route_xcd(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
-                                                   const float2 *__restrict__ nr, int metric, int dp, int64_t n, int n_trees,
-                                                   const unsigned char *__restrict__ node_pack,
-                                                   const float *__restrict__ node_hf, int hs,
-                                                   const int32_t *__restrict__ leafscan, uint32_t seed,
-                                                   int32_t *__restrict__ cell_count, int32_t *__restrict__ cell_of,
-                                                   int32_t *__restrict__ rank_of, int l_top) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char top_tab[];
-    const int rec = 2 * dp + 16, r16 = rec >> 4, nslots = 1 << l_top;
-    int32_t *top_node = (int32_t *)(top_tab + (size_t)nslots * rec);  // node id of every heap slot (-1: no node there)
-    const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
-    const int sub = threadIdx.x & 3, qpb = blockDim.x >> 2;
-    for (int t = xcd; t < n_trees; t += 8) {
-        __syncthreads();  // the previous tree's table is no longer read
-        if (threadIdx.x == 0) {
-            top_node[0] = -1;
-            top_node[1] = t;  // the root of tree t is node t
+// ------------------------------------------------------------ coherent routing --
+// k_route above walks a point through a whole recorded tree in one go: beyond the first few levels every step is a
+// dependent fetch of a random 2 * dp + 16-byte record that misses the 4 MB L2 of its XCD (9.3 GB of fetches for 0.5 GB
+// of rows at 1 M points x 8 trees; a 10 M-point tree has 11 MB of records).  The coherent form makes every record
+// fetch an LDS read, in two passes:
+//   pass 1  k_route_top     every point walks the first L1 levels of every tree from an LDS copy of those levels
+//                           (heap order, k_top_heap) and lands in a BUCKET = one of the 2^L1 subtrees below them;
+//           k_bucket_prefix / k_bucket_scatter   counting sort of the (tree, point) pairs by bucket;
+//   pass 2  k_route_bucket  a workgroup takes a run of one bucket's points, stages that subtree's records in LDS ONCE
+//                           (breadth-first, k_bucket_tables) and walks the run through them, rows read as bf16 (the
+//                           screening operand; the f32 row is touched only inside the error band).
+// Same arithmetic, same coins, same cells as k_route (tests/test_gpu_kernels.py compares the two): a point's cell does
+// not depend on the order in which points arrive.  The walk works on any row range [row_lo, row_lo + nrows) and any
+// set of packed trees -- the sharded build routes a rank's own rows through the gathered tops of ALL trees.
+#define RP_GLOBAL_TAG 0x40000000  // child code in an LDS record: >= TAG: node id + TAG, fetched from global memory
+
+// heap-ordered copy of the first L1 levels of every tree: slot 1 = root, children of slot s at 2s and 2s + 1
+__global__ __launch_bounds__(256) void k_top_heap(const unsigned char *__restrict__ pack, int rec, int dp, const int32_t *__restrict__ roots,
+                                                  int L1, unsigned char *__restrict__ top_rec, int32_t *__restrict__ top_node,
+                                                  int32_t *__restrict__ bucket_root) {
+    __shared__ int32_t hn[256];  // 2^(L1 + 1) <= 256
+    const int t = blockIdx.x, nslots = 1 << L1, r16 = rec >> 4;
+    if (threadIdx.x == 0) {
+        hn[0] = -1;
+        hn[1] = roots[t];
+    }
+    __syncthreads();
+    for (int l = 0; l < L1; l++) {
+        for (int sl = (1 << l) + threadIdx.x; sl < (2 << l); sl += blockDim.x) {
+            const int nd = hn[sl];
+            int c0 = -1, c1 = -1;
+            if (nd >= 0) {
+                const uint4 meta = *(const uint4 *)(pack + (int64_t)nd * rec + 2 * dp);
+                c0 = (int)meta.z;
+                c1 = (int)meta.w;
+            }
+            hn[2 * sl] = c0 >= 0 ? c0 : -1;  // cells (<= -2) have no record
+            hn[2 * sl + 1] = c1 >= 0 ? c1 : -1;
         }
         __syncthreads();
-        for (int l = 0; l + 1 < l_top; l++) {  // children of the slots of level l
-            for (int sl = (1 << l) + threadIdx.x; sl < (2 << l); sl += blockDim.x) {
-                const int nd = top_node[sl];
-                int c0 = -1, c1 = -1;
-                if (nd >= 0) {
-                    const uint4 meta = *(const uint4 *)(node_pack + (int64_t)nd * rec + 2 * dp);
-                    c0 = (int)meta.z;
-                    c1 = (int)meta.w;
+    }
+    for (int q = threadIdx.x; q < nslots * r16; q += blockDim.x) {
+        const int sl = q / r16, wd = q - sl * r16;
+        const int nd = hn[sl];
+        if (nd >= 0) ((uint4 *)(top_rec + (size_t)t * nslots * rec))[q] = ((const uint4 *)(pack + (int64_t)nd * rec))[wd];
+    }
+    for (int sl = threadIdx.x; sl < nslots; sl += blockDim.x) {
+        top_node[t * nslots + sl] = hn[sl];
+        bucket_root[t * nslots + sl] = hn[nslots + sl];
+    }
+}
+
+// Both passes give a point to a PAIR of lanes (lane `sub` holds the 16-byte chunks sub, sub + 2, ... of the half-precision
+// row: NC2 = dp / 16 of them): the walk is bound by VALU issue (SQ counters: the four waves of a SIMD are issuing all the
+// time), and per point a pair spends ~40 % fewer wave instructions than a quad -- the per-step overhead (address, band,
+// side, child) is paid once per lane, the dot products are the same.
+__device__ __forceinline__ float rp_pair_sum(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+}
+// exact f32 margin (without the offset) by a pair of lanes, in the summation order of the quad kernels (rp_exact_quad,
+// k_route): lane `sub` computes the partial sums the quad's lanes sub and sub + 2 would, and the four are added as
+// (e0 + e1) + (e2 + e3) -- bitwise the quad's result, so both routing forms make the same decision on every margin
+template <int NC>
+__device__ __forceinline__ float rp_exact_pair(const float *__restrict__ xrow, const float *__restrict__ h, int sub) {
+    const float4 *x4 = (const float4 *)xrow;
+    const float4 *h4 = (const float4 *)h;
+    float ea = 0.0f, eb = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NC; q++) {
+        const int c = sub + 4 * q, c2 = sub + 2 + 4 * q;
+        ea = rp_dot4f(x4[2 * c], h4[2 * c], ea);
+        ea = rp_dot4f(x4[2 * c + 1], h4[2 * c + 1], ea);
+        eb = rp_dot4f(x4[2 * c2], h4[2 * c2], eb);
+        eb = rp_dot4f(x4[2 * c2 + 1], h4[2 * c2 + 1], eb);
+    }
+    ea = rp_pair_sum(ea);
+    eb = rp_pair_sum(eb);
+    return ea + eb;
+}
+
+// pass 1.  The trees of the group [tg0, tg0 + tgn) one after the other; the half-precision row stays in registers for all
+// of them.  code[t * nrows + r] = the point's bucket (t * 2^L1 + b), or -1 when the walk ended in a cell inside the top
+// levels (counted and placed here).  Bucket populations are counted in LDS and flushed once per workgroup.
+template <int NC>
+__global__ __launch_bounds__(1024) void k_route_top(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
+                                                    const float2 *__restrict__ nr, int metric, int dp, int64_t n, int64_t row_lo,
+                                                    int64_t nrows, int tg0, int tgn, int L1, const unsigned char *__restrict__ top_rec,
+                                                    const int32_t *__restrict__ top_node, const float *__restrict__ node_hf, int hs,
+                                                    uint32_t seed, int32_t *__restrict__ cell_count, int32_t *__restrict__ cell_of,
+                                                    int32_t *__restrict__ rank_of, int32_t *__restrict__ code,
+                                                    int32_t *__restrict__ bucket_count, const float *__restrict__ scal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char top_tab[];
+    constexpr int NC2 = 2 * NC;
+    const int rec = 2 * dp + 16, nslots = 1 << L1;
+    const float inv_s2 = scal[1];
+    int32_t *hist = (int32_t *)(top_tab + (size_t)tgn * nslots * rec);
+    int32_t *tnode = hist + tgn * nslots;
+    {
+        const uint4 *src = (const uint4 *)(top_rec + (size_t)tg0 * nslots * rec);
+        uint4 *dst = (uint4 *)top_tab;
+        const int total = tgn * nslots * (rec >> 4);
+        for (int q = threadIdx.x; q < total; q += blockDim.x) dst[q] = src[q];
+        for (int q = threadIdx.x; q < tgn * nslots; q += blockDim.x) {
+            hist[q] = 0;
+            tnode[q] = top_node[tg0 * nslots + q];
+        }
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 1;
+    const int ppb = blockDim.x >> 1;
+    for (int64_t r0 = (int64_t)blockIdx.x * ppb; r0 < nrows; r0 += (int64_t)gridDim.x * ppb) {
+        const int64_t r = r0 + (threadIdx.x >> 1);
+        const bool on = r < nrows;  // (idle pairs of the last round walk row 0 and write nothing: no divergent loop bounds)
+        const int64_t i = row_lo + (on ? r : 0);
+        uint4 xq[NC2];
+        {
+            const uint4 *row = (const uint4 *)(xh + i * dp);
+#pragma unroll
+            for (int q = 0; q < NC2; q++) xq[q] = row[sub + 2 * q];
+        }
+        const float2 nrv = nr[i];
+        const float xnorm = metric == 0 ? sqrtf(nrv.x) : nrv.x;
+        const float bA = nrv.y + RP_ACC * xnorm, bB = xnorm + nrv.y;  // band = |h| bA + |h - half(h)| bB + eps (rp_band regrouped)
+        for (int tl = 0; tl < tgn; tl++) {
+            const int t = tg0 + tl;
+            const int64_t slot = (int64_t)t * n + i;
+            int hidx = 1, rk = 0;
+            bool fin = false;
+            for (int depth = 0; depth < L1; depth++) {
+                if (!__ballot(!fin)) break;  // wave-uniform
+                const uint4 *r8 = (const uint4 *)(top_tab + ((size_t)tl * nslots + (fin ? 1 : hidx)) * rec);
+                uint4 p[NC2];
+#pragma unroll
+                for (int q = 0; q < NC2; q++) p[q] = r8[sub + 2 * q];
+                const uint4 meta = r8[dp >> 3];
+                float acc = 0.0f;
+#pragma unroll
+                for (int q = 0; q < NC2; q++) acc = rp_dot8(xq[q], p[q], acc);
+                if (fin) continue;  // whole pair
+                const float off = __uint_as_float(meta.x), hnorm = __uint_as_float(meta.y & 0xFFFF0000u), rh = __uint_as_float(meta.y << 16);
+                float m = rp_pair_sum(acc) * inv_s2 + off;
+                const float band = hnorm * bA + rh * bB + RP_EPS;
+                if (RP_IN_BAND(m, band))  // inside the screening error band: the exact f32 margin decides (pair-uniform)
+                    m = rp_exact_pair<NC>(xp + i * dp, node_hf + (int64_t)tnode[tl * nslots + hidx] * hs, sub) + off;
+                int side;
+                if (fabsf(m) < RP_EPS) side = (int)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)slot, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
+                else side = m > 0.0f ? 0 : 1;                                                                             // rp_trees.py:386-391
+                const int nxt = (int)(side ? meta.w : meta.z);
+                if (nxt <= -2) {  // reached a cell inside the top levels
+                    if (sub == 0 && on) {
+                        const int cell = -2 - nxt;
+                        cell_of[(int64_t)t * nrows + r] = cell;
+                        rk = atomicAdd(&cell_count[cell], 1);
+                    }
+                    fin = true;
+                } else {
+                    hidx = 2 * hidx + side;
                 }
-                top_node[2 * sl] = c0 >= 0 ? c0 : -1;  // cells (<= -2) have no record
-                top_node[2 * sl + 1] = c1 >= 0 ? c1 : -1;
             }
+            if (sub == 0 && on) {
+                const int64_t o = (int64_t)t * nrows + r;
+                if (fin) {
+                    rank_of[o] = rk;
+                    code[o] = -1;
+                } else {
+                    const int b = hidx - nslots;  // L1 steps taken: the walk stands at a root of the bucket level
+                    code[o] = t * nslots + b;
+                    atomicAdd(&hist[tl * nslots + b], 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < tgn * nslots; q += blockDim.x)
+        if (hist[q]) atomicAdd(&bucket_count[tg0 * nslots + q], hist[q]);
+}
+
+// single workgroup: bucket offsets and the work items of pass 2 (a bucket's points in runs of `chunk`)
+__global__ __launch_bounds__(256) void k_bucket_prefix(const int32_t *__restrict__ bucket_count, int nb, int chunk,
+                                                       int32_t *__restrict__ bucket_start, int2 *__restrict__ items,
+                                                       int32_t *__restrict__ n_items, int max_items) {
+    __shared__ int pa[256], pi[256];
+    const int per = (nb + 255) / 256;
+    const int b0 = threadIdx.x * per < nb ? threadIdx.x * per : nb, b1 = b0 + per < nb ? b0 + per : nb;
+    int sa = 0, si = 0;
+    for (int b = b0; b < b1; b++) {
+        const int c = bucket_count[b];
+        sa += c;
+        si += (c + chunk - 1) / chunk;
+    }
+    pa[threadIdx.x] = sa;
+    pi[threadIdx.x] = si;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ra = 0, ri = 0;
+        for (int q = 0; q < 256; q++) {
+            const int va = pa[q], vi = pi[q];
+            pa[q] = ra;
+            pi[q] = ri;
+            ra += va;
+            ri += vi;
+        }
+        bucket_start[nb] = ra;
+        n_items[0] = ri < max_items ? ri : max_items;
+    }
+    __syncthreads();
+    int ra = pa[threadIdx.x], ri = pi[threadIdx.x];
+    for (int b = b0; b < b1; b++) {
+        const int c = bucket_count[b];
+        bucket_start[b] = ra;
+        ra += c;
+        const int nc = (c + chunk - 1) / chunk;
+        for (int j = 0; j < nc; j++)
+            if (ri + j < max_items) items[ri + j] = make_int2(b, j);
+        ri += nc;
+    }
+}
+
+// counting sort of the (tree, point) pairs by bucket: grid (runs of 4096 points, trees); a workgroup counts its run per
+// bucket in LDS, reserves its share of every bucket with ONE global atomic, and places the points
+__global__ __launch_bounds__(256) void k_bucket_scatter(const int32_t *__restrict__ code, int64_t nrows, int64_t row_lo, int L1,
+                                                        const int32_t *__restrict__ bucket_start, int32_t *__restrict__ bucket_cursor,
+                                                        int32_t *__restrict__ bucket_rows) {
+    __shared__ int cnt[256], base[256];
+    const int t = blockIdx.y, nslots = 1 << L1;
+    for (int q = threadIdx.x; q < nslots; q += 256) cnt[q] = 0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * 4096;
+    int myc[16], myr[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        const int64_t r = r0 + it * 256 + threadIdx.x;
+        const int c = r < nrows ? code[(int64_t)t * nrows + r] : -1;
+        myc[it] = c;
+        myr[it] = c >= 0 ? atomicAdd(&cnt[c - t * nslots], 1) : 0;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nslots; q += 256) base[q] = cnt[q] ? atomicAdd(&bucket_cursor[t * nslots + q], cnt[q]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        const int c = myc[it];
+        if (c < 0) continue;
+        const int64_t r = r0 + it * 256 + threadIdx.x;
+        bucket_rows[bucket_start[c] + base[c - t * nslots] + myr[it]] = (int32_t)(row_lo + r);
+    }
+}
+
+// one wave per bucket: the subtree below the bucket's root, breadth first, up to R nodes: bt_node[slot] = node id,
+// bt_child[slot][c] = the child's code: < TAG a slot of this table, >= TAG a node beyond it (id + TAG), <= -2 a cell
+// bt_rec: the records themselves, in slot order, children replaced by their codes: what pass 2 copies into LDS in one
+// coalesced sweep (gathering them per work item through bt_node cost two dependent fetches per 16 bytes, with nothing
+// else running on the CU)
+__global__ __launch_bounds__(64) void k_bucket_tables(const unsigned char *__restrict__ pack, int rec, int dp,
+                                                      const int32_t *__restrict__ bucket_root, int R, int32_t *__restrict__ bt_cnt,
+                                                      int32_t *__restrict__ bt_node, int32_t *__restrict__ bt_child,
+                                                      unsigned char *__restrict__ bt_rec, int32_t *__restrict__ bt_cell) {
+    // Cells below the staged nodes get LOCAL numbers (child code -2 - local number; bt_cell[local] = the cell, at most
+    // R + 1 of them): pass 2 counts a run's points per cell in LDS and reserves their slots with one global atomic per
+    // cell and run -- the points of a bucket all fall into its few dozen cells, and hundreds of same-address atomics from
+    // every workgroup working on the bucket are serialised at the L2.
+    const int b = blockIdx.x, lane = nnd_lane();
+    int32_t *nodes = bt_node + (size_t)b * R;
+    int32_t *child = bt_child + (size_t)b * R * 2;
+    int32_t *cells = bt_cell + (size_t)b * (R + 8);
+    const int root = bucket_root[b];
+    if (root < 0) {
+        if (lane == 0) bt_cnt[b] = 0;
+        return;
+    }
+    int ccount = 0;
+    __shared__ int32_t q_nodes[1024];  // R <= 1024
+    if (lane == 0) q_nodes[0] = root;
+    int count = 1, lb = 0, le = 1;
+    nnd_wave_lds_sync();
+    while (lb < le) {
+        for (int i0 = lb; i0 < le; i0 += 64) {  // wave-uniform bounds
+            const int idx = i0 + lane;
+            int c0 = -1, c1 = -1;
+            if (idx < le) {
+                const uint4 meta = *(const uint4 *)(pack + (int64_t)q_nodes[idx] * rec + 2 * dp);
+                c0 = (int)meta.z;
+                c1 = (int)meta.w;
+            }
+            const unsigned long long m0 = __ballot(idx < le && c0 >= 0), m1 = __ballot(idx < le && c1 >= 0);
+            const int p0 = count + nnd_prefix_popc(m0), p1 = count + __popcll(m0) + nnd_prefix_popc(m1);
+            const unsigned long long z0 = __ballot(idx < le && c0 <= -2), z1 = __ballot(idx < le && c1 <= -2);
+            const int l0 = ccount + nnd_prefix_popc(z0), l1 = ccount + __popcll(z0) + nnd_prefix_popc(z1);
+            ccount += __popcll(z0) + __popcll(z1);
+            if (idx < le) {
+                int k0 = c0, k1 = c1;
+                if (c0 <= -2) { cells[l0] = -2 - c0; k0 = -2 - l0; }
+                if (c1 <= -2) { cells[l1] = -2 - c1; k1 = -2 - l1; }
+                if (c0 >= 0) {
+                    if (p0 < R) { q_nodes[p0] = c0; k0 = p0; } else k0 = c0 + RP_GLOBAL_TAG;
+                }
+                if (c1 >= 0) {
+                    if (p1 < R) { q_nodes[p1] = c1; k1 = p1; } else k1 = c1 + RP_GLOBAL_TAG;
+                }
+                child[2 * idx] = k0;
+                child[2 * idx + 1] = k1;
+            }
+            count += __popcll(m0) + __popcll(m1);
+            if (count > R) count = R;
+            nnd_wave_lds_sync();
+        }
+        lb = le;
+        le = count;
+    }
+    for (int i = lane; i < count; i += 64) nodes[i] = q_nodes[i];
+    if (lane == 0) bt_cnt[b] = count;
+    __threadfence_block();  // this wave's child codes (global stores above) are read back below
+    const int r16 = rec >> 4;
+    uint4 *dst = (uint4 *)(bt_rec + (size_t)b * R * rec);
+    for (int q = lane; q < count * r16; q += 64) {
+        const int sl = q / r16, wd = q - sl * r16;
+        uint4 v = ((const uint4 *)(pack + (int64_t)q_nodes[sl] * rec))[wd];
+        if (wd == r16 - 1) {
+            v.z = (uint32_t)child[2 * sl];
+            v.w = (uint32_t)child[2 * sl + 1];
+        }
+        dst[q] = v;
+    }
+}
+
+// pass 2.  Persistent workgroups over the work items (bucket, run); a pair of lanes per point.
+template <int NC>
+__global__ __launch_bounds__(1024) void k_route_bucket(const float *__restrict__ xp, const uint16_t *__restrict__ xh,
+                                                      const float2 *__restrict__ nr, int metric, int dp, int64_t n, int64_t row_lo,
+                                                      int64_t nrows, int L1, int chunk, const unsigned char *__restrict__ pack,
+                                                      const float *__restrict__ node_hf, int hs, const int2 *__restrict__ items,
+                                                      const int32_t *__restrict__ n_items, const int32_t *__restrict__ bucket_start,
+                                                      const int32_t *__restrict__ bucket_rows, int R, const int32_t *__restrict__ bt_cnt,
+                                                      const int32_t *__restrict__ bt_node, const unsigned char *__restrict__ bt_rec,
+                                                      const int32_t *__restrict__ bt_cell, uint32_t seed, int32_t *__restrict__ cell_count,
+                                                      int32_t *__restrict__ cell_of, int32_t *__restrict__ rank_of,
+                                                      const float *__restrict__ scal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sub_tab[];
+    constexpr int NC2 = 2 * NC;
+    const int rec = 2 * dp + 16, r16 = rec >> 4;
+    const float inv_s2 = scal[1];
+    int32_t *lcnt = (int32_t *)(sub_tab + (size_t)R * rec);  // (R + 8) points of this run per local cell
+    int32_t *lbase = lcnt + (R + 8);                          // (R + 8) first slot reserved for them in the cell
+    int32_t *lcell = lbase + (R + 8);                         // (R + 8) local -> global cell number
+    uint32_t *rowbuf = (uint32_t *)(lcell + (R + 8));         // (chunk) per point of the run: local cell << 16 | rank inside the run
+    const int sub = threadIdx.x & 1, ppb = blockDim.x >> 1, pair = threadIdx.x >> 1;
+    const int ni = n_items[0];
+#ifndef NND_ROUTE_CONTIG
+    const int item0 = (int)blockIdx.x, item1 = ni, istep = (int)gridDim.x;
+#else
+    const int per = (ni + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int item0 = (int)blockIdx.x * per, item1 = item0 + per < ni ? item0 + per : ni, istep = 1;
+#endif
+    int cur_b = -1;
+    for (int item = item0; item < item1; item += istep) {
+        const int2 it = items[item];
+        const int b = it.x;
+        if (b != cur_b) {
+            __syncthreads();  // the previous table is no longer read
+            const int cnt = bt_cnt[b];
+            const uint4 *src = (const uint4 *)(bt_rec + (size_t)b * R * rec);
+            for (int q = threadIdx.x; q < cnt * r16; q += blockDim.x) ((uint4 *)sub_tab)[q] = src[q];
+            for (int q = threadIdx.x; q < R + 8; q += blockDim.x) {
+                lcnt[q] = 0;
+                lcell[q] = q <= cnt ? bt_cell[(size_t)b * (R + 8) + q] : 0;  // a subtree of cnt staged nodes has <= cnt + 1 cells below them
+            }
+            cur_b = b;
             __syncthreads();
         }
-        for (int q = threadIdx.x; q < nslots * r16; q += blockDim.x) {
-            const int sl = q / r16, wd = q - sl * r16;
-            const int nd = top_node[sl];
-            if (nd >= 0) ((uint4 *)top_tab)[q] = ((const uint4 *)(node_pack + (int64_t)nd * rec))[wd];
+        const int t = b >> L1;
+        const int base = bucket_start[b] + it.y * chunk;
+        int cnt_rows = bucket_start[b + 1] - base;
+        if (cnt_rows > chunk) cnt_rows = chunk;
+        for (int r0 = 0; r0 < cnt_rows; r0 += ppb) {
+            const int idx = r0 + pair;
+            const bool on = idx < cnt_rows;
+            const int64_t pi = bucket_rows[base + (on ? idx : 0)];
+            uint4 xq[NC2];
+            {
+                const uint4 *row = (const uint4 *)(xh + pi * dp);
+#pragma unroll
+                for (int q = 0; q < NC2; q++) xq[q] = row[sub + 2 * q];
+            }
+            const float2 nrv = nr[pi];
+            const float xnorm = metric == 0 ? sqrtf(nrv.x) : nrv.x;
+            const float bA = nrv.y + RP_ACC * xnorm, bB = xnorm + nrv.y;
+            const int64_t slot = (int64_t)t * n + pi;
+            int cur = on ? 0 : -1;  // >= 0: code of the node the walk stands at; -1: over
+            int rk = -1;            // local cell << 16 | rank: the LDS atomic's return value is not touched before the walk is over
+            for (int depth = L1;; depth++) {
+                if (!__ballot(cur >= 0)) break;  // wave-uniform
+                uint4 p[NC2], meta;
+                const bool glob = cur >= RP_GLOBAL_TAG;  // the record comes from global memory: its cell children are GLOBAL cell numbers
+                if (glob) {  // beyond the staged subtree (pair-uniform)
+                    const uint4 *r8 = (const uint4 *)(pack + (int64_t)(cur - RP_GLOBAL_TAG) * rec);
+#pragma unroll
+                    for (int q = 0; q < NC2; q++) p[q] = r8[sub + 2 * q];
+                    meta = r8[dp >> 3];
+                    if ((int)meta.z >= 0) meta.z += RP_GLOBAL_TAG;
+                    if ((int)meta.w >= 0) meta.w += RP_GLOBAL_TAG;
+                } else {
+                    const uint4 *r8 = (const uint4 *)(sub_tab + (size_t)(cur >= 0 ? cur : 0) * rec);
+#pragma unroll
+                    for (int q = 0; q < NC2; q++) p[q] = r8[sub + 2 * q];
+                    meta = r8[dp >> 3];
+                }
+                float acc = 0.0f;
+#pragma unroll
+                for (int q = 0; q < NC2; q++) acc = rp_dot8(xq[q], p[q], acc);
+                if (cur < 0) continue;  // whole pair
+                const float off = __uint_as_float(meta.x), hnorm = __uint_as_float(meta.y & 0xFFFF0000u), rh = __uint_as_float(meta.y << 16);
+                float m = rp_pair_sum(acc) * inv_s2 + off;
+                const float band = hnorm * bA + rh * bB + RP_EPS;
+                if (RP_IN_BAND(m, band)) {  // inside the screening error band: the exact f32 margin decides (pair-uniform)
+                    const int nd = glob ? cur - RP_GLOBAL_TAG : bt_node[(size_t)b * R + cur];
+                    m = rp_exact_pair<NC>(xp + pi * dp, node_hf + (int64_t)nd * hs, sub) + off;
+                }
+                int side;
+                if (fabsf(m) < RP_EPS) side = (int)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)slot, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
+                else side = m > 0.0f ? 0 : 1;                                                                             // rp_trees.py:386-391
+                const int nxt = (int)(side ? meta.w : meta.z);
+                if (nxt <= -2) {  // reached a cell
+                    if (sub == 0) {
+                        const int cell = -2 - nxt;
+                        if (glob) {  // (rare) a cell below a node that is not staged: straight to the global counter
+                            const int64_t o = (int64_t)t * nrows + (pi - row_lo);
+                            cell_of[o] = cell;
+                            rank_of[o] = atomicAdd(&cell_count[cell], 1);
+                        } else {
+                            rk = (cell << 16) | atomicAdd(&lcnt[cell], 1);  // LDS
+                        }
+                    }
+                    cur = -1;
+                } else {
+                    cur = nxt;
+                }
+            }
+            if (sub == 0 && on) rowbuf[idx] = (uint32_t)rk;
+        }
+        // the run's points are counted: one global atomic per cell reserves their slots, then every point gets its own
+        __syncthreads();
+        for (int q = threadIdx.x; q < R + 8; q += blockDim.x) {
+            const int c = lcnt[q];
+            if (c) {
+                lbase[q] = atomicAdd(&cell_count[lcell[q]], c);
+                lcnt[q] = 0;
+            }
         }
         __syncthreads();
-        for (int64_t i0 = (int64_t)bx * qpb * PB; i0 < n; i0 += (int64_t)nbx * qpb * PB) {
-            int64_t pi[PB];
-            uint4 xq[PB][NC];
-            float xnorm[PB], rxv[PB];
-            int node[PB], hidx[PB];
-#pragma unroll
-            for (int u = 0; u < PB; u++) {
-                pi[u] = i0 + (int64_t)u * qpb + (threadIdx.x >> 2);
-                const bool on = pi[u] < n;
-                const int64_t ic = on ? pi[u] : 0;
-                const uint4 *row = (const uint4 *)(xh + ic * dp);
-#pragma unroll
-                for (int q = 0; q < NC; q++) xq[u][q] = row[sub + 4 * q];
-                const float2 nrv = nr[ic];
-                const float xn = nrv.x;
-                rxv[u] = nrv.y;
-                xnorm[u] = metric == 0 ? sqrtf(xn) : xn;
-                node[u] = on ? t : -1;  // >= 0: current node; -1: this walk is over (whole quad)
-                hidx[u] = 1;
-            }
-            for (int depth = 0;; depth++) {
-                bool any = false;
-#pragma unroll
-                for (int u = 0; u < PB; u++) any |= node[u] >= 0;
-                if (!__ballot(any)) break;  // wave-uniform
-                uint4 p[PB][NC], meta[PB];
-                if (depth < l_top) {  // every live walk is at depth `depth`: heap slot hidx < 2^l_top
-#pragma unroll
-                    for (int u = 0; u < PB; u++) {
-                        const uint4 *r8 = (const uint4 *)(top_tab + (size_t)(node[u] >= 0 ? hidx[u] : 1) * rec);
-#pragma unroll
-                        for (int q = 0; q < NC; q++) p[u][q] = r8[sub + 4 * q];
-                        meta[u] = r8[dp >> 3];
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < PB; u++) {
-                        const uint4 *r8 = (const uint4 *)(node_pack + (int64_t)(node[u] >= 0 ? node[u] : t) * rec);
-#pragma unroll
-                        for (int q = 0; q < NC; q++) p[u][q] = r8[sub + 4 * q];
-                        meta[u] = r8[dp >> 3];
-                    }
-                }
-                float acc[PB];
-#pragma unroll
-                for (int u = 0; u < PB; u++) {
-                    acc[u] = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < NC; q++) acc[u] = rp_dot8(xq[u][q], p[u][q], acc[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < PB; u++) {
-                    if (node[u] < 0) continue;  // whole quad
-                    const float off = __uint_as_float(meta[u].x), hnorm = __uint_as_float(meta[u].y & 0xFFFF0000u),
-                                rh = __uint_as_float(meta[u].y << 16);
-                    float m = rp_quad_sum(acc[u]) + off;
-                    const float band = rp_band(xnorm[u], rxv[u], hnorm, rh);
-#ifdef NND_RX_NORECHECK  // timing experiments only
-                    if (band < 0.0f) {
-#else
-                    if (!(fabsf(m) > band)) {  // inside the bf16 error band: the exact f32 margin decides (quad-uniform)
-#endif
-                        const float4 *h4 = (const float4 *)(node_hf + (int64_t)node[u] * hs);
-                        const float4 *x4 = (const float4 *)(xp + pi[u] * dp);
-                        float e = 0.0f;
-#pragma unroll
-                        for (int q = 0; q < NC; q++) {
-                            const int c = sub + 4 * q;
-                            e = rp_dot4f(x4[2 * c], h4[2 * c], e);
-                            e = rp_dot4f(x4[2 * c + 1], h4[2 * c + 1], e);
-                        }
-                        m = rp_quad_sum(e) + off;
-                    }
-                    const int64_t slot = (int64_t)t * n + pi[u];
-                    int side;
-                    if (fabsf(m) < RP_EPS) side = (int)(nnd_hash3(seed ^ 0x5bd1e995u, (uint32_t)slot, (uint32_t)depth) & 1u);  // rp_trees.py:380-385
-                    else side = m > 0.0f ? 0 : 1;                                                                             // rp_trees.py:386-391
-                    const int nxt = (int)(side ? meta[u].w : meta[u].z);
-                    if (nxt <= -2) {  // reached a cell: first sample position -2 - nxt -> cell index
-                        if (sub == 0) {
-                            const int cell = leafscan[-2 - nxt];
-                            cell_of[slot] = cell;
-#ifdef NND_RX_NOATOMIC  // timing experiments only
-                            rank_of[slot] = 0;
-#else
-                            rank_of[slot] = atomicAdd(&cell_count[cell], 1);
-#endif
-                        }
-                        node[u] = -1;
-                    } else {
-                        node[u] = nxt;
-                        hidx[u] = 2 * hidx[u] + side;
-                    }
-                }
-            }
+        for (int idx = threadIdx.x; idx < cnt_rows; idx += blockDim.x) {
+            const uint32_t v = rowbuf[idx];
+            if (v == 0xFFFFFFFFu) continue;  // placed through the global counter
+            const int lc = (int)(v >> 16);
+            const int64_t o = (int64_t)t * nrows + (bucket_rows[base + idx] - row_lo);
+            cell_of[o] = lcell[lc];
+            rank_of[o] = lbase[lc] + (int)(v & 0xFFFFu);
         }
+        __syncthreads();  // rowbuf / lcnt are reused by the next run
     }
 }
 
@@ -1300,11 +1661,11 @@ __global__ void k_cell_lists(const int32_t *__restrict__ cell_count, const int32
 }
 
 __global__ void k_place(const int32_t *__restrict__ cell_of, const int32_t *__restrict__ rank_of,
-                        const int32_t *__restrict__ cell_start, int64_t n, int32_t *__restrict__ perm) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t slot = (int64_t)blockIdx.y * n + i;
-    perm[cell_start[cell_of[slot]] + rank_of[slot]] = (int32_t)i;
+                        const int32_t *__restrict__ cell_start, int64_t nrows, int64_t row_lo, int32_t *__restrict__ perm) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const int64_t slot = (int64_t)blockIdx.y * nrows + r;
+    perm[cell_start[cell_of[slot]] + rank_of[slot]] = (int32_t)(row_lo + r);
 }
 
 // -------------------------------------------------------------- host side --
@@ -1336,11 +1697,14 @@ struct forest_view {
     int cur = 0, depth = 0;
     int64_t n_nodes = 0;
     std::vector<int64_t> level_base;  // recording: first node id of every level (+ the total at the end)
+    int T = 0;                        // trees in the view (0: ctx->p.n_trees)
+    int tree_bias = 0;                // global number of the view's first tree (sharded build: tops split by tree)
+    int64_t n_low = 0, high_lo = 0;   // recording: node ids in use are [0, n_low) and [high_lo, node_cap) (k_pack_nodes compacts)
 };
 
 // big list (global-memory variant; its nodes join the workgroup list as they shrink) -> workgroup list -> small list
 static int launch_finishers(nnd_ctx *ctx, int32_t *perm, int32_t *other, const int32_t *big_start, const int32_t *big_len,
-                            const int32_t *big_depth, int depth0, long long n_big, long long n_small = 0) {
+                            const int32_t *big_depth, int depth0, long long n_big, long long n_small = 0, rp_tree_map tm = rp_tree_map{}) {
     const int dp = ctx->dp, angular = ctx->p.metric == NND_METRIC_ALT_COSINE;
     int32_t *fin_start = ctx->seg_child + 2 * ctx->max_segs;  // finisher work list lives behind seg_child
     int32_t *fin_len = fin_start + ctx->max_segs;
@@ -1352,13 +1716,13 @@ static int launch_finishers(nnd_ctx *ctx, int32_t *perm, int32_t *other, const i
         const int32_t *sl = ctx->small_list;
         hipLaunchKernelGGL((k_finish_subtrees<false, 64, FIN_SMALL>), dim3((unsigned)n_small), dim3(64), fin_smem_bytes(dp, FIN_SMALL),
                            ctx->stream, FIN_ARGS(sl, sl + ctx->cell_cap, sl + 2 * ctx->cell_cap, 0, n_small), (int32_t *)nullptr,
-                           (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, fin_count);
+                           (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, fin_count, tm, ctx->mean + ctx->dp);
         NND_HIP_CHECK(hipGetLastError());
     }
     if (n_big > 0) {
         hipLaunchKernelGGL((k_finish_subtrees<true, 256, 0>), dim3((unsigned)n_big), dim3(256), fin_smem_bytes(dp, 0), ctx->stream,
                            FIN_ARGS(big_start, big_len, big_depth, depth0, n_big), other, ctx->side, FIN_MAX, fin_start, fin_len,
-                           fin_depth, fin_count);
+                           fin_depth, fin_count, tm, ctx->mean + ctx->dp);
         NND_HIP_CHECK(hipGetLastError());
     }
     NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 34, fin_count, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -1371,7 +1735,7 @@ static int launch_finishers(nnd_ctx *ctx, int32_t *perm, int32_t *other, const i
     if (nfin > 0) {
         hipLaunchKernelGGL((k_finish_subtrees<false, 256, FIN_MAX>), dim3((unsigned)nfin), dim3(256), fin_smem_bytes(dp, FIN_MAX),
                            ctx->stream, FIN_ARGS(fin_start, fin_len, fin_depth, 0, nfin), (int32_t *)nullptr, (uint8_t *)nullptr,
-                           FIN_MAX, fin_start, fin_len, fin_depth, fin_count);
+                           FIN_MAX, fin_start, fin_len, fin_depth, fin_count, tm, ctx->mean + ctx->dp);
         NND_HIP_CHECK(hipGetLastError());
     }
 #undef FIN_ARGS
@@ -1381,7 +1745,10 @@ static int launch_finishers(nnd_ctx *ctx, int32_t *perm, int32_t *other, const i
 // The level-synchronous passes on `v`.  Returns 0, 1 (error) or 2 (recording ran out of node slots: caller falls back).
 static int forest_levels(nnd_ctx *ctx, forest_view &v) {
     const int64_t n = v.n, P = v.P;
-    const int T = ctx->p.n_trees, dp = ctx->dp, leaf_size = v.leaf_size, max_depth = ctx->p.max_depth;
+    const int T = v.T > 0 ? v.T : ctx->p.n_trees, dp = ctx->dp, leaf_size = v.leaf_size, max_depth = ctx->p.max_depth;
+    const uint32_t pos_bias = (uint32_t)((int64_t)v.tree_bias * n);
+    rp_tree_map tm;
+    tm.tree_bias = v.tree_bias;
     const int angular = ctx->p.metric == NND_METRIC_ALT_COSINE;
     const int hs = dp + 4;
     int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);  // device scratch word(s)
@@ -1428,18 +1795,18 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
         uint16_t *hyper_h = v.record ? ctx->node_hh + node_base * dp : ctx->hyper_h;
         hipLaunchKernelGGL(k_hyperplane, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, ctx->stream, v.xp, dp,
                            ctx->perm[cur], ctx->seg_start[cur], ctx->seg_len[cur], (int)S, angular, ctx->tree_seed, depth,
-                           hyper, hs, hyper_h);
+                           hyper, hs, hyper_h, pos_bias, ctx->mean + ctx->dp);
         // point-major pass: hyperplane table fits in L2 AND enough positions are still active to amortise
         // streaming every row once (it costs n rows regardless of how many positions are active)
         const bool fused = inv_live && (S * (int64_t)dp * 2 <= (int64_t)6 << 20) && (active_pos * 2 >= 3 * n);
         if (fused) {
             hipLaunchKernelGGL(k_margin_fused, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, v.xp, v.xh, v.nr,
-                               ctx->p.metric, dp, n, T, ctx->inv, hyper, hs, hyper_h, ctx->tree_seed, depth, ctx->side_pt);
+                               ctx->p.metric, dp, n, T, ctx->inv, hyper, hs, hyper_h, ctx->tree_seed, depth, ctx->side_pt, pos_bias, ctx->mean + ctx->dp);
         } else {
             inv_live = false;
             hipLaunchKernelGGL(k_margin, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, ctx->stream, v.xp, v.xh, v.nr,
                                ctx->p.metric, dp, ctx->perm[cur], ctx->pos_seg[cur], P, hyper, hs, hyper_h, ctx->tree_seed, depth,
-                               ctx->side);
+                               ctx->side, pos_bias, ctx->mean + ctx->dp);
         }
         if (run_scan(ctx, fused ? 2 : 0, ctx->pos_seg[cur], ctx->side, scan_total, P, n, ctx->perm[cur])) return 1;
         hipLaunchKernelGGL(k_seg_count, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, ctx->seg_start[cur],
@@ -1473,7 +1840,7 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
         // still costs P positions per kernel for a few hundred segments: the global-memory variant of the finisher
         // takes them (its nodes are split in place until they fit the LDS finisher, whose work list they join).
         if (!v.record && S > 0 && (active_pos * 2 < 3 * n) && next[5] <= BIG_MAX) {  // next[5] = CNT_SCRATCH + 3: longest stayer
-            if (launch_finishers(ctx, ctx->perm[cur], ctx->perm[1 - cur], ctx->seg_start[cur], ctx->seg_len[cur], nullptr, depth, S)) return 1;
+            if (launch_finishers(ctx, ctx->perm[cur], ctx->perm[1 - cur], ctx->seg_start[cur], ctx->seg_len[cur], nullptr, depth, S, 0, tm)) return 1;
             v.cur = cur;
             v.depth = depth;
             v.n_nodes = node_base;
@@ -1493,6 +1860,8 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
             if (nnd_knob("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
             return 2;
         }
+        v.n_low = node_base;
+        v.high_lo = ctx->node_cap;
         if (nfin > 0) {
             int *flags = (int *)(ctx->counters + CNT_SCRATCH + 2);  // [0] id counter, [1] overflow
             NND_HIP_CHECK(hipMemsetAsync(flags, 0, 2 * sizeof(int), ctx->stream));
@@ -1505,12 +1874,12 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
             hipLaunchKernelGGL((k_finish_subtrees<false, 64, FIN_SMALL, true>), dim3((unsigned)nfin), dim3(64), fin_smem_bytes(dp, FIN_SMALL),
                                ctx->stream, v.xp, v.xh, v.nr, ctx->p.metric, dp, n, ctx->perm[cur], fin_start, fin_len, fin_depth, 0,
                                (int)nfin, angular, ctx->tree_seed, max_depth, leaf_size, ctx->leaf_flag, (int32_t *)nullptr,
-                               (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, ctx->counters + CNT_SCRATCH + 1, rs);
+                               (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, ctx->counters + CNT_SCRATCH + 1, tm, ctx->mean + ctx->dp, rs);
             if (v.fin_max > FIN_SMALL)
                 hipLaunchKernelGGL((k_finish_subtrees<false, 256, FIN_MAX, true>), dim3((unsigned)nfin), dim3(256), fin_smem_bytes(dp, FIN_MAX),
                                    ctx->stream, v.xp, v.xh, v.nr, ctx->p.metric, dp, n, ctx->perm[cur], fin_start, fin_len, fin_depth, 0,
                                    (int)nfin, angular, ctx->tree_seed, max_depth, leaf_size, ctx->leaf_flag, (int32_t *)nullptr,
-                                   (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, ctx->counters + CNT_SCRATCH + 1, rl);
+                                   (uint8_t *)nullptr, FIN_MAX, fin_start, fin_len, fin_depth, ctx->counters + CNT_SCRATCH + 1, tm, ctx->mean + ctx->dp, rl);
             NND_HIP_CHECK(hipGetLastError());
             NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 38, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             NND_HIP_CHECK(nnd_sync_spin(ctx));
@@ -1518,127 +1887,248 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
                 if (nnd_knob("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
                 return 2;
             }
+            // ids taken downwards: the segments' own (node_cap - nfin ..), then one per recorded split below them
+            v.high_lo = ctx->node_cap - nfin - ((const int *)(ctx->h_pin + 38))[0];
         }
         v.n_nodes = ctx->node_cap;  // ids are spread over the table: level-synchronous nodes upwards, recorded subtrees downwards
         return 0;
     }
-    if (launch_finishers(ctx, ctx->perm[cur], ctx->perm[1 - cur], nullptr, nullptr, nullptr, 0, 0)) return 1;
+    if (launch_finishers(ctx, ctx->perm[cur], ctx->perm[1 - cur], nullptr, nullptr, nullptr, 0, 0, 0, tm)) return 1;
     return 0;
 }
 
-template <int NC, int TB>
-static int launch_route(nnd_ctx *ctx, const int32_t *leafscan, int n_top, int l_top) {
-    auto kern = k_route<NC, TB>;
-    const size_t smem = (size_t)n_top * (2 * ctx->dp + 16);
+static int device_cus(nnd_ctx *ctx, int *out) {
     static int n_cu_dev[64] = {0};
     int &n_cu = n_cu_dev[ctx->p.device & 63];
     if (n_cu == 0) {
-        NND_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
         hipDeviceProp_t prop;
         NND_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->p.device));
         n_cu = prop.multiProcessorCount;
     }
+    *out = n_cu;
+    return 0;
+}
+
+// What a routing pass reads and writes: packed trees (k_pack_nodes), the rows [row_lo, row_lo + nrows) of the prepared point
+// set, and per (tree, row): the cell and the slot inside it (cell_of / rank_of at [t * nrows + row - row_lo]).
+struct rp_route_io {
+    const unsigned char *pack;
+    const float *hf;          // f32 hyperplanes of the packed nodes (exact rechecks)
+    const int32_t *roots;     // device (T): root node of every tree
+    int T;
+    int64_t row_lo, nrows;
+    int64_t n_cells;          // cells of all T trees (sizes the subtree tables)
+    int32_t *cell_count, *cell_of, *rank_of;
+    int32_t *code, *bucket_rows;  // scratch, T * nrows int32 each (coherent form only)
+};
+
+template <int NC, int TB>
+static int launch_route(nnd_ctx *ctx, const rp_route_io &io, int n_top, int l_top) {
+    auto kern = k_route<NC, TB>;
+    const size_t smem = (size_t)n_top * (2 * ctx->dp + 16);
+    static bool attr_dev[64] = {false};
+    if (!attr_dev[ctx->p.device & 63]) {
+        NND_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        attr_dev[ctx->p.device & 63] = true;
+    }
+    int n_cu = 0;
+    if (device_cus(ctx, &n_cu)) return 1;
     int64_t blocks = (ctx->n + 127) / 128;
     if (blocks > 2 * (int64_t)n_cu) blocks = 2 * (int64_t)n_cu;  // persistent: two 512-thread workgroups per CU
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), smem, ctx->stream, ctx->xp, ctx->nr2, ctx->p.metric, ctx->dp, ctx->n,
-                       ctx->p.n_trees, ctx->node_pack, ctx->node_hf, ctx->dp + 4, leafscan, ctx->tree_seed, ctx->cell_count,
-                       ctx->pos_seg[0], ctx->pos_seg[1], n_top, l_top);
+                       io.T, io.pack, io.hf, ctx->dp + 4, ctx->tree_seed, io.cell_count, io.cell_of, io.rank_of, n_top, l_top, ctx->mean + ctx->dp);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-template <int NC, int PB>
-static int launch_route_xcd(nnd_ctx *ctx, const int32_t *leafscan) {
-    auto kern = k_route_xcd<NC, PB>;
-    const int rec = 2 * ctx->dp + 16;
-    int l_top = 1;
-    while (((size_t)2 << l_top) * (rec + 4) <= NND_RX_LDS_KB * 1024) l_top++;  // 2^l_top heap slots (+ their node ids)
-    const size_t smem = ((size_t)1 << l_top) * (rec + 4);
-    static int n_cu_dev[64] = {0};
-    int &n_cu = n_cu_dev[ctx->p.device & 63];
-    if (n_cu == 0) {
-        NND_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-        hipDeviceProp_t prop;
-        NND_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->p.device));
-        n_cu = prop.multiProcessorCount;
-    }
-    int64_t blocks = (NND_RX_OCC / 2) * (int64_t)n_cu;  // persistent: NND_RX_OCC / 2 512-thread workgroups per CU
-    blocks = blocks < 8 ? 8 : (blocks & ~(int64_t)7);  // the same number of workgroups on every XCD
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), smem, ctx->stream, ctx->xp, ctx->xh, ctx->nr2, ctx->p.metric, ctx->dp,
-                       ctx->n, ctx->p.n_trees, ctx->node_pack, ctx->node_hf, ctx->dp + 4, leafscan, ctx->tree_seed, ctx->cell_count,
-                       ctx->pos_seg[0], ctx->pos_seg[1], l_top);
-    NND_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-// sample forest -> routing pass -> cells -> finishers.  Returns 0, 1, or 2 (fall back to the whole-set passes).
-static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
-    const int64_t n = ctx->n, P = ctx->P, M = ctx->s_m, Ps = (int64_t)ctx->p.n_trees * M;
-    const int T = ctx->p.n_trees, dp = ctx->dp;
-    int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
-    hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nr2,
-                       dp, M, ctx->s_stride, ctx->tree_seed, ctx->xs, ctx->xsh, ctx->nr2s);
-    // sample subtrees of <= 512 members leave the level-synchronous passes for the (one-wave) recording finisher;
-    // 2048 (+ a workgroup class) means 4 fewer levels but a slower finisher: 6.9-7.2 ms vs 6.6 ms per forest at 1 M points
-    static const int rec_fin = [] { const char *e = nnd_knob("NND_REC_FIN"); const int r = e ? atoi(e) : FIN_SMALL; return r <= FIN_SMALL ? FIN_SMALL : FIN_MAX; }();
-    forest_view v{ctx->xs, ctx->xsh, ctx->nr2s, M, Ps, ctx->cell_leaf, rec_fin, true};
-    int rc = forest_levels(ctx, v);
-    if (rc) return rc;
-    // cells = leaves of the recorded trees, numbered in position order (tree-major)
-    if (run_scan(ctx, 1, nullptr, ctx->leaf_flag, scan_total, Ps, M)) return 1;
-    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 35, scan_total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    NND_HIP_CHECK(nnd_sync_spin(ctx));
-    const int32_t n_cells = *(const int32_t *)(ctx->h_pin + 35);
-    if (n_cells > ctx->cell_cap || n_cells + P / (ctx->p.leaf_size + 1) > ctx->max_segs) {
-        if (nnd_knob("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
-        return 2;
-    }
-    hipLaunchKernelGGL(k_cell_depths, dim3((unsigned)((Ps + 255) / 256)), dim3(256), 0, ctx->stream, ctx->leaf_flag, ctx->scan_out,
-                       ctx->s_leaf_depth, Ps, ctx->cell_depth);
-    NND_HIP_CHECK(hipMemsetAsync(ctx->cell_count, 0, sizeof(int32_t) * (size_t)n_cells, ctx->stream));
-    hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)((v.n_nodes + 15) / 16)), dim3(256), 0, ctx->stream, ctx->node_hh, ctx->node_hf,
-                       dp + 4, ctx->node_child, dp, v.n_nodes, ctx->node_pack);
+// the plain walk (whole point set, the handle's own trees): kept for the comparison test and as the fallback
+static int route_plain(nnd_ctx *ctx, const rp_route_io &io, const forest_view &v) {
+    const int dp = ctx->dp;
     // levels whose records fit the route kernel's LDS copy (<= 72 KB: two workgroups per CU)
     int l_top = 0;
     while (l_top + 1 < (int)v.level_base.size() && v.level_base[l_top + 1] * (2 * dp + 16) <= 72 * 1024) l_top++;
     const int n_top = (int)v.level_base[l_top];
-    int rrc = 2;
-    // one tree per XCD (k_route_xcd) measured no faster than all trees per point (2.8-3.2 ms vs 2.8 ms at 1 M points):
-    // the walk is bound by its dependent record fetches and rechecks, not by where the records are cached.  Opt-in.
-    static const bool route_xcd = [] { const char *e = nnd_knob("NND_ROUTE_XCD"); return e && atoi(e) != 0; }();
-    if (route_xcd && T % 8 == 0 && dp % 32 == 0 && dp <= 256) {  // every XCD gets the same number of trees
-        switch (dp / 32) {
-            case 1: rrc = launch_route_xcd<1, 4>(ctx, ctx->scan_out); break;
-            case 2: rrc = launch_route_xcd<2, 2>(ctx, ctx->scan_out); break;
-            case 3: rrc = launch_route_xcd<3, 2>(ctx, ctx->scan_out); break;
-#ifdef NND_RX_PB
-            case 4: rrc = launch_route_xcd<4, NND_RX_PB>(ctx, ctx->scan_out); break;
-#else
-            case 4: rrc = launch_route_xcd<4, 2>(ctx, ctx->scan_out); break;
-#endif
-            case 5: rrc = launch_route_xcd<5, 1>(ctx, ctx->scan_out); break;
-            case 6: rrc = launch_route_xcd<6, 1>(ctx, ctx->scan_out); break;
-            case 7: rrc = launch_route_xcd<7, 1>(ctx, ctx->scan_out); break;
-            case 8: rrc = launch_route_xcd<8, 1>(ctx, ctx->scan_out); break;
-            default: break;
-        }
-    } else
     switch (dp / 32) {  // NC = 8-float chunks per lane; trees per batch sized for <= 128 VGPRs
-        case 1: rrc = launch_route<1, 4>(ctx, ctx->scan_out, n_top, l_top); break;
-        case 2: rrc = launch_route<2, 4>(ctx, ctx->scan_out, n_top, l_top); break;
-        case 3: rrc = launch_route<3, 2>(ctx, ctx->scan_out, n_top, l_top); break;
-        case 4: rrc = launch_route<4, 2>(ctx, ctx->scan_out, n_top, l_top); break;
-        case 5: rrc = launch_route<5, 1>(ctx, ctx->scan_out, n_top, l_top); break;
-        case 6: rrc = launch_route<6, 1>(ctx, ctx->scan_out, n_top, l_top); break;
-        case 7: rrc = launch_route<7, 1>(ctx, ctx->scan_out, n_top, l_top); break;
-        case 8: rrc = launch_route<8, 1>(ctx, ctx->scan_out, n_top, l_top); break;
+        case 1: return launch_route<1, 4>(ctx, io, n_top, l_top);
+        case 2: return launch_route<2, 4>(ctx, io, n_top, l_top);
+        case 3: return launch_route<3, 2>(ctx, io, n_top, l_top);
+        case 4: return launch_route<4, 2>(ctx, io, n_top, l_top);
+        case 5: return launch_route<5, 1>(ctx, io, n_top, l_top);
+        case 6: return launch_route<6, 1>(ctx, io, n_top, l_top);
+        case 7: return launch_route<7, 1>(ctx, io, n_top, l_top);
+        case 8: return launch_route<8, 1>(ctx, io, n_top, l_top);
         default: break;  // wider rows: whole-set passes (nnd_create does not enable routing for them)
     }
-    if (rrc) return rrc;
+    return 2;
+}
+
+#ifndef NND_ROUTE_L1
+#define NND_ROUTE_L1 6      // levels walked in pass 1: 2^L1 buckets per tree
+#endif
+#ifndef NND_ROUTE_CHUNK
+#define NND_ROUTE_CHUNK 2048  // points per work item of pass 2
+#endif
+#ifndef NND_ROUTE_RMAX
+#define NND_ROUTE_RMAX 384    // most records of a bucket's subtree staged in LDS
+#endif
+
+struct rp_route_geom {
+    int L1, ns, nb, R, chunk, tg;  // levels / slots per tree / buckets / staged records / run length / trees per pass-1 launch
+    int64_t max_items;
+    size_t o_top_rec, o_top_node, o_bucket_root, o_bcount, o_bcursor, o_bstart, o_nitems, o_btcnt, o_btnode, o_btchild, o_btrec, o_btcell, o_items, total;
+};
+static rp_route_geom route_geometry(int dp, int T, int64_t nrows, int64_t n_cells) {
+    rp_route_geom g;
+    const int rec = 2 * dp + 16;
+    g.L1 = NND_ROUTE_L1;
+    g.ns = 1 << g.L1;
+    g.nb = T * g.ns;
+    // a subtree of c cells has c - 1 inner nodes, and the buckets are very uneven (six random splits: a few buckets hold
+    // several times the mean, and most of the points): stage up to 6x the mean, what does not fit is walked from L2
+    int64_t r = 6 * n_cells / g.nb + 16;
+    const int64_t r_lds = (int64_t)150 * 1024 / rec;
+    if (r > NND_ROUTE_RMAX) r = NND_ROUTE_RMAX;
+    if (r > r_lds) r = r_lds;
+    g.R = (int)(r < 64 ? 64 : r);
+    g.chunk = NND_ROUTE_CHUNK;
+    g.tg = (int)((size_t)140 * 1024 / ((size_t)g.ns * (rec + 8)));
+    if (g.tg < 1) g.tg = 1;
+    if (g.tg > T) g.tg = T;
+    g.max_items = (int64_t)g.nb + (int64_t)T * nrows / g.chunk + 1;
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; };
+    g.o_top_rec = take((size_t)g.nb * rec);
+    g.o_top_node = take(sizeof(int32_t) * g.nb);
+    g.o_bucket_root = take(sizeof(int32_t) * g.nb);
+    g.o_bcount = take(sizeof(int32_t) * g.nb);   // bcount and bcursor are adjacent: one memset
+    g.o_bcursor = take(sizeof(int32_t) * g.nb);
+    g.o_bstart = take(sizeof(int32_t) * (g.nb + 1));
+    g.o_nitems = take(sizeof(int32_t) * 4);
+    g.o_btcnt = take(sizeof(int32_t) * g.nb);
+    g.o_btnode = take(sizeof(int32_t) * (size_t)g.nb * g.R);
+    g.o_btchild = take(sizeof(int32_t) * (size_t)g.nb * g.R * 2);
+    g.o_btrec = take((size_t)g.nb * g.R * rec);
+    g.o_btcell = take(sizeof(int32_t) * (size_t)g.nb * (g.R + 8));
+    g.o_items = take(sizeof(int2) * (size_t)g.max_items);
+    g.total = at;
+    return g;
+}
+
+template <int NC>
+static int launch_route_coherent(nnd_ctx *ctx, const rp_route_io &io, const rp_route_geom &g) {
+    const int dp = ctx->dp, rec = 2 * dp + 16, hs = dp + 4;
+    unsigned char *ws = ctx->route_ws;
+    unsigned char *top_rec = ws + g.o_top_rec;
+    int32_t *top_node = (int32_t *)(ws + g.o_top_node), *bucket_root = (int32_t *)(ws + g.o_bucket_root);
+    int32_t *bcount = (int32_t *)(ws + g.o_bcount), *bcursor = (int32_t *)(ws + g.o_bcursor), *bstart = (int32_t *)(ws + g.o_bstart);
+    int32_t *n_items = (int32_t *)(ws + g.o_nitems), *bt_cnt = (int32_t *)(ws + g.o_btcnt), *bt_node = (int32_t *)(ws + g.o_btnode);
+    int32_t *bt_child = (int32_t *)(ws + g.o_btchild);
+    unsigned char *bt_rec = ws + g.o_btrec;
+    int32_t *bt_cell = (int32_t *)(ws + g.o_btcell);
+    int2 *items = (int2 *)(ws + g.o_items);
+    auto ktop = k_route_top<NC>;
+    auto kbkt = k_route_bucket<NC>;
+    static bool attr_dev[64] = {false};
+    if (!attr_dev[ctx->p.device & 63]) {
+        NND_HIP_CHECK(hipFuncSetAttribute((const void *)ktop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NND_HIP_CHECK(hipFuncSetAttribute((const void *)kbkt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_dev[ctx->p.device & 63] = true;
+    }
+    int n_cu = 0;
+    if (device_cus(ctx, &n_cu)) return 1;
+    NND_HIP_CHECK(hipMemsetAsync(bcount, 0, g.o_bstart - g.o_bcount, ctx->stream));  // counts and cursors
+    hipLaunchKernelGGL(k_top_heap, dim3((unsigned)io.T), dim3(256), 0, ctx->stream, io.pack, rec, dp, io.roots, g.L1, top_rec, top_node,
+                       bucket_root);
+    hipLaunchKernelGGL(k_bucket_tables, dim3((unsigned)g.nb), dim3(64), 0, ctx->stream, io.pack, rec, dp, bucket_root, g.R, bt_cnt, bt_node,
+                       bt_child, bt_rec, bt_cell);
+    for (int tg0 = 0; tg0 < io.T; tg0 += g.tg) {  // pass 1, a group of trees per launch (the group's top levels fill the LDS)
+        const int tgn = io.T - tg0 < g.tg ? io.T - tg0 : g.tg;
+        const size_t smem = (size_t)tgn * g.ns * (rec + 8);
+        int64_t blocks = (io.nrows + 511) / 512;
+        if (blocks > n_cu) blocks = n_cu;  // persistent: one 1024-thread workgroup per CU
+        hipLaunchKernelGGL(ktop, dim3((unsigned)blocks), dim3(1024), smem, ctx->stream, ctx->xp, ctx->xh, ctx->nr2, ctx->p.metric, dp, ctx->n, io.row_lo,
+                           io.nrows, tg0, tgn, g.L1, top_rec, top_node, io.hf, hs, ctx->tree_seed, io.cell_count, io.cell_of, io.rank_of,
+                           io.code, bcount, ctx->mean + ctx->dp);
+    }
+    hipLaunchKernelGGL(k_bucket_prefix, dim3(1), dim3(256), 0, ctx->stream, bcount, g.nb, g.chunk, bstart, items, n_items, (int)g.max_items);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3((unsigned)((io.nrows + 4095) / 4096), (unsigned)io.T), dim3(256), 0, ctx->stream, io.code,
+                       io.nrows, io.row_lo, g.L1, bstart, bcursor, io.bucket_rows);
+    const size_t smem2 = (size_t)g.R * rec + sizeof(int32_t) * 3 * (size_t)(g.R + 8) + sizeof(uint32_t) * (size_t)g.chunk;
+    int per_cu = 0;
+    NND_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kbkt, 1024, smem2));
+    if (per_cu < 1) per_cu = 1;
+    int64_t blocks2 = (int64_t)n_cu * per_cu;
+    if (blocks2 > g.max_items) blocks2 = g.max_items;
+    hipLaunchKernelGGL(kbkt, dim3((unsigned)blocks2), dim3(1024), smem2, ctx->stream, ctx->xp, ctx->xh, ctx->nr2, ctx->p.metric, dp, ctx->n,
+                       io.row_lo, io.nrows, g.L1, g.chunk, io.pack, io.hf, hs, items, n_items, bstart, io.bucket_rows, g.R, bt_cnt, bt_node,
+                       bt_rec, bt_cell, ctx->tree_seed, io.cell_count, io.cell_of, io.rank_of, ctx->mean + ctx->dp);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// pass 1 by bucket, pass 2 from LDS (see "coherent routing" above).  Returns 0 / 1 / 2 (not available for this geometry).
+static int route_coherent(nnd_ctx *ctx, const rp_route_io &io) {
+    const int dp = ctx->dp;
+    if (dp % 32 != 0 || dp > 256 || io.T < 1 || io.T > 4096) return 2;
+    const rp_route_geom g = route_geometry(dp, io.T, io.nrows, io.n_cells);
+    if (g.total > ctx->route_ws_cap) {  // grow-only
+        NND_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->route_ws) { NND_HIP_CHECK(hipFree(ctx->route_ws)); ctx->route_ws = nullptr; }
+        ctx->route_ws_cap = 0;
+        NND_HIP_CHECK(hipMalloc((void **)&ctx->route_ws, g.total + g.total / 4));
+        ctx->route_ws_cap = g.total + g.total / 4;
+    }
+    switch (dp / 32) {
+        case 1: return launch_route_coherent<1>(ctx, io, g);
+        case 2: return launch_route_coherent<2>(ctx, io, g);
+        case 3: return launch_route_coherent<3>(ctx, io, g);
+        case 4: return launch_route_coherent<4>(ctx, io, g);
+        case 5: return launch_route_coherent<5>(ctx, io, g);
+        case 6: return launch_route_coherent<6>(ctx, io, g);
+        case 7: return launch_route_coherent<7>(ctx, io, g);
+        case 8: return launch_route_coherent<8>(ctx, io, g);
+        default: break;
+    }
+    return 2;
+}
+
+__global__ void k_iota_i32(int32_t *__restrict__ out, int n, int base) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = base + i;
+}
+
+// The top of the view's trees from the sample (level passes + recording finisher), then the cells = leaves of the recorded
+// trees, numbered in position order (tree-major): ctx->scan_out[p] = cell number of the cell that starts at sample
+// position p, ctx->cell_depth filled.  Returns 0, 1, or 2 (fall back to the whole-set passes).
+static int forest_tops(nnd_ctx *ctx, forest_view &v, int32_t *n_cells_out) {
+    int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
+    const int rc = forest_levels(ctx, v);
+    if (rc) return rc;
+    if (run_scan(ctx, 1, nullptr, ctx->leaf_flag, scan_total, v.P, v.n)) return 1;
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 35, scan_total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(nnd_sync_spin(ctx));
+    const int32_t n_cells = *(const int32_t *)(ctx->h_pin + 35);
+    if (n_cells > ctx->cell_cap) {
+        if (nnd_knob("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+        return 2;
+    }
+    hipLaunchKernelGGL(k_cell_depths, dim3((unsigned)((v.P + 255) / 256)), dim3(256), 0, ctx->stream, ctx->leaf_flag, ctx->scan_out,
+                       ctx->s_leaf_depth, v.P, ctx->cell_depth);
+    NND_HIP_CHECK(hipGetLastError());
+    *n_cells_out = n_cells;
+    return 0;
+}
+
+// cells (counts known) -> positions: cell_start = exclusive scan, work lists by size class, points placed, cells finished.
+// n_rows_routed rows x T trees were routed (cell_of / rank_of as rp_route_io lays them out); perm is written at
+// [0, sum of the counts).
+static int forest_place_finish(nnd_ctx *ctx, int32_t n_cells, int T, int64_t row_lo, int64_t nrows, const int32_t *cell_of,
+                               const int32_t *rank_of, int64_t P_used, rp_tree_map tm) {
+    int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
     // cell_start = exclusive scan of the counts (k_scan_blocks scans in place: copy first)
     NND_HIP_CHECK(hipMemcpyAsync(ctx->cell_start, ctx->cell_count, sizeof(int32_t) * (size_t)n_cells, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->cell_start, (int)n_cells, scan_total);
-    NND_HIP_CHECK(hipMemsetAsync(ctx->leaf_flag, 0, (size_t)P, ctx->stream));
+    NND_HIP_CHECK(hipMemsetAsync(ctx->leaf_flag, 0, (size_t)P_used, ctx->stream));
     long long *counts = ctx->counters + CNT_SCRATCH + 1;  // [0] workgroup list (what launch_finishers reads), [1] big, [2] small
     NND_HIP_CHECK(hipMemsetAsync(counts, 0, 3 * sizeof(long long), ctx->stream));
     int32_t *fin_start = ctx->seg_child + 2 * ctx->max_segs, *fin_len = fin_start + ctx->max_segs, *fin_depth = fin_len + ctx->max_segs;
@@ -1646,8 +2136,9 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     hipLaunchKernelGGL(k_cell_lists, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->cell_count, ctx->cell_start,
                        ctx->cell_depth, (int)n_cells, FIN_SMALL, FIN_MAX, ctx->small_list, fin_start, fin_len, fin_depth, big_start,
                        big_len, big_depth, ctx->cell_cap, counts);
-    hipLaunchKernelGGL(k_place, dim3((unsigned)((n + 255) / 256), (unsigned)T), dim3(256), 0, ctx->stream, ctx->pos_seg[0], ctx->pos_seg[1],
-                       ctx->cell_start, n, ctx->perm[0]);
+    if (cell_of)
+        hipLaunchKernelGGL(k_place, dim3((unsigned)((nrows + 255) / 256), (unsigned)T), dim3(256), 0, ctx->stream, cell_of, rank_of,
+                           ctx->cell_start, nrows, row_lo, ctx->perm[0]);
     NND_HIP_CHECK(hipGetLastError());
     NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 36, counts + 1, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     NND_HIP_CHECK(nnd_sync_spin(ctx));
@@ -1656,9 +2147,45 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
         if (nnd_knob("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
         return 2;
     }
-    if (launch_finishers(ctx, ctx->perm[0], ctx->perm[1], big_start, big_len, big_depth, 0, n_big, n_small)) return 1;
-    *levels_out = v.depth;
+    if (launch_finishers(ctx, ctx->perm[0], ctx->perm[1], big_start, big_len, big_depth, 0, n_big, n_small, tm)) return 1;
     ctx->cur = 0;
+    return 0;
+}
+
+// sample forest -> routing pass -> cells -> finishers.  Returns 0, 1, or 2 (fall back to the whole-set passes).
+static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
+    const int64_t n = ctx->n, P = ctx->P, M = ctx->s_m, Ps = (int64_t)ctx->p.n_trees * M;
+    const int T = ctx->p.n_trees, dp = ctx->dp;
+    hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nr2,
+                       dp, (int64_t)0, M, ctx->s_stride, ctx->tree_seed, ctx->xs, ctx->xsh, ctx->nr2s);
+    // sample subtrees of <= 512 members leave the level-synchronous passes for the (one-wave) recording finisher;
+    // 2048 (+ a workgroup class) means 4 fewer levels but a slower finisher: 6.9-7.2 ms vs 6.6 ms per forest at 1 M points
+    static const int rec_fin = [] { const char *e = nnd_knob("NND_REC_FIN"); const int r = e ? atoi(e) : FIN_SMALL; return r <= FIN_SMALL ? FIN_SMALL : FIN_MAX; }();
+    forest_view v{ctx->xs, ctx->xsh, ctx->nr2s, M, Ps, ctx->cell_leaf, rec_fin, true};
+    int32_t n_cells = 0;
+    int rc = forest_tops(ctx, v, &n_cells);
+    if (rc) return rc;
+    if (n_cells + P / (ctx->p.leaf_size + 1) > ctx->max_segs) {
+        if (nnd_knob("NND_FOREST_DEBUG")) fprintf(stderr, "forest: fallback at line %d\n", __LINE__);
+        return 2;
+    }
+    NND_HIP_CHECK(hipMemsetAsync(ctx->cell_count, 0, sizeof(int32_t) * (size_t)n_cells, ctx->stream));
+    const int64_t n_packed = v.n_low + (ctx->node_cap - v.high_lo);
+    rp_pack_map mp{v.n_low, v.high_lo, 0, 0, nullptr};
+    hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)((n_packed + 15) / 16)), dim3(256), 0, ctx->stream, ctx->node_hh, ctx->node_hf,
+                       dp + 4, ctx->node_child, ctx->scan_out, dp, n_packed, mp, ctx->node_pack, ctx->node_hfc);
+    int32_t *roots = ctx->route_roots;
+    hipLaunchKernelGGL(k_iota_i32, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, roots, T, 0);
+    // ctx->inv (segment table of the sample passes) and ctx->scan_out (the cell numbers: baked into the records by now)
+    // are free: they hold the (tree, point) codes and the bucket-sorted point lists of the coherent form
+    rp_route_io io{ctx->node_pack, ctx->node_hfc, roots, T, 0, n, n_cells, ctx->cell_count, ctx->pos_seg[0], ctx->pos_seg[1], ctx->inv, ctx->scan_out};
+    int rrc = 2;
+    if (!(ctx->p.flags & NND_FLAG_TEST_ROUTE_PLAIN)) rrc = route_coherent(ctx, io);
+    if (rrc == 2) rrc = route_plain(ctx, io, v);
+    if (rrc) return rrc;
+    rc = forest_place_finish(ctx, n_cells, T, 0, n, ctx->pos_seg[0], ctx->pos_seg[1], P, rp_tree_map{});
+    if (rc) return rc;
+    *levels_out = v.depth;
     ctx->stats.n_cells = n_cells;
     return 0;
 }

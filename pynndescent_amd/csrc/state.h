@@ -87,7 +87,7 @@ struct nnd_handle_s {
     float *nrm = nullptr;  // (n) |x-mu|^2 (euclid) or 1/0 non-zero flag (cosine)
     float2 *nr2 = nullptr;                    // (n) (nrm, |x - bf16(x)|) per row: what the forest's margin kernels read (rpforest.hip rp_band)
     uint16_t *xh = nullptr; // (n,dp) bf16 copy of xp: screening pass of the rp-forest margins (half the bytes)
-    float *mean = nullptr; // (dp)
+    float *mean = nullptr; // (dp + 4): column means | [dp] scale of the half-precision screening copies (prep.hip k_screen_scale) | [dp + 1] 1 / scale^2 | [dp + 2] sampled max |x|
 
     // k-lists, rows ascending by (dist, idx)
     uint32_t *knn_e = nullptr; // (n,ks) neighbour | NEW_BIT ; 0xFFFFFFFF = empty
@@ -130,7 +130,11 @@ struct nnd_handle_s {
     float *node_hf = nullptr;                 // (node_cap, dp + 4) f32 hyperplane + offset + |h|
     uint16_t *node_hh = nullptr;              // (node_cap, dp) bf16 hyperplane
     int32_t *node_child = nullptr;            // (node_cap, 2) child node id, or -2 - first sample position of a cell
-    unsigned char *node_pack = nullptr;       // (node_cap, 2 * dp + 16) packed records read by k_route
+    unsigned char *node_pack = nullptr;       // (node_cap, 2 * dp + 16) packed records read by the routing passes (compacted ids)
+    float *node_hfc = nullptr;                // (node_cap, dp + 4) node_hf compacted like node_pack (exact rechecks of the routing passes)
+    int32_t *route_roots = nullptr;           // (4096) root node of every routed tree
+    unsigned char *route_ws = nullptr;        // workspace of the coherent routing passes (rpforest.hip route_geometry), grow-only
+    size_t route_ws_cap = 0;
     int32_t *s_leaf_depth = nullptr;          // (n_trees * s_m) depth of the cell that starts at a sample position
     int32_t *cell_count = nullptr, *cell_start = nullptr, *cell_depth = nullptr;  // (cell_cap)
     int32_t *small_list = nullptr;            // (3, cell_cap) start / len / depth of the cells finished one wave per cell
@@ -174,6 +178,13 @@ typedef nnd_handle_s nnd_ctx;
 int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bounds_host, int n_ranks, int rank);
 // ---- implemented in the kernel translation units; each returns 0 / sets ctx->err ----
 int nnd_launch_prep(nnd_ctx *ctx);
+// the pieces of nnd_launch_prep (prep.hip), for the sharded build: a rank preps its own rows first, the others once they arrive
+void nnd_prep_mean_geometry(int64_t n, int64_t *n_s, int64_t *stride);
+int nnd_prep_partial_blocks(int64_t members);
+double *nnd_prep_partial_buffer(nnd_ctx *ctx, size_t doubles);
+int nnd_prep_mean_partial(nnd_ctx *ctx, const float *x_rows, int64_t row0, int64_t r_lo, int64_t r_hi, int64_t stride, double *partial);
+int nnd_prep_mean_finish(nnd_ctx *ctx, const double *partial, int nblocks, int64_t n_s);
+int nnd_prep_rows(nnd_ctx *ctx, const float *x_all, int64_t row_lo, int64_t row_hi, bool first);
 int nnd_launch_reset_graph(nnd_ctx *ctx);
 int nnd_launch_forest(nnd_ctx *ctx);
 int nnd_launch_leaf_array(nnd_ctx *ctx, int32_t *out_dev /* (n_leaves,max_leaf) */);

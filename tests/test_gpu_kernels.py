@@ -320,6 +320,31 @@ def test_half_wave_select_equals_wave_select(k, mc):
     assert has_new.any()
 
 
+@pytest.mark.parametrize("metric,n,d,T", [("euclidean", 300000, 128, 8), ("cosine", 200000, 100, 5), ("euclidean", 180000, 40, 12)])
+def test_coherent_routing_equals_plain_walk(metric, n, d, T):
+    """The two-pass routing of the forest (top levels from LDS -> counting sort by bucket -> the bucket's subtree from
+    LDS, rpforest.hip k_route_top / k_route_bucket) sends every point to the cell the one-walk kernel k_route sends it
+    to: same splits, same coins (rp_trees.py:380-391).  The finishers are order independent, so the whole forest --
+    the leaf array -- is identical."""
+    from pynndescent_amd import _capi
+
+    x = clustered(n, d, 16, 64, seed=23)
+    leaves = []
+    for flags in (0, _capi.NND_FLAG_TEST_ROUTE_PLAIN):
+        b = make_builder(x, metric, k=15, n_trees=T, flags=flags)
+        b.make_forest()
+        la = b.leaf_array()
+        assert b.stats()["n_cells"] > 0, "the routing forest did not run"
+        leaves.append(la)
+        b.close()
+    assert leaves[0].shape == leaves[1].shape
+    np.testing.assert_array_equal(leaves[0], leaves[1])
+    # every tree is a partition of the points
+    la = leaves[0]
+    ids = la[la >= 0]
+    assert ids.size == n * T and np.array_equal(np.bincount(ids, minlength=n), np.full(n, T))
+
+
 @pytest.mark.parametrize("metric,n,d,k,T", [("euclidean", 6000, 32, 15, 4), ("cosine", 3000, 20, 10, 3),
                                             ("euclidean", 2500, 12, 30, 3)])
 def test_leaf_array_seam_matches_reference_init_rp_tree(metric, n, d, k, T):
