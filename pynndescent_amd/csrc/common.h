@@ -70,6 +70,64 @@ __device__ __forceinline__ float nnd_group16_sum_f32(float v) {
     return v;
 }
 
+// ---- wave reductions without the LDS crossbar.  __shfl_xor is ds_bpermute_b32: an LDS-pipeline round trip per step, six
+// dependent ones per reduction -- ~700 cycles that a latency-bound kernel (one wave per tree cell, a few reductions per
+// node) cannot hide.  DPP row rotations are VALU operands: four steps leave every lane with its ROW's result, v_readlane
+// fetches the four row results, three more operations combine them.  Every lane must be active (EXEC all ones).
+template <int CTRL>
+__device__ __forceinline__ int nnd_dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+#define NND_DPP_ROW_SHR(n) (0x110 + (n))
+#define NND_DPP_ROW_ROR(n) (0x120 + (n))
+// the same value in every lane: rows by rotations (lanes of a row may differ in the last bit: lane 0 of the row is taken),
+// then (r0 + r1) + (r2 + r3)
+__device__ __forceinline__ float nnd_wave_sum_f32_u(float v) {
+    v += __int_as_float(nnd_dpp_i32<NND_DPP_ROW_ROR(8)>(__float_as_int(v)));
+    v += __int_as_float(nnd_dpp_i32<NND_DPP_ROW_ROR(4)>(__float_as_int(v)));
+    v += __int_as_float(nnd_dpp_i32<NND_DPP_ROW_ROR(2)>(__float_as_int(v)));
+    v += __int_as_float(nnd_dpp_i32<NND_DPP_ROW_ROR(1)>(__float_as_int(v)));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float nnd_wave_max_f32_u(float v) {
+    v = fmaxf(v, __int_as_float(nnd_dpp_i32<NND_DPP_ROW_ROR(8)>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(nnd_dpp_i32<NND_DPP_ROW_ROR(4)>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(nnd_dpp_i32<NND_DPP_ROW_ROR(2)>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(nnd_dpp_i32<NND_DPP_ROW_ROR(1)>(__float_as_int(v))));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ uint64_t nnd_dpp_min_u64_step(uint64_t k, uint32_t olo, uint32_t ohi) {
+    const uint64_t o = ((uint64_t)ohi << 32) | olo;
+    return o < k ? o : k;
+}
+// smallest 64-bit key of the wave, in every lane
+__device__ __forceinline__ uint64_t nnd_wave_min_u64_u(uint64_t k) {
+    k = nnd_dpp_min_u64_step(k, (uint32_t)nnd_dpp_i32<NND_DPP_ROW_ROR(8)>((int)(uint32_t)k), (uint32_t)nnd_dpp_i32<NND_DPP_ROW_ROR(8)>((int)(uint32_t)(k >> 32)));
+    k = nnd_dpp_min_u64_step(k, (uint32_t)nnd_dpp_i32<NND_DPP_ROW_ROR(4)>((int)(uint32_t)k), (uint32_t)nnd_dpp_i32<NND_DPP_ROW_ROR(4)>((int)(uint32_t)(k >> 32)));
+    k = nnd_dpp_min_u64_step(k, (uint32_t)nnd_dpp_i32<NND_DPP_ROW_ROR(2)>((int)(uint32_t)k), (uint32_t)nnd_dpp_i32<NND_DPP_ROW_ROR(2)>((int)(uint32_t)(k >> 32)));
+    k = nnd_dpp_min_u64_step(k, (uint32_t)nnd_dpp_i32<NND_DPP_ROW_ROR(1)>((int)(uint32_t)k), (uint32_t)nnd_dpp_i32<NND_DPP_ROW_ROR(1)>((int)(uint32_t)(k >> 32)));
+    uint64_t best = ~0ull;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint64_t o = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), 16 * r) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, 16 * r);
+        best = o < best ? o : best;
+    }
+    return best;
+}
+// inclusive prefix sum over the lanes of the wave
+__device__ __forceinline__ int nnd_wave_incl_scan_i32(int v) {
+    v += nnd_dpp_i32<NND_DPP_ROW_SHR(1)>(v);  // (lanes shifted in from outside the row read 0)
+    v += nnd_dpp_i32<NND_DPP_ROW_SHR(2)>(v);
+    v += nnd_dpp_i32<NND_DPP_ROW_SHR(4)>(v);
+    v += nnd_dpp_i32<NND_DPP_ROW_SHR(8)>(v);
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = nnd_lane() >> 4;
+    return v + (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0);
+}
+
 // Make this wave's LDS writes visible to its own later LDS reads (cross-lane through LDS).
 // One wave executes LDS operations in order; this only stops the compiler from reordering
 // and waits for outstanding LDS traffic.

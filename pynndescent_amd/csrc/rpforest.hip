@@ -664,8 +664,36 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
     const uint32_t seedt = seed ^ (rp_tree_of(tm, a, n) * 0x9E3779B9u);  // per tree
     const float hsc = scal[0], hinv = 1.0f / hsc, inv_s2 = scal[1];
-    if (!BIG)
-        for (int i = tid; i < len; i += NTHR) ids[i] = perm[a + i];
+    // The screening band of a member is |h| (r_x + ACC |x|) + |h - half(h)| (|x| + r_x) + eps (rp_band regrouped).  The LDS
+    // variants take the LARGEST (r_x + ACC |x|) and (|x| + r_x) of the cell for all its members: they are read ONCE per
+    // member, while the ids are loaded, instead of once per member and level (a random 8-byte gather that costs a whole
+    // line: a quarter of this kernel's fetches); members of a cell lie close together, so the common band is hardly wider.
+    float cellA = 0.0f, cellB = 0.0f;
+    if (!BIG) {
+        for (int i = tid; i < len; i += NTHR) {
+            const int32_t id = perm[a + i];
+            ids[i] = id;
+            const float2 nrv = nr[id];
+            const float xnm = metric == 0 ? sqrtf(nrv.x) : nrv.x;
+            cellA = fmaxf(cellA, nrv.y + RP_ACC * xnm);
+            cellB = fmaxf(cellB, xnm + nrv.y);
+        }
+        cellA = nnd_wave_max_f32_u(cellA);
+        cellB = nnd_wave_max_f32_u(cellB);
+        if (NW > 1) {
+            if (lane == 0) {
+                ((float *)wsum)[w] = cellA;
+                ((float *)wsum)[8 + w] = cellB;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                cellA = fmaxf(cellA, ((float *)wsum)[q]);
+                cellB = fmaxf(cellB, ((float *)wsum)[8 + q]);
+            }
+            __syncthreads();
+        }
+    }
     if (tid == 0) {
         stk[0] = 0; stk[1] = len; stk[2] = seg_depth ? seg_depth[s] : depth0;
         stk[3] = RECORD ? rec.node_top - s : 0;  // k_children numbered the finisher segments downwards from node_top
@@ -709,11 +737,11 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
             const uint32_t id = (uint32_t)ids[ss + i];
             rp_top2_push(k1, k2, ((uint64_t)nnd_hash3(seedt, id, (uint32_t)(2 * dep)) << 32) | id);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint64_t o1 = rp_shfl_xor_u64(k1, o), o2 = rp_shfl_xor_u64(k2, o);
-            rp_top2_push(k1, k2, o1);
-            rp_top2_push(k1, k2, o2);
+        {  // the wave's two smallest keys: the smallest, then the smallest of what is left (keys are distinct: they end in the id)
+            const uint64_t g1 = nnd_wave_min_u64_u(k1);
+            const uint64_t g2 = nnd_wave_min_u64_u(k1 == g1 ? k2 : k1);
+            k1 = g1;
+            k2 = g2;
         }
         if (lane == 0) {
             wkeys[2 * w] = k1;
@@ -734,8 +762,8 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
             part += angular ? v * v : v * (lv + rv);
             psq += v * v;
         }
-        part = nnd_wave_sum_f32(part);
-        psq = nnd_wave_sum_f32(psq);
+        part = nnd_wave_sum_f32_u(part);
+        psq = nnd_wave_sum_f32_u(psq);
         if (lane == 0) {
             ((float *)wsum)[w] = part;
         }
@@ -770,7 +798,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
             const float e = v - nnd_h16_to_f32(b, hinv);
             pres += e * e;
         }
-        pres = nnd_wave_sum_f32(pres);
+        pres = nnd_wave_sum_f32_u(pres);
         if (lane == 0) ((float *)wsum)[w] = pres;
         __syncthreads();
         float rhv = 0.0f;
@@ -804,11 +832,13 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
                 pt[u] = ids[ss + (i < l ? i : 0)];
                 acc[u] = 0.0f;
             }
+            if (BIG) {
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const float2 nrv = nr[pt[u]];
-                xn[u] = nrv.x;
-                rxv[u] = nrv.y;
+                for (int u = 0; u < 2; u++) {
+                    const float2 nrv = nr[pt[u]];
+                    xn[u] = nrv.x;
+                    rxv[u] = nrv.y;
+                }
             }
             for (int c = sub; c < nch; c += 16) {
                 uint4 q[2][4], p[4];
@@ -829,7 +859,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
                 const int i = i0 + u * GQ + grp;
                 if (i >= l) continue;  // whole quad
                 const float m = rp_quad_sum(acc[u]) * inv_s2 + off;
-                const float band = rp_band(metric == 0 ? sqrtf(xn[u]) : xn[u], rxv[u], hnorm, rhv);
+                const float band = BIG ? rp_band(metric == 0 ? sqrtf(xn[u]) : xn[u], rxv[u], hnorm, rhv) : hnorm * cellA + rhv * cellB + RP_EPS;
                 const uint8_t side = rp_side(m, band, xp + pt[u] * dp, h, off, dp, sub, seedt, (uint32_t)pt[u], dep);
                 if (sub == 0) sd[i] = side;
             }
@@ -844,12 +874,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 64 ? 5 : 1) void k_finish_subtrees(co
         for (int attempt = 0;; attempt++) {
             cntl = 0;
             for (int i = b0; i < b1; i++) cntl += sd[i] == 0;
-            incl = cntl;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += t;
-            }
+            incl = nnd_wave_incl_scan_i32(cntl);
             if (lane == 63) wsum[w] = incl;
             __syncthreads();
             woff = 0;
@@ -1383,7 +1408,10 @@ __global__ __launch_bounds__(256) void k_bucket_prefix(const int32_t *__restrict
 // bucket in LDS, reserves its share of every bucket with ONE global atomic, and places the points
 __global__ __launch_bounds__(256) void k_bucket_scatter(const int32_t *__restrict__ code, int64_t nrows, int64_t row_lo, int L1,
                                                         const int32_t *__restrict__ bucket_start, int32_t *__restrict__ bucket_cursor,
-                                                        int32_t *__restrict__ bucket_rows) {
+                                                        int32_t *__restrict__ bucket_rows, const float2 *__restrict__ nr, int metric,
+                                                        uint32_t *__restrict__ bucket_ab) {
+    // bucket_ab: the point's band constants (r_x + ACC |x|, |x| + r_x), each rounded UP to 16 bits (bf16), next to its id:
+    // read here in row order (coalesced); pass 2 would gather them one 128-byte line per 8 bytes
     __shared__ int cnt[256], base[256];
     const int t = blockIdx.y, nslots = 1 << L1;
     for (int q = threadIdx.x; q < nslots; q += 256) cnt[q] = 0;
@@ -1405,7 +1433,11 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const int32_t *__restric
         const int c = myc[it];
         if (c < 0) continue;
         const int64_t r = r0 + it * 256 + threadIdx.x;
-        bucket_rows[bucket_start[c] + base[c - t * nslots] + myr[it]] = (int32_t)(row_lo + r);
+        const int at = bucket_start[c] + base[c - t * nslots] + myr[it];
+        bucket_rows[at] = (int32_t)(row_lo + r);
+        const float2 nrv = nr[row_lo + r];
+        const float xnm = metric == 0 ? sqrtf(nrv.x) : nrv.x;
+        bucket_ab[at] = (rp_bf16_up(nrv.y + RP_ACC * xnm) << 16) | rp_bf16_up(xnm + nrv.y);
     }
 }
 
@@ -1493,9 +1525,9 @@ __global__ __launch_bounds__(1024) void k_route_bucket(const float *__restrict__
                                                       int64_t nrows, int L1, int chunk, const unsigned char *__restrict__ pack,
                                                       const float *__restrict__ node_hf, int hs, const int2 *__restrict__ items,
                                                       const int32_t *__restrict__ n_items, const int32_t *__restrict__ bucket_start,
-                                                      const int32_t *__restrict__ bucket_rows, int R, const int32_t *__restrict__ bt_cnt,
-                                                      const int32_t *__restrict__ bt_node, const unsigned char *__restrict__ bt_rec,
-                                                      const int32_t *__restrict__ bt_cell, uint32_t seed, int32_t *__restrict__ cell_count,
+                                                      const int32_t *__restrict__ bucket_rows, const uint32_t *__restrict__ bucket_ab, int R,
+                                                      const int32_t *__restrict__ bt_cnt, const int32_t *__restrict__ bt_node,
+                                                      const unsigned char *__restrict__ bt_rec, const int32_t *__restrict__ bt_cell, uint32_t seed, int32_t *__restrict__ cell_count,
                                                       int32_t *__restrict__ cell_of, int32_t *__restrict__ rank_of,
                                                       const float *__restrict__ scal) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sub_tab[];
@@ -1538,15 +1570,14 @@ __global__ __launch_bounds__(1024) void k_route_bucket(const float *__restrict__
             const int idx = r0 + pair;
             const bool on = idx < cnt_rows;
             const int64_t pi = bucket_rows[base + (on ? idx : 0)];
+            const uint32_t ab = bucket_ab[base + (on ? idx : 0)];
             uint4 xq[NC2];
             {
                 const uint4 *row = (const uint4 *)(xh + pi * dp);
 #pragma unroll
                 for (int q = 0; q < NC2; q++) xq[q] = row[sub + 2 * q];
             }
-            const float2 nrv = nr[pi];
-            const float xnorm = metric == 0 ? sqrtf(nrv.x) : nrv.x;
-            const float bA = nrv.y + RP_ACC * xnorm, bB = xnorm + nrv.y;
+            const float bA = __uint_as_float(ab & 0xFFFF0000u), bB = __uint_as_float(ab << 16);
             const int64_t slot = (int64_t)t * n + pi;
             int cur = on ? 0 : -1;  // >= 0: code of the node the walk stands at; -1: over
             int rk = -1;            // local cell << 16 | rank: the LDS atomic's return value is not touched before the walk is over
@@ -1919,7 +1950,7 @@ struct rp_route_io {
     int64_t row_lo, nrows;
     int64_t n_cells;          // cells of all T trees (sizes the subtree tables)
     int32_t *cell_count, *cell_of, *rank_of;
-    int32_t *code, *bucket_rows;  // scratch, T * nrows int32 each (coherent form only)
+    int32_t *code, *bucket_rows, *bucket_ab;  // scratch, T * nrows int32 each (coherent form only)
 };
 
 template <int NC, int TB>
@@ -2052,7 +2083,7 @@ static int launch_route_coherent(nnd_ctx *ctx, const rp_route_io &io, const rp_r
     }
     hipLaunchKernelGGL(k_bucket_prefix, dim3(1), dim3(256), 0, ctx->stream, bcount, g.nb, g.chunk, bstart, items, n_items, (int)g.max_items);
     hipLaunchKernelGGL(k_bucket_scatter, dim3((unsigned)((io.nrows + 4095) / 4096), (unsigned)io.T), dim3(256), 0, ctx->stream, io.code,
-                       io.nrows, io.row_lo, g.L1, bstart, bcursor, io.bucket_rows);
+                       io.nrows, io.row_lo, g.L1, bstart, bcursor, io.bucket_rows, ctx->nr2, ctx->p.metric, (uint32_t *)io.bucket_ab);
     const size_t smem2 = (size_t)g.R * rec + sizeof(int32_t) * 3 * (size_t)(g.R + 8) + sizeof(uint32_t) * (size_t)g.chunk;
     int per_cu = 0;
     NND_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kbkt, 1024, smem2));
@@ -2060,7 +2091,7 @@ static int launch_route_coherent(nnd_ctx *ctx, const rp_route_io &io, const rp_r
     int64_t blocks2 = (int64_t)n_cu * per_cu;
     if (blocks2 > g.max_items) blocks2 = g.max_items;
     hipLaunchKernelGGL(kbkt, dim3((unsigned)blocks2), dim3(1024), smem2, ctx->stream, ctx->xp, ctx->xh, ctx->nr2, ctx->p.metric, dp, ctx->n,
-                       io.row_lo, io.nrows, g.L1, g.chunk, io.pack, io.hf, hs, items, n_items, bstart, io.bucket_rows, g.R, bt_cnt, bt_node,
+                       io.row_lo, io.nrows, g.L1, g.chunk, io.pack, io.hf, hs, items, n_items, bstart, io.bucket_rows, (const uint32_t *)io.bucket_ab, g.R, bt_cnt, bt_node,
                        bt_rec, bt_cell, ctx->tree_seed, io.cell_count, io.cell_of, io.rank_of, ctx->mean + ctx->dp);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
@@ -2178,7 +2209,7 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     hipLaunchKernelGGL(k_iota_i32, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, roots, T, 0);
     // ctx->inv (segment table of the sample passes) and ctx->scan_out (the cell numbers: baked into the records by now)
     // are free: they hold the (tree, point) codes and the bucket-sorted point lists of the coherent form
-    rp_route_io io{ctx->node_pack, ctx->node_hfc, roots, T, 0, n, n_cells, ctx->cell_count, ctx->pos_seg[0], ctx->pos_seg[1], ctx->inv, ctx->scan_out};
+    rp_route_io io{ctx->node_pack, ctx->node_hfc, roots, T, 0, n, n_cells, ctx->cell_count, ctx->pos_seg[0], ctx->pos_seg[1], ctx->inv, ctx->scan_out, ctx->perm[1]};
     int rrc = 2;
     if (!(ctx->p.flags & NND_FLAG_TEST_ROUTE_PLAIN)) rrc = route_coherent(ctx, io);
     if (rrc == 2) rrc = route_plain(ctx, io, v);
