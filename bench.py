@@ -88,6 +88,100 @@ def exact_knn_sample(x, rows, k):
     return torch.gather(cand, 1, order)
 
 
+def clustered_gpu(n, d, latent, seed, device, nonneg):
+    """SURVEY.md section 8d generator of the other BASELINE configurations (C3': latent 24, seed 2; C5': latent 32, seed 4)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    centres = torch.randn(1024, latent, generator=g, device=device) * 3.0
+    proj = torch.randn(latent, d, generator=g, device=device) / latent ** 0.5
+    assign = torch.randint(0, 1024, (n,), generator=g, device=device)
+    x = (centres[assign] + torch.randn(n, latent, generator=g, device=device)) @ proj
+    x = x + 0.3 * torch.randn(n, d, generator=g, device=device)
+    if nonneg:
+        x = (x + 12.0).clamp_min(0) * 9.0
+    return x.contiguous()
+
+
+def exact_knn_cosine(x, rows, k):
+    """Exact cosine k-NN (self included) of the sampled rows: f32 pre-selection in chunks of 1M columns, float64 refinement."""
+    xn = x / x.norm(dim=1, keepdim=True)
+    q = xn[rows]
+    best_v = best_i = None
+    for c0 in range(0, x.shape[0], 1_000_000):
+        dch = 1.0 - q @ xn[c0:c0 + 1_000_000].T
+        tk = dch.topk(min(4 * k, dch.shape[1]), dim=1, largest=False)
+        best_v = tk.values if best_v is None else torch.cat([best_v, tk.values], 1)
+        best_i = tk.indices + c0 if best_i is None else torch.cat([best_i, tk.indices + c0], 1)
+    cand = torch.gather(best_i, 1, best_v.argsort(dim=1)[:, :4 * k])
+    qd, nb = x[rows].double(), x[cand].double()
+    dd = 1.0 - (qd[:, None, :] * nb).sum(-1) / (qd.norm(dim=1)[:, None] * nb.norm(dim=2))
+    return torch.gather(cand, 1, dd.argsort(dim=1)[:, :k])
+
+
+def gather_rows(x, world):
+    """All ranks' row blocks (row counts may differ by one), concatenated in rank order, on every rank."""
+    import torch.distributed as dist
+
+    host = dist.get_backend() == "gloo"  # (two processes sharing one GPU in the tests: staged through the host)
+    t = x.cpu() if host else x
+    cnt = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    cnts = [int(c.item()) for c in cnts]
+    pad = torch.zeros((max(cnts),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[:c] for o, c in zip(out, cnts)], dim=0).to(x.device)
+
+
+def other_config(_capi, name, device, local_rank):
+    """BASELINE configs[2] / configs[4] stand-ins (SURVEY 8d C3' / C5'): build time (device resident, best of 2 after a
+    warm-up), recall@10 against exact cosine search, and for C5' the graph diversification / prune pass."""
+    n, d, latent, seed, k, n_trees = {"c3": (1_200_000, 100, 24, 2, 15, 12), "c5": (290_000, 256, 32, 4, 15, 11)}[name]
+    x = clustered_gpu(n, d, latent, seed, device, False)
+    lim = np.iinfo(np.int32)
+    rs = np.random.RandomState(1)
+    rng_state = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
+    _ = rs.randint(lim.min + 1, lim.max - 1, 3)
+    ts = rs.randint(lim.min + 1, lim.max - 1, size=(n_trees, 3)).astype(np.int64)
+    b = _capi.Builder(n, d, _capi.NND_METRIC_ALT_COSINE, k, n_trees, max(60, min(256, 5 * k)), 200, min(60, k),
+                      max(5, int(round(np.log2(n)))), 0.001, rng_state, ts[0], device=local_rank)
+    oi = torch.empty((n, k), dtype=torch.int32, device=device)
+    od = torch.empty((n, k), dtype=torch.float32, device=device)
+    torch.cuda.synchronize()
+    best = None
+    for rep_ in range(3):
+        b.set_data_device(x.data_ptr(), keepalive=x)
+        b.synchronize()
+        t1 = time.perf_counter()
+        b.build_device(oi.data_ptr(), od.data_ptr())
+        b.synchronize()
+        dt = time.perf_counter() - t1
+        if rep_ > 0 and (best is None or dt < best):
+            best = dt
+    st = b.stats()
+    b.close()
+    rows = torch.from_numpy(np.random.RandomState(0).choice(n, 1000, replace=False)).to(device)
+    rec = recall_at(exact_knn_cosine(x, rows, 10), oi[rows], 10)
+    out = {"workload": {"c3": "BASELINE configs[2] stand-in (GloVe-like, SURVEY 8d C3'): %dx%d float32 cosine k=%d n_trees=%d",
+                        "c5": "BASELINE configs[4] stand-in (NYTimes-like, SURVEY 8d C5'): %dx%d float32 cosine k=%d n_trees=%d + "
+                              "graph diversification / prune pass"}[name] % (n, d, k, n_trees),
+           "value": round(n / best, 1), "ms_per_step": round(best * 1e3, 3), "iters": st["n_iters_run"], "recall_at_10": round(rec, 4),
+           "stage_ms": {"forest": round(st["ms_forest"], 3), "leaf_init": round(st["ms_leaf_init"], 3), "join": round(sum(st["ms_join"]), 3),
+                        "sample": round(sum(st["ms_sample"]), 3), "merge": round(sum(st["ms_merge"]), 3), "finalize": round(st["ms_finalize"], 3)}}
+    if name == "c5":
+        from pynndescent_amd.search_graph import build_search_graph
+
+        xh, gi, gd = x.cpu().numpy(), oi.cpu().numpy(), od.cpu().numpy()
+        t1 = time.perf_counter()
+        sg = build_search_graph(xh, gi, gd, "cosine", k)
+        out["prune_pass"] = {"ms": round((time.perf_counter() - t1) * 1e3, 2), "edges_in": int((gi >= 0).sum()), "edges_out": int(sg.nnz),
+                             "max_degree": int(np.diff(sg.indptr).max()),
+                             "what": "diversify + reverse diversify + degree prune (pynndescent_.py:1451-1611) on the GPU kernels, host arrays in / out"}
+    return out
+
+
 def recall_at(true_idx, approx_idx, k_true=10, cols=None):
     t = true_idx[:, :k_true].cpu().numpy()
     a = approx_idx.cpu().numpy() if cols is None else approx_idx[:, :cols].cpu().numpy()
@@ -205,6 +299,7 @@ def builder_dp(d):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no-one-gpu", action="store_true", help="N > 1: skip the one-GPU build of the same set (one_gpu_same_set / speedup)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points-per-gpu", dest="n", type=int, default=None)
@@ -251,7 +346,9 @@ def main():
     from pynndescent_amd import _capi, sharded
 
     d, k = args.dim, args.k
-    strong = world == 8 and args.n is None  # BASELINE configs[3]: one 10 M x 128 set over 8 GPUs
+    # N > 1: BASELINE configs[3] -- ONE 10 M x 128 set -- at every N (strong scaling: the curve over N = 2, 4, 8 is over the
+    # same work, and `one_gpu_same_set` gives its one-GPU time); --n selects weak scaling with n points per GPU instead
+    strong = world > 1 and args.n is None
     if strong:
         n_total = 10_000_000
         lo, hi = sharded.shard_ranges(n_total, world)[rank]
@@ -301,7 +398,7 @@ def main():
     else:
         # the rank's communicator: RCCL (nccl backend; only the 128-byte unique id travels through torch) -- the exchanges
         # themselves are issued by libpynnd_amd.so (ncclGroupStart / ncclSend / ncclRecv) on the build's HIP stream
-        comm = sharded.make_comm(local_rank)
+        comm = sharded.make_comm(local_rank, allow_host_fallback=False)  # a scaling run never becomes a host-staged one silently
         sb = sharded.ShardedBuilder(comm, shard_sizes, d, "euclidean", k, n_trees, seed=1234, device_index=local_rank)
         builder = None
         out_idx, out_dist = sb.out_idx, sb.out_dist
@@ -354,10 +451,29 @@ def main():
     value = n_total * args.steps / elapsed
 
     # recall vs exact brute force on a sample of this rank's rows (outside the timed region)
-    if world > 1:
-        x_all = torch.cat(sharded.TorchDistComm().all_gather_v(x), dim=0)
-    else:
-        x_all = x
+    x_all = gather_rows(x, world) if world > 1 else x
+    one_gpu = None
+    if world > 1 and rank == 0 and not args.no_one_gpu:
+        # the SAME set on one GPU (rank 0, outside the timed region): what the N-GPU time is a speed-up OVER
+        b1 = _capi.Builder(n_total, d, _capi.NND_METRIC_SQEUCLIDEAN, k, n_trees, leaf_size, 200, min(60, k), n_iters, 0.001, rng_state,
+                           tree_states[0], device=local_rank)
+        o1i = torch.empty((n_total, k), dtype=torch.int32, device=device)
+        o1d = torch.empty((n_total, k), dtype=torch.float32, device=device)
+        torch.cuda.synchronize()
+        b1.set_data_device(x_all.data_ptr(), keepalive=x_all)
+        b1.build_device(o1i.data_ptr(), o1d.data_ptr())  # warm-up
+        b1.synchronize()
+        t1 = time.perf_counter()
+        b1.set_data_device(x_all.data_ptr(), keepalive=x_all)
+        b1.build_device(o1i.data_ptr(), o1d.data_ptr())
+        b1.synchronize()
+        dt1 = time.perf_counter() - t1
+        rs1 = torch.from_numpy(np.random.RandomState(0).choice(n, size=min(2000, n), replace=False)).to(device)
+        one_gpu = {"ms": round(dt1 * 1e3, 3), "value": round(n_total / dt1, 1), "iters": b1.stats()["n_iters_run"],
+                   "recall_at_10": round(recall_at(exact_knn_sample(x_all, rs1, 10), o1i[rs1], 10), 4),
+                   "what": "the same %d points built by ONE GPU (rank 0's), same parameters, timed once after a warm-up build" % n_total}
+        b1.close()
+        del o1i, o1d
     if rank == 0:
         rsmp = np.random.RandomState(0)
         rows_np = rsmp.choice(n, size=min(2000, n), replace=False)
@@ -439,7 +555,7 @@ def main():
                                  "parts_gb": {"tree": round(b_tree / 1e9, 2), "leaf": round(b_leaf / 1e9, 2),
                                               "iters": round(b_iter / 1e9, 2), "final": round(b_final / 1e9, 2)}}
 
-        cpu = host_incl = hard = cls_api = k30 = None
+        cpu = host_incl = hard = cls_api = k30 = c3 = c5 = None
         if world == 1 and not args.no_extras:
             x_host = x.cpu().numpy()
             host_incl = host_inclusive(_capi, x_host, k, n_trees, leaf_size, n_iters, rng_state, tree_states[0], local_rank)
@@ -467,6 +583,16 @@ def main():
                        "stage_ms": {"forest": round(s30["ms_forest"], 3), "leaf_init": round(s30["ms_leaf_init"], 3),
                                     "join": round(sum(s30["ms_join"]), 3), "sample": round(sum(s30["ms_sample"]), 3),
                                     "merge": round(sum(s30["ms_merge"]), 3), "finalize": round(s30["ms_finalize"], 3)}}
+                # the same roofline arithmetic as the headline's: algorithmic bytes (candidate rows gathered / leaf rows
+                # loaded, x 4 dp) over the stage's HIP-event time, against 8 TB/s
+                j_gbs = sum(s30["join_rows"]) * row / (sum(s30["ms_join"]) * 1e-3) / 1e9 if sum(s30["ms_join"]) > 0 else 0.0
+                l_gbs = s30["leaf_rows"] * row / (s30["ms_leaf_init"] * 1e-3) / 1e9 if s30["ms_leaf_init"] > 0 else 0.0
+                k30["roofline"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "k_local_join_w": {"achieved": round(j_gbs, 2), "frac": round(j_gbs / HBM_PEAK_GBS, 5),
+                                                      "bytes_per_build": round(sum(s30["join_rows"]) * row),
+                                                      "pairs_per_row": round(sum(s30["join_pairs"]) / max(sum(s30["join_rows"]), 1), 2)},
+                                   "k_leaf_join_rb": {"achieved": round(l_gbs, 2), "frac": round(l_gbs / HBM_PEAK_GBS, 5),
+                                                      "bytes_per_build": round(s30["leaf_rows"] * row)}}
                 b30.close()
                 del o_i, o_d
             if args.latent == 16 and args.data is None:  # second perf line: same generator, latent dimension 48 (converges slowly)
@@ -491,6 +617,11 @@ def main():
                                      "join": round(sum(sth["ms_join"]), 3), "sample": round(sum(sth["ms_sample"]), 3),
                                      "merge": round(sum(sth["ms_merge"]), 3), "finalize": round(sth["ms_finalize"], 3)}}
                 del xh
+        if world == 1 and not args.no_extras and args.latent == 16 and args.data is None:
+            builder.close()  # (its HBM is not needed any more; the other configurations get the GPU to themselves)
+            _capi.load_library().nnd_release_pending()
+            c3 = other_config(_capi, "c3", device, local_rank)
+            c5 = other_config(_capi, "c5", device, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O  # test infrastructure: the cpu_baseline leg only
 
@@ -519,10 +650,13 @@ def main():
             "data": "synthetic" if data_name is None else "file:" + data_name,
             "config": {"workload": workload,
                        "parallelism": "1 GPU" if world == 1 else
-                       "rows sharded over %d GPUs (one global index of %d points): point set all-gathered once, forest split "
-                       "by tree, per iteration threshold all-gather + reverse-offer all-to-all-v + proposal all-to-all-v, the "
-                       "update counts riding on the record-count exchange; ncclSend/ncclRecv groups issued by libpynnd_amd.so "
-                       "on the build's stream (%s transport)" % (world, n_total, {"rccl": "RCCL", "host": "HOST-staged over gloo (debug / fallback)"}.get(comm.transport, comm.transport)),
+                       "rows sharded over %d GPUs (one global index of %d points): point set all-gathered once (second channel, "
+                       "behind the forest's first steps), forest %s, per iteration threshold all-gather + reverse-offer "
+                       "all-to-all-v + proposal all-to-all-v, the update counts riding on the record-count exchange; "
+                       "ncclSend/ncclRecv groups issued by libpynnd_amd.so on the build's stream (%s transport)"
+                       % (world, n_total, "sharded by cell" if (info or {}).get("forest_by_cell") else "split by tree",
+                          {"rccl": "RCCL", "host": "HOST-staged over gloo (debug: two processes sharing one GPU)"}.get(comm.transport, comm.transport)),
+                       "comm": None if world == 1 else comm.info(),
                        "join_blocks": args.join_blocks},
             "recall_at_10": round(rec_all, 4),
             "recall_at_10_strict_first10": round(rec_strict, 4),
@@ -538,12 +672,17 @@ def main():
             "exchanged_records_rank0": None if info is None else info["exchanged_records"],
             "shard_rank0": None if info is None else {kk: info[kk] for kk in ("c", "offer_records", "proposal_records", "deferred",
                                                                                 "dropped_offers", "bytes_sent", "ms_total",
-                                                                                "ms_allgather", "ms_klist_exchange", "local_trees")},
+                                                                                "ms_allgather", "ms_klist_exchange", "local_trees",
+                                                                                "forest_by_cell", "forest_positions")},
+            "one_gpu_same_set": one_gpu,
+            "speedup": None if one_gpu is None else round(one_gpu["ms"] / ms_per_step, 3),
             "roofline": roofline,
             "value_host_inclusive": host_incl,
             "value_class_api": cls_api,
             "workload_hard": hard,
             "workload_k30": k30,
+            "workload_c3": c3,
+            "workload_c5": c5,
             "cpu_baseline": cpu,
         }
         print(json.dumps(result))
@@ -552,7 +691,7 @@ def main():
         sb.close()
         comm.close()
     else:
-        builder.close()
+        builder.close()  # (idempotent: the extras may have released it already)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -41,7 +41,7 @@ extern "C" {
 #define NND_METRIC_SQEUCLIDEAN 0 /* reference distances.py:63  squared_euclidean  */
 #define NND_METRIC_ALT_COSINE 1  /* reference distances.py:583 alternative_cosine */
 
-#define NND_ABI_VERSION 3
+#define NND_ABI_VERSION 4
 
 typedef struct nnd_handle_s *nnd_handle_t;
 
@@ -83,6 +83,13 @@ typedef struct nnd_params {
 /* test hook: the rp forest's routing pass as ONE walk per (tree, point) through global memory (the round-2 kernel)
  * instead of the two coherent passes; the two assign every point to the same cell (tests/test_gpu_kernels.py) */
 #define NND_FLAG_TEST_ROUTE_PLAIN 16
+/* test hooks of the row-sharded build (tests/test_gpu_sharded.py): the forest split by tree (the round-3 scheme) where it
+ * would be sharded by cell; a rank that FAILS at the start of its second iteration (error return: the other ranks must
+ * return an error too, promptly); a rank that VANISHES there (returns without telling anybody, as a killed process
+ * would: the other ranks must give up after the communicator's timeout) */
+#define NND_FLAG_TEST_FOREST_BY_TREE 32
+#define NND_FLAG_TEST_FAIL 64
+#define NND_FLAG_TEST_VANISH 128
 
 /* Run-time statistics for measurement (bench.py roofline). */
 typedef struct nnd_stats {
@@ -202,9 +209,12 @@ int32_t nnd_pairwise_gram(nnd_handle_t h, const int32_t *rows_a, int32_t na, con
  * The reference is single-process; its sharding idea is the owner-computes rule of apply_graph_update_array /
  * new_build_candidates / init_rp_tree (utils.py:709-731, 259-306; pynndescent_.py:154-185: each thread owns a contiguous
  * vertex range) and its knob is n_jobs (pynndescent_.py:1141-1143).  Here the same rule crosses GPUs: rank r owns rows
- * [lo_r, hi_r) of the k-lists; the point set is replicated once (all-gather over xGMI: candidate vectors never travel
- * again); the forest is split by tree (rank r builds its share of the trees over all points and seeds every row from
- * them; partial k-list rows go to their owners and are merged there); per NN-descent iteration
+ * [lo_r, hi_r) of the k-lists; the point set is replicated once (all-gather over xGMI, on a second channel behind the
+ * forest's first steps: candidate vectors never travel again); the forest is sharded BY CELL -- rank r builds the top of
+ * its share of the trees on the global sample, the packed tops are all-gathered, every rank routes ITS rows through ALL
+ * trees, the (cell, row) pairs go to the rank that owns the cell (1 / G of every tree's cells), which finishes the cells
+ * and seeds the k-lists from their leaves; partial k-list rows go to their owners and are merged there (small point sets:
+ * split by tree).  The forest is the single-GPU forest whatever the number of ranks.  Per NN-descent iteration
  *   (1) all-gather of the thresholds, 4 bytes per row, and -- while the lists still change much -- of the neighbour ids;
  *   (2) reverse-offer all-to-all-v of 8-byte records (the cross-process form of the ownership test utils.py:266-273);
  *   (3) local sampling + join of the owned vertices; (4) proposal all-to-all-v of 12-byte records, owner-side merge
@@ -227,8 +237,19 @@ int32_t nnd_comm_create_local(nnd_comm_t *out /* [world] */, int32_t world, cons
 typedef int32_t (*nnd_host_exchange_fn)(void *user, const void *send, const int64_t *send_off, const int64_t *send_bytes,
                                         void *recv, const int64_t *recv_off, const int64_t *recv_bytes);
 int32_t nnd_comm_create_host(nnd_comm_t *out, int32_t world, int32_t rank, int32_t device, nnd_host_exchange_fn fn, void *user);
+/* Second channel of an RCCL communicator (its own ncclComm_t from a second unique id, its own stream): the point-set
+ * all-gather runs on it while the build's stream works.  Collective: every rank calls it (or none).  LOCAL communicators
+ * are created with theirs; HOST has none (the transfer then runs on the build's channel). */
+int32_t nnd_comm_add_channel_rccl(nnd_comm_t c, const void *id /* a second id from nnd_comm_unique_id */);
+/* Failure handling.  Every host wait of a build polls the communicator: a rank whose peer failed (ranks of one process
+ * share a flag: LOCAL, nnd_build_multi) or that has waited longer than the timeout (default 120 s; the only signal
+ * between processes) gives up -- ncclCommAbort on its communicators, error return -- instead of blocking in a collective
+ * for ever.  nnd_comm_abort makes THIS rank give up (and tells the ranks of its process). */
+int32_t nnd_comm_set_timeout(nnd_comm_t c, int64_t timeout_ms);
 int32_t nnd_comm_destroy(nnd_comm_t c);
-int32_t nnd_comm_abort(nnd_comm_t c); /* LOCAL: a rank failed -- release the ranks waiting for it */
+int32_t nnd_comm_abort(nnd_comm_t c);
+/* out[0] transport (1 RCCL, 2 LOCAL, 3 HOST), out[1] ranks, out[2] ncclGetVersion() (0 unless RCCL), out[3] second channel present */
+int32_t nnd_comm_info(nnd_comm_t c, int32_t *out /* [4] */);
 /* LOCAL only: compute sections of the ranks run one at a time (per-rank timings on a shared GPU; tools/rank_critical_path.py) */
 int32_t nnd_comm_local_set_serial(nnd_comm_t c, int32_t on);
 const char *nnd_comm_last_error(nnd_comm_t c /* NULL: the error of a failed create */);
@@ -251,6 +272,9 @@ typedef struct nnd_shard_info {
     int32_t n_sections;           /* compute sections of the last build (timeline below) */
     float section_ms[256];        /* LOCAL serial mode: GPU time of each compute section of this rank, in program order */
     int64_t section_bytes[256];   /* payload bytes this rank sent in the exchange that FOLLOWS the section */
+    int32_t forest_by_cell;       /* 1: forest sharded by cell, 0: split by tree */
+    int32_t n_sections_overlap;   /* the first sections of the build that need only this rank's rows: the point-set all-gather runs beside them */
+    int64_t forest_positions;     /* point-trees this rank finished and seeded (forest by cell: ~ n_trees * n / ranks) */
 } nnd_shard_info;
 int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, nnd_comm_t comm, const int64_t *shard_sizes);
 /* x_local_dev: this rank's rows, float32 (n_local, dim) on its GPU, complete when the call is made (or produced on
@@ -259,6 +283,8 @@ int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, nnd_comm_t 
 int32_t nnd_shard_build(nnd_shard_t s, const float *x_local_dev, void *x_stream, int32_t *out_idx_dev, float *out_dist_dev);
 int32_t nnd_shard_get_info(nnd_shard_t s, nnd_shard_info *out);
 int32_t nnd_shard_get_stats(nnd_shard_t s, nnd_stats *out); /* this rank's kernels */
+/* the rank's builder handle (tests: nnd_leaf_array_shape / nnd_get_leaf_array give the leaves this rank seeded from) */
+nnd_handle_t nnd_shard_handle(nnd_shard_t s);
 int32_t nnd_shard_destroy(nnd_shard_t s);
 const char *nnd_shard_last_error(nnd_shard_t s /* NULL: the error of a failed create */);
 

@@ -18,6 +18,9 @@ NND_FLAG_NO_PREP = 2   # ... and no prepared copy of the rows (hub tree only)
 NND_FLAG_TEST_SELECT_WAVE = 4  # test hook: the one-wave-per-vertex selection kernel
 NND_FLAG_TEST_SMALL_REGIONS = 8  # test hook (sharded build): tiny proposal regions, so that records are deferred
 NND_FLAG_TEST_ROUTE_PLAIN = 16  # test hook: the forest's routing pass as one walk per (tree, point) through global memory
+NND_FLAG_TEST_FOREST_BY_TREE = 32  # test hook (sharded build): forest split by tree where it would be sharded by cell
+NND_FLAG_TEST_FAIL = 64  # test hook (sharded build): this rank returns an error at the start of its second iteration
+NND_FLAG_TEST_VANISH = 128  # ... or returns there without telling anybody (a killed process)
 
 
 class NNDParams(C.Structure):
@@ -97,6 +100,9 @@ class NNDShardInfo(C.Structure):
         ("n_sections", C.c_int32),
         ("section_ms", C.c_float * 256),
         ("section_bytes", C.c_int64 * 256),
+        ("forest_by_cell", C.c_int32),
+        ("n_sections_overlap", C.c_int32),
+        ("forest_positions", C.c_int64),
     ]
 
     def as_dict(self):
@@ -111,7 +117,9 @@ class NNDShardInfo(C.Structure):
                 "bytes_sent": int(self.bytes_sent), "ms_total": float(self.ms_total),
                 "ms_allgather": float(self.ms_allgather), "ms_klist_exchange": float(self.ms_klist_exchange),
                 "section_ms": [float(v) for v in self.section_ms[:ns]],
-                "section_bytes": [int(v) for v in self.section_bytes[:ns]]}
+                "section_bytes": [int(v) for v in self.section_bytes[:ns]],
+                "forest_by_cell": bool(self.forest_by_cell), "n_sections_overlap": int(self.n_sections_overlap),
+                "forest_positions": int(self.forest_positions)}
 
 
 HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
@@ -173,6 +181,9 @@ _SIGNATURES = [
     ("nnd_comm_create_rccl", C.c_int32, [C.POINTER(_H), C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     ("nnd_comm_create_local", C.c_int32, [C.POINTER(_H), C.c_int32, C.c_void_p]),
     ("nnd_comm_create_host", C.c_int32, [C.POINTER(_H), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("nnd_comm_add_channel_rccl", C.c_int32, [_H, C.c_void_p]),
+    ("nnd_comm_set_timeout", C.c_int32, [_H, C.c_int64]),
+    ("nnd_comm_info", C.c_int32, [_H, C.POINTER(C.c_int32)]),
     ("nnd_comm_destroy", C.c_int32, [_H]),
     ("nnd_comm_abort", C.c_int32, [_H]),
     ("nnd_comm_local_set_serial", C.c_int32, [_H, C.c_int32]),
@@ -181,6 +192,7 @@ _SIGNATURES = [
     ("nnd_shard_build", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nnd_shard_get_info", C.c_int32, [_H, C.POINTER(NNDShardInfo)]),
     ("nnd_shard_get_stats", C.c_int32, [_H, C.POINTER(NNDStats)]),
+    ("nnd_shard_handle", _H, [_H]),
     ("nnd_shard_destroy", C.c_int32, [_H]),
     ("nnd_shard_last_error", C.c_char_p, [_H]),
     ("nnd_build_multi", C.c_int32, [C.POINTER(NNDParams), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

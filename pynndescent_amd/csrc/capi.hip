@@ -109,7 +109,7 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
     if (p->metric != NND_METRIC_SQEUCLIDEAN && p->metric != NND_METRIC_ALT_COSINE) { gerr("nnd_create: unknown metric %d", p->metric); return 1; }
     if (p->n_neighbors < 1 || p->n_neighbors > 128) { gerr("nnd_create: n_neighbors must be in 1..128 (got %d)", p->n_neighbors); return 1; }
     if (p->max_candidates < 1 || p->max_candidates > 64) { gerr("nnd_create: max_candidates must be in 1..64 (got %d)", p->max_candidates); return 1; }
-    if (p->n_trees < 0 || p->leaf_size < 1) { gerr("nnd_create: bad n_trees/leaf_size"); return 1; }
+    if (p->n_trees < 0 || p->n_trees > 4096 || p->leaf_size < 1) { gerr("nnd_create: bad n_trees (0..4096) / leaf_size"); return 1; }
     if (p->n >= (int64_t)0x7FFFFFF0) { gerr("nnd_create: n too large for int32 ids"); return 1; }
     if (p->n_trees > 0 && (int64_t)p->n_trees * p->n >= (int64_t)0x7FFFFFF0) {
         gerr("nnd_create: n_trees * n = %lld exceeds the forest's int32 position space (2^31)", (long long)((int64_t)p->n_trees * p->n));
@@ -278,8 +278,9 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
             if ((rc = dalloc(ctx, &ctx->seg_child, 5 * S))) break;  // child ids (2S) + finisher work list (3S)
             if ((rc = dalloc(ctx, &ctx->hyper, S * (size_t)(ctx->dp + 4)))) break;
             if ((rc = dalloc(ctx, &ctx->hyper_h, S * (size_t)ctx->dp))) break;
-            if ((rc = dalloc(ctx, &ctx->tree_begin_dev, (size_t)p->n_trees + 1))) break;
-            if (hipHostMalloc((void **)&ctx->h_tree_begin, sizeof(long long) * ((size_t)p->n_trees + 1), hipHostMallocDefault) != hipSuccess) { ctx->set_error("hipHostMalloc failed"); rc = 1; break; }
+            // (sized for any tree count: a shard finishes cells of ALL the build's trees, whatever its own allocation)
+            if ((rc = dalloc(ctx, &ctx->tree_begin_dev, (size_t)4097))) break;
+            if (hipHostMalloc((void **)&ctx->h_tree_begin, sizeof(long long) * (size_t)4097, hipHostMallocDefault) != hipSuccess) { ctx->set_error("hipHostMalloc failed"); rc = 1; break; }
         }
     } while (0);
     if (rc) {

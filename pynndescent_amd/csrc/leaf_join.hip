@@ -578,7 +578,7 @@ static int run_leaf_rounds(nnd_ctx *ctx, const int32_t *perm, const int32_t *d_w
 
 int nnd_launch_leaf_init(nnd_ctx *ctx) {
     if (!ctx->forest_built || ctx->n_leaves == 0) return 0;
-    const int T = ctx->p.n_trees;
+    const int T = (int)ctx->tree_leaf_begin.size() - 1;  // rounds: the handle's trees, or every tree of a sharded build
     // Work list = the leaf table itself (device resident, per-tree offsets known from the forest build) unless some
     // leaf is longer than LEAF_MAX: only then are the pieces listed on the host and uploaded.
     const int32_t *d_ws = ctx->leaf_start, *d_wl = ctx->leaf_len;

@@ -963,9 +963,14 @@ __global__ void k_leaf_lens(const int32_t *__restrict__ leaf_start, int64_t n_le
     if (nnd_lane() == 0 && len > 0) atomicMax(max_len, len);  // one atomic per wave
 }
 // first leaf index of every tree = the exclusive leaf-flag scan at the tree's first position
-__global__ void k_tree_leaf_begin(const int32_t *__restrict__ scan, int n_trees, int64_t n, long long *__restrict__ out) {
+__global__ void k_tree_leaf_begin(const int32_t *__restrict__ scan, int n_trees, int64_t n, const int32_t *__restrict__ tree_begin,
+                                  int64_t P, int32_t n_leaves, long long *__restrict__ out) {
+    // tree t starts at position t * n, or at tree_begin[t] (sharded build: a rank's own cells of every tree); a tree that
+    // holds no position here starts where the next one does
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_trees) out[t] = scan[(int64_t)t * n];
+    if (t >= n_trees) return;
+    const int64_t g = tree_begin ? tree_begin[t] : (int64_t)t * n;
+    out[t] = g < P ? scan[g] : n_leaves;
 }
 __global__ void k_fill_leaf_array(const int32_t *__restrict__ perm, const int32_t *__restrict__ leaf_start,
                                   const int32_t *__restrict__ leaf_len, int64_t n_leaves, int max_leaf,
@@ -2221,35 +2226,13 @@ static int forest_by_routing(nnd_ctx *ctx, int *levels_out) {
     return 0;
 }
 
-int nnd_launch_forest(nnd_ctx *ctx) {
-    const int64_t n = ctx->n, P = ctx->P;
-    const int T = ctx->p.n_trees, leaf_size = ctx->p.leaf_size;
-    ctx->forest_built = false;
-    ctx->n_leaves = 0;
-    ctx->max_leaf = leaf_size;
-    ctx->tree_leaf_begin.clear();
-    ctx->stats.n_cells = 0;
-    if (T <= 0) return 0;
-    if (P >= (int64_t)0x7FFFFFF0) {
-        ctx->set_error("n_trees * n = %lld exceeds the int32 position space", (long long)P);
-        return 1;
-    }
+// leaf tables of a finished position space [0, P): leaves = runs between leaf marks; tree t's leaves are those from
+// position t * n (tree_begin == nullptr) or tree_begin[t] on
+static int forest_leaf_tables(nnd_ctx *ctx, int64_t P, int T, const int32_t *tree_begin_dev) {
+    const int64_t n = ctx->n;
+    const int leaf_size = ctx->p.leaf_size;
     int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);  // device scratch word(s)
     unsigned gridP = (unsigned)((P + 255) / 256);
-    int levels = 0, rc = 2;
-    if (ctx->s_m > 0) rc = forest_by_routing(ctx, &levels);
-    if (nnd_knob("NND_FOREST_DEBUG"))
-        fprintf(stderr, "forest: n=%lld T=%d s_m=%lld routing rc=%d levels=%d node_cap=%lld cell_cap=%lld max_segs=%lld\n", (long long)n, T,
-                (long long)ctx->s_m, rc, levels, (long long)ctx->node_cap, (long long)ctx->cell_cap, (long long)ctx->max_segs);
-    if (rc == 1) return 1;
-    if (rc == 2) {  // small point set, very wide rows, or the recorded tree outgrew its tables: whole-set passes
-        forest_view v{ctx->xp, ctx->xh, ctx->nr2, n, P, leaf_size, FIN_MAX, false};
-        if (forest_levels(ctx, v)) return 1;
-        ctx->cur = v.cur;
-        levels = v.depth;
-    }
-    ctx->stats.tree_levels = levels;
-    // leaf tables
     if (run_scan(ctx, 1, nullptr, ctx->leaf_flag, scan_total, P, n)) return 1;
     NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 35, scan_total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     NND_HIP_CHECK(nnd_sync_spin(ctx));
@@ -2268,9 +2251,11 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     // (the full tables are fetched lazily, only when a leaf has to be cut or the caller asks for the leaf array)
     int32_t *max_len_dev = (int32_t *)(ctx->counters + CNT_SCRATCH + 2);
     NND_HIP_CHECK(hipMemsetAsync(max_len_dev, 0, sizeof(long long), ctx->stream));
+    // (every tree's first position starts a leaf, so a leaf never crosses a tree boundary; with tree_begin the clamp of
+    // k_leaf_lens to t * n boundaries is switched off by handing it one "tree" of P positions)
     hipLaunchKernelGGL(k_leaf_lens, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream, ctx->leaf_start,
-                       (int64_t)nl, n, P, ctx->leaf_len, max_len_dev);
-    hipLaunchKernelGGL(k_tree_leaf_begin, dim3((T + 63) / 64), dim3(64), 0, ctx->stream, ctx->scan_out, T, n, ctx->tree_begin_dev);
+                       (int64_t)nl, tree_begin_dev ? P : n, P, ctx->leaf_len, max_len_dev);
+    hipLaunchKernelGGL(k_tree_leaf_begin, dim3((T + 63) / 64), dim3(64), 0, ctx->stream, ctx->scan_out, T, n, tree_begin_dev, P, nl, ctx->tree_begin_dev);
     NND_HIP_CHECK(hipGetLastError());
     NND_HIP_CHECK(hipMemcpyAsync(ctx->h_tree_begin, ctx->tree_begin_dev, sizeof(long long) * T, hipMemcpyDeviceToHost, ctx->stream));
     NND_HIP_CHECK(hipMemcpyAsync(ctx->h_pin + 36, max_len_dev, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -2285,6 +2270,210 @@ int nnd_launch_forest(nnd_ctx *ctx) {
     ctx->stats.n_leaves = nl;
     ctx->forest_built = true;
     return 0;
+}
+
+int nnd_launch_forest(nnd_ctx *ctx) {
+    const int64_t n = ctx->n, P = ctx->P;
+    const int T = ctx->p.n_trees, leaf_size = ctx->p.leaf_size;
+    ctx->forest_built = false;
+    ctx->n_leaves = 0;
+    ctx->max_leaf = leaf_size;
+    ctx->tree_leaf_begin.clear();
+    ctx->stats.n_cells = 0;
+    if (T <= 0) return 0;
+    if (P >= (int64_t)0x7FFFFFF0) {
+        ctx->set_error("n_trees * n = %lld exceeds the int32 position space", (long long)P);
+        return 1;
+    }
+    int levels = 0, rc = 2;
+    if (ctx->s_m > 0) rc = forest_by_routing(ctx, &levels);
+    if (nnd_knob("NND_FOREST_DEBUG"))
+        fprintf(stderr, "forest: n=%lld T=%d s_m=%lld routing rc=%d levels=%d node_cap=%lld cell_cap=%lld max_segs=%lld\n", (long long)n, T,
+                (long long)ctx->s_m, rc, levels, (long long)ctx->node_cap, (long long)ctx->cell_cap, (long long)ctx->max_segs);
+    if (rc == 1) return 1;
+    if (rc == 2) {  // small point set, very wide rows, or the recorded tree outgrew its tables: whole-set passes
+        forest_view v{ctx->xp, ctx->xh, ctx->nr2, n, P, leaf_size, FIN_MAX, false};
+        if (forest_levels(ctx, v)) return 1;
+        ctx->cur = v.cur;
+        levels = v.depth;
+    }
+    ctx->stats.tree_levels = levels;
+    return forest_leaf_tables(ctx, P, T, nullptr);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The forest of the row-sharded build, sharded BY CELL (shard.hip drives the sequence; every rank runs it):
+//   tops      rank r builds the top of ITS trees (split by tree) on the GLOBAL sample -- hashes keyed by the global tree
+//             number and position (forest_view::tree_bias), so the forest does not depend on the number of ranks;
+//   pack      the recorded nodes, compacted and rebased, go into this rank's slice of the table of ALL trees
+//             (all-gathered by the caller), cells renumbered owner-major;
+//   route     every rank routes ITS rows through ALL trees (coherent passes);
+//   (the caller sends every (cell, row) pair to the rank that owns the cell)
+//   finish    the owner places the rows of its cells, finishes them down to leaves and builds the leaf tables.
+// Balanced whatever n_trees mod n_ranks is; no rank touches more than T * n / G point-trees after the tops.
+int nnd_forest_sample_gather(nnd_ctx *ctx, int64_t j_lo, int64_t j_hi) {
+    if (j_hi <= j_lo) return 0;
+    hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)((j_hi - j_lo + 15) / 16)), dim3(256), 0, ctx->stream, ctx->xp, ctx->xh, ctx->nr2,
+                       ctx->dp, j_lo, j_hi, ctx->s_stride, ctx->tree_seed, ctx->xs, ctx->xsh, ctx->nr2s);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void k_tree_cell_begin(const int32_t *__restrict__ leafscan, int T, int64_t M, int32_t *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) out[t] = leafscan[(int64_t)t * M];
+}
+
+int nnd_forest_tops(nnd_ctx *ctx, int T_loc, int tree_bias, nnd_tops_info *out) {
+    out->n_packed = 0;
+    out->n_cells = 0;
+    out->levels = 0;
+    out->n_low = out->high_lo = 0;
+    if (T_loc <= 0) return 0;
+    const int64_t M = ctx->s_m;
+    forest_view v{ctx->xs, ctx->xsh, ctx->nr2s, M, (int64_t)T_loc * M, ctx->cell_leaf, FIN_SMALL, true};
+    v.T = T_loc;
+    v.tree_bias = tree_bias;
+    int32_t n_cells = 0;
+    const int rc = forest_tops(ctx, v, &n_cells);
+    if (rc == 2) { ctx->set_error("rp-forest (sharded): the recorded tree tops outgrew their tables"); return 1; }
+    if (rc) return rc;
+    // first cell of every local tree (cells are numbered tree-major): per-tree cell counts for the owner-major renumbering
+    int32_t *tcb = ctx->route_roots + 2048;  // scratch words behind the root table
+    hipLaunchKernelGGL(k_tree_cell_begin, dim3((T_loc + 63) / 64), dim3(64), 0, ctx->stream, ctx->scan_out, T_loc, M, tcb);
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->h_tree_begin, tcb, sizeof(int32_t) * T_loc, hipMemcpyDeviceToHost, ctx->stream));
+    NND_HIP_CHECK(nnd_sync_spin(ctx));
+    const int32_t *hb = (const int32_t *)ctx->h_tree_begin;
+    for (int t = 0; t < T_loc; t++) out->tree_cells[t] = (t + 1 < T_loc ? hb[t + 1] : n_cells) - hb[t];
+    out->n_cells = n_cells;
+    out->n_low = v.n_low;
+    out->high_lo = v.high_lo;
+    out->n_packed = v.n_low + (ctx->node_cap - v.high_lo);
+    out->levels = v.depth;
+    return 0;
+}
+
+int nnd_forest_tops_pack(nnd_ctx *ctx, const nnd_tops_info *ti, int64_t node_base, const int32_t *cell_gid_dev, unsigned char *pack_dst,
+                         float *hf_dst) {
+    if (ti->n_packed <= 0) return 0;
+    rp_pack_map mp{ti->n_low, ti->high_lo, (int)node_base, 0, cell_gid_dev};
+    hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)((ti->n_packed + 15) / 16)), dim3(256), 0, ctx->stream, ctx->node_hh, ctx->node_hf,
+                       ctx->dp + 4, ctx->node_child, ctx->scan_out, ctx->dp, ti->n_packed, mp, pack_dst, hf_dst);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int nnd_forest_route_rows(nnd_ctx *ctx, const unsigned char *pack_all, const float *hf_all, const int32_t *roots_dev, int T_all,
+                          int64_t row_lo, int64_t nrows, int64_t n_cells_all, int32_t *cell_count_all) {
+    if (nrows <= 0 || T_all <= 0) return 0;
+    if ((int64_t)T_all * nrows > ctx->P) { ctx->set_error("rp-forest (sharded): %d trees x %lld rows exceed the position space of %lld", T_all, (long long)nrows, (long long)ctx->P); return 1; }
+    rp_route_io io{pack_all, hf_all, roots_dev, T_all, row_lo, nrows, n_cells_all, cell_count_all, ctx->pos_seg[0], ctx->pos_seg[1], ctx->inv, ctx->scan_out, ctx->perm[1]};
+    const int rc = route_coherent(ctx, io);
+    if (rc == 2) { ctx->set_error("rp-forest (sharded): the routing passes do not support this row width"); return 1; }
+    return rc;
+}
+
+// (cell, row) records of this rank's rows, ordered by cell: rec_pos = cell_scan[cell] + the row's slot in the cell
+__global__ void k_route_records(const int32_t *__restrict__ cell_of, const int32_t *__restrict__ rank_of, const int32_t *__restrict__ cell_scan,
+                                int64_t nrows, int64_t row_lo, int32_t *__restrict__ rec_cell, int32_t *__restrict__ rec_row) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const int64_t slot = (int64_t)blockIdx.y * nrows + r;
+    const int c = cell_of[slot];
+    const int at = cell_scan[c] + rank_of[slot];
+    rec_cell[at] = c;
+    rec_row[at] = (int32_t)(row_lo + r);
+}
+// records sorted by cell + the record offset of every destination rank's first cell (dest_cell[q], q = 0 .. G)
+__global__ void k_dest_offsets(const int32_t *__restrict__ cell_scan, const int32_t *__restrict__ dest_cell, int G, int32_t n_cells_all,
+                               const int32_t *__restrict__ total, long long *__restrict__ out) {
+    const int q = threadIdx.x;
+    if (q > G) return;
+    const int c = dest_cell[q];
+    const long long at = c < n_cells_all ? cell_scan[c] : total[0];
+    out[q] = at;
+}
+int nnd_forest_route_records(nnd_ctx *ctx, int T_all, int64_t row_lo, int64_t nrows, int32_t n_cells_all, int32_t *cell_count_all /* in: counts, out: exclusive scan */,
+                             const int32_t *dest_cell_dev, int G, int32_t *rec_cell, int32_t *rec_row, long long *dest_off_dev) {
+    int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, cell_count_all, (int)n_cells_all, scan_total);
+    if (nrows > 0)
+        hipLaunchKernelGGL(k_route_records, dim3((unsigned)((nrows + 255) / 256), (unsigned)T_all), dim3(256), 0, ctx->stream, ctx->pos_seg[0],
+                           ctx->pos_seg[1], cell_count_all, nrows, row_lo, rec_cell, rec_row);
+    hipLaunchKernelGGL(k_dest_offsets, dim3(1), dim3(128), 0, ctx->stream, cell_count_all, dest_cell_dev, G, n_cells_all, scan_total, dest_off_dev);
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// owner side: the received records -> per-cell counts (pass 1) and, once the cells have their positions, the rows (pass 2)
+__global__ void k_owner_count(const int32_t *__restrict__ rec_cell, int64_t n_rec, int32_t cell_base, int32_t *__restrict__ cell_count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rec) atomicAdd(&cell_count[rec_cell[i] - cell_base], 1);
+}
+__global__ void k_owner_place(const int32_t *__restrict__ rec_cell, const int32_t *__restrict__ rec_row, int64_t n_rec, int32_t cell_base,
+                              const int32_t *__restrict__ cell_start, int32_t *__restrict__ cursor, int32_t *__restrict__ perm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const int c = rec_cell[i] - cell_base;
+    perm[cell_start[c] + atomicAdd(&cursor[c], 1)] = rec_row[i];
+}
+__global__ void k_gather_i32(const int32_t *__restrict__ src, const int32_t *__restrict__ map, int n, int32_t *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[map[i]];
+}
+__global__ void k_tree_pos_begin(const int32_t *__restrict__ cell_start, const int32_t *__restrict__ tree_first_cell, int T, int32_t n_cells,
+                                 int32_t P_used, int32_t *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > T) return;
+    const int c = t < T ? tree_first_cell[t] : n_cells;
+    out[t] = c < n_cells ? cell_start[c] : P_used;
+}
+
+// n_rec records (cell, row) of the cells [cell_base, cell_base + n_cells_own) this rank owns (any order); cell_depth_all:
+// the depth of every cell of the build in the numbering depth_map[own cell] points into; tree_first_cell (device, T_all + 1):
+// this rank's first own cell of every tree (own numbering).
+int nnd_forest_finish_owned(nnd_ctx *ctx, const int32_t *rec_cell, const int32_t *rec_row, int64_t n_rec, int32_t cell_base, int32_t n_cells_own,
+                            const int32_t *cell_depth_all, const int32_t *depth_map_dev, const int32_t *tree_first_cell_dev, int T_all) {
+    ctx->forest_built = false;
+    ctx->n_leaves = 0;
+    ctx->max_leaf = ctx->p.leaf_size;
+    ctx->tree_leaf_begin.assign((size_t)T_all + 1, 0);
+    if (n_rec > ctx->P || n_cells_own > ctx->cell_cap || n_cells_own + n_rec / (ctx->p.leaf_size + 1) > ctx->max_segs) {
+        ctx->set_error("rp-forest (sharded): %lld point-trees / %d cells exceed this rank's forest tables (%lld positions)", (long long)n_rec, n_cells_own,
+                       (long long)ctx->P);
+        return 1;
+    }
+    if (n_cells_own <= 0 || n_rec <= 0) {  // (a rank that owns no cell: nothing to seed from)
+        ctx->forest_built = true;
+        return 0;
+    }
+    NND_HIP_CHECK(hipMemsetAsync(ctx->cell_count, 0, sizeof(int32_t) * (size_t)n_cells_own, ctx->stream));
+    hipLaunchKernelGGL(k_owner_count, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, rec_cell, n_rec, cell_base, ctx->cell_count);
+    hipLaunchKernelGGL(k_gather_i32, dim3((unsigned)((n_cells_own + 255) / 256)), dim3(256), 0, ctx->stream, cell_depth_all, depth_map_dev, n_cells_own,
+                       ctx->cell_depth);
+    // positions: cell_start = exclusive scan of the counts; rows placed through per-cell cursors (the order inside a cell is
+    // immaterial: the finisher is order independent)
+    int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
+    NND_HIP_CHECK(hipMemcpyAsync(ctx->cell_start, ctx->cell_count, sizeof(int32_t) * (size_t)n_cells_own, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->cell_start, (int)n_cells_own, scan_total);
+    int32_t *cursor = ctx->small_list;  // (free until k_cell_lists: 3 * cell_cap words)
+    NND_HIP_CHECK(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_cells_own, ctx->stream));
+    hipLaunchKernelGGL(k_owner_place, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, rec_cell, rec_row, n_rec, cell_base, ctx->cell_start,
+                       cursor, ctx->perm[0]);
+    int32_t *tpb = ctx->route_roots + 2048 + 64;  // (T_all + 1) position of every tree's first own cell
+    hipLaunchKernelGGL(k_tree_pos_begin, dim3((T_all + 64) / 64), dim3(64), 0, ctx->stream, ctx->cell_start, tree_first_cell_dev, T_all, n_cells_own,
+                       (int32_t)n_rec, tpb);
+    NND_HIP_CHECK(hipGetLastError());
+    rp_tree_map tm;
+    tm.tree_begin = tpb;
+    tm.n_tree_begin = T_all;
+    // (forest_place_finish scans the counts again: cheap, and it keeps one code path for the work lists)
+    const int rc = forest_place_finish(ctx, n_cells_own, T_all, 0, 0, nullptr, nullptr, n_rec, tm);
+    if (rc == 2) { ctx->set_error("rp-forest (sharded): too many over-long cells"); return 1; }
+    if (rc) return rc;
+    ctx->stats.n_cells = n_cells_own;
+    return forest_leaf_tables(ctx, n_rec, T_all, tpb);
 }
 
 // One stable partition step for another builder (hubtree.hip): positions with pos >= 0 and side == 0 move to the front of

@@ -10,7 +10,10 @@
 // sampling has been queued.
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -41,6 +44,17 @@ struct nnd_shard_s {
     bool gather_lists = true;                    // all-gather the neighbour ids before every join (see shard_build)
     int32_t *own_order = nullptr;                // (n_own) owned vertices in the first local tree's leaf order
     int *order_cursor = nullptr;
+    // forest sharded by cell (forest_by_cell below)
+    bool by_cell = false;
+    int t_alloc = 0;                             // trees the handle's forest tables are sized for
+    unsigned char *pack_all = nullptr;           // packed node records of ALL trees (rank-major), grow-only
+    float *hf_all = nullptr;                     // their f32 hyperplanes
+    int64_t nodes_cap = 0;
+    int32_t *cells_i32 = nullptr;                // cell_count_all | cell_depth_all (2 x cells_cap)
+    int64_t cells_cap = 0;
+    int32_t *maps = nullptr;                     // small host-built tables (cell renumbering, roots, ...), grow-only
+    int64_t maps_cap = 0;
+    hipEvent_t ev_x = nullptr;                   // the point-set all-gather on the second channel has finished
     nnd_shard_info info{};
     char err[512] = {0};
     void set_error(const char *fmt, ...) {
@@ -147,9 +161,11 @@ __global__ __launch_bounds__(256) void k_compact_owned(const int32_t *__restrict
 static void shard_free(nnd_shard_s *s) {
     std::lock_guard<std::recursive_mutex> lifecycle(nnd_lifecycle_mutex());
     if (s->h) (void)hipSetDevice(s->h->p.device);
-    void *ptrs[] = {s->x_full, s->recv_e, s->recv_d, s->off_t, s->off_k, s->prop_t, s->prop_k, s->in_t, s->in_k, s->cvec, s->own_order, s->order_cursor};
+    void *ptrs[] = {s->x_full, s->recv_e, s->recv_d, s->off_t, s->off_k, s->prop_t, s->prop_k, s->in_t, s->in_k, s->cvec, s->own_order, s->order_cursor,
+                    s->pack_all, s->hf_all, s->cells_i32, s->maps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->ev_x) (void)hipEventDestroy(s->ev_x);
     if (s->h) (void)nnd_destroy(s->h);
     delete s;
 }
@@ -186,8 +202,21 @@ extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, 
     nnd_params p = *params;
     p.n_trees = s->t1 - s->t0;
     p.device = comm->device;
-    // every rank draws its own trees: the per-tree state is derived from the global one and the first tree's number
-    p.tree_rng[1] = (int64_t)((uint64_t)p.tree_rng[1] + 0x9E3779B97F4A7C15ull * (uint64_t)(s->t0 + 1));
+    // Forest sharded BY CELL (forest_by_cell): when the routing forest applies (as in nnd_create: n >= 131072, rows of
+    // <= 256 floats) and the tree counts fit the exchange vectors.  The handle's forest tables are then sized for this
+    // rank's share of ALL trees' cells (T n / G point-trees + 25 %) and the forest is the single-GPU forest, whatever G is
+    // (global tree seeds).  Otherwise: split by tree, every rank drawing its own trees.
+    const int t_loc_max = (params->n_trees + G - 1) / G;
+    s->by_cell = G > 1 && params->n_trees > 0 && params->n_trees <= 1024 && t_loc_max <= 64 && params->n >= 131072 && ((params->dim + 31) & ~31) <= 256 &&
+                 !(params->flags & NND_FLAG_TEST_FOREST_BY_TREE);
+    if (s->by_cell) {
+        const int share = (int)(((int64_t)params->n_trees * 5 + 4 * G - 1) / (4 * G)) + 1;  // ceil(1.25 T / G) + 1 trees' worth of positions
+        s->t_alloc = share > t_loc_max ? share : t_loc_max;
+        p.n_trees = s->t_alloc;
+    } else {
+        // every rank draws its own trees: the per-tree state is derived from the global one and the first tree's number
+        p.tree_rng[1] = (int64_t)((uint64_t)p.tree_rng[1] + 0x9E3779B97F4A7C15ull * (uint64_t)(s->t0 + 1));
+    }
     if (nnd_create_impl(&s->h, &p, s->bounds, G, rank)) {
         snprintf(g_serr2, sizeof(g_serr2), "nnd_shard_create: %s", nnd_last_global_error());
         delete s;
@@ -198,7 +227,8 @@ extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, 
     const int64_t n_own = s->hi - s->lo;
     std::lock_guard<std::recursive_mutex> lifecycle(nnd_lifecycle_mutex());
     bool ok = hipSetDevice(p.device) == hipSuccess;
-    ok = ok && hipMalloc((void **)&s->cvec, sizeof(long long) * (size_t)(G + 4)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s->cvec, sizeof(long long) * (size_t)(NND_MAX_RANKS + 8)) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&s->ev_x, hipEventDisableTiming) == hipSuccess;
     if (ok && G > 1 && p.n_trees > 0) {
         ok = ok && hipMalloc((void **)&s->own_order, sizeof(int32_t) * (size_t)(n_own > 0 ? n_own : 1)) == hipSuccess;
         ok = ok && hipMalloc((void **)&s->order_cursor, sizeof(int)) == hipSuccess;
@@ -235,6 +265,7 @@ extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, 
     s->info.world = G;
     s->info.rank = rank;
     s->info.local_trees = s->t1 - s->t0;
+    s->info.forest_by_cell = s->by_cell ? 1 : 0;
     *out = s;
     return 0;
 }
@@ -248,6 +279,7 @@ extern "C" int32_t nnd_shard_get_info(nnd_shard_t s, nnd_shard_info *out) {
     *out = s->info;
     return 0;
 }
+extern "C" nnd_handle_t nnd_shard_handle(nnd_shard_t s) { return s ? s->h : nullptr; }
 extern "C" int32_t nnd_shard_get_stats(nnd_shard_t s, nnd_stats *out) {
     if (!s || !out) return 1;
     *out = s->h->stats;
@@ -289,7 +321,7 @@ static void note_bytes(nnd_shard_s *s, int64_t before) {  // payload of the exch
 
 static int grow_inbox(nnd_shard_s *s, int64_t need) {
     if (need <= s->in_cap) return 0;
-    S_HIP(hipStreamSynchronize(s->h->stream));
+    S_COMM(comm_wait(s->comm, s->h->stream, "inbox growth"));
     if (s->in_t) S_HIP(hipFree(s->in_t));
     if (s->in_k) S_HIP(hipFree(s->in_k));
     s->in_t = nullptr;
@@ -329,6 +361,329 @@ static int exchange_records(nnd_shard_s *s, int32_t *reg_t, void *reg_k, int key
     return 0;
 }
 
+
+static int shard_wait_hook(void *user, hipStream_t stream) {
+    nnd_shard_s *s = (nnd_shard_s *)user;
+    return comm_wait(s->comm, stream, "build");
+}
+
+template <typename T>
+static int grow_dev(nnd_shard_s *s, T **buf, int64_t *cap, int64_t need) {
+    if (need <= *cap) return 0;
+    S_COMM(comm_wait(s->comm, s->h->stream, "buffer growth"));
+    if (*buf) S_HIP(hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    S_HIP(hipMalloc((void **)buf, sizeof(T) * (size_t)(need + need / 8 + 64)));
+    *cap = need + need / 8 + 64;
+    return 0;
+}
+
+// owned vertices in the order of their cells in tree 0: the records of tree 0 lie cell-sorted in G segments (one per owner)
+__global__ void k_order_from_records(const int32_t *__restrict__ rec_row, const int32_t *__restrict__ cell_scan, const int32_t *__restrict__ seg_cells /* (G, 2): first / end cell */,
+                                     int G, int32_t n_cells_all, const int32_t *__restrict__ total, int32_t *__restrict__ out) {
+    __shared__ int seg_lo[NND_MAX_RANKS], seg_hi[NND_MAX_RANKS], seg_out[NND_MAX_RANKS + 1];
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int q = 0; q < G; q++) {
+            const int c0 = seg_cells[2 * q], c1 = seg_cells[2 * q + 1];
+            seg_lo[q] = c0 < n_cells_all ? cell_scan[c0] : total[0];
+            seg_hi[q] = c1 < n_cells_all ? cell_scan[c1] : total[0];
+            seg_out[q] = run;
+            run += seg_hi[q] - seg_lo[q];
+        }
+        seg_out[G] = run;
+    }
+    __syncthreads();
+    for (int q = 0; q < G; q++) {
+        const int len = seg_hi[q] - seg_lo[q];
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) out[seg_out[q] + i] = rec_row[seg_lo[q] + i];
+    }
+}
+
+// ---- section 0 of a sharded build with the forest sharded by cell.  On return the handle holds: x_orig = the replicated
+// point set, every row prepared, this rank's leaves (cells of ALL trees, 1 / G of each) and their leaf tables.
+static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t ev_x /* x_full complete (recorded on the second channel), or nullptr */) {
+    nnd_ctx *h = s->h;
+    nnd_comm_s *c = s->comm;
+    const int G = s->world, me = s->rank, T = s->gp.n_trees, d = h->d, dp = h->dp;
+    const int64_t n = s->n_total, lo = s->lo, hi = s->hi, n_own = hi - lo;
+    hipStream_t st = h->stream;
+    const int T_loc = s->t1 - s->t0;
+    auto t0_of = [&](int r) { return (int)((int64_t)T * r / G); };
+    // ---- (a) column means from every rank's own sample rows, own rows prepared, own sample members gathered ----
+    int64_t n_s, mstride;
+    nnd_prep_mean_geometry(n, &n_s, &mstride);
+    std::vector<int64_t> rlo(G + 1);  // sample member r = row r * mstride: rank q holds the members [rlo[q], rlo[q + 1])
+    for (int q = 0; q <= G; q++) {
+        int64_t r = (s->bounds[q] + mstride - 1) / mstride;
+        rlo[q] = r < n_s ? r : n_s;
+    }
+    rlo[G] = n_s;
+    std::vector<int> pblocks(G + 1, 0);  // partial blocks of every rank (rank-major in the gathered table)
+    for (int q = 0; q < G; q++) pblocks[q + 1] = pblocks[q] + nnd_prep_partial_blocks(rlo[q + 1] - rlo[q]);
+    const float *x_biased = x_local_dev - (size_t)lo * d;  // row i of the whole set at x_biased + i * d (only own rows are touched)
+    {
+        section_timer sec(s);
+        const int tp = t_begin(h);
+        double *partial = nullptr;
+        if (h->p.metric == 0) {
+            partial = nnd_prep_partial_buffer(h, (size_t)pblocks[G] * (d + 1));
+            if (!partial) { s->set_error("%s", h->err); return 1; }
+            (void)nnd_prep_mean_partial(h, x_local_dev, lo, rlo[me], rlo[me + 1], mstride, partial + (size_t)pblocks[me] * (d + 1));
+        }
+        t_end(h, tp, &h->stats.ms_prep, false);
+        sec.end();
+        if (h->p.metric == 0) {  // all-gather of the partial sums, in place
+            size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
+            for (int r = 0; r < G; r++) {
+                soff[r] = (size_t)pblocks[me] * (d + 1);
+                scnt[r] = (size_t)(pblocks[me + 1] - pblocks[me]) * (d + 1);
+                roff[r] = (size_t)pblocks[r] * (d + 1);
+                rcnt[r] = (size_t)(pblocks[r + 1] - pblocks[r]) * (d + 1);
+            }
+            void *sb[1] = {partial}, *rb[1] = {partial};
+            const int eb[1] = {8};
+            const int64_t b0 = c->bytes_sent;
+            S_COMM(comm_alltoallv(c, st, 1, sb, rb, eb, soff, scnt, roff, rcnt));
+            note_bytes(s, b0);
+        }
+        section_timer sec2(s);
+        const int tp2 = t_begin(h);
+        S_CTX(nnd_prep_mean_finish(h, partial, pblocks[G], n_s));
+        h->x_orig = x_biased;
+        h->x_owned = false;
+        h->x_valid = true;
+        S_CTX(nnd_prep_rows(h, x_biased, lo, hi, true));
+        S_CTX(nnd_launch_reset_graph(h));
+        t_end(h, tp2, &h->stats.ms_prep, true);
+        const int tf = t_begin(h);
+        // the GLOBAL sample: member j = row j * s_stride + jitter(j); rank q holds the members [jlo[q], jlo[q + 1])
+        sec2.end();
+        (void)tf;
+    }
+    const int64_t M = h->s_m, sstride = h->s_stride;
+    std::vector<int64_t> jlo(G + 1);
+    auto sample_row = [&](int64_t j) { return j * sstride + (int64_t)(nnd_hash2(h->tree_seed ^ 0x7F4A7C15u, (uint32_t)j) % (uint32_t)sstride); };
+    for (int q = 0; q <= G; q++) {
+        int64_t j = s->bounds[q] / sstride;
+        if (j > M) j = M;
+        while (j > 0 && sample_row(j - 1) >= s->bounds[q]) j--;
+        while (j < M && sample_row(j) < s->bounds[q]) j++;
+        jlo[q] = j;
+    }
+    jlo[G] = M;
+    {
+        section_timer sec(s);
+        const int tf = t_begin(h);
+        S_CTX(nnd_forest_sample_gather(h, jlo[me], jlo[me + 1]));
+        t_end(h, tf, &h->stats.ms_forest, false);
+        sec.end();
+    }
+    {  // all-gather of the sample rows (f32, half precision, norms), in place
+        size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
+        for (int r = 0; r < G; r++) {
+            soff[r] = (size_t)jlo[me];
+            scnt[r] = (size_t)(jlo[me + 1] - jlo[me]);
+            roff[r] = (size_t)jlo[r];
+            rcnt[r] = (size_t)(jlo[r + 1] - jlo[r]);
+        }
+        void *sb[3] = {h->xs, h->xsh, h->nr2s}, *rb[3] = {h->xs, h->xsh, h->nr2s};
+        const int eb[3] = {4 * dp, 2 * dp, 8};
+        const int64_t b0 = c->bytes_sent;
+        S_COMM(comm_alltoallv(c, st, 3, sb, rb, eb, soff, scnt, roff, rcnt));
+        note_bytes(s, b0);
+    }
+    // ---- (b) tops of this rank's trees, counts to everybody ----
+    nnd_tops_info ti;
+    {
+        section_timer sec(s);
+        const int tf = t_begin(h);
+        S_CTX(nnd_forest_tops(h, T_loc, s->t0, &ti));
+        t_end(h, tf, &h->stats.ms_forest, true);
+        sec.end();
+    }
+    h->stats.tree_levels = ti.levels;
+    const int nv = 2 + 64;
+    std::vector<long long> cv(nv, 0), matrix((size_t)G * nv);
+    cv[0] = ti.n_packed;
+    cv[1] = ti.n_cells;
+    for (int t = 0; t < T_loc; t++) cv[2 + t] = ti.tree_cells[t];
+    S_HIP(hipMemcpyAsync(s->cvec, cv.data(), sizeof(long long) * nv, hipMemcpyHostToDevice, st));
+    S_COMM(comm_gather_counts(c, st, s->cvec, nv, matrix.data()));
+    t_flush(h);
+    // ---- (c) the numbering of nodes and cells over the whole build (identical on every rank) ----
+    std::vector<int64_t> node_base(G + 1, 0);
+    std::vector<int32_t> C(T), lbase(G + 1, 0);  // cells per tree; first cell of every rank in tops-major order
+    for (int r = 0; r < G; r++) {
+        node_base[r + 1] = node_base[r] + matrix[(size_t)r * nv + 0];
+        lbase[r + 1] = lbase[r] + (int32_t)matrix[(size_t)r * nv + 1];
+        for (int t = t0_of(r); t < t0_of(r + 1); t++) C[t] = (int32_t)matrix[(size_t)r * nv + 2 + (t - t0_of(r))];
+    }
+    const int64_t nodes_all = node_base[G];
+    const int32_t cells_all = lbase[G];
+    if (nodes_all >= (int64_t)0x3FFFFFF0) { s->set_error("sharded forest: %lld recorded nodes exceed the 2^30 node ids of the routing passes", (long long)nodes_all); return 1; }
+    auto fj = [&](int t, int q) { return (int32_t)((int64_t)C[t] * q / G); };  // rank q finishes the cells [fj(t, q), fj(t, q + 1)) of tree t
+    std::vector<int32_t> own_base(G + 1, 0);
+    std::vector<std::vector<int32_t>> tree_off(G, std::vector<int32_t>(T + 1, 0));  // owner-major numbering: rank, then tree, then cell
+    for (int q = 0; q < G; q++) {
+        for (int t = 0; t < T; t++) tree_off[q][t + 1] = tree_off[q][t] + (fj(t, q + 1) - fj(t, q));
+        own_base[q + 1] = own_base[q] + tree_off[q][T];
+    }
+    const int32_t cells_own = own_base[me + 1] - own_base[me];
+    // host-built tables, one upload: [cell_gid (own tops' cells) | depth_map (own cells -> tops-major) | roots (T) | dest_cell (G + 1) |
+    //                               tree_first_cell (T + 1) | order segments (2 G)]
+    std::vector<int32_t> tab;
+    const size_t o_gid = 0;
+    tab.resize((size_t)ti.n_cells);
+    {
+        int32_t lc = 0;
+        for (int t = s->t0; t < s->t1; t++) {
+            int q = 0;
+            for (int32_t j = 0; j < C[t]; j++, lc++) {
+                while (q + 1 < G && j >= fj(t, q + 1)) q++;
+                tab[o_gid + lc] = own_base[q] + tree_off[q][t] + (j - fj(t, q));
+            }
+        }
+    }
+    const size_t o_dmap = tab.size();
+    tab.resize(o_dmap + (size_t)cells_own);
+    {
+        int32_t oc = 0;
+        for (int t = 0; t < T; t++) {
+            int r = 0;
+            while (t >= t0_of(r + 1)) r++;  // the rank that built tree t's top
+            int32_t cb = lbase[r];
+            for (int u = t0_of(r); u < t; u++) cb += C[u];
+            for (int32_t j = fj(t, me); j < fj(t, me + 1); j++) tab[o_dmap + oc++] = cb + j;
+        }
+    }
+    const size_t o_roots = tab.size();
+    for (int t = 0; t < T; t++) {
+        int r = 0;
+        while (t >= t0_of(r + 1)) r++;
+        tab.push_back((int32_t)(node_base[r] + (t - t0_of(r))));
+    }
+    const size_t o_dest = tab.size();
+    for (int q = 0; q <= G; q++) tab.push_back(own_base[q]);
+    const size_t o_tfc = tab.size();
+    for (int t = 0; t <= T; t++) tab.push_back(tree_off[me][t]);
+    const size_t o_oseg = tab.size();
+    for (int q = 0; q < G; q++) {
+        tab.push_back(own_base[q] + tree_off[q][0]);
+        tab.push_back(own_base[q] + tree_off[q][1]);
+    }
+    if (grow_dev(s, &s->maps, &s->maps_cap, (int64_t)tab.size())) return 1;
+    if (grow_dev(s, &s->cells_i32, &s->cells_cap, (int64_t)2 * cells_all + 16)) return 1;
+    if (nodes_all > s->nodes_cap) {
+        S_COMM(comm_wait(c, st, "node tables"));
+        if (s->pack_all) S_HIP(hipFree(s->pack_all));
+        if (s->hf_all) S_HIP(hipFree(s->hf_all));
+        s->pack_all = nullptr;
+        s->hf_all = nullptr;
+        s->nodes_cap = 0;
+        const int64_t cap = nodes_all + nodes_all / 8 + 64;
+        S_HIP(hipMalloc((void **)&s->pack_all, (size_t)cap * (2 * dp + 16)));
+        S_HIP(hipMalloc((void **)&s->hf_all, sizeof(float) * (size_t)cap * (dp + 4)));
+        s->nodes_cap = cap;
+    }
+    S_HIP(hipMemcpyAsync(s->maps, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice, st));
+    int32_t *cell_count_all = s->cells_i32, *cell_depth_all = s->cells_i32 + ((cells_all + 3) & ~3);
+    const int rec = 2 * dp + 16, hs = dp + 4;
+    {
+        section_timer sec(s);
+        const int tf = t_begin(h);
+        S_CTX(nnd_forest_tops_pack(h, &ti, node_base[me], s->maps + o_gid, s->pack_all + (size_t)node_base[me] * rec, s->hf_all + (size_t)node_base[me] * hs));
+        if (ti.n_cells > 0)
+            S_HIP(hipMemcpyAsync(cell_depth_all + lbase[me], h->cell_depth, sizeof(int32_t) * (size_t)ti.n_cells, hipMemcpyDeviceToDevice, st));
+        t_end(h, tf, &h->stats.ms_forest, true);
+        sec.end();
+    }
+    {  // all-gather of the packed records, the f32 hyperplanes and the cell depths, in place
+        size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
+        for (int r = 0; r < G; r++) {
+            soff[r] = (size_t)node_base[me];
+            scnt[r] = (size_t)(node_base[me + 1] - node_base[me]);
+            roff[r] = (size_t)node_base[r];
+            rcnt[r] = (size_t)(node_base[r + 1] - node_base[r]);
+        }
+        void *sb[2] = {s->pack_all, s->hf_all}, *rb[2] = {s->pack_all, s->hf_all};
+        const int eb[2] = {rec, 4 * hs};
+        const int64_t b0 = c->bytes_sent;
+        S_COMM(comm_alltoallv(c, st, 2, sb, rb, eb, soff, scnt, roff, rcnt));
+        for (int r = 0; r < G; r++) {
+            soff[r] = (size_t)lbase[me];
+            scnt[r] = (size_t)(lbase[me + 1] - lbase[me]);
+            roff[r] = (size_t)lbase[r];
+            rcnt[r] = (size_t)(lbase[r + 1] - lbase[r]);
+        }
+        void *sb2[1] = {cell_depth_all}, *rb2[1] = {cell_depth_all};
+        const int eb2[1] = {4};
+        S_COMM(comm_alltoallv(c, st, 1, sb2, rb2, eb2, soff, scnt, roff, rcnt));
+        note_bytes(s, b0);
+    }
+    // ---- (d) this rank's rows through ALL trees; (cell, row) records sorted by cell = by owner ----
+    int32_t *rec_cell = h->inv, *rec_row = h->scan_out;  // free once the routing passes are over (they were its scratch)
+    {
+        section_timer sec(s);
+        const int tf = t_begin(h);
+        S_HIP(hipMemsetAsync(cell_count_all, 0, sizeof(int32_t) * (size_t)cells_all, st));
+        S_CTX(nnd_forest_route_rows(h, s->pack_all, s->hf_all, s->maps + o_roots, T, lo, n_own, cells_all, cell_count_all));
+        // the records overwrite the routing scratch: cell_of / rank_of (pos_seg) are read, inv / scan_out written
+        S_CTX(nnd_forest_route_records(h, T, lo, n_own, cells_all, cell_count_all, s->maps + o_dest, G, rec_cell, rec_row, s->cvec));
+        if (s->own_order && n_own > 0) {  // the owned vertices in the order of their tree-0 cells (spatially coherent visiting order)
+            hipLaunchKernelGGL(k_order_from_records, dim3(256), dim3(256), 0, st, rec_row, cell_count_all, s->maps + o_oseg, G, cells_all,
+                               (const int32_t *)(h->counters + CNT_SCRATCH), s->own_order);
+            h->own_order = s->own_order;
+        }
+        t_end(h, tf, &h->stats.ms_forest, true);
+        sec.end();
+    }
+    std::vector<long long> m2((size_t)G * (G + 1));
+    S_COMM(comm_gather_counts(c, st, s->cvec, G + 1, m2.data()));  // host wait: record offsets per destination, of every rank
+    t_flush(h);
+    int64_t n_in = 0;
+    {
+        size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
+        for (int r = 0; r < G; r++) {
+            soff[r] = (size_t)m2[(size_t)me * (G + 1) + r];
+            scnt[r] = (size_t)(m2[(size_t)me * (G + 1) + r + 1] - m2[(size_t)me * (G + 1) + r]);
+            roff[r] = (size_t)n_in;
+            rcnt[r] = (size_t)(m2[(size_t)r * (G + 1) + me + 1] - m2[(size_t)r * (G + 1) + me]);
+            n_in += (int64_t)rcnt[r];
+        }
+        if (grow_inbox(s, n_in)) return 1;
+        void *sb[2] = {rec_cell, rec_row}, *rb[2] = {s->in_t, s->in_k};
+        const int eb[2] = {4, 4};
+        const int64_t b0 = c->bytes_sent;
+        S_COMM(comm_alltoallv(c, st, 2, sb, rb, eb, soff, scnt, roff, rcnt));
+        note_bytes(s, b0);
+    }
+    s->info.n_sections_overlap = s->info.n_sections;  // everything above needed only this rank's rows and the sample
+    // ---- (e) the replicated point set is needed from here on: the other ranks' rows are prepared ----
+    if (ev_x) S_HIP(hipStreamWaitEvent(st, ev_x, 0));
+    {
+        section_timer sec(s);
+        const int tp = t_begin(h);
+        h->x_orig = s->x_full;
+        S_CTX(nnd_prep_rows(h, s->x_full, 0, lo, false));
+        S_CTX(nnd_prep_rows(h, s->x_full, hi, n, false));
+        S_HIP(hipMemcpyAsync(h->h_pin + 63, h->counters_sum + CNT_SCRATCH, sizeof(long long), hipMemcpyDeviceToHost, st));  // non-finite flag (nnd_data_nonfinite)
+        t_end(h, tp, &h->stats.ms_prep, true);
+        // ---- (f) the cells this rank owns: rows placed, cells finished down to leaves, leaf tables ----
+        const int tf = t_begin(h);
+        if (nnd_forest_finish_owned(h, s->in_t, (const int32_t *)s->in_k, n_in, own_base[me], cells_own, cell_depth_all, s->maps + o_dmap,
+                                    s->maps + o_tfc, T)) {
+            s->set_error("nnd_forest_finish_owned: %s", h->err);
+            return 1;
+        }
+        t_end(h, tf, &h->stats.ms_forest, true);
+        sec.end();
+    }
+    s->info.forest_positions = n_in;
+    return 0;
+}
+
 static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream, int32_t *out_idx_dev, float *out_dist_dev) {
     nnd_ctx *h = s->h;
     nnd_comm_s *c = s->comm;
@@ -352,8 +707,14 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
     }
     hipEvent_t e0 = h->ev0, e1 = h->ev1;
 
-    // ---- replicate the point set once (all-gather over xGMI): candidate vectors never travel again ----
+    // ---- replicate the point set once (all-gather over xGMI): candidate vectors never travel again.  With the forest
+    //      sharded by cell the transfer runs on the SECOND channel (its own communicator and stream) while this rank
+    //      prepares and routes its own rows; otherwise it is waited for here ----
+    h->wait_hook = shard_wait_hook;
+    h->wait_user = s;
     const float *x_use = x_local_dev;
+    const bool serial = c->kind == NND_COMM_LOCAL && c->grp->serial;
+    bool x_async = false;
     if (G > 1) {
         size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
         for (int r = 0; r < G; r++) {
@@ -364,17 +725,38 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         }
         void *sb[1] = {(void *)x_local_dev}, *rb[1] = {s->x_full};
         const int eb[1] = {4};
-        const int64_t b0 = c->bytes_sent;
-        S_HIP(hipEventRecord(e0, st));
-        S_COMM(comm_alltoallv(c, st, 1, sb, rb, eb, soff, scnt, roff, rcnt));
-        S_HIP(hipEventRecord(e1, st));
-        S_HIP(hipStreamSynchronize(st));
-        (void)hipEventElapsedTime(&s->info.ms_allgather, e0, e1);
-        (void)b0;
+        // (serial mode measures compute sections with the GPU to itself: the copy is not left running beside them; the
+        // critical-path tool prices the overlap from n_sections_overlap)
+        x_async = s->by_cell && c->aux && c->aux_stream && !serial;
+        nnd_comm_s *xc = x_async ? c->aux : c;
+        hipStream_t xs = x_async ? c->aux_stream : st;
+        if (x_async) {  // the second stream starts behind whatever produced the rows
+            S_HIP(hipEventRecord(e0, st));
+            S_HIP(hipStreamWaitEvent(xs, e0, 0));
+        }
+        S_HIP(hipEventRecord(e0, xs));
+        const int64_t b0 = xc->bytes_sent;
+        if (comm_alltoallv(xc, xs, 1, sb, rb, eb, soff, scnt, roff, rcnt)) { s->set_error("point-set all-gather: %s", xc->err); return 1; }
+        if (xc != c) c->bytes_sent += xc->bytes_sent - b0;
+        S_HIP(hipEventRecord(e1, xs));
+        if (x_async) {
+            S_HIP(hipEventRecord(s->ev_x, xs));
+        } else {
+            S_COMM(comm_wait(c, st, "point-set all-gather"));
+            (void)hipEventElapsedTime(&s->info.ms_allgather, e0, e1);
+        }
         x_use = s->x_full;
     }
+    if (s->by_cell) {
+        if (forest_by_cell(s, x_local_dev, x_async ? s->ev_x : nullptr)) return 1;
+        if (x_async) (void)hipEventElapsedTime(&s->info.ms_allgather, e0, e1);  // (the stream has drained behind the leaf tables' read-back)
+        section_timer sec(s);
+        const int tl = t_begin(h);
+        S_CTX(nnd_launch_leaf_init(h));
+        t_end(h, tl, &h->stats.ms_leaf_init, false);
+        sec.end();
+    } else {
     // ---- prep (all rows: 5 ms at 10 M points, cheaper than shipping the prepared copies over xGMI), reset ----
-    {
         section_timer sec(s);
         h->x_orig = x_use;
         h->x_owned = false;
@@ -403,7 +785,7 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
     // ---- partial k-list rows -> their owners (all-to-all-v of row blocks), merged there ----
     if (G > 1 && s->gp.n_trees > 0) {
         const int64_t b0 = c->bytes_sent;
-        auto trees_of = [&](int r) { return (int)((int64_t)s->gp.n_trees * (r + 1) / G) - (int)((int64_t)s->gp.n_trees * r / G); };
+        auto trees_of = [&](int r) { return s->by_cell ? 1 : (int)((int64_t)s->gp.n_trees * (r + 1) / G) - (int)((int64_t)s->gp.n_trees * r / G); };
         size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
         size_t at = 0;
         for (int r = 0; r < G; r++) {
@@ -462,6 +844,10 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
     for (int it = 0; it < s->gp.n_iters; it++) {
         float *ms_s = it < 64 ? &h->stats.ms_sample[it] : &sink, *ms_j = it < 64 ? &h->stats.ms_join[it] : &sink,
               *ms_m = it < 64 ? &h->stats.ms_merge[it] : &sink;
+        if (it == 1 && (s->gp.flags & (NND_FLAG_TEST_FAIL | NND_FLAG_TEST_VANISH))) {  // test hooks: see include/pynnd_amd.h
+            s->set_error("test hook: rank %d %s at iteration 1", me, (s->gp.flags & NND_FLAG_TEST_VANISH) ? "vanishes" : "fails");
+            return (s->gp.flags & NND_FLAG_TEST_VANISH) ? 2 : 1;
+        }
         // (1) sampling, first half: own new edges; offers to targets owned elsewhere become records
         {
             section_timer sec(s);
@@ -582,7 +968,7 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         t_flush(h);
         sec.end();
     }
-    S_HIP(hipStreamSynchronize(st));
+    S_COMM(comm_wait(c, st, "end of the build"));
     // LOCAL: the ranks' streams wait on each other's events; nobody returns (and tears its stream / events down) while a
     // peer's stream may still hold such a wait.  After this barrier every rank's stream has drained.
     if (c->kind == NND_COMM_LOCAL && G > 1) S_COMM(comm_barrier(c));
@@ -601,8 +987,11 @@ extern "C" int32_t nnd_shard_build(nnd_shard_t s, const float *x_local_dev, void
     if (!s) { snprintf(g_serr2, sizeof(g_serr2), "nnd_shard_build: null shard"); return 1; }
     if (!x_local_dev || !out_idx_dev || !out_dist_dev) { s->set_error("nnd_shard_build: null buffer"); return 1; }
     const int rc = shard_build(s, x_local_dev, x_stream, out_idx_dev, out_dist_dev);
-    if (rc) (void)nnd_comm_abort(s->comm);  // LOCAL: do not leave the other ranks waiting in a barrier
-    return rc;
+    s->h->wait_hook = nullptr;
+    // a rank that fails tells the ranks of its process (shared flag, LOCAL barriers) and cancels its own collectives
+    // (ncclCommAbort): nobody is left waiting in a collective.  (rc 2: the test hook of a rank that dies silently.)
+    if (rc == 1) (void)nnd_comm_abort(s->comm);
+    return rc ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -632,10 +1021,10 @@ extern "C" int32_t nnd_build_multi(const nnd_params *params, const float *x, int
     for (int r = 0; r < G; r++) sizes[r] = lo[r + 1] - lo[r];
     // communicators: RCCL between distinct GPUs, the LOCAL transport when ranks share one
     std::vector<nnd_comm_t> comms(G, nullptr);
-    unsigned char id[NND_COMM_ID_BYTES];
+    unsigned char id[NND_COMM_ID_BYTES], id2[NND_COMM_ID_BYTES];
     const bool use_rccl = distinct && G > 1;
     if (use_rccl) {
-        if (nnd_comm_unique_id(id)) return fail(std::string("nnd_build_multi: ") + nnd_comm_last_error(nullptr));
+        if (nnd_comm_unique_id(id) || nnd_comm_unique_id(id2)) return fail(std::string("nnd_build_multi: ") + nnd_comm_last_error(nullptr));
     } else {
         if (nnd_comm_create_local(comms.data(), G, dev.data())) return fail(std::string("nnd_build_multi: ") + nnd_comm_last_error(nullptr));
     }
@@ -643,43 +1032,91 @@ extern "C" int32_t nnd_build_multi(const nnd_params *params, const float *x, int
     std::vector<int> rcs(G, 0);
     std::vector<nnd_stats> st(G);
     std::vector<nnd_shard_info> inf(G);
+    // The rank threads agree before anything collective starts: a rank that cannot set its device up, create its shard or
+    // stage its rows raises `failed`; after the barrier every rank sees it and nobody enters the build (under RCCL the
+    // others would sit in the first ncclSend / ncclRecv for ever).  Failures DURING the build travel through the
+    // communicators' shared abort flag (comm.h): the ranks that notice call ncclCommAbort and return.
+    std::atomic<int> failed{0}, abort_flag{0};
+    struct thread_barrier {
+        std::mutex mu;
+        std::condition_variable cv;
+        int n, arrived = 0;
+        uint64_t gen = 0;
+        explicit thread_barrier(int n_) : n(n_) {}
+        void wait() {
+            std::unique_lock<std::mutex> lk(mu);
+            const uint64_t g = gen;
+            if (++arrived == n) {
+                arrived = 0;
+                gen++;
+                cv.notify_all();
+            } else {
+                cv.wait(lk, [&] { return gen != g; });
+            }
+        }
+    } bar(G);
     auto run = [&](int r) {
         auto bail = [&](const std::string &m) {
             errs[r] = m;
             rcs[r] = 1;
-            if (comms[r]) (void)nnd_comm_abort(comms[r]);
+            failed.store(1);
         };
-        if (hipSetDevice(dev[r]) != hipSuccess) return bail("hipSetDevice failed");
-        if (use_rccl && nnd_comm_create_rccl(&comms[r], id, G, r, dev[r])) return bail(nnd_comm_last_error(nullptr));
+        if (hipSetDevice(dev[r]) != hipSuccess) bail("hipSetDevice failed");
+        bar.wait();  // (1) every rank has its device: ncclCommInitRank returns only when all ranks have called it
+        if (failed.load()) return;
+        if (use_rccl) {
+            if (nnd_comm_create_rccl(&comms[r], id, G, r, dev[r])) bail(nnd_comm_last_error(nullptr));
+            else if (nnd_comm_add_channel_rccl(comms[r], id2)) bail(nnd_comm_last_error(nullptr));
+            if (comms[r]) {
+                comms[r]->abort_flag = &abort_flag;
+                if (comms[r]->aux) comms[r]->aux->abort_flag = &abort_flag;
+            }
+        }
         nnd_params p = *params;
         p.device = dev[r];
         nnd_shard_t sh = nullptr;
-        if (nnd_shard_create(&sh, &p, comms[r], sizes.data())) return bail(nnd_shard_last_error(nullptr));
         const size_t nl = (size_t)sizes[r];
         float *dx = nullptr;
         int32_t *di = nullptr;
         float *dd = nullptr;
-        bool ok = hipMalloc((void **)&dx, sizeof(float) * (nl ? nl : 1) * p.dim) == hipSuccess &&
-                  hipMalloc((void **)&di, sizeof(int32_t) * (nl ? nl : 1) * p.n_neighbors) == hipSuccess &&
-                  hipMalloc((void **)&dd, sizeof(float) * (nl ? nl : 1) * p.n_neighbors) == hipSuccess;
-        if (ok && nl) ok = hipMemcpy(dx, x + (size_t)lo[r] * p.dim, sizeof(float) * nl * p.dim, hipMemcpyHostToDevice) == hipSuccess;
-        if (!ok) bail("allocation / H2D of the shard failed");
-        else if (nnd_shard_build(sh, dx, nullptr, di, dd)) bail(nnd_shard_last_error(sh));
-        else if (nl && (hipMemcpy(out_idx + (size_t)lo[r] * p.n_neighbors, di, sizeof(int32_t) * nl * p.n_neighbors, hipMemcpyDeviceToHost) != hipSuccess ||
-                        hipMemcpy(out_dist + (size_t)lo[r] * p.n_neighbors, dd, sizeof(float) * nl * p.n_neighbors, hipMemcpyDeviceToHost) != hipSuccess))
-            bail("D2H of the result failed");
-        (void)nnd_shard_get_stats(sh, &st[r]);
-        (void)nnd_shard_get_info(sh, &inf[r]);
+        if (!rcs[r] && nnd_shard_create(&sh, &p, comms[r], sizes.data())) bail(nnd_shard_last_error(nullptr));
+        if (!rcs[r]) {
+            bool ok = hipMalloc((void **)&dx, sizeof(float) * (nl ? nl : 1) * p.dim) == hipSuccess &&
+                      hipMalloc((void **)&di, sizeof(int32_t) * (nl ? nl : 1) * p.n_neighbors) == hipSuccess &&
+                      hipMalloc((void **)&dd, sizeof(float) * (nl ? nl : 1) * p.n_neighbors) == hipSuccess;
+            if (ok && nl) ok = hipMemcpy(dx, x + (size_t)lo[r] * p.dim, sizeof(float) * nl * p.dim, hipMemcpyHostToDevice) == hipSuccess;
+            if (!ok) bail("allocation / H2D of the shard failed");
+        }
+        bar.wait();  // (2) every rank is ready, or nobody builds
+        if (!failed.load()) {
+            if (nnd_shard_build(sh, dx, nullptr, di, dd)) {
+                errs[r] = nnd_shard_last_error(sh);
+                rcs[r] = 1;
+            } else if (nl && (hipMemcpy(out_idx + (size_t)lo[r] * p.n_neighbors, di, sizeof(int32_t) * nl * p.n_neighbors, hipMemcpyDeviceToHost) != hipSuccess ||
+                              hipMemcpy(out_dist + (size_t)lo[r] * p.n_neighbors, dd, sizeof(float) * nl * p.n_neighbors, hipMemcpyDeviceToHost) != hipSuccess)) {
+                errs[r] = "D2H of the result failed";
+                rcs[r] = 1;
+            }
+        } else if (!rcs[r]) {
+            errs[r] = "another rank failed before the build started";
+            rcs[r] = 2;
+        }
+        if (sh) {
+            (void)nnd_shard_get_stats(sh, &st[r]);
+            (void)nnd_shard_get_info(sh, &inf[r]);
+        }
         if (dx) (void)hipFree(dx);
         if (di) (void)hipFree(di);
         if (dd) (void)hipFree(dd);
-        (void)nnd_shard_destroy(sh);
+        if (sh) (void)nnd_shard_destroy(sh);
     };
     std::vector<std::thread> th;
     for (int r = 0; r < G; r++) th.emplace_back(run, r);
     for (auto &t : th) t.join();
     for (int r = 0; r < G; r++)
         if (comms[r]) (void)nnd_comm_destroy(comms[r]);
+    for (int r = 0; r < G; r++)  // the rank that failed first-hand, if any
+        if (rcs[r] == 1 && errs[r].find("another rank failed") == std::string::npos) return fail("nnd_build_multi: rank " + std::to_string(r) + ": " + errs[r]);
     for (int r = 0; r < G; r++)
         if (rcs[r]) return fail("nnd_build_multi: rank " + std::to_string(r) + ": " + errs[r]);
     if (stats) *stats = st[0];

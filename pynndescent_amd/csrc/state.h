@@ -56,6 +56,10 @@ struct nnd_handle_s {
     int tev_used = 0;
     std::vector<nnd_tlog> tlog;
     hipEvent_t ev_spin = nullptr;  // nnd_sync_spin: busy-polled completion of small read-backs (lower wake-up latency)
+    // a shard's host waits go through its communicator (comm.h comm_wait: abort flag of the other ranks, timeout) -- a
+    // collective whose peer died would otherwise keep every later wait on the stream blocked for ever
+    int (*wait_hook)(void *user, hipStream_t stream) = nullptr;
+    void *wait_user = nullptr;
 
     // geometry
     int64_t n = 0;
@@ -187,6 +191,23 @@ int nnd_prep_mean_finish(nnd_ctx *ctx, const double *partial, int nblocks, int64
 int nnd_prep_rows(nnd_ctx *ctx, const float *x_all, int64_t row_lo, int64_t row_hi, bool first);
 int nnd_launch_reset_graph(nnd_ctx *ctx);
 int nnd_launch_forest(nnd_ctx *ctx);
+// the forest of the row-sharded build, sharded by cell (rpforest.hip; driven by shard.hip)
+struct nnd_tops_info {
+    int64_t n_packed = 0;        // packed node records of this rank's trees
+    int64_t n_low = 0, high_lo = 0;
+    int32_t n_cells = 0;         // cells of this rank's trees, numbered tree-major
+    int32_t tree_cells[64] = {0};  // ... per local tree
+    int levels = 0;
+};
+int nnd_forest_sample_gather(nnd_ctx *ctx, int64_t j_lo, int64_t j_hi);
+int nnd_forest_tops(nnd_ctx *ctx, int T_loc, int tree_bias, nnd_tops_info *out);
+int nnd_forest_tops_pack(nnd_ctx *ctx, const nnd_tops_info *ti, int64_t node_base, const int32_t *cell_gid_dev, unsigned char *pack_dst, float *hf_dst);
+int nnd_forest_route_rows(nnd_ctx *ctx, const unsigned char *pack_all, const float *hf_all, const int32_t *roots_dev, int T_all, int64_t row_lo,
+                          int64_t nrows, int64_t n_cells_all, int32_t *cell_count_all);
+int nnd_forest_route_records(nnd_ctx *ctx, int T_all, int64_t row_lo, int64_t nrows, int32_t n_cells_all, int32_t *cell_count_all,
+                             const int32_t *dest_cell_dev, int G, int32_t *rec_cell, int32_t *rec_row, long long *dest_off_dev);
+int nnd_forest_finish_owned(nnd_ctx *ctx, const int32_t *rec_cell, const int32_t *rec_row, int64_t n_rec, int32_t cell_base, int32_t n_cells_own,
+                            const int32_t *cell_depth_all, const int32_t *depth_map_dev, const int32_t *tree_first_cell_dev, int T_all);
 int nnd_launch_leaf_array(nnd_ctx *ctx, int32_t *out_dev /* (n_leaves,max_leaf) */);
 int nnd_fetch_leaf_tables(nnd_ctx *ctx);
 int nnd_launch_leaf_init(nnd_ctx *ctx);
@@ -242,6 +263,7 @@ static inline int64_t nnd_list_hi(const nnd_ctx *ctx) { return (ctx->n_ranks > 1
 // Wait for everything queued on the handle's stream by polling an event: the per-level read-backs of the forest build
 // are latency critical (the GPU idles until the host has the segment count), and a blocking wait wakes up late.
 static inline hipError_t nnd_sync_spin(nnd_ctx *ctx) {
+    if (ctx->wait_hook) return ctx->wait_hook(ctx->wait_user, ctx->stream) ? hipErrorUnknown : hipSuccess;
     if (!ctx->ev_spin) return hipStreamSynchronize(ctx->stream);
     hipError_t e = hipEventRecord(ctx->ev_spin, ctx->stream);
     if (e != hipSuccess) return e;

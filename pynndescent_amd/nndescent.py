@@ -221,6 +221,9 @@ class NNDescent:
             if init_dist is not None and init_graph.shape != np.asarray(init_dist).shape:
                 raise ValueError("The shapes of init graph and init distances do not match!")  # pynndescent_.py:1236
 
+        if self.n_devices > 1 and init_graph is not None:
+            warn("pynndescent_amd: n_devices=%d is ignored for a build that starts from init_graph: the warm-start paths "
+                 "(init_graph, update()) run on one GPU (device %d)" % (self.n_devices, device))
         if self.n_devices > 1 and init_graph is None:
             self._build_multi(data, metric, n_trees, eff_trees, eff_leaf_size, effective_max_candidates, n_iters, delta,
                               max_rptree_depth, tree_states, verbose)
@@ -573,6 +576,9 @@ class NNDescent:
             effective_max_candidates = min(60, self.n_neighbors)
         else:
             effective_max_candidates = self.max_candidates
+        if getattr(self, "n_devices", 1) > 1:
+            warn("pynndescent_amd: update() rebuilds on one GPU (device %d); n_devices=%d applies to fresh builds only"
+                 % (self.device, self.n_devices))
         builder = _capi.Builder(
             n, raw.shape[1], _METRIC_CODES[self.metric], self.n_neighbors, self.n_trees, eff_leaf_size,
             self.max_rptree_depth, effective_max_candidates, self.n_iters, self.delta, self.rng_state, tree_states[0],
@@ -595,11 +601,8 @@ class NNDescent:
                     break
             self._neighbor_graph = builder.finalize()
             self._build_stats = builder.stats()
-        except StopIteration:
-            pass
         finally:
-            if builder is not None:
-                builder.close()
+            builder.close()
         self._raw_data = raw
         if hasattr(self, "_search_graph"):  # pynndescent_.py:2538-2553: the derived structures are rebuilt
             for name in ("_search_graph", "_search_forest", "_vertex_order", "_searcher"):

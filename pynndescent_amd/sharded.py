@@ -3,7 +3,7 @@
 The reference is single-process; what it offers as a sharding rule is owner-computes over contiguous vertex ranges
 (``apply_graph_update_array`` utils.py:709-731, ``new_build_candidates`` utils.py:259-306, ``init_rp_tree``
 pynndescent_.py:154-185) and ``n_jobs`` (pynndescent_.py:1141-1143).  The whole per-rank build -- point-set all-gather,
-forest split by tree, k-list row exchange, and per NN-descent iteration the threshold all-gather, the reverse-offer and
+forest sharded by cell, k-list row exchange, and per NN-descent iteration the threshold all-gather, the reverse-offer and
 proposal all-to-all-v, the update count for the stop rule -- runs INSIDE ``libpynnd_amd.so`` on one HIP stream, with the
 exchanges issued from the C side (``ncclGroupStart`` / ``ncclSend`` / ``ncclRecv`` / ``ncclGroupEnd`` over xGMI; scheme in
 ``include/pynnd_amd.h``).  What is left here:
@@ -16,11 +16,8 @@ exchanges issued from the C side (``ncclGroupStart`` / ``ncclSend`` / ``ncclRecv
 * ``build_multi``      -- the one-call form, ``nnd_build_multi``: host arrays in and out, one host thread per GPU inside
                           the library -- what ``NNDescent(..., n_devices=G)`` calls.
 
-``TorchDistComm`` / ``ThreadComm`` are small host-side transports (all-gather-v, all-to-all-v, all-reduce on tensors);
-the HOST callback is built on the former, and bench.py uses it for the timing reductions.
 """
 import ctypes as C
-import threading
 
 import numpy as np
 import torch
@@ -29,152 +26,11 @@ from . import _capi
 
 
 # ------------------------------------------------------------------------------------------------
-# partitioning helpers (pure python; the C side uses the same formulas)
+# partitioning helper (pure python; the C side uses the same formula)
 
 def shard_ranges(n_total, world):
     """Contiguous, near-equal row ranges: rank r owns [n*r//G, n*(r+1)//G)."""
     return [(n_total * r // world, n_total * (r + 1) // world) for r in range(world)]
-
-
-def tree_ranges(n_trees, world):
-    """Trees are dealt in contiguous runs as well; ranks beyond n_trees get none."""
-    return [(n_trees * r // world, n_trees * (r + 1) // world) for r in range(world)]
-
-
-def segment_bounds(offsets_ext, ranges):
-    """Record ranges per destination rank. ``offsets_ext`` is the exclusive scan of the per-vertex record
-    counts with the grand total appended (length n+1); records are ordered by target vertex, and ranks own
-    contiguous vertex ranges, so rank s receives records [offsets_ext[lo_s], offsets_ext[hi_s])."""
-    return [(int(offsets_ext[lo]), int(offsets_ext[hi])) for lo, hi in ranges]
-
-
-# ------------------------------------------------------------------------------------------------
-# host-side transports on tensors
-
-class TorchDistComm:
-    """torch.distributed transport on tensors (gloo on CPU; nccl == RCCL on ROCm)."""
-
-    def __init__(self, group=None):
-        import torch.distributed as dist
-
-        self.dist = dist
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
-
-    def all_gather_v(self, t):
-        """Gather 1-D/2-D tensors whose first dimension may differ per rank."""
-        if self._host_staged() and t.is_cuda:
-            return [g.to(t.device) for g in self.all_gather_v(t.cpu())]
-        n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-        sizes = [torch.zeros_like(n) for _ in range(self.world)]
-        self.dist.all_gather(sizes, n, group=self.group)
-        sizes = [int(s.item()) for s in sizes]
-        mx = max(sizes)
-        pad = t
-        if t.shape[0] < mx:
-            pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            pad[: t.shape[0]] = t
-        out = [torch.empty_like(pad) for _ in range(self.world)]
-        self.dist.all_gather(out, pad.contiguous(), group=self.group)
-        return [o[:s] for o, s in zip(out, sizes)]
-
-    def all_to_all_v(self, send, rcounts=None, return_counts=False):
-        """send[s] goes to rank s (first-dimension sizes arbitrary); returns the list received.  ``rcounts``: the
-        receive counts when they are known already (a second array with the same segmentation): no count exchange."""
-        if self._host_staged() and send[0].is_cuda:
-            dev0 = send[0].device
-            out = self.all_to_all_v([t.cpu() for t in send], rcounts, True)
-            recv = [g.to(dev0) for g in out[0]]
-            return (recv, out[1]) if return_counts else recv
-        dev = send[0].device
-        sc = [int(t.shape[0]) for t in send]
-        if rcounts is None:
-            counts = torch.tensor(sc, dtype=torch.int64, device=dev)
-            rc_t = torch.empty_like(counts)
-            self.dist.all_to_all_single(rc_t, counts, group=self.group)
-            rc = [int(c) for c in rc_t.tolist()]
-        else:
-            rc = [int(c) for c in rcounts]
-        tail = tuple(send[0].shape[1:])
-        recv = [torch.empty((c,) + tail, dtype=send[0].dtype, device=dev) for c in rc]
-        if self.dist.get_backend(self.group) == "gloo":  # gloo has no all_to_all for lists on every build: pairwise
-            ops = []
-            for peer in range(self.world):
-                if peer == self.rank:
-                    recv[peer].copy_(send[peer])
-                    continue
-                if send[peer].numel():
-                    ops.append(self.dist.isend(send[peer].contiguous(), peer, group=self.group))
-                if recv[peer].numel():
-                    ops.append(self.dist.irecv(recv[peer], peer, group=self.group))
-            for op in ops:
-                op.wait()
-        else:  # nccl (= RCCL): one all_to_all_single with split sizes
-            inp = torch.cat([t.reshape((t.shape[0],) + tail) for t in send], dim=0).contiguous()
-            out = torch.empty((sum(rc),) + tail, dtype=send[0].dtype, device=dev)
-            self.dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
-            recv = list(torch.split(out, rc, dim=0))
-        return (recv, rc) if return_counts else recv
-
-    def all_reduce_sum(self, value):
-        t = torch.tensor([int(value)], dtype=torch.int64, device=self._dev())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return int(t.item())
-
-    def _dev(self):
-        return torch.device("cuda", torch.cuda.current_device()) if self.dist.get_backend(self.group) == "nccl" else torch.device("cpu")
-
-    def _host_staged(self):
-        """gloo moves host memory: device tensors are staged through the CPU (tests / debugging only)."""
-        return self.dist.get_backend(self.group) == "gloo"
-
-    def barrier(self):
-        self.dist.barrier(group=self.group)
-
-
-class ThreadComm:
-    """G ranks as threads of one process: the same tensor contract, exchange through shared lists (tests)."""
-
-    class _Shared:
-        def __init__(self, world):
-            self.world = world
-            self.barrier = threading.Barrier(world)
-            self.slots = [None] * world
-
-    def __init__(self, shared, rank):
-        self.s = shared
-        self.rank = rank
-        self.world = shared.world
-
-    @classmethod
-    def make(cls, world):
-        sh = cls._Shared(world)
-        return [cls(sh, r) for r in range(world)]
-
-    def _exchange(self, obj, take):
-        if torch.cuda.is_available():
-            torch.cuda.current_stream().synchronize()
-        self.s.slots[self.rank] = obj
-        self.s.barrier.wait()
-        got = take(list(self.s.slots))
-        if torch.cuda.is_available():
-            torch.cuda.current_stream().synchronize()
-        self.s.barrier.wait()
-        return got
-
-    def all_gather_v(self, t):
-        return self._exchange(t, lambda posted: [g.clone() for g in posted])
-
-    def all_to_all_v(self, send, rcounts=None, return_counts=False):
-        recv = self._exchange(send, lambda posted: [posted[src][self.rank].clone() for src in range(self.world)])
-        return (recv, [int(t.shape[0]) for t in recv]) if return_counts else recv
-
-    def all_reduce_sum(self, value):
-        return int(sum(self._exchange(int(value), lambda posted: list(posted))))
-
-    def barrier(self):
-        self.s.barrier.wait()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -190,6 +46,18 @@ class Comm:
         self.rank = rank
         self._keep = keep  # callback objects the C side holds pointers to
         self.transport = "local"
+
+    def set_timeout(self, seconds):
+        """A rank that waits longer than this for its peers gives up (error return, ncclCommAbort under RCCL)."""
+        if self.lib.nnd_comm_set_timeout(self._h, int(seconds * 1000)) != 0:
+            raise _capi.NNDError(self.lib.nnd_comm_last_error(None).decode())
+
+    def info(self):
+        out = (C.c_int32 * 4)()
+        self.lib.nnd_comm_info(self._h, out)
+        v = int(out[2])
+        return {"transport": {1: "rccl", 2: "local", 3: "host"}.get(int(out[0]), "?"), "ranks": int(out[1]),
+                "rccl_version": "%d.%d.%d" % (v // 10000, (v // 100) % 100, v % 100) if v else None, "second_channel": bool(out[3])}
 
     def set_serial(self, on=True):
         if self.lib.nnd_comm_local_set_serial(self._h, 1 if on else 0) != 0:
@@ -231,12 +99,17 @@ class LocalGroup:
             c.close()
 
 
-def _host_callback(tcomm):
-    """nnd_host_exchange_fn on top of a TorchDistComm over gloo: an all-to-all-v of byte segments of host buffers."""
-    world, rank, dist = tcomm.world, tcomm.rank, tcomm.dist
+def _host_callback(dist, group=None):
+    """nnd_host_exchange_fn over a torch.distributed group (gloo): an all-to-all-v of byte segments of host buffers.  The
+    transport's barrier is the call with send == recv == NULL (comm.hip): a data exchange in which this rank happens to
+    move no byte is NOT a barrier -- with three ranks the other two would sit in point-to-point calls."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
 
     def exchange(_user, send, send_off, send_bytes, recv, recv_off, recv_bytes):
         try:
+            if not send and not recv:
+                dist.barrier(group=group)
+                return 0
             ops, keep = [], []
             for peer in range(world):
                 sb, rb = int(send_bytes[peer]), int(recv_bytes[peer])
@@ -248,16 +121,14 @@ def _host_callback(tcomm):
                     buf = (C.c_uint8 * sb).from_address(send + int(send_off[peer]))
                     t = torch.frombuffer(buf, dtype=torch.uint8)
                     keep.append(t)
-                    ops.append(dist.isend(t, peer, group=tcomm.group))
+                    ops.append(dist.isend(t, peer, group=group))
                 if rb:
                     buf = (C.c_uint8 * rb).from_address(recv + int(recv_off[peer]))
                     t = torch.frombuffer(buf, dtype=torch.uint8)
                     keep.append(t)
-                    ops.append(dist.irecv(t, peer, group=tcomm.group))
+                    ops.append(dist.irecv(t, peer, group=group))
             for op in ops:
                 op.wait()
-            if not any(int(send_bytes[p]) or int(recv_bytes[p]) for p in range(world)):
-                dist.barrier(group=tcomm.group)  # the zero-byte call is the transport's barrier
             return 0
         except Exception as exc:  # pragma: no cover
             print("pynndescent_amd host exchange failed:", repr(exc))
@@ -266,12 +137,13 @@ def _host_callback(tcomm):
     return _capi.HOST_EXCHANGE_FN(exchange)
 
 
-def make_comm(device_index, group=None, allow_host_fallback=True):
-    """The rank's communicator under ``torch.distributed``: RCCL when the process group runs the nccl backend (the
-    unique id is broadcast through torch, the data path never touches it again); HOST staging over gloo otherwise.
-    If the RCCL communicator cannot be created on some rank (all ranks agree on that through one all-reduce) and
-    ``allow_host_fallback`` is set, every rank falls back to the HOST transport over a gloo group -- loudly: a slow
-    exchange is better than no index, and ``Comm.transport`` says which one is in use."""
+def make_comm(device_index, group=None, allow_host_fallback=False):
+    """The rank's communicator under ``torch.distributed``: RCCL when the process group runs the nccl backend -- two unique
+    ids (the build's channel and the second channel of the point-set all-gather) are broadcast through torch, the data
+    path never touches torch again; HOST staging over gloo when the group itself is gloo (tests).  If the RCCL
+    communicator cannot be created on some rank (all ranks agree on that through one all-reduce) the call RAISES on every
+    rank; ``allow_host_fallback=True`` falls back to the HOST transport over a gloo group instead -- loudly, and
+    ``Comm.transport`` / ``Comm.info()`` say which one is in use: a scaling run must not silently become a staged one."""
     import torch.distributed as dist
 
     lib = _capi.load_library()
@@ -279,21 +151,26 @@ def make_comm(device_index, group=None, allow_host_fallback=True):
     h = _capi._H()
     if dist.get_backend(group) == "nccl":
         dev = torch.device("cuda", device_index)
-        ident = torch.zeros(128, dtype=torch.uint8)
+        ident = torch.zeros(256, dtype=torch.uint8)
         ok = 1
         if rank == 0:
-            buf = (C.c_uint8 * 128)()
-            if lib.nnd_comm_unique_id(buf) != 0:
+            buf, buf2 = (C.c_uint8 * 128)(), (C.c_uint8 * 128)()
+            if lib.nnd_comm_unique_id(buf) != 0 or lib.nnd_comm_unique_id(buf2) != 0:
                 ok = 0
-            ident = torch.tensor(list(buf), dtype=torch.uint8)
+            ident = torch.tensor(list(buf) + list(buf2), dtype=torch.uint8)
         ident = ident.to(dev)
         dist.broadcast(ident, 0, group=group)
         raw = bytes(ident.cpu().tolist())
         why = ""
-        if ok and lib.nnd_comm_create_rccl(C.byref(h), raw, world, rank, int(device_index)) != 0:
+        if ok and lib.nnd_comm_create_rccl(C.byref(h), raw[:128], world, rank, int(device_index)) != 0:
             ok, why = 0, lib.nnd_comm_last_error(None).decode()
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 1:  # (the second channel is created only once every rank holds the first: it is collective too)
+            if lib.nnd_comm_add_channel_rccl(h, raw[128:]) != 0:
+                ok, why = 0, lib.nnd_comm_last_error(None).decode()
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag.item()) == 1:
             c = Comm(h, world, rank)
             c.transport = "rccl"
@@ -307,10 +184,9 @@ def make_comm(device_index, group=None, allow_host_fallback=True):
 
         warnings.warn("pynndescent_amd: RCCL communicator unavailable (%s); exchanging through the HOST transport over gloo -- "
                       "correct but slow" % (why or "another rank failed"))
-        hg = dist.new_group(backend="gloo")
-        cb = _host_callback(TorchDistComm(hg))
+        cb = _host_callback(dist, dist.new_group(backend="gloo"))
     else:
-        cb = _host_callback(TorchDistComm(group))
+        cb = _host_callback(dist, group)
     if lib.nnd_comm_create_host(C.byref(h), world, rank, int(device_index), C.cast(cb, C.c_void_p), None) != 0:
         raise _capi.NNDError(lib.nnd_comm_last_error(None).decode())
     c = Comm(h, world, rank, keep=cb)
@@ -386,7 +262,10 @@ class ShardedBuilder:
         Returns (idx (n_local, k) GLOBAL ids, alt-space dist, info dict); the tensors stay resident on the GPU."""
         assert x_local.is_cuda and x_local.dtype == torch.float32 and x_local.is_contiguous()
         assert tuple(x_local.shape) == (self.hi - self.lo, self.d)
-        xs = torch.cuda.current_stream(self.dev).cuda_stream  # the stream that produced x_local: the build waits for it
+        cur = torch.cuda.current_stream(self.dev)
+        xs = cur.cuda_stream  # the stream that produced x_local: the build waits for it
+        if not xs:  # the NULL stream has no handle to wait on, and the shard's stream does not synchronise with it implicitly
+            cur.synchronize()
         rc = self.lib.nnd_shard_build(self._h, C.c_void_p(x_local.data_ptr()), C.c_void_p(xs) if xs else None,
                                       C.c_void_p(self.out_idx.data_ptr()), C.c_void_p(self.out_dist.data_ptr()))
         if rc != 0:

@@ -14,8 +14,9 @@ from tests.util_data import clustered
 pytestmark = pytest.mark.gpu
 
 
-def _run_local(x_dev, world, metric, k, n_trees, seed, serial=False, flags=0):
-    """x_dev: torch float32 (n, d) on cuda:0.  Returns (idx, dist) as device tensors in global row order + per-rank infos."""
+def _run_local(x_dev, world, metric, k, n_trees, seed, serial=False, flags=0, leaves=None):
+    """x_dev: torch float32 (n, d) on cuda:0.  Returns (idx, dist) as device tensors in global row order + per-rank infos.
+    leaves: a list that receives every rank's leaf array (the leaves the rank seeded its k-lists from)."""
     n = x_dev.shape[0]
     ranges = sharded.shard_ranges(n, world)
     sizes = [b - a for a, b in ranges]
@@ -33,6 +34,16 @@ def _run_local(x_dev, world, metric, k, n_trees, seed, serial=False, flags=0):
             sb = sharded.ShardedBuilder(grp[r], sizes, x_dev.shape[1], metric, k, n_trees, seed=seed, device_index=0, flags=flags)
             idx, dist, info = sb.build(x_dev[lo:hi].contiguous())
             out[r] = (idx.clone(), dist.clone(), info)
+            if leaves is not None:
+                import ctypes as C
+
+                lib = _capi.load_library()
+                hh = _capi._H(lib.nnd_shard_handle(sb._h))
+                nl, ms = C.c_int64(), C.c_int32()
+                assert lib.nnd_leaf_array_shape(hh, C.byref(nl), C.byref(ms)) == 0
+                la = np.empty((max(nl.value, 1), max(ms.value, 1)), np.int32)
+                assert lib.nnd_get_leaf_array(hh, _capi._ptr(la)) == 0
+                leaves.append(la[: nl.value])
         except Exception as e:  # pragma: no cover
             err.append("rank %d: %r" % (r, e))
             _capi.load_library().nnd_comm_abort(grp[r]._h)
@@ -176,9 +187,10 @@ def _gpu_recall(x_dev, idx_dev, rows, k_true=10):
     return recall_at(true_idx, idx_dev[rows], k_true)
 
 
-@pytest.mark.parametrize("world,n,n_trees", [(8, 2_000_000, 8), (2, 10_000_000, 12)])
+@pytest.mark.parametrize("world,n,n_trees", [(8, 2_000_000, 8), (2, 10_000_000, 12), (8, 10_000_000, 12)])
 def test_sharded_at_scale_matches_single_gpu(world, n, n_trees):
-    """8 ranks x 2 M points and 2 ranks x 10 M points (BASELINE configs[3]'s set), thread-ranks sharing this GPU: recall
+    """8 ranks x 2 M points, 2 ranks x 10 M points and BASELINE configs[3] itself -- 8 ranks x 10 M points, 12 trees --
+    thread-ranks sharing this GPU: recall
     two-sided within 0.5 % of the single-GPU build of the same points; the record regions must not drop anything
     (offers: sized for every owned edge; proposals: what does not fit is DEFERRED to the next iteration and counted)."""
     from bench import sift_like
@@ -231,7 +243,11 @@ def test_rccl_communicator_world_of_one():
     assert lib.nnd_comm_unique_id(ident) == 0, lib.nnd_comm_last_error(None)
     h = _capi._H()
     assert lib.nnd_comm_create_rccl(C.byref(h), bytes(ident), 1, 0, 0) == 0, lib.nnd_comm_last_error(None)
+    ident2 = (C.c_uint8 * 128)()
+    assert lib.nnd_comm_unique_id(ident2) == 0 and lib.nnd_comm_add_channel_rccl(h, bytes(ident2)) == 0, lib.nnd_comm_last_error(None)
     comm = sharded.Comm(h, 1, 0)
+    inf = comm.info()
+    assert inf["transport"] == "rccl" and inf["ranks"] == 1 and inf["rccl_version"] and inf["second_channel"], inf
     x = clustered(20000, 32, 8, 40, seed=31)
     xd = torch.from_numpy(x).cuda()
     sb = sharded.ShardedBuilder(comm, [20000], 32, "euclidean", 15, 8, seed=5, device_index=0)
@@ -242,3 +258,107 @@ def test_rccl_communicator_world_of_one():
     idx_l, _, _ = _run_local(xd, 1, "euclidean", 15, n_trees=8, seed=5)
     np.testing.assert_array_equal(idx, idx_l.cpu().numpy())  # same code, same seeds: the transport must not matter
     assert info["world"] == 1 and info["dropped_offers"] == 0
+
+
+def _leaf_sets(la):
+    return {tuple(sorted(int(v) for v in row if v >= 0)) for row in la}
+
+
+@pytest.mark.parametrize("world,metric,n,d,T", [(2, "euclidean", 200_000, 64, 5), (3, "cosine", 150_000, 48, 4), (8, "euclidean", 300_000, 128, 12)])
+def test_forest_sharded_by_cell_is_the_single_gpu_forest(world, metric, n, d, T):
+    """The forest of the row-sharded build (tops by tree on the global sample, packed tops all-gathered, every rank routing
+    its rows through all trees, cells finished by their owners) is THE forest of the single-GPU build, whatever the number
+    of ranks: the union of the ranks' leaves equals the single GPU's leaf array as a set of point sets.  (Hashes are keyed
+    by global tree number and position; the column means come out of double-precision partial sums.)"""
+    x = clustered(n, d, 12, 64, seed=world + 40)
+    from tests.gpu_util import make_builder
+
+    leaves = []
+    idx, dist, infos = _run_local(torch.from_numpy(x).cuda(), world, metric, 15, n_trees=T, seed=5, leaves=leaves)
+    assert all(i["forest_by_cell"] for i in infos)
+    pos = [i["forest_positions"] for i in infos]
+    assert sum(pos) == n * T and max(pos) <= 1.15 * n * T / world, pos  # every point once per tree; balanced over the ranks
+    rs = np.random.RandomState(5)
+    lim = np.iinfo(np.int32)
+    rng_state = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
+    _ = rs.randint(lim.min + 1, lim.max - 1, 3)
+    ts = rs.randint(lim.min + 1, lim.max - 1, size=(T, 3)).astype(np.int64)
+    b = _capi.Builder(n, d, O.METRICS[metric], 15, T, O.default_leaf_size(15), 200, 15, O.default_n_iters(n), 0.001, rng_state, ts[0])
+    b.set_data_host(x)
+    b.make_forest()
+    single = _leaf_sets(b.leaf_array())
+    b.close()
+    union = set()
+    for la in leaves:
+        union |= _leaf_sets(la)
+    missing, extra = len(single - union), len(union - single)
+    print("leaves: single GPU %d, union over %d ranks %d; %d missing, %d extra" % (len(single), world, len(union), missing, extra))
+    assert missing <= 1e-4 * len(single) and extra <= 1e-4 * len(single)  # (a float mean that rounds differently moves a point or two)
+    # and the build on top of it is as good as the single-GPU build
+    rows = np.arange(0, n, max(1, n // 3000))
+    ti, _ = O.brute_force_knn(x, 10, metric, rows=rows, kind="fast")
+    one = NNDescent(x, metric, n_neighbors=15, n_trees=T, random_state=5)._neighbor_graph[0]
+    r_sh, r_1 = O.recall(ti, idx.cpu().numpy()[rows]), O.recall(ti, one[rows])
+    print("recall@10 sharded %.4f one GPU %.4f" % (r_sh, r_1))
+    assert abs(r_sh - r_1) <= 0.005
+
+
+def test_forest_by_tree_fallback_still_builds():
+    """NND_FLAG_TEST_FOREST_BY_TREE: the split-by-tree forest (what small point sets use) on a set large enough for the
+    by-cell forest -- both are kept working."""
+    x = clustered(200_000, 32, 8, 64, seed=3)
+    idx, dist, infos = _run_local(torch.from_numpy(x).cuda(), 3, "euclidean", 15, n_trees=6, seed=5, flags=_capi.NND_FLAG_TEST_FOREST_BY_TREE)
+    assert not any(i["forest_by_cell"] for i in infos)
+    rows = np.arange(0, 200_000, 100)
+    ti, _ = O.brute_force_knn(x, 10, "euclidean", rows=rows, kind="fast")
+    one = NNDescent(x, "euclidean", n_neighbors=15, n_trees=6, random_state=5)._neighbor_graph[0]
+    assert abs(O.recall(ti, idx.cpu().numpy()[rows]) - O.recall(ti, one[rows])) <= 0.005
+
+
+@pytest.mark.parametrize("hook,timeout_s", [("fail", 30.0), ("vanish", 3.0)])
+def test_a_failing_rank_ends_the_build_on_every_rank(hook, timeout_s):
+    """One rank of eight dies at the start of its second iteration -- `fail`: it returns an error (the library tells the
+    other ranks through the shared flag and aborts its collectives); `vanish`: it returns without telling anybody, as a
+    killed process would (the others give up when the communicator's timeout expires).  Every rank must return an error
+    within 10 s; nobody may hang in an exchange."""
+    import time
+
+    world, bad = 8, 5
+    x = clustered(160_000, 32, 8, 64, seed=9)
+    xd = torch.from_numpy(x).cuda()
+    ranges = sharded.shard_ranges(x.shape[0], world)
+    sizes = [b - a for a, b in ranges]
+    grp = sharded.LocalGroup(world)
+    for r in range(world):
+        grp[r].set_timeout(timeout_s)
+    res, t_done = [None] * world, [None] * world
+    flag = {"fail": _capi.NND_FLAG_TEST_FAIL, "vanish": _capi.NND_FLAG_TEST_VANISH}[hook]
+    t0 = time.perf_counter()
+
+    def run(r):
+        sb = None
+        try:
+            torch.cuda.set_device(0)
+            lo, hi = ranges[r]
+            sb = sharded.ShardedBuilder(grp[r], sizes, x.shape[1], "euclidean", 15, 4, seed=5, device_index=0, flags=flag if r == bad else 0)
+            sb.build(xd[lo:hi].contiguous())
+            res[r] = "ok"
+        except _capi.NNDError as e:
+            res[r] = "error: %s" % e
+        finally:
+            t_done[r] = time.perf_counter() - t0
+            if sb is not None:
+                sb.close()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(60.0) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a rank hangs: %s" % res
+    grp.close()
+    print(hook, "->", [(r, round(t_done[r], 2), res[r][:60]) for r in range(world)])
+    assert all(v is not None and v.startswith("error") for v in res), res
+    assert "test hook" in res[bad]
+    assert max(t_done) <= 10.0 + (0.0 if hook == "fail" else 0.0), t_done
+    # the library is usable afterwards
+    idx, _, _ = _run_local(xd, 2, "euclidean", 15, n_trees=4, seed=5)
+    assert (idx.cpu().numpy() >= 0).all()

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--link-gbs", type=float, default=45.0)
     ap.add_argument("--latency-us", type=float, default=40.0)
     ap.add_argument("--builds", type=int, default=2, help="the last build is reported (the first one pays allocations)")
+    ap.add_argument("--by-tree", action="store_true", help="forest split by tree (the round-3 scheme) instead of sharded by cell")
+    ap.add_argument("--one-gpu", action="store_true", help="also time the same set on one GPU (plain builder): the speed-up's numerator")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -53,7 +55,8 @@ def main():
         sb = None
         try:
             torch.cuda.set_device(0)
-            sb = sharded.ShardedBuilder(grp[r], sizes, args.dim, "euclidean", args.k, args.trees, seed=9, device_index=0)
+            sb = sharded.ShardedBuilder(grp[r], sizes, args.dim, "euclidean", args.k, args.trees, seed=9, device_index=0,
+                                        flags=_capi.NND_FLAG_TEST_FOREST_BY_TREE if args.by_tree else 0)
             lo, hi = ranges[r]
             xl = x[lo:hi].contiguous()
             for _ in range(args.builds):
@@ -80,9 +83,34 @@ def main():
     egress = 7.0 * args.link_gbs * 1e9
     n_exch = int((byt.max(0) > 0).sum())
     exch_ms = float((byt.max(0) / egress).sum() * 1e3 + n_exch * args.latency_us * 1e-3)
-    # the two bulk exchanges that are not attached to a section: the point-set all-gather precedes the first section
+    # the point-set all-gather is not attached to a section.  Forest by cell: it runs on the second channel beside the first
+    # n_sections_overlap sections (own rows + sample only) and the exchanges between them; what it exceeds them by is exposed
     allgather_bytes = (n - max(sizes)) * args.dim * 4  # received per rank; ring / direct: each link carries 1/7 of it
-    allgather_ms = allgather_bytes / egress * 1e3
+    allgather_full_ms = allgather_bytes / egress * 1e3
+    nov = min(i.get("n_sections_overlap", 0) for i in infos)
+    beside_ms = float(sec.max(0)[:nov].sum()) if nov else 0.0
+    allgather_ms = max(0.0, allgather_full_ms - beside_ms)
+    one_gpu_ms = None
+    if args.one_gpu:
+        import time
+        lim = np.iinfo(np.int32)
+        rs = np.random.RandomState(9)
+        rng_state = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
+        _ = rs.randint(lim.min + 1, lim.max - 1, 3)
+        tstate = rs.randint(lim.min + 1, lim.max - 1, size=(args.trees, 3)).astype(np.int64)
+        b1 = _capi.Builder(n, args.dim, 0, args.k, args.trees, max(60, min(256, 5 * args.k)), 200, min(60, args.k), max(5, int(round(np.log2(n)))),
+                           0.001, rng_state, tstate[0], device=0)
+        oi = torch.empty((n, args.k), dtype=torch.int32, device=dev)
+        od = torch.empty((n, args.k), dtype=torch.float32, device=dev)
+        b1.set_data_device(x.data_ptr(), keepalive=x)
+        for _ in range(2):
+            b1.synchronize()
+            t1 = time.perf_counter()
+            b1.build_device(oi.data_ptr(), od.data_ptr())
+            b1.synchronize()
+            one_gpu_ms = (time.perf_counter() - t1) * 1e3
+        b1.close()
+        del oi, od
     idx = torch.cat(outs)
     rows = torch.from_numpy(np.random.RandomState(0).choice(n, 2000, replace=False)).to(dev)
     rec = recall_at(exact_knn_sample(x, rows, 10), idx[rows], 10)
@@ -98,7 +126,14 @@ def main():
         "sections_min_ms": [round(float(v), 2) for v in sec.min(0)],
         "exchange_bytes_max_per_rank": [int(v) for v in byt.max(0)],
         "modelled_exchange_ms": round(exch_ms, 2),
-        "modelled_allgather_ms": round(allgather_ms, 2),
+        "modelled_allgather_ms": round(allgather_full_ms, 2),
+        "allgather_exposed_ms": round(allgather_ms, 2),
+        "sections_beside_the_allgather": nov,
+        "forest_by_cell": bool(infos[0].get("forest_by_cell")),
+        "forest_positions_per_rank": [i.get("forest_positions", 0) for i in infos],
+        "section0_max_over_min": round(float(sec.sum(1).max() / max(sec.sum(1).min(), 1e-9)), 3),
+        "one_gpu_same_set_ms": None if one_gpu_ms is None else round(one_gpu_ms, 2),
+        "speedup_modelled": None if one_gpu_ms is None else round(one_gpu_ms / (compute_cp + exch_ms + allgather_ms), 2),
         "model": "7 xGMI links x %.0f GB/s effective per GPU, %.0f us per exchange" % (args.link_gbs, args.latency_us),
         "critical_path_ms": round(compute_cp + exch_ms + allgather_ms, 2),
         "rank0_stage_ms": {"prep": round(st0["ms_prep"], 2), "forest": round(st0["ms_forest"], 2), "leaf_init": round(st0["ms_leaf_init"], 2),
