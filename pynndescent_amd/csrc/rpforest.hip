@@ -2016,7 +2016,10 @@ struct rp_route_geom {
 static rp_route_geom route_geometry(int dp, int T, int64_t nrows, int64_t n_cells) {
     rp_route_geom g;
     const int rec = 2 * dp + 16;
+    // 2^L1 buckets per tree: one more level when the subtrees below 64 buckets would not fit the staged table (10 M-point
+    // trees: ~730 nodes per bucket at L1 = 6) -- what does not fit is walked through L2 misses
     g.L1 = NND_ROUTE_L1;
+    if (g.L1 < 7 && n_cells / ((int64_t)T << g.L1) > NND_ROUTE_RMAX / 2) g.L1 = 7;
     g.ns = 1 << g.L1;
     g.nb = T * g.ns;
     // a subtree of c cells has c - 1 inner nodes, and the buckets are very uneven (six random splits: a few buckets hold
