@@ -421,6 +421,46 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(int mode, const int32
     }
 }
 
+// In-place exclusive scan of an int32 array of any length (cell counts: 37 k entries at 1 M points, 560 k in a sharded
+// 10 M build -- k_scan_blocks alone walks its input with ONE workgroup: 0.47 ms there): tile sums, scan of the tile sums,
+// tile-local scan + offset.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_i32_reduce(const int32_t *__restrict__ data, int64_t n, int32_t *__restrict__ blk) {
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) s += base + i < n ? data[base + i] : 0;
+    s = nnd_wave_sum_i32(s);
+    if (nnd_lane() == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; w++) t += wsum[w];
+        blk[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_i32_apply(int32_t *__restrict__ data, int64_t n, const int32_t *__restrict__ blk) {
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int f[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        f[i] = base + i < n ? data[base + i] : 0;
+        s += f[i];
+    }
+    const int incl = nnd_wave_incl_scan_i32(s);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int run = blk[blockIdx.x] + incl - s;
+    for (int i = 0; i < w; i++) run += wsum[i];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) data[base + i] = run;
+        run += f[i];
+    }
+}
+
 // ------------------------------------------------------------- per segment --
 // n_left from the scan.  A one-sided split (rp_trees.py:393-403) is encoded as nleft = -(ceil(len/2)) - 1:
 // k_children / k_scatter then send the members at even offsets left and those at odd offsets right.
@@ -1716,6 +1756,20 @@ static int run_scan(nnd_ctx *ctx, int mode, const int32_t *pos_seg, uint8_t *byt
     return 0;
 }
 
+// exclusive scan of data[0 .. n) in place, the grand total to total_dev[0] (ctx->scan_blk holds the tile sums)
+static int scan_i32_inplace(nnd_ctx *ctx, int32_t *data, int64_t n, int32_t *total_dev) {
+    if (n <= SCAN_TILE) {
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, data, (int)n, total_dev);
+    } else {
+        const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL(k_scan_i32_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, data, n, ctx->scan_blk);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->scan_blk, nb, total_dev);
+        hipLaunchKernelGGL(k_scan_i32_apply, dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, data, n, ctx->scan_blk);
+    }
+    NND_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static size_t fin_smem_bytes(int dp, int cap /* 0: ids in global memory */) {
     const size_t tail = sizeof(float) * (dp + 4) + sizeof(uint16_t) * dp + sizeof(int32_t) * (FIN_STACK * 4 + FIN_WS);
     return (size_t)cap * 9 + tail;
@@ -2166,7 +2220,7 @@ static int forest_place_finish(nnd_ctx *ctx, int32_t n_cells, int T, int64_t row
     int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
     // cell_start = exclusive scan of the counts (k_scan_blocks scans in place: copy first)
     NND_HIP_CHECK(hipMemcpyAsync(ctx->cell_start, ctx->cell_count, sizeof(int32_t) * (size_t)n_cells, hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->cell_start, (int)n_cells, scan_total);
+    if (scan_i32_inplace(ctx, ctx->cell_start, n_cells, scan_total)) return 1;
     NND_HIP_CHECK(hipMemsetAsync(ctx->leaf_flag, 0, (size_t)P_used, ctx->stream));
     long long *counts = ctx->counters + CNT_SCRATCH + 1;  // [0] workgroup list (what launch_finishers reads), [1] big, [2] small
     NND_HIP_CHECK(hipMemsetAsync(counts, 0, 3 * sizeof(long long), ctx->stream));
@@ -2398,9 +2452,11 @@ __global__ void k_dest_offsets(const int32_t *__restrict__ cell_scan, const int3
     out[q] = at;
 }
 int nnd_forest_route_records(nnd_ctx *ctx, int T_all, int64_t row_lo, int64_t nrows, int32_t n_cells_all, int32_t *cell_count_all /* in: counts, out: exclusive scan */,
+                             int32_t *count_copy /* out: the counts (sent to the cells' owners) */,
                              const int32_t *dest_cell_dev, int G, int32_t *rec_cell, int32_t *rec_row, long long *dest_off_dev) {
     int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, cell_count_all, (int)n_cells_all, scan_total);
+    NND_HIP_CHECK(hipMemcpyAsync(count_copy, cell_count_all, sizeof(int32_t) * (size_t)n_cells_all, hipMemcpyDeviceToDevice, ctx->stream));
+    if (scan_i32_inplace(ctx, cell_count_all, n_cells_all, scan_total)) return 1;
     if (nrows > 0)
         hipLaunchKernelGGL(k_route_records, dim3((unsigned)((nrows + 255) / 256), (unsigned)T_all), dim3(256), 0, ctx->stream, ctx->pos_seg[0],
                            ctx->pos_seg[1], cell_count_all, nrows, row_lo, rec_cell, rec_row);
@@ -2410,9 +2466,14 @@ int nnd_forest_route_records(nnd_ctx *ctx, int T_all, int64_t row_lo, int64_t nr
 }
 
 // owner side: the received records -> per-cell counts (pass 1) and, once the cells have their positions, the rows (pass 2)
-__global__ void k_owner_count(const int32_t *__restrict__ rec_cell, int64_t n_rec, int32_t cell_base, int32_t *__restrict__ cell_count) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_rec) atomicAdd(&cell_count[rec_cell[i] - cell_base], 1);
+// cell_count[c] = sum over the G source ranks of their count of cell c (count vectors exchanged by the caller: no counting
+// pass over the records)
+__global__ void k_owner_sum_counts(const int32_t *__restrict__ cnt_src /* (G, n_cells) */, int G, int32_t n_cells, int32_t *__restrict__ cell_count) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    int s = 0;
+    for (int q = 0; q < G; q++) s += cnt_src[(size_t)q * n_cells + c];
+    cell_count[c] = s;
 }
 __global__ void k_owner_place(const int32_t *__restrict__ rec_cell, const int32_t *__restrict__ rec_row, int64_t n_rec, int32_t cell_base,
                               const int32_t *__restrict__ cell_start, int32_t *__restrict__ cursor, int32_t *__restrict__ perm) {
@@ -2437,7 +2498,8 @@ __global__ void k_tree_pos_begin(const int32_t *__restrict__ cell_start, const i
 // the depth of every cell of the build in the numbering depth_map[own cell] points into; tree_first_cell (device, T_all + 1):
 // this rank's first own cell of every tree (own numbering).
 int nnd_forest_finish_owned(nnd_ctx *ctx, const int32_t *rec_cell, const int32_t *rec_row, int64_t n_rec, int32_t cell_base, int32_t n_cells_own,
-                            const int32_t *cell_depth_all, const int32_t *depth_map_dev, const int32_t *tree_first_cell_dev, int T_all) {
+                            const int32_t *cnt_src, int G, const int32_t *cell_depth_all, const int32_t *depth_map_dev,
+                            const int32_t *tree_first_cell_dev, int T_all) {
     ctx->forest_built = false;
     ctx->n_leaves = 0;
     ctx->max_leaf = ctx->p.leaf_size;
@@ -2451,15 +2513,14 @@ int nnd_forest_finish_owned(nnd_ctx *ctx, const int32_t *rec_cell, const int32_t
         ctx->forest_built = true;
         return 0;
     }
-    NND_HIP_CHECK(hipMemsetAsync(ctx->cell_count, 0, sizeof(int32_t) * (size_t)n_cells_own, ctx->stream));
-    hipLaunchKernelGGL(k_owner_count, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, rec_cell, n_rec, cell_base, ctx->cell_count);
+    hipLaunchKernelGGL(k_owner_sum_counts, dim3((unsigned)((n_cells_own + 255) / 256)), dim3(256), 0, ctx->stream, cnt_src, G, n_cells_own, ctx->cell_count);
     hipLaunchKernelGGL(k_gather_i32, dim3((unsigned)((n_cells_own + 255) / 256)), dim3(256), 0, ctx->stream, cell_depth_all, depth_map_dev, n_cells_own,
                        ctx->cell_depth);
     // positions: cell_start = exclusive scan of the counts; rows placed through per-cell cursors (the order inside a cell is
     // immaterial: the finisher is order independent)
     int32_t *scan_total = (int32_t *)(ctx->counters + CNT_SCRATCH);
     NND_HIP_CHECK(hipMemcpyAsync(ctx->cell_start, ctx->cell_count, sizeof(int32_t) * (size_t)n_cells_own, hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, ctx->cell_start, (int)n_cells_own, scan_total);
+    if (scan_i32_inplace(ctx, ctx->cell_start, n_cells_own, scan_total)) return 1;
     int32_t *cursor = ctx->small_list;  // (free until k_cell_lists: 3 * cell_cap words)
     NND_HIP_CHECK(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_cells_own, ctx->stream));
     hipLaunchKernelGGL(k_owner_place, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, rec_cell, rec_row, n_rec, cell_base, ctx->cell_start,

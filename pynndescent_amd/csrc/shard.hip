@@ -574,7 +574,11 @@ static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t e
         tab.push_back(own_base[q] + tree_off[q][1]);
     }
     if (grow_dev(s, &s->maps, &s->maps_cap, (int64_t)tab.size())) return 1;
-    if (grow_dev(s, &s->cells_i32, &s->cells_cap, (int64_t)2 * cells_all + 16)) return 1;
+    int32_t cells_own_max = 0;
+    for (int q = 0; q < G; q++) cells_own_max = own_base[q + 1] - own_base[q] > cells_own_max ? own_base[q + 1] - own_base[q] : cells_own_max;
+    const int64_t cpad = (cells_all + 3) & ~3;
+    // [counts of this rank's rows per cell (scanned in place) | depths, tops-major | the counts again (sent to the owners) | G count vectors received]
+    if (grow_dev(s, &s->cells_i32, &s->cells_cap, 3 * cpad + (int64_t)G * cells_own_max + 16)) return 1;
     if (nodes_all > s->nodes_cap) {
         S_COMM(comm_wait(c, st, "node tables"));
         if (s->pack_all) S_HIP(hipFree(s->pack_all));
@@ -588,7 +592,7 @@ static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t e
         s->nodes_cap = cap;
     }
     S_HIP(hipMemcpyAsync(s->maps, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice, st));
-    int32_t *cell_count_all = s->cells_i32, *cell_depth_all = s->cells_i32 + ((cells_all + 3) & ~3);
+    int32_t *cell_count_all = s->cells_i32, *cell_depth_all = s->cells_i32 + cpad, *count_copy = s->cells_i32 + 2 * cpad, *cnt_recv = s->cells_i32 + 3 * cpad;
     const int rec = 2 * dp + 16, hs = dp + 4;
     {
         section_timer sec(s);
@@ -630,7 +634,7 @@ static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t e
         S_HIP(hipMemsetAsync(cell_count_all, 0, sizeof(int32_t) * (size_t)cells_all, st));
         S_CTX(nnd_forest_route_rows(h, s->pack_all, s->hf_all, s->maps + o_roots, T, lo, n_own, cells_all, cell_count_all));
         // the records overwrite the routing scratch: cell_of / rank_of (pos_seg) are read, inv / scan_out written
-        S_CTX(nnd_forest_route_records(h, T, lo, n_own, cells_all, cell_count_all, s->maps + o_dest, G, rec_cell, rec_row, s->cvec));
+        S_CTX(nnd_forest_route_records(h, T, lo, n_own, cells_all, cell_count_all, count_copy, s->maps + o_dest, G, rec_cell, rec_row, s->cvec));
         if (s->own_order && n_own > 0) {  // the owned vertices in the order of their tree-0 cells (spatially coherent visiting order)
             hipLaunchKernelGGL(k_order_from_records, dim3(256), dim3(256), 0, st, rec_row, cell_count_all, s->maps + o_oseg, G, cells_all,
                                (const int32_t *)(h->counters + CNT_SCRATCH), s->own_order);
@@ -657,6 +661,16 @@ static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t e
         const int eb[2] = {4, 4};
         const int64_t b0 = c->bytes_sent;
         S_COMM(comm_alltoallv(c, st, 2, sb, rb, eb, soff, scnt, roff, rcnt));
+        // ... and every rank's counts of the destination's cells (the owner sums them: no counting pass over the records)
+        for (int r = 0; r < G; r++) {
+            soff[r] = (size_t)own_base[r];
+            scnt[r] = (size_t)(own_base[r + 1] - own_base[r]);
+            roff[r] = (size_t)r * cells_own;
+            rcnt[r] = (size_t)cells_own;
+        }
+        void *sb2[1] = {count_copy}, *rb2[1] = {cnt_recv};
+        const int eb2[1] = {4};
+        S_COMM(comm_alltoallv(c, st, 1, sb2, rb2, eb2, soff, scnt, roff, rcnt));
         note_bytes(s, b0);
     }
     s->info.n_sections_overlap = s->info.n_sections;  // everything above needed only this rank's rows and the sample
@@ -672,7 +686,7 @@ static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t e
         t_end(h, tp, &h->stats.ms_prep, true);
         // ---- (f) the cells this rank owns: rows placed, cells finished down to leaves, leaf tables ----
         const int tf = t_begin(h);
-        if (nnd_forest_finish_owned(h, s->in_t, (const int32_t *)s->in_k, n_in, own_base[me], cells_own, cell_depth_all, s->maps + o_dmap,
+        if (nnd_forest_finish_owned(h, s->in_t, (const int32_t *)s->in_k, n_in, own_base[me], cells_own, cnt_recv, G, cell_depth_all, s->maps + o_dmap,
                                     s->maps + o_tfc, T)) {
             s->set_error("nnd_forest_finish_owned: %s", h->err);
             return 1;

@@ -204,10 +204,11 @@ int nnd_forest_tops(nnd_ctx *ctx, int T_loc, int tree_bias, nnd_tops_info *out);
 int nnd_forest_tops_pack(nnd_ctx *ctx, const nnd_tops_info *ti, int64_t node_base, const int32_t *cell_gid_dev, unsigned char *pack_dst, float *hf_dst);
 int nnd_forest_route_rows(nnd_ctx *ctx, const unsigned char *pack_all, const float *hf_all, const int32_t *roots_dev, int T_all, int64_t row_lo,
                           int64_t nrows, int64_t n_cells_all, int32_t *cell_count_all);
-int nnd_forest_route_records(nnd_ctx *ctx, int T_all, int64_t row_lo, int64_t nrows, int32_t n_cells_all, int32_t *cell_count_all,
+int nnd_forest_route_records(nnd_ctx *ctx, int T_all, int64_t row_lo, int64_t nrows, int32_t n_cells_all, int32_t *cell_count_all, int32_t *count_copy,
                              const int32_t *dest_cell_dev, int G, int32_t *rec_cell, int32_t *rec_row, long long *dest_off_dev);
 int nnd_forest_finish_owned(nnd_ctx *ctx, const int32_t *rec_cell, const int32_t *rec_row, int64_t n_rec, int32_t cell_base, int32_t n_cells_own,
-                            const int32_t *cell_depth_all, const int32_t *depth_map_dev, const int32_t *tree_first_cell_dev, int T_all);
+                            const int32_t *cnt_src, int G, const int32_t *cell_depth_all, const int32_t *depth_map_dev,
+                            const int32_t *tree_first_cell_dev, int T_all);
 int nnd_launch_leaf_array(nnd_ctx *ctx, int32_t *out_dev /* (n_leaves,max_leaf) */);
 int nnd_fetch_leaf_tables(nnd_ctx *ctx);
 int nnd_launch_leaf_init(nnd_ctx *ctx);
