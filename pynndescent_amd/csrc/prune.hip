@@ -169,6 +169,143 @@ __global__ __launch_bounds__(256) void k_diversify_csr(const float *__restrict__
     if (lane < len && !((retained >> lane) & 1ull)) data[a + lane] = 0.0f;
 }
 
+
+// ---- rows of 65 .. 128 entries (n_neighbors up to 128: the reference has no bound, utils.py:130-158).  The same walks with
+// the row in LDS (indices, distances / weights, factors, kept flags per wave) instead of one entry per lane: LDS
+// broadcasts take the place of v_readlane.  Same decisions as the kernels above on rows that fit both (tests).
+#define PRUNE_WIDE 128
+struct prune_wide_row {
+    int32_t idx[PRUNE_WIDE];
+    float w[PRUNE_WIDE];
+    float fac[PRUNE_WIDE];
+    int32_t rank[PRUNE_WIDE];  // csr: storage position of the entry with this rank in ascending weight order (order[])
+    uint8_t kept[PRUNE_WIDE];
+};
+
+template <bool AWARE>
+__global__ __launch_bounds__(256) void k_diversify_rows_wide(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
+                                                             int metric, int64_t n, int k, int32_t *__restrict__ idx,
+                                                             float *__restrict__ dist, float prob, uint32_t seed,
+                                                             const int32_t *__restrict__ degree, int max_degree,
+                                                             float base_rate, float alpha) {
+    __shared__ prune_wide_row rows[4];
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + w;
+    if (i >= n) return;
+    prune_wide_row &r = rows[w];
+    for (int j = lane; j < PRUNE_WIDE; j += 64) {
+        const int32_t id = j < k ? idx[i * k + j] : -1;
+        r.idx[j] = id;
+        r.w[j] = j < k ? dist[i * k + j] : INFINITY;
+        float fac = 1.0f;
+        if (AWARE && id >= 0) {  // pynndescent_.py:506-521
+            const float ratio = (float)degree[id] / (float)max_degree;
+            if (ratio > 1.0f) fac = fmaxf(0.8f, fminf(1.2f, 1.0f + base_rate * fminf(ratio - 1.0f, 2.0f)));
+        }
+        r.fac[j] = fac;
+        r.kept[j] = j == 0 ? 1 : 0;  // position 0 is always kept (pynndescent_.py:374-375)
+    }
+    nnd_wave_lds_sync();
+    for (int j = 1; j < k; j++) {
+        const int32_t idj = r.idx[j];
+        if (idj < 0) break;  // pynndescent_.py:377-378
+        const float dj = r.w[j];
+        const float lim = AWARE ? dj * r.fac[j] * alpha : dj;
+        bool flag = true;
+        for (int c = 0; c < j; c++) {
+            if (!r.kept[c]) continue;
+            if (r.w[c] > PRUNE_EPS) {
+                const float d = prune_pair_dist(xp, dp, nrm, metric, idj, r.idx[c]);
+                if (d < lim && (AWARE || prune_coin(seed, (uint32_t)i, (uint32_t)j, (uint32_t)c, prob))) {  // pynndescent_.py:386-389
+                    flag = false;
+                    break;
+                }
+            }
+        }
+        if (flag && lane == 0) r.kept[j] = 1;
+        nnd_wave_lds_sync();
+    }
+    // the kept entries, in order, then (-1, +inf)
+    int nk = 0;
+    for (int j = 0; j < k; j++) {
+        if (!r.kept[j]) continue;
+        if (lane == 0) {
+            idx[i * k + nk] = r.idx[j];
+            dist[i * k + nk] = r.w[j];
+        }
+        nk++;
+    }
+    for (int j = nk + lane; j < k; j += 64) {
+        idx[i * k + j] = -1;
+        dist[i * k + j] = INFINITY;
+    }
+}
+
+template <bool AWARE>
+__global__ __launch_bounds__(256) void k_diversify_csr_wide(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
+                                                            int metric, int64_t n_rows, const int32_t *__restrict__ indptr,
+                                                            const int32_t *__restrict__ indices, float *__restrict__ data,
+                                                            int *__restrict__ too_long, float prob, uint32_t seed,
+                                                            const int32_t *__restrict__ degree, int max_degree,
+                                                            float aggressiveness) {
+    __shared__ prune_wide_row rows[4];
+    const int lane = nnd_lane(), w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + w;
+    if (i >= n_rows) return;
+    const int a = indptr[i], len = indptr[i + 1] - a;
+    if (len <= 1) return;
+    if (len > PRUNE_WIDE) {
+        if (lane == 0) atomicAdd(too_long, 1);
+        return;
+    }
+    prune_wide_row &r = rows[w];
+    for (int j = lane; j < len; j += 64) {
+        const int32_t id = indices[a + j];
+        r.idx[j] = id;
+        r.w[j] = data[a + j];
+        float fac = 1.0f;
+        if (AWARE) {  // pynndescent_.py:700-709
+            const int tgt = (int64_t)id < n_rows ? degree[id] : 0;
+            const float ratio = (float)tgt / (float)(max_degree > 1 ? max_degree : 1);
+            fac = fmaxf(1.0f + 0.04f * aggressiveness * fminf(ratio - 1.0f, 2.0f), 1.0f);
+        }
+        r.fac[j] = fac;
+        r.kept[j] = 1;
+    }
+    nnd_wave_lds_sync();
+    // order[]: storage position by ascending weight, ties by position (np.argsort order up to ties)
+    for (int j = lane; j < len; j += 64) {
+        const float wj = r.w[j];
+        int rk = 0;
+        for (int t = 0; t < len; t++) rk += (r.w[t] < wj || (r.w[t] == wj && t < j)) ? 1 : 0;
+        r.rank[rk] = j;
+    }
+    nnd_wave_lds_sync();
+    for (int idx = AWARE ? 0 : 1; idx < len; idx++) {
+        const int j = r.rank[idx];  // order[idx]
+        const float wj = r.w[j];
+        if (AWARE && wj == 0.0f) continue;  // pynndescent_.py:685-686
+        const int32_t idj = r.idx[j];
+        const float fj = r.fac[j];
+        for (int kk = 0; kk < idx; kk++) {
+            const int l = r.rank[kk];  // order[kk]
+            if (!r.kept[l]) continue;
+            const float wl = r.w[l];
+            if (AWARE || wl > PRUNE_EPS) {
+                const int32_t idk = r.idx[AWARE ? l : kk];  // AWARE: the point at order[kk]; standard: storage position kk (reference quirk)
+                const float d = (AWARE && wl <= PRUNE_EPS) ? wj : prune_pair_dist(xp, dp, nrm, metric, idj, idk);
+                if ((AWARE ? d * fj : d) < wj && prune_coin(seed, (uint32_t)i, (uint32_t)j, (uint32_t)kk, prob)) {
+                    if (lane == 0) r.kept[j] = 0;
+                    break;
+                }
+            }
+        }
+        nnd_wave_lds_sync();
+    }
+    for (int j = lane; j < len; j += 64)
+        if (!r.kept[j]) data[a + j] = 0.0f;
+}
+
 // pynndescent_.py:728-738: rows longer than max_degree keep the entries <= sorted(row)[max_degree]
 __global__ __launch_bounds__(256) void k_degree_prune(int64_t n_rows, const int32_t *__restrict__ indptr,
                                                       float *__restrict__ data, int max_degree) {
@@ -201,6 +338,18 @@ __global__ __launch_bounds__(256) void k_degree_prune(int64_t n_rows, const int3
 
 int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev, const nnd_prune_opts *o, const int32_t *degree_dev) {
     const dim3 grid((unsigned)((ctx->n + 3) / 4));
+    if (ctx->k > PRUNE_WIDE) { ctx->set_error("the pruning pass handles rows of at most %d neighbours", PRUNE_WIDE); return 1; }
+    if (ctx->k > 64) {  // rows that do not fit one entry per lane: the LDS variants
+        const float base_rate = 0.04f * fmaxf(0.0f, o->aggressiveness);
+        if (o->degree_aware)
+            hipLaunchKernelGGL(k_diversify_rows_wide<true>, grid, dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->n, ctx->k,
+                               idx_dev, dist_dev, 1.0f, o->seed, degree_dev, o->max_degree, base_rate, o->alpha);
+        else
+            hipLaunchKernelGGL(k_diversify_rows_wide<false>, grid, dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->n, ctx->k,
+                               idx_dev, dist_dev, o->prune_probability, o->seed, (const int32_t *)nullptr, 1, 0.0f, 1.0f);
+        NND_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (o->degree_aware) {
         const float base_rate = 0.04f * fmaxf(0.0f, o->aggressiveness);  // pynndescent_.py:487-488
         hipLaunchKernelGGL(k_diversify_rows<true>, grid, dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric,
@@ -215,6 +364,16 @@ int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev, c
 int nnd_launch_diversify_csr(nnd_ctx *ctx, const int32_t *indptr_dev, const int32_t *indices_dev, float *data_dev,
                              int *too_long_dev, const nnd_prune_opts *o, const int32_t *degree_dev) {
     const dim3 grid((unsigned)((ctx->n + 3) / 4));
+    if (ctx->k > 64) {  // rows of up to 128 entries: the LDS variants
+        if (o->degree_aware)
+            hipLaunchKernelGGL(k_diversify_csr_wide<true>, grid, dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->n, indptr_dev,
+                               indices_dev, data_dev, too_long_dev, o->prune_probability, o->seed ^ 0x51ED270Bu, degree_dev, o->max_degree, o->aggressiveness);
+        else
+            hipLaunchKernelGGL(k_diversify_csr_wide<false>, grid, dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->n, indptr_dev,
+                               indices_dev, data_dev, too_long_dev, o->prune_probability, o->seed ^ 0x51ED270Bu, (const int32_t *)nullptr, 1, 0.0f);
+        NND_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (o->degree_aware)
         hipLaunchKernelGGL(k_diversify_csr<true>, grid, dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric,
                            ctx->n, indptr_dev, indices_dev, data_dev, too_long_dev, o->prune_probability, o->seed ^ 0x51ED270Bu,

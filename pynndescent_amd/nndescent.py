@@ -10,7 +10,7 @@ if the HIP library or a gfx950 device is missing, construction raises.
 Also on the GPU: ``update`` (warm start, pynndescent_.py:2381-2553), ``build_search_graph`` (the pruning
 pass of ``_init_search_graph``, all diversify methods), ``prepare`` (hub search tree + reordering) and
 ``query``.  Out of scope: sparse input, metrics other than euclidean / l2 / cosine, ``n_neighbors`` above 128 or
-``max_candidates`` above 64 (``prepare`` / ``query``: ``n_neighbors`` above 64).  Those raise ``NotImplementedError`` naming the reference entry point to use
+``max_candidates`` above 64 (``query``: more than 64 results per query).  Those raise ``NotImplementedError`` naming the reference entry point to use
 instead; ``pynndescent_amd.make_index`` hands such inputs to ``pynndescent.NNDescent`` when it is importable.
 """
 import time

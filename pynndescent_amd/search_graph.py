@@ -52,9 +52,9 @@ def build_search_graph(data, indices, distances, metric="euclidean", n_neighbors
     ``indices``/``distances`` are ``NNDescent._neighbor_graph`` (rows ascending, squared-L2 / log2-cosine)."""
     if diversify_method not in ("standard", "degree_aware"):
         raise ValueError("diversify_method must be 'standard' or 'degree_aware'")
-    if np.shape(indices)[1] > 64:
-        raise NotImplementedError("the pruning pass (prepare / query) handles graphs of at most 64 neighbours per row "
-                                  "(got %d); the build itself goes up to 128" % np.shape(indices)[1])
+    if np.shape(indices)[1] > 128:
+        raise NotImplementedError("the pruning pass (prepare / query) handles graphs of at most 128 neighbours per row (got %d)"
+                                  % np.shape(indices)[1])
     aware = diversify_method == "degree_aware"
     x = np.ascontiguousarray(data, dtype=np.float32)
     n, d = x.shape

@@ -392,7 +392,22 @@ def test_wide_rows_up_to_128_neighbours(metric, k, n_trees):
     # an init graph as wide as the rows, and the update() warm start
     index2 = NNDescent(x, metric, n_neighbors=k, init_graph=idx, init_dist=dist, random_state=3, n_iters=2)
     assert O.recall(ti, index2._neighbor_graph[0][rows]) >= rg - 0.005
-    with pytest.raises(NotImplementedError, match="at most 64"):
-        index.prepare()
+    # prepare() / query() on the wide graph: the pruning pass (rows through LDS above 64 entries, prune.hip) against the
+    # reference algorithm's pass on the SAME graph (oracle), then queries answered from it
+    from pynndescent_amd.search_graph import build_search_graph
+
+    sg = build_search_graph(x, idx, dist, metric, k)
+    osg = O.search_graph(x, idx, dist, metric, k)
+    ka = np.repeat(np.arange(n, dtype=np.int64), np.diff(sg.indptr)) * n + sg.indices
+    kb = np.repeat(np.arange(n, dtype=np.int64), np.diff(osg.indptr)) * n + osg.indices
+    sym = np.setxor1d(ka, kb).shape[0]
+    print("search graph nnz gpu %d oracle %d, symmetric difference %d" % (sg.nnz, osg.nnz, sym))
+    assert sym <= 0.01 * osg.nnz and np.diff(sg.indptr).max() <= int(np.round(1.5 * k)) + 1
+    index.prepare()
+    q = x[rows[:300]] + 0.01
+    qi, qd = index.query(q, k=10, epsilon=0.2)
+    tq, _ = O.brute_force_knn(np.vstack([x, q]), 330, metric, rows=np.arange(n, n + 300), kind="fast")  # (the other queries are points of that set too)
+    tq = np.array([[v for v in row if v < n][:10] for row in tq])
+    assert O.recall(tq, qi) >= 0.9, O.recall(tq, qi)
     with pytest.raises(NotImplementedError, match="n_neighbors <= 128"):
         NNDescent(x, metric, n_neighbors=129)
