@@ -509,7 +509,7 @@ def main():
         # HBM traffic per launch from the committed PMC passes (tools/pmc_traffic.py; separate --pmc runs, FETCH_SIZE
         # corrected by the factor calibrated for this access pattern); null if no profile of this kernel is committed
         traffic = None
-        for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 tj = json.load(open(tpath))

@@ -7,7 +7,7 @@ FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE under-counts reads by 
 pattern (the guide: exactly 1/2 for wide coalesced streaming reads; other patterns uncalibrated).  The factor applied
 to a kernel is the one MEASURED for its pattern by tools/fetch_calib.hip (profiles/r02_fetch_calibration.json):
   gather : the local join's operand gather (random 512-byte rows, lane (r16, g) loads 16-byte chunks 4t + g)
-  quad   : a quad per random 256-byte bf16 row (forest margins, finishers)
+  quad   : a quad (or a pair) of lanes per random 256-byte half-precision row (forest margins, finishers, routing passes)
   stream : everything else (16 B per lane, consecutive)
 WRITE_SIZE is used uncorrected (uncalibrated)."""
 import csv
@@ -18,7 +18,7 @@ import sys
 from collections import defaultdict
 
 PATTERN = (("k_local_join", "gather"), ("k_finalize", "gather"), ("k_leaf_join", "gather"), ("k_margin", "quad"),
-           ("k_finish_subtrees", "quad"), ("k_hyperplane", "quad"))
+           ("k_finish_subtrees", "quad"), ("k_hyperplane", "quad"), ("k_route", "quad"))
 
 
 def per_kernel(d, counter):
