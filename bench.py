@@ -249,7 +249,10 @@ def host_inclusive(_capi, x_host, k, n_trees, leaf_size, n_iters, rng_state, tre
 
 
 def class_api(x_host, k, n_trees, device, reps=3):
-    """SURVEY.md section 8d's metric, literally: n / wall(NNDescent(x, ...) -> neighbor_graph arrays on the host), warm."""
+    """SURVEY.md section 8d's metric, literally: n / wall(NNDescent(x, ...) -> neighbor_graph arrays on the host), warm.
+    Measured twice: in THIS process (which has allocated and released many GB by now: the result arrays then come out of
+    fragmented 4 KB pages and their first touch costs tens of ms) and in a FRESH process (a user's script: the same call
+    after one warm-up call), the latter being the figure reported as `ms`."""
     import pynndescent_amd
 
     best = None
@@ -259,8 +262,26 @@ def class_api(x_host, k, n_trees, device, reps=3):
                                               device=device).neighbor_graph
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    n = x_host.shape[0]
-    return {"value": round(n / best, 1), "unit": "points/s", "ms": round(best * 1e3, 2),
+    n, d = x_host.shape
+    fresh = None
+    try:
+        code = ("import sys, time, torch, numpy as np; sys.path.insert(0, %r); import bench, pynndescent_amd\n"
+                "x = bench.sift_like(%d, %d, seed=1, device=torch.device('cuda', %d), sample_seed=100).cpu().numpy()\n"
+                "best = None\n"
+                "for r in range(%d):\n"
+                "    t0 = time.perf_counter(); g = pynndescent_amd.NNDescent(x, 'euclidean', n_neighbors=%d, n_trees=%d, random_state=1234, device=%d).neighbor_graph\n"
+                "    dt = time.perf_counter() - t0\n"
+                "    if r > 0: best = dt if best is None else min(best, dt)\n"
+                "print('CLASS_API_MS', best * 1e3)\n") % (ROOT, n, d, device, reps + 1, k, n_trees, device)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout
+        for line in out.splitlines():
+            if line.startswith("CLASS_API_MS"):
+                fresh = float(line.split()[1]) * 1e-3
+    except Exception:  # the in-process figure stands
+        fresh = None
+    use = fresh if fresh is not None else best
+    return {"value": round(n / use, 1), "unit": "points/s", "ms": round(use * 1e3, 2), "ms_in_this_process": round(best * 1e3, 2),
+            "measured_in": "a fresh process (one warm-up call, best of %d)" % reps if fresh is not None else "this process",
             "what": "pynndescent_amd.NNDescent(x, 'euclidean', n_neighbors=%d, n_trees=%d).neighbor_graph: check_array + handle "
                     "creation + H2D + build (host-driven iteration loop) + D2H + sqrt correction, best of %d" % (k, n_trees, reps)}
 

@@ -223,6 +223,8 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
         if ((rc = dalloc(ctx, &ctx->counters, (size_t)CNT_COUNT * NND_CNT_STRIPES))) break;
         if ((rc = dalloc(ctx, &ctx->counters_sum, (size_t)CNT_COUNT))) break;
         if (hipHostMalloc((void **)&ctx->h_pin, sizeof(long long) * 64, hipHostMallocDefault) != hipSuccess) { ctx->set_error("hipHostMalloc failed"); rc = 1; break; }
+        memset(ctx->h_pin, 0, sizeof(long long) * 64);
+        if (hipHostGetDevicePointer((void **)&ctx->h_pin_dev, ctx->h_pin, 0) != hipSuccess) { (void)hipGetLastError(); ctx->h_pin_dev = nullptr; }
         if (p->n_trees > 0) {
             ctx->P = (int64_t)p->n_trees * ctx->n;
             const size_t P = (size_t)ctx->P;

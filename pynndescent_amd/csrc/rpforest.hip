@@ -26,6 +26,9 @@
 //
 // Random choices come from the counter hash (common.h), not from a sequential Tausworthe stream:
 // the forest is statistically, not bitwise, the reference's.
+#include <atomic>
+#include <chrono>
+
 #include "common.h"
 #include "state.h"
 
@@ -486,7 +489,12 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
                                                   int32_t *__restrict__ fin_start, int32_t *__restrict__ fin_len,
                                                   int32_t *__restrict__ fin_depth, long long *__restrict__ counters,
                                                   int32_t *__restrict__ node_child, int node_base, int next_base,
-                                                  int32_t *__restrict__ leaf_depth, int node_top) {
+                                                  int32_t *__restrict__ leaf_depth, int node_top, long long *__restrict__ host_words,
+                                                  long long seq) {
+    // host_words (optional): pinned HOST memory.  The host needs this level's segment count before it can launch the next
+    // level; instead of a device-to-host copy behind the scatter kernel and a stream synchronisation (the GPU then idles
+    // for a launch latency per level), this workgroup writes the six words itself and raises a sequence number: the host,
+    // spinning on it, queues the next level WHILE the scatter kernel runs.
     // node_child != nullptr (sample forest, see nnd_launch_forest): the tree itself is recorded -- node (node_base + s)
     // gets its two children: >= 0 the child's node id (next_base + its index in the next level; node_top - its index in
     // the finisher's work list when its subtree is recorded by k_finish_subtrees<.., RECORD>), <= -2 a final leaf
@@ -563,6 +571,16 @@ __global__ __launch_bounds__(256) void k_children(const int32_t *__restrict__ se
     }
     if (active_pos) atomicAdd((unsigned long long *)&counters[CNT_LEAVES], (unsigned long long)active_pos);  // positions still in the passes
     if (max_stay) atomicMax((unsigned long long *)&counters[CNT_SCRATCH + 3], (unsigned long long)max_stay);  // longest of them
+    if (host_words) {
+        __syncthreads();  // (with its release / acquire fences: every thread's atomics above have been performed)
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                host_words[q] = __hip_atomic_load(&counters[CNT_ACTIVE_SEGS + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(&host_words[6], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // stable partition (rp_trees.py:405-418): lefts keep their order at the front, rights behind them
@@ -1858,6 +1876,8 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
     int32_t *fin_len = fin_start + ctx->max_segs;
     int32_t *fin_depth = fin_len + ctx->max_segs;
     int64_t node_base = 0;
+    // (a shard's host waits go through its communicator -- abort flag, timeout -- so it keeps the copy + wait form)
+    long long *flag_words = (ctx->h_pin_dev && !ctx->wait_hook && !nnd_knob("NND_NO_LEVEL_FLAG")) ? ctx->h_pin_dev + 40 : nullptr;
     NND_HIP_CHECK(hipMemsetAsync(ctx->counters + CNT_SCRATCH + 1, 0, sizeof(long long), ctx->stream));
     if (!v.record && S > 0 && n <= fin_max) {  // small point sets: the roots go straight to the finisher
         std::vector<int32_t> h_s(T), h_l(T), h_d(T, 0);
@@ -1910,17 +1930,31 @@ static int forest_levels(nnd_ctx *ctx, forest_view &v) {
                            ctx->seg_nleft, (int)S, leaf_size, child_can_split, fin_max, depth + 1, ctx->seg_start[1 - cur],
                            ctx->seg_len[1 - cur], ctx->seg_child, ctx->leaf_flag, fin_start, fin_len, fin_depth, ctx->counters,
                            v.record ? ctx->node_child : (int32_t *)nullptr, (int)node_base, (int)(node_base + S), ctx->s_leaf_depth,
-                           (int)ctx->node_cap - 1);
+                           (int)ctx->node_cap - 1, flag_words, flag_words ? ++ctx->flag_seq : 0);
         hipLaunchKernelGGL(k_scatter, dim3(gridP), dim3(256), 0, ctx->stream, ctx->perm[cur], ctx->pos_seg[cur], ctx->side,
                            ctx->scan_out, ctx->seg_start[cur], ctx->seg_nleft, ctx->seg_child, P, n, ctx->perm[1 - cur],
                            ctx->pos_seg[1 - cur], inv_live ? ctx->inv : (int32_t *)nullptr);
         NND_HIP_CHECK(hipGetLastError());
-        // one small read-back per level: the number of segments that stay in the level-synchronous passes
-        long long *next = ctx->h_pin + 32;  // CNT_ACTIVE_SEGS, CNT_LEAVES, CNT_SCRATCH.. are adjacent; pinned words
+        // one small hand-over per level: the number of segments that stay in the level-synchronous passes
         static_assert(CNT_LEAVES == CNT_ACTIVE_SEGS + 1 && CNT_SCRATCH == CNT_LEAVES + 1, "counter layout");
-        NND_HIP_CHECK(hipMemcpyAsync(next, ctx->counters + CNT_ACTIVE_SEGS, 6 * sizeof(long long), hipMemcpyDeviceToHost,
-                                     ctx->stream));
-        NND_HIP_CHECK(nnd_sync_spin(ctx));
+        long long *next = ctx->h_pin + 32;  // CNT_ACTIVE_SEGS, CNT_LEAVES, CNT_SCRATCH.. are adjacent; pinned words
+        if (flag_words) {  // written by k_children itself (see there): no copy, no stream synchronisation
+            next = ctx->h_pin + 40;
+            volatile long long *seqw = ctx->h_pin + 46;
+            const auto t_spin = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (*seqw != ctx->flag_seq) {
+                if ((++spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t_spin > std::chrono::seconds(30)) {
+                    ctx->set_error("rp-forest: the device did not hand over the segment count of level %d within 30 s", depth);
+                    return 1;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else {
+            NND_HIP_CHECK(hipMemcpyAsync(next, ctx->counters + CNT_ACTIVE_SEGS, 6 * sizeof(long long), hipMemcpyDeviceToHost,
+                                         ctx->stream));
+            NND_HIP_CHECK(nnd_sync_spin(ctx));
+        }
         node_base += S;
         S = next[0];
         active_pos = next[1];

@@ -168,6 +168,8 @@ struct nnd_handle_s {
     long long h_counters[CNT_COUNT] = {0};
     long long *counters_sum = nullptr;        // (CNT_COUNT) device: stripes summed by k_counters_reduce
     long long *h_pin = nullptr;               // pinned host words for the small latency-critical read-backs
+    long long *h_pin_dev = nullptr;           // the same words as the device sees them: a kernel can hand the host a few values itself
+    long long flag_seq = 0;                   // sequence number of the last such hand-over (rpforest.hip forest_levels)
 
     void set_error(const char *fmt, ...) {
         va_list ap;
