@@ -191,9 +191,11 @@ def recall_at(true_idx, approx_idx, k_true=10, cols=None):
 
 def cpu_baseline(O, xs, k, n_trees, true_rows=None, true_idx=None):
     """The CPU oracle (restatement of the reference algorithm) on this box's host cores, on the SAME points as the
-    GPU build.  The reference's parallel scheme makes every thread scan all edges (utils.py:266-273), so more threads
-    is not always faster: the thread count is picked by a probe on the first 200 k points, then the whole set is
-    timed once."""
+    GPU build.  The number of vertex blocks (the reference's numba thread count, utils.py:259-273) decides both the
+    result and how much of the box is busy: it is picked by a probe on the first 200 k points, then the whole set is
+    timed once.  (Round 4: the port no longer makes every thread scan all edges / all updates as the reference does --
+    same pushes in the same order, pinned bit-exact against the reference -- so it is a STRONGER baseline than the
+    reference's own scheme would be on many cores.)"""
     cores = os.cpu_count() or 1
     O.build()
     probe = xs[: min(200_000, xs.shape[0])]
@@ -215,8 +217,9 @@ def cpu_baseline(O, xs, k, n_trees, true_rows=None, true_idx=None):
             "note": "PORT: a C/OpenMP restatement of the reference algorithm (oracle/), NOT the reference's numba code "
                     "(numba is not installable in this image)",
             "sample": "all %d points of the same set, same k/n_trees/defaults; gcc -O3 -ffast-math + OpenMP, %d threads "
-                      "(fastest of a probe over 32/64/128/256/all cores on the first %d points; the reference's scheme makes "
-                      "every thread scan all edges, so more threads is not always faster)" % (xs.shape[0], best_t, probe.shape[0])}
+                      "(fastest of a probe over 32/64/128/256/all cores on the first %d points); the port buckets edges and "
+                      "updates by owner block instead of letting every thread scan all of them (bit-identical results)"
+                      % (xs.shape[0], best_t, probe.shape[0])}
 
 
 def host_inclusive(_capi, x_host, k, n_trees, leaf_size, n_iters, rng_state, tree_state, device, reps=2):
