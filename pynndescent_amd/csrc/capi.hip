@@ -229,19 +229,22 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
             ctx->P = (int64_t)p->n_trees * ctx->n;
             const size_t P = (size_t)ctx->P;
             ctx->max_segs = ctx->P / (p->leaf_size + 1) + p->n_trees + 8;
-            // Routing pass (rpforest.hip): the top of the trees is built from every 8th point when the set is large
+            // Routing pass (rpforest.hip): the top of the trees is built from every 16th point when the set is large
             // enough for that sample to resolve cells of a few hundred points, and rows fit the route kernel's registers.
+            // (Round 4: stride 8 / cells of <= 48 sample members -> 16 / 24: the same cells on average, half the sample
+            // passes -- 4.66 -> 4.28 ms per forest at 1 M x 8 trees, 14.5 -> 12.2 ms at 10 M x 2; in a sharded build the
+            // sample tops are the part of the forest that is not divided by the number of ranks.)
             // NND_FOREST_WHOLE=1 forces the whole-set level-synchronous build (A/B measurements).
             const char *whole = nnd_knob("NND_FOREST_WHOLE");
             if (graph && p->n >= 131072 && ctx->dp <= 256 && !(whole && whole[0] == '1')) {
                 const char *ss = nnd_knob("NND_SAMPLE_STRIDE");
-                ctx->s_stride = ss ? atoi(ss) : 8;
+                ctx->s_stride = ss ? atoi(ss) : 16;
                 if (ctx->s_stride < 2) ctx->s_stride = 2;
                 ctx->s_m = p->n / ctx->s_stride;
                 const char *cl = nnd_knob("NND_CELL_LEAF");
                 const char *es = nnd_knob("NND_EARLY_STOP");
                 ctx->early_stop = es ? atoi(es) : 0;
-                ctx->cell_leaf = cl ? atoi(cl) : 48;  // x stride: cells of <= ~450 points, ~215 on average (one wave per cell)
+                ctx->cell_leaf = cl ? atoi(cl) : 24;  // x stride: cells of <= ~450 points, ~215 on average (one wave per cell)
                 if (ctx->cell_leaf < 8) ctx->cell_leaf = 8;
                 const int64_t Ps = (int64_t)p->n_trees * ctx->s_m;
                 ctx->node_cap = Ps / (ctx->cell_leaf / 4 > 1 ? ctx->cell_leaf / 4 : 1) + 4 * p->n_trees + 64;
