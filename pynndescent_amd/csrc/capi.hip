@@ -69,7 +69,11 @@ struct nnd_scratch {
 };
 
 std::recursive_mutex &nnd_lifecycle_mutex() {
+#ifdef NND_TEST_NO_LIFECYCLE_LOCK  // heap-check builds only (tools/gpu_asan.sh nolock): every thread gets its own mutex
+    static thread_local std::recursive_mutex m;
+#else
     static std::recursive_mutex m;
+#endif
     return m;
 }
 
