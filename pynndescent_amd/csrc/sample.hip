@@ -26,7 +26,22 @@
 
 // per-target, per-iteration salt of the reverse priorities
 __device__ __forceinline__ uint32_t nnd_offer_salt(uint32_t it_seed, uint32_t u) { return nnd_hash2(it_seed ^ 0x3C6EF372u, u); }
-__device__ __forceinline__ uint32_t nnd_offer_prio(uint32_t it_seed, uint32_t v, uint32_t u) { return nnd_mix32(v ^ nnd_offer_salt(it_seed, u)); }
+
+// slot of source v in target u's bank.  It depends on the TARGET as well (through its salt): until the end of round 4 it was
+// a function of (iteration, v) alone, so two sources that shared a slot shared it in EVERY bank of the iteration -- the
+// pair could not meet as reverse candidates of any common neighbour, and two vertices with a common neighbour are exactly
+// the pairs NN-descent exists to evaluate.  Measured at 1.2 M x 100 cosine (tools/recall_study.py, 20 000 rows, 4 seeds):
+// see DESIGN.md section 2.
+__device__ __forceinline__ uint32_t nnd_offer_slot(uint32_t salt_u, uint32_t v, int rcap) { return nnd_hash2(salt_u ^ 0x68E31DA4u, v) & (uint32_t)(rcap - 1); }
+// word of u's bank pair [old class | new class] that the offer v -> u competes for.  WIDE: before the first sampling pass
+// every edge is new (ctx->all_new), the old-class bank would stay empty -- the new class takes both, 2 * rcap slots.  That
+// is the iteration with the most offers per bank (in-degree ~k, all of one class) and the one that moves the graph most:
+// with 32 slots a fifth of its reverse offers were lost to collisions and the lists held too few reverse candidates (the
+// forward ones are each other's leaf mates and mostly compared already): recall@10 0.9884 -> see DESIGN.md section 2
+// (the CPU oracle: 0.9901; 64 slots per class everywhere: 0.9893 and 3 % more time).
+__device__ __forceinline__ int64_t nnd_offer_addr(uint32_t u, uint32_t cls, uint32_t salt_u, uint32_t v, int rcap, int wide) {
+    return wide ? (int64_t)u * 2 * rcap + nnd_offer_slot(salt_u, v, 2 * rcap) : ((int64_t)u * 2 + cls) * rcap + nnd_offer_slot(salt_u, v, rcap);
+}
 // slot word of vertex u's bank -> the 64-bit item key (priority << 32 | source) the selection ranks
 __device__ __forceinline__ uint64_t nnd_offer_key(uint32_t slot_word, uint32_t salt_u) {
     return ((uint64_t)slot_word << 32) | (uint64_t)(nnd_unmix32(slot_word) ^ salt_u);
@@ -41,7 +56,7 @@ __device__ __forceinline__ uint64_t nnd_offer_key(uint32_t slot_word, uint32_t s
 // of a window of rows are each other's neighbours, so the offers of a window land in a few slot banks that stay in L2.
 __global__ __launch_bounds__(256) void k_sample_reverse(const uint32_t *__restrict__ knn_e, int64_t row_lo, int64_t n, int k, int ks, uint32_t it_seed,
                                                         uint32_t *__restrict__ rbuf, int rcap, int64_t own_lo, int64_t own_hi, int pass,
-                                                        uint8_t *__restrict__ active, const int32_t *__restrict__ order) {
+                                                        uint8_t *__restrict__ active, const int32_t *__restrict__ order, int wide) {
     int64_t b = blockIdx.x;
     if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
     const int64_t g = row_lo + b * blockDim.y + threadIdx.y;  // rows [row_lo, n): all of them, or the owned slice (sharded)
@@ -57,8 +72,8 @@ __global__ __launch_bounds__(256) void k_sample_reverse(const uint32_t *__restri
     if ((int64_t)u < own_lo || (int64_t)u >= own_hi) return;  // owner-computes: only targets this handle owns (utils.py:270-273)
     if (pass == 0) active[u] = 1;
     else if (!active[u]) return;
-    uint32_t slot = nnd_hash2(it_seed ^ 0x68E31DA4u, (uint32_t)v) & (uint32_t)(rcap - 1);
-    atomicMin(&rbuf[((int64_t)u * 2 + cls) * rcap + slot], nnd_offer_prio(it_seed, (uint32_t)v, u));  // (a priority equal to NND_EMPTY_SLOT, 1 in 2^32, is a lost offer)
+    const uint32_t salt = nnd_offer_salt(it_seed, u);
+    atomicMin(&rbuf[nnd_offer_addr(u, cls, salt, (uint32_t)v, rcap, wide)], nnd_mix32((uint32_t)v ^ salt));  // (a priority equal to NND_EMPTY_SLOT, 1 in 2^32, is a lost offer)
 }
 
 #define SAMPLE_MAX_ITEMS 128  // k (<=64) forward + rcap (<=64) reverse offers per class
@@ -70,7 +85,7 @@ struct sample_scratch {
 __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
                                                        int mcp, uint32_t it_seed, uint32_t *__restrict__ rbuf, int rcap,
                                                        int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
-                                                       const uint8_t *__restrict__ active) {
+                                                       const uint8_t *__restrict__ active, int wide) {
     __shared__ sample_scratch scr[4];
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
     const int64_t v = own_lo + (int64_t)blockIdx.x * 4 + w;
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
     const uint32_t salt = nnd_offer_salt(it_seed, (uint32_t)v);
     // reverse offers: when both classes' slot banks fit one wave (2 * rcap <= 64) they are fetched and screened together
     if (2 * rcap <= 64) {
-        const int c = lane >= rcap ? 1 : 0;
+        const int c = (wide || lane >= rcap) ? 1 : 0;  // wide: both banks hold new-class offers (nnd_offer_addr)
         uint32_t *slots = rbuf + v * 2 * rcap;  // [class 0 | class 1] are adjacent
         uint32_t rw = NND_EMPTY_SLOT;
         if (lane < 2 * rcap) {
@@ -123,7 +138,7 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
         }
     } else {
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < 2; c++) {  // (never wide: the launcher asks for it only with 32 slots per class)
             uint32_t *slots = rbuf + (v * 2 + c) * rcap;
             for (int s0 = 0; s0 < rcap; s0 += 64) {
                 int s = s0 + lane;
@@ -374,6 +389,10 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
 
 // rows scanned for reverse offers: every row on a plain handle; the owned slice when shard bounds are set (row-sharded
 // build: offers to targets owned elsewhere travel as records, see k_offer_export)
+// both banks of a vertex for the new class while no old edge exists (nnd_offer_addr): 32 slots per class (the
+// max_candidates <= 32 regime) and k <= 64, so that k forward + 64 reverse items fit the selection's 128-item lists
+static bool sample_wide(const nnd_ctx *ctx) { return ctx->all_new && ctx->rcap == 32 && ctx->k <= 64; }
+
 static void launch_reverse_pass(nnd_ctx *ctx, int pass, uint32_t it_seed) {
     const bool shard = ctx->n_ranks > 1;
     const int64_t row_lo = shard ? ctx->own_lo : 0, row_hi = shard ? ctx->own_hi : ctx->n;
@@ -386,12 +405,12 @@ static void launch_reverse_pass(nnd_ctx *ctx, int pass, uint32_t it_seed) {
     const int32_t *order = (!shard && ctx->forest_built && ctx->p.n_trees > 0) ? ctx->perm[ctx->cur] : nullptr;
     ctx->rbuf_clean = false;
     hipLaunchKernelGGL(k_sample_reverse, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->knn_e, row_lo, row_hi, ctx->k, ctx->ks,
-                       it_seed, ctx->rbuf, ctx->rcap, ctx->own_lo, ctx->own_hi, pass, ctx->active, order);
+                       it_seed, ctx->rbuf, ctx->rcap, ctx->own_lo, ctx->own_hi, pass, ctx->active, order, sample_wide(ctx) ? 1 : 0);
 }
 
 static uint32_t sample_seed(const nnd_ctx *ctx) { return nnd_hash2(ctx->seed ^ 0x9E3779B9u, (uint32_t)ctx->iter + 1u); }
 
-static void launch_select(nnd_ctx *ctx, uint32_t it_seed) {
+static void launch_select(nnd_ctx *ctx, uint32_t it_seed, bool wide) {
     if (ctx->k > 64) {
         hipLaunchKernelGGL(k_sample_select_wide, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream,
                            ctx->knn_e, ctx->n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand, ctx->own_lo,
@@ -400,7 +419,7 @@ static void launch_select(nnd_ctx *ctx, uint32_t it_seed) {
         return;
     }
     const bool force_old = (ctx->p.flags & NND_FLAG_TEST_SELECT_WAVE) != 0;  // parity test: the one-wave-per-vertex kernel
-    if (ctx->k <= 32 && ctx->rcap == 32 && ctx->mc <= 32 && !force_old) {
+    if (ctx->k <= 32 && ctx->rcap == 32 && ctx->mc <= 32 && !force_old && !wide) {
         hipLaunchKernelGGL(k_sample_select_h, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 7) / 8)), dim3(256), 0, ctx->stream,
                            ctx->knn_e, ctx->n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->cand, ctx->own_lo,
                            ctx->own_hi, ctx->active);
@@ -409,7 +428,7 @@ static void launch_select(nnd_ctx *ctx, uint32_t it_seed) {
     }
     hipLaunchKernelGGL(k_sample_select, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream,
                        ctx->knn_e, ctx->n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand, ctx->own_lo,
-                       ctx->own_hi, ctx->active);
+                       ctx->own_hi, ctx->active, wide ? 1 : 0);
     if (ctx->n_ranks <= 1) ctx->rbuf_clean = true;  // every bank that received an offer belongs to an active vertex and was re-armed
 }
 
@@ -422,9 +441,10 @@ int nnd_launch_sample(nnd_ctx *ctx) {
     NND_HIP_CHECK(hipMemsetAsync(ctx->active, 0, (size_t)ctx->n, ctx->stream));
     // every edge still carries the "new" flag before the first sampling pass: there are no old edges to offer
     const int n_pass = ctx->all_new ? 1 : 2;
+    const bool wide = sample_wide(ctx);
     for (int pass = 0; pass < n_pass; pass++) launch_reverse_pass(ctx, pass, it_seed);
     ctx->all_new = false;
-    launch_select(ctx, it_seed);
+    launch_select(ctx, it_seed, wide);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -503,7 +523,7 @@ __global__ __launch_bounds__(256) void k_offer_export(const uint32_t *__restrict
 
 __global__ void k_offer_import(const int32_t *__restrict__ targets, const uint32_t *__restrict__ sources, int64_t count, uint32_t want_cls,
                                uint32_t it_seed, uint32_t *__restrict__ rbuf, int rcap, uint8_t *__restrict__ active,
-                               int64_t own_lo, int64_t own_hi) {
+                               int64_t own_lo, int64_t own_hi, int wide) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint32_t t = (uint32_t)targets[i];
@@ -512,8 +532,8 @@ __global__ void k_offer_import(const int32_t *__restrict__ targets, const uint32
     if (cls == 1u) active[u] = 1;
     else if (!active[u]) return;  // no new candidate reaches u: its old list is never read
     const uint32_t v = sources[i];  // the priority is a function of (source, target): it does not travel
-    const uint32_t slot = nnd_hash2(it_seed ^ 0x68E31DA4u, v) & (uint32_t)(rcap - 1);
-    atomicMin(&rbuf[((int64_t)u * 2 + cls) * rcap + slot], nnd_offer_prio(it_seed, v, u));
+    const uint32_t salt = nnd_offer_salt(it_seed, u);
+    atomicMin(&rbuf[nnd_offer_addr(u, cls, salt, v, rcap, wide)], nnd_mix32(v ^ salt));
 }
 
 // first half of a sharded sampling pass: local new edges, and the records for targets owned elsewhere (both classes)
@@ -543,19 +563,20 @@ int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uin
 int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uint32_t *sources_dev, int64_t count) {
     const uint32_t it_seed = sample_seed(ctx);
     const unsigned grid = (unsigned)((count + 255) / 256);
+    const bool wide = sample_wide(ctx);  // (all_new is still what it was when nnd_launch_sample_begin ran)
     if (count > 0) {
         ctx->rbuf_clean = false;
         hipLaunchKernelGGL(k_offer_import, dim3(grid), dim3(256), 0, ctx->stream, targets_dev, sources_dev, count, 1u, it_seed, ctx->rbuf,
-                           ctx->rcap, ctx->active, ctx->own_lo, ctx->own_hi);
+                           ctx->rcap, ctx->active, ctx->own_lo, ctx->own_hi, wide ? 1 : 0);
     }
     if (!ctx->all_new) {
         launch_reverse_pass(ctx, 1, it_seed);
         if (count > 0)
             hipLaunchKernelGGL(k_offer_import, dim3(grid), dim3(256), 0, ctx->stream, targets_dev, sources_dev, count, 0u, it_seed, ctx->rbuf,
-                               ctx->rcap, ctx->active, ctx->own_lo, ctx->own_hi);
+                               ctx->rcap, ctx->active, ctx->own_lo, ctx->own_hi, 0);
     }
     ctx->all_new = false;
-    launch_select(ctx, it_seed);
+    launch_select(ctx, it_seed, wide);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }

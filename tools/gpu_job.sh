@@ -13,8 +13,8 @@ for job in "$@"; do
   log=$O/${tag}_${name}.log
   case $name in
     tests)
-      ( cd $R && timeout 1500 python -m pytest tests -m gpu -q --maxfail=10 --durations=10 -p no:cacheprovider ${arg:+-k "$arg"} > $log 2>&1; echo "pytest rc=$?" >> $log )
-      tail -n 25 $log ;;
+      ( cd $R && timeout 1500 python -m pytest tests -m gpu -q -rP --maxfail=10 --durations=10 -p no:cacheprovider ${arg:+-k "$arg"} > $log 2>&1; echo "pytest rc=$?" >> $log )
+      grep -c PASSED $log; tail -n 25 $log | cut -c1-200 ;;
     bench)
       ( cd $R && timeout 900 python bench.py ${arg:---steps 5 --warmup 2} > $log 2>&1; echo "bench rc=$?" >> $log )
       tail -c 2500 $log ;;
