@@ -288,6 +288,9 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
 // over the forward ids, rank count over the items) run for both vertices at once.  Lane j of a half holds forward edge
 // j, reverse slots j (old class) and 32 + j (new class), and items j and 32 + j of each class's list (<= k + 32 <= 64
 // items).  Same keys, same duplicate rule, same ranks: the candidate lists are identical to k_sample_select's.
+// WIDE (the first pass of a build: every edge new, both banks hold new-class offers, nnd_offer_addr): one list of up to
+// k + 64 <= 96 items -- the two classes' LDS arrays of a half-wave are adjacent and are used as one, three items per lane.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
                                                          int mcp, uint32_t it_seed, uint32_t *__restrict__ rbuf,
                                                          int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
@@ -333,6 +336,62 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
     }
     nnd_wave_lds_sync();
     const int nf0 = cnt[0], nf1 = cnt[1];
+    int32_t *out = cand + vv * 2 * mcp;
+    int my_rank = 1 << 30;  // rank of this lane's forward new edge among the new offers
+    const int my_item = (valid && cls == 1u) ? __popc(fmask1 & below) : -1;
+    if constexpr (WIDE) {
+        // every forward edge is new (nf0 == 0): the items live in ONE list fl[0 .. M), forward edges first.  fl aliases
+        // sk[0] | sk[1]; the forward keys were written to sk[1] = fl + 64 above and move to the front here.
+        uint64_t *fl = &sk[0][0];
+        const uint64_t fk = j < nf1 ? sk[1][j] : NND_EMPTY_KEY;
+        nnd_wave_lds_sync();
+        if (j < nf1) fl[j] = fk;
+        nnd_wave_lds_sync();
+        bool ok0 = rw0 != NND_EMPTY_SLOT, ok1 = rw1 != NND_EMPTY_SLOT;
+        {
+            const int a0 = __builtin_amdgcn_readlane(nf1, 0), a1 = __builtin_amdgcn_readlane(nf1, 32);
+            const int nfm = a0 > a1 ? a0 : a1;  // wave-uniform trip count
+            const uint32_t s0 = (uint32_t)rk0, s1 = (uint32_t)rk1;
+            for (int q = 0; q < nfm; q++) {
+                const uint32_t f = (uint32_t)fl[q];
+                ok0 = ok0 && !(q < nf1 && f == s0);
+                ok1 = ok1 && !(q < nf1 && f == s1);
+            }
+        }
+        int M = nf1;
+        {   // bank order [old-class bank | new-class bank] = the order k_sample_select walks the 64 slots in
+            const uint32_t hm0 = (uint32_t)(__ballot(ok0) >> hb), hm1 = (uint32_t)(__ballot(ok1) >> hb);
+            if (ok0) fl[M + __popc(hm0 & below)] = rk0;
+            M += __popc(hm0);
+            if (ok1) fl[M + __popc(hm1 & below)] = rk1;
+            M += __popc(hm1);
+        }
+        nnd_wave_lds_sync();
+        const int m0 = __builtin_amdgcn_readlane(M, 0), m1 = __builtin_amdgcn_readlane(M, 32);
+        const int mm = m0 > m1 ? m0 : m1;  // wave-uniform trip count
+        const uint64_t key0 = j < M ? fl[j] : NND_EMPTY_KEY, key1 = 32 + j < M ? fl[32 + j] : NND_EMPTY_KEY, key2 = 64 + j < M ? fl[64 + j] : NND_EMPTY_KEY;
+        int r0 = 0, r1 = 0, r2 = 0;
+        for (int q = 0; q < mm; q++) {
+            const uint64_t kq = fl[q];
+            const bool in = q < M;
+            r0 += (in && kq < key0) ? 1 : 0;
+            r1 += (in && kq < key1) ? 1 : 0;
+            r2 += (in && kq < key2) ? 1 : 0;
+        }
+        if (act) {
+            if (j < M && r0 < mc) out[r0] = (int32_t)(uint32_t)key0;
+            if (32 + j < M && r1 < mc) out[r1] = (int32_t)(uint32_t)key1;
+            if (64 + j < M && r2 < mc) out[r2] = (int32_t)(uint32_t)key2;
+            const int filled = M < mc ? M : mc;
+            for (int q = filled + j; q < mcp; q += 32) out[q] = -1;
+            for (int q = j; q < mcp; q += 32) out[mcp + q] = -1;  // no old candidates yet
+        }
+        // forward item i < k <= 32 is item 0 of lane i of my half
+        const int got = __builtin_amdgcn_ds_bpermute((hb + (my_item >= 0 ? my_item : 0)) << 2, r0);
+        if (my_item >= 0) my_rank = got;
+        if (act && valid && cls == 1u && my_rank < mc) knn_e[vv * ks + j] = u;
+        return;
+    }
     // utils.py:427-430: an id already in the list is not pushed again (a reverse offer that repeats a forward edge)
     bool ok0 = rw0 != NND_EMPTY_SLOT, ok1 = rw1 != NND_EMPTY_SLOT;
     {
@@ -355,9 +414,6 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
     }
     nnd_wave_lds_sync();
 
-    int32_t *out = cand + vv * 2 * mcp;
-    int my_rank = 1 << 30;  // rank of this lane's forward new edge among the new offers
-    const int my_item = (valid && cls == 1u) ? __popc(fmask1 & below) : -1;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const int M = cnt[c];
@@ -419,8 +475,9 @@ static void launch_select(nnd_ctx *ctx, uint32_t it_seed, bool wide) {
         return;
     }
     const bool force_old = (ctx->p.flags & NND_FLAG_TEST_SELECT_WAVE) != 0;  // parity test: the one-wave-per-vertex kernel
-    if (ctx->k <= 32 && ctx->rcap == 32 && ctx->mc <= 32 && !force_old && !wide) {
-        hipLaunchKernelGGL(k_sample_select_h, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 7) / 8)), dim3(256), 0, ctx->stream,
+    if (ctx->k <= 32 && ctx->rcap == 32 && ctx->mc <= 32 && !force_old) {
+        auto kern = wide ? k_sample_select_h<true> : k_sample_select_h<false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 7) / 8)), dim3(256), 0, ctx->stream,
                            ctx->knn_e, ctx->n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->cand, ctx->own_lo,
                            ctx->own_hi, ctx->active);
         if (ctx->n_ranks <= 1) ctx->rbuf_clean = true;

@@ -302,21 +302,26 @@ def test_half_wave_select_equals_wave_select(k, mc):
         b.make_forest()
         b.init_from_leaves()
         b.init_random()
+        # the first pass of a build: every edge new, the new class uses both slot banks (the WIDE forms of both kernels)
+        b.sample_candidates()
+        new0, old0 = b.candidates()
+        _, _, fl0 = b.graph()
+        assert (old0 == -1).all() and (new0[:, 0] >= 0).all()
         b.descent_iter()  # a mix of old and new entries
         b.sample_candidates()
         new, old = b.candidates()
         idx, _, fl = b.graph()
-        # second sampling pass on the resulting state (mostly old edges, many inactive vertices)
+        # another sampling pass on the resulting state (mostly old edges, many inactive vertices)
         b.descent_iter()
         b.sample_candidates()
         new2, old2 = b.candidates()
         _, _, fl2 = b.graph()
-        outs.append((new, old, idx, fl, new2, fl2))
+        outs.append((new, old, idx, fl, new2, fl2, new0, fl0))
         b.close()
     for a, c in zip(outs[0], outs[1]):
         np.testing.assert_array_equal(a, c)
     # the old lists of vertices without new candidates are not defined (the join skips them): compare where they are
-    has_new = outs[0][4][:, 0] >= 0
+    has_new = outs[0][0][:, 0] >= 0
     assert has_new.any()
 
 
