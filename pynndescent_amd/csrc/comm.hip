@@ -136,6 +136,45 @@ static nnd_comm_s *make_rccl(const void *id_bytes, int32_t world, int32_t rank, 
     return c;
 }
 
+// The first exchange of a new RCCL communicator, done at creation (which is collective anyway): every rank sends its
+// rank number to every other rank through the same send / recv group every later exchange uses, waits with the bounded
+// wait, and checks what arrived.  RCCL sets its peer-to-peer connections up lazily at the first use: doing that HERE keeps
+// the set-up (allocations, IPC handles, proxy threads) away from the first build, where the second channel's transfer is
+// already in flight on another stream, and a transport that does not work fails at creation with a message that says so.
+static int rccl_first_exchange(nnd_comm_s *c, hipStream_t st) {
+    const int G = c->world, me = c->rank;
+    if (G < 2) return 0;
+    int32_t *buf = nullptr;
+    C_HIP(hipMalloc((void **)&buf, sizeof(int32_t) * 2 * (size_t)G));
+    int32_t h[2 * NND_MAX_RANKS];
+    for (int i = 0; i < 2 * G; i++) h[i] = -1;
+    h[me] = me;  // [0, G): the word this rank sends (slot me); [G, 2 G): what the ranks sent
+    int rc = hipMemcpy(buf, h, sizeof(int32_t) * 2 * (size_t)G, hipMemcpyHostToDevice) != hipSuccess;
+    size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
+    for (int p = 0; p < G; p++) {
+        soff[p] = (size_t)me;
+        scnt[p] = 1;
+        roff[p] = (size_t)(G + p);
+        rcnt[p] = 1;
+    }
+    void *sb[1] = {buf}, *rb[1] = {buf};
+    const int eb[1] = {4};
+    if (!rc) rc = comm_alltoallv(c, st, 1, sb, rb, eb, soff, scnt, roff, rcnt);
+    if (!rc) rc = comm_wait(c, st, "first exchange of a new communicator");
+    if (!rc) rc = hipMemcpy(h, buf, sizeof(int32_t) * 2 * (size_t)G, hipMemcpyDeviceToHost) != hipSuccess;
+    if (!rc)
+        for (int p = 0; p < G; p++)
+            if (h[G + p] != p) {
+                c->set_error("first exchange of a new communicator: rank %d received %d from rank %d", me, h[G + p], p);
+                rc = 1;
+                break;
+            }
+    if (rc && !c->err[0]) c->set_error("first exchange of a new communicator: a HIP call failed");
+    (void)hipFree(buf);
+    c->bytes_sent = 0;
+    return rc;
+}
+
 extern "C" int32_t nnd_comm_create_rccl(nnd_comm_t *out, const void *id_bytes, int32_t world, int32_t rank, int32_t device) {
     if (!out || !id_bytes || world < 1 || world > NND_MAX_RANKS || rank < 0 || rank >= world) { cgerr("nnd_comm_create_rccl: bad arguments"); return 1; }
     *out = nullptr;
@@ -144,6 +183,17 @@ extern "C" int32_t nnd_comm_create_rccl(nnd_comm_t *out, const void *id_bytes, i
     if (hipSetDevice(device) != hipSuccess) { cgerr("nnd_comm_create_rccl: hipSetDevice(%d) failed", device); return 1; }
     nnd_comm_s *c = make_rccl(id_bytes, world, rank, device);
     if (!c) return 1;
+    if (world > 1) {
+        hipStream_t st = nullptr;
+        int rc = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess;
+        if (!rc) rc = rccl_first_exchange(c, st);
+        if (st) (void)hipStreamDestroy(st);
+        if (rc) {
+            cgerr("nnd_comm_create_rccl: %s", c->err[0] ? c->err : "hipStreamCreate failed");
+            (void)nnd_comm_destroy(c);
+            return 1;
+        }
+    }
     *out = c;
     return 0;
 }
@@ -162,6 +212,13 @@ extern "C" int32_t nnd_comm_add_channel_rccl(nnd_comm_t c, const void *id_bytes)
     a->timeout_ms = c->timeout_ms;
     if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) {
         cgerr("nnd_comm_add_channel_rccl: hipStreamCreate failed");
+        (void)nnd_comm_destroy(a);
+        return 1;
+    }
+    if (rccl_first_exchange(a, c->aux_stream)) {
+        cgerr("nnd_comm_add_channel_rccl: %s", a->err);
+        (void)hipStreamDestroy(c->aux_stream);
+        c->aux_stream = nullptr;
         (void)nnd_comm_destroy(a);
         return 1;
     }
