@@ -1080,7 +1080,8 @@ extern "C" int32_t nnd_build_multi(const nnd_params *params, const float *x, int
         if (failed.load()) return;
         if (use_rccl) {
             if (nnd_comm_create_rccl(&comms[r], id, G, r, dev[r])) bail(nnd_comm_last_error(nullptr));
-            else if (nnd_comm_add_channel_rccl(comms[r], id2)) bail(nnd_comm_last_error(nullptr));
+            bar.wait();  // (1b) every rank has its first channel, or nobody asks for the second (its creation is collective too)
+            if (!failed.load() && nnd_comm_add_channel_rccl(comms[r], id2)) bail(nnd_comm_last_error(nullptr));
             if (comms[r]) {
                 comms[r]->abort_flag = &abort_flag;
                 if (comms[r]->aux) comms[r]->aux->abort_flag = &abort_flag;
