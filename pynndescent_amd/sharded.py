@@ -151,17 +151,19 @@ def make_comm(device_index, group=None, allow_host_fallback=False):
     h = _capi._H()
     if dist.get_backend(group) == "nccl":
         dev = torch.device("cuda", device_index)
-        ident = torch.zeros(256, dtype=torch.uint8)
+        ident = torch.zeros(257, dtype=torch.uint8)  # two ids + rank 0's status (nobody waits in ncclCommInitRank for ids that were never made)
         ok = 1
+        why = ""
         if rank == 0:
             buf, buf2 = (C.c_uint8 * 128)(), (C.c_uint8 * 128)()
             if lib.nnd_comm_unique_id(buf) != 0 or lib.nnd_comm_unique_id(buf2) != 0:
-                ok = 0
-            ident = torch.tensor(list(buf) + list(buf2), dtype=torch.uint8)
+                ok, why = 0, lib.nnd_comm_last_error(None).decode()
+            ident = torch.tensor(list(buf) + list(buf2) + [ok], dtype=torch.uint8)
         ident = ident.to(dev)
         dist.broadcast(ident, 0, group=group)
         raw = bytes(ident.cpu().tolist())
-        why = ""
+        if raw[256] != 1 and ok:
+            ok, why = 0, "rank 0 could not create the RCCL unique ids"
         if ok and lib.nnd_comm_create_rccl(C.byref(h), raw[:128], world, rank, int(device_index)) != 0:
             ok, why = 0, lib.nnd_comm_last_error(None).decode()
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
