@@ -9,7 +9,8 @@ exchanges issued from the C side (``ncclGroupStart`` / ``ncclSend`` / ``ncclRecv
 ``include/pynnd_amd.h``).  What is left here:
 
 * ``make_comm``        -- create the rank's communicator: **RCCL** when ``torch.distributed`` runs the ``nccl`` backend
-                          (the 128-byte unique id is the only thing that travels through torch); **HOST** staging with
+                          (two 128-byte unique ids -- the build's channel and the second channel -- and three status
+                          words are all that travels through torch); **HOST** staging with
                           a gloo callback otherwise (two processes sharing one GPU in the tests);
 * ``LocalGroup``       -- G ranks as threads of this process on one or several GPUs (LOCAL transport: device copies);
 * ``ShardedBuilder``   -- the rank's persistent state (``nnd_shard_t``), ``build(x_local)``;
