@@ -250,6 +250,10 @@ int32_t nnd_comm_destroy(nnd_comm_t c);
 int32_t nnd_comm_abort(nnd_comm_t c);
 /* out[0] transport (1 RCCL, 2 LOCAL, 3 HOST), out[1] ranks, out[2] ncclGetVersion() (0 unless RCCL), out[3] second channel present */
 int32_t nnd_comm_info(nnd_comm_t c, int32_t *out /* [4] */);
+/* Collective (every rank of the world calls it): each rank sends its rank number to every other rank through the transport's
+ * ordinary exchange and checks what arrived -- the exchange nnd_comm_create_rccl / nnd_comm_add_channel_rccl end with.
+ * RCCL and LOCAL transports; 0 = every pair of ranks moved its bytes (both channels). */
+int32_t nnd_comm_self_test(nnd_comm_t c);
 /* LOCAL only: compute sections of the ranks run one at a time (per-rank timings on a shared GPU; tools/rank_critical_path.py) */
 int32_t nnd_comm_local_set_serial(nnd_comm_t c, int32_t on);
 const char *nnd_comm_last_error(nnd_comm_t c /* NULL: the error of a failed create */);

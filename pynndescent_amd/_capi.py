@@ -184,6 +184,7 @@ _SIGNATURES = [
     ("nnd_comm_add_channel_rccl", C.c_int32, [_H, C.c_void_p]),
     ("nnd_comm_set_timeout", C.c_int32, [_H, C.c_int64]),
     ("nnd_comm_info", C.c_int32, [_H, C.POINTER(C.c_int32)]),
+    ("nnd_comm_self_test", C.c_int32, [_H]),
     ("nnd_comm_destroy", C.c_int32, [_H]),
     ("nnd_comm_abort", C.c_int32, [_H]),
     ("nnd_comm_local_set_serial", C.c_int32, [_H, C.c_int32]),

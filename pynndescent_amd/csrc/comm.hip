@@ -136,12 +136,13 @@ static nnd_comm_s *make_rccl(const void *id_bytes, int32_t world, int32_t rank, 
     return c;
 }
 
-// The first exchange of a new RCCL communicator, done at creation (which is collective anyway): every rank sends its
+// The first exchange of a new RCCL communicator, done at creation (which is collective anyway; nnd_comm_self_test runs the
+// same exchange on any transport -- that is how this function is tested on a one-GPU box): every rank sends its
 // rank number to every other rank through the same send / recv group every later exchange uses, waits with the bounded
 // wait, and checks what arrived.  RCCL sets its peer-to-peer connections up lazily at the first use: doing that HERE keeps
 // the set-up (allocations, IPC handles, proxy threads) away from the first build, where the second channel's transfer is
 // already in flight on another stream, and a transport that does not work fails at creation with a message that says so.
-static int rccl_first_exchange(nnd_comm_s *c, hipStream_t st) {
+static int comm_first_exchange(nnd_comm_s *c, hipStream_t st) {
     const int G = c->world, me = c->rank;
     if (G < 2) return 0;
     int32_t *buf = nullptr;
@@ -186,7 +187,7 @@ extern "C" int32_t nnd_comm_create_rccl(nnd_comm_t *out, const void *id_bytes, i
     if (world > 1) {
         hipStream_t st = nullptr;
         int rc = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess;
-        if (!rc) rc = rccl_first_exchange(c, st);
+        if (!rc) rc = comm_first_exchange(c, st);
         if (st) (void)hipStreamDestroy(st);
         if (rc) {
             cgerr("nnd_comm_create_rccl: %s", c->err[0] ? c->err : "hipStreamCreate failed");
@@ -215,7 +216,7 @@ extern "C" int32_t nnd_comm_add_channel_rccl(nnd_comm_t c, const void *id_bytes)
         (void)nnd_comm_destroy(a);
         return 1;
     }
-    if (rccl_first_exchange(a, c->aux_stream)) {
+    if (comm_first_exchange(a, c->aux_stream)) {
         cgerr("nnd_comm_add_channel_rccl: %s", a->err);
         (void)hipStreamDestroy(c->aux_stream);
         c->aux_stream = nullptr;
@@ -384,6 +385,26 @@ extern "C" int32_t nnd_comm_set_timeout(nnd_comm_t c, int64_t timeout_ms) {
         }
     }
     return 0;
+}
+
+// Collective self test: the exchange a new RCCL communicator does at creation, on this communicator's transport (and on
+// its second channel when there is one).  0 = every pair of ranks moved its bytes.
+extern "C" int32_t nnd_comm_self_test(nnd_comm_t c) {
+    if (!c) { cgerr("nnd_comm_self_test: null communicator"); return 1; }
+    if (c->kind == NND_COMM_HOST) { c->set_error("nnd_comm_self_test: the HOST transport has no device-side exchange to test"); return 1; }
+    if (hipSetDevice(c->device) != hipSuccess) { c->set_error("nnd_comm_self_test: hipSetDevice(%d) failed", c->device); return 1; }
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { c->set_error("nnd_comm_self_test: hipStreamCreate failed"); return 1; }
+    int rc = comm_first_exchange(c, st);
+    if (!rc && c->aux) {
+        rc = comm_first_exchange(c->aux, c->aux_stream ? c->aux_stream : st);
+        if (rc) c->set_error("second channel: %s", c->aux->err);
+    }
+    // LOCAL: a rank's stream may still hold waits on its peers' events: nobody tears its stream down before all are through
+    if (!rc && c->kind == NND_COMM_LOCAL && c->world > 1) rc = comm_barrier(c);
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    return rc;
 }
 
 // out[0] transport (NND_COMM_RCCL = 1, LOCAL = 2, HOST = 3), out[1] world, out[2] ncclGetVersion() (0 unless RCCL),

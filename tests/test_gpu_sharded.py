@@ -362,3 +362,23 @@ def test_a_failing_rank_ends_the_build_on_every_rank(hook, timeout_s):
     # the library is usable afterwards
     idx, _, _ = _run_local(xd, 2, "euclidean", 15, n_trees=4, seed=5)
     assert (idx.cpu().numpy() >= 0).all()
+
+
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_comm_self_test_moves_bytes_between_every_pair_of_ranks(world):
+    """nnd_comm_self_test = the checked exchange of rank numbers a new RCCL communicator ends its creation with, here on the
+    LOCAL transport (both channels): the only multi-rank run of that function a one-GPU box allows."""
+    grp = sharded.LocalGroup(world)
+    lib = _capi.load_library()
+    rcs = [None] * world
+
+    def run(r):
+        torch.cuda.set_device(0)
+        rcs[r] = lib.nnd_comm_self_test(grp[r]._h)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    errs = [lib.nnd_comm_last_error(grp[r]._h).decode() for r in range(world) if rcs[r] != 0]
+    grp.close()
+    assert rcs == [0] * world, errs
