@@ -90,6 +90,9 @@ typedef struct nnd_params {
 #define NND_FLAG_TEST_FOREST_BY_TREE 32
 #define NND_FLAG_TEST_FAIL 64
 #define NND_FLAG_TEST_VANISH 128
+/* test hook: the reverse offers of the candidate sampling through the round-1..4 kernel (one device-scope atomicMin per
+ * edge into 32 hashed slots per bank) instead of the bucketed transposition (sample.hip): comparison / timing */
+#define NND_FLAG_TEST_SAMPLE_ATOMIC 256
 
 /* Run-time statistics for measurement (bench.py roofline). */
 typedef struct nnd_stats {

@@ -21,6 +21,7 @@ NND_FLAG_TEST_ROUTE_PLAIN = 16  # test hook: the forest's routing pass as one wa
 NND_FLAG_TEST_FOREST_BY_TREE = 32  # test hook (sharded build): forest split by tree where it would be sharded by cell
 NND_FLAG_TEST_FAIL = 64  # test hook (sharded build): this rank returns an error at the start of its second iteration
 NND_FLAG_TEST_VANISH = 128  # ... or returns there without telling anybody (a killed process)
+NND_FLAG_TEST_SAMPLE_ATOMIC = 256  # test hook: reverse offers by one global atomicMin per edge (rounds 1-4) instead of the bucketed transposition
 
 
 class NNDParams(C.Structure):

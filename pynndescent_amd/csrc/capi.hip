@@ -44,7 +44,12 @@ static int dalloc(nnd_ctx *ctx, T **p, size_t count) {
     // debugging aid: fresh hipMalloc pages are usually zero, recycled ones are not -- NND_POISON=<byte> fills every buffer with
     // that byte (try 165: negative ints / tiny floats, and 1 or 127: positive ints) before the build initialises it
     static const int poison = [] { const char *e = nnd_knob("NND_POISON"); return e ? atoi(e) : 0; }();  // the fill byte
-    if (poison) API_HIP(hipMemset(*p, poison & 0xFF, sizeof(T) * (count ? count : 1)));
+    // (on the handle's own stream, like the memsets of nnd_create_impl below: a hipMemset on the NULL stream queues behind
+    // whatever the caller's framework still has in flight there and would land in the middle of the build)
+    if (poison) {
+        API_HIP(hipMemsetAsync(*p, poison & 0xFF, sizeof(T) * (count ? count : 1), ctx->stream));
+        API_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return 0;
 }
 
@@ -85,6 +90,7 @@ static void free_all(nnd_ctx *ctx) {
     for (void *&a : ctx->slim_alloc) { F(a); a = nullptr; }  // cand / rbuf / active (the working pointers may be biased)
     F(ctx->xp); F(ctx->nrm); F(ctx->nr2); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->pbuf_r);
     F(ctx->pdirty); F(ctx->out_idx); F(ctx->out_dist);
+    F(ctx->rv_pos); F(ctx->rv_count); F(ctx->rv_start); F(ctx->rv_cursor); F(ctx->rv_word); F(ctx->rv_meta); F(ctx->rv_stage);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
     F(ctx->xs); F(ctx->xsh); F(ctx->nr2s); F(ctx->node_hf); F(ctx->node_hh); F(ctx->node_child); F(ctx->node_pack); F(ctx->node_hfc); F(ctx->route_roots); F(ctx->route_ws); F(ctx->s_leaf_depth);
@@ -216,7 +222,9 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
             ctx->pbuf = a_pbuf - (size_t)ctx->own_lo * (ctx->slim ? 1 : 0) * ctx->pcap;
             if (ctx->slim && (rc = dalloc(ctx, &ctx->pbuf_r, n * ctx->pcap_r))) break;
             if ((rc = dalloc(ctx, &ctx->pdirty, n))) break;
-            if (hipMemset(ctx->pdirty, 0, n) != hipSuccess) { ctx->set_error("hipMemset failed"); rc = 1; break; }
+            // on the handle's stream: the NULL-stream form is ordered behind the caller's pending NULL-stream work (torch's
+            // default stream) and not with this handle's non-blocking stream -- it could clear the flags of a build in progress
+            if (hipMemsetAsync(ctx->pdirty, 0, n, ctx->stream) != hipSuccess) { ctx->set_error("hipMemset failed"); rc = 1; break; }
             if (ctx->n_ranks > 0) {
                 if (hipMalloc((void **)&ctx->shard_bounds, sizeof(int64_t) * 65) != hipSuccess || hipMalloc((void **)&ctx->shard_cursors, sizeof(long long) * 66) != hipSuccess ||
                     hipMemcpy(ctx->shard_bounds, bounds_host, sizeof(int64_t) * (size_t)(n_ranks + 1), hipMemcpyHostToDevice) != hipSuccess) {
@@ -599,6 +607,7 @@ static int descent_iter(nnd_ctx *ctx, int64_t *c_out, bool timed) {
         ctx->stats.join_mfma[it] = ctx->h_counters[CNT_MFMA];
     }
     *c_out = ctx->h_counters[CNT_ACCEPT];
+    ctx->last_updates = ctx->h_counters[CNT_ACCEPT];
     ctx->iter++;
     ctx->stats.n_iters_run = ctx->iter;
     return 0;

@@ -298,6 +298,7 @@ __global__ void k_reset_graph(uint32_t *__restrict__ e, float *__restrict__ dd, 
 
 int nnd_launch_reset_graph(nnd_ctx *ctx) {
     ctx->all_new = true;
+    ctx->last_updates = -1;
     int64_t total = ctx->n * ctx->ks;
     hipLaunchKernelGGL(k_reset_graph, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e,
                        ctx->knn_d, total, ctx->th, ctx->n);

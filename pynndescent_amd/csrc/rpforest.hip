@@ -2360,6 +2360,7 @@ static int forest_leaf_tables(nnd_ctx *ctx, int64_t P, int T, const int32_t *tre
     ctx->max_leaf = mx;
     ctx->stats.n_leaves = nl;
     ctx->forest_built = true;
+    ctx->forest_gen++;
     return 0;
 }
 

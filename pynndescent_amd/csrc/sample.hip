@@ -290,33 +290,13 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
 // items).  Same keys, same duplicate rule, same ranks: the candidate lists are identical to k_sample_select's.
 // WIDE (the first pass of a build: every edge new, both banks hold new-class offers, nnd_offer_addr): one list of up to
 // k + 64 <= 96 items -- the two classes' LDS arrays of a half-wave are adjacent and are used as one, three items per lane.
+// The selection for one vertex per half-wave (both halves of the wave at once): forward edge word `e` of lane j, reverse slot
+// words rw0 (old-class bank, slot j) and rw1 (new-class bank) however the caller obtained them -- from rbuf
+// (k_sample_select_h) or from the LDS banks of the bucketed reverse pass (k_rev_select).  `sk`: the half-wave's LDS lists.
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
-                                                         int mcp, uint32_t it_seed, uint32_t *__restrict__ rbuf,
-                                                         int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
-                                                         const uint8_t *__restrict__ active) {
-    constexpr int RCAP = 32;
-    __shared__ uint64_t skey[8][2][64];  // [half-wave of the workgroup][class][item] priority<<32 | id
-    const int lane = nnd_lane(), w = threadIdx.x >> 6, h = lane >> 5, j = lane & 31, hb = lane & 32;
-    const int64_t v = own_lo + ((int64_t)blockIdx.x * 4 + w) * 2 + h;
-    const bool von = v < own_hi;
-    const bool act = von && active[von ? v : own_lo] != 0;
-    if (von && !act)  // no new candidate can reach v: empty new list, nothing else to do (no offers were stored for it)
-        for (int q = j; q < mcp; q += 32) cand[v * 2 * mcp + q] = -1;
-    if (!__ballot(act)) return;  // wave-uniform
-    uint64_t(*sk)[64] = skey[w * 2 + h];
-    const int64_t vv = act ? v : own_lo;
-
-    uint32_t e = NND_EMPTY_E;
-    if (act && j < k) e = knn_e[vv * ks + j];
-    uint32_t rw0 = NND_EMPTY_SLOT, rw1 = NND_EMPTY_SLOT;  // reverse offers: old class, new class
-    uint32_t *slots = rbuf + vv * 2 * RCAP;                // [class 0 | class 1] are adjacent: one 256-byte bank pair per vertex
-    if (act) {
-        rw0 = slots[j];
-        rw1 = slots[RCAP + j];
-        if (rw0 != NND_EMPTY_SLOT) slots[j] = NND_EMPTY_SLOT;  // re-arm for the next iteration
-        if (rw1 != NND_EMPTY_SLOT) slots[RCAP + j] = NND_EMPTY_SLOT;
-    }
+__device__ __forceinline__ void nnd_select_half(uint32_t *__restrict__ knn_e, int k, int ks, int mc, int mcp, uint32_t it_seed,
+                                                int32_t *__restrict__ cand, int64_t vv, bool act, uint32_t e, uint32_t rw0, uint32_t rw1,
+                                                uint64_t (*sk)[64], int j, int hb) {
     const uint32_t salt = nnd_offer_salt(it_seed, (uint32_t)vv);
     const uint64_t rk0 = nnd_offer_key(rw0, salt), rk1 = nnd_offer_key(rw1, salt);
     const bool valid = e != NND_EMPTY_E;
@@ -443,6 +423,399 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
     if (act && valid && cls == 1u && my_rank < mc) knn_e[vv * ks + j] = u;
 }
 
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
+                                                         int mcp, uint32_t it_seed, uint32_t *__restrict__ rbuf,
+                                                         int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
+                                                         const uint8_t *__restrict__ active) {
+    constexpr int RCAP = 32;
+    __shared__ uint64_t skey[8][2][64];  // [half-wave of the workgroup][class][item] priority<<32 | id
+    const int lane = nnd_lane(), w = threadIdx.x >> 6, h = lane >> 5, j = lane & 31, hb = lane & 32;
+    const int64_t v = own_lo + ((int64_t)blockIdx.x * 4 + w) * 2 + h;
+    const bool von = v < own_hi;
+    const bool act = von && active[von ? v : own_lo] != 0;
+    if (von && !act)  // no new candidate can reach v: empty new list, nothing else to do (no offers were stored for it)
+        for (int q = j; q < mcp; q += 32) cand[v * 2 * mcp + q] = -1;
+    if (!__ballot(act)) return;  // wave-uniform
+    uint64_t(*sk)[64] = skey[w * 2 + h];
+    const int64_t vv = act ? v : own_lo;
+
+    uint32_t e = NND_EMPTY_E;
+    if (act && j < k) e = knn_e[vv * ks + j];
+    uint32_t rw0 = NND_EMPTY_SLOT, rw1 = NND_EMPTY_SLOT;  // reverse offers: old class, new class
+    uint32_t *slots = rbuf + vv * 2 * RCAP;                // [class 0 | class 1] are adjacent: one 256-byte bank pair per vertex
+    if (act) {
+        rw0 = slots[j];
+        rw1 = slots[RCAP + j];
+        if (rw0 != NND_EMPTY_SLOT) slots[j] = NND_EMPTY_SLOT;  // re-arm for the next iteration
+        if (rw1 != NND_EMPTY_SLOT) slots[RCAP + j] = NND_EMPTY_SLOT;
+    }
+    nnd_select_half<WIDE>(knn_e, k, ks, mc, mcp, it_seed, cand, vv, act, e, rw0, rw1, sk, j, hb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bucketed reverse pass (round 5; plain handles).  k_sample_reverse above is 15 M random device-scope atomicMin per launch:
+// on this chip EVERY global atomic is executed at the memory side (per-XCD L2s are not coherent; workgroup- and agent-scope
+// atomics are the same instruction), 0.28 ms per launch whatever the traffic, and 32 hashed slots lose a fifth of the
+// offers of a bank to collisions -- the reference's heaps lose an offer only by priority (utils.py:277-306), and that loss
+// was the measured recall gap to the reference algorithm.  Here the reverse offers are TRANSPOSED
+// instead of scattered one atomic at a time:
+//   k_rev_count    one thread per edge: marks the endpoints of new edges active, looks the target's POSITION in the visiting
+//                  order up (the only random access per edge of the whole pass), counts the offers per target BUCKET
+//                  (128 or 256 consecutive positions) -- per 16-lane row first (a row's neighbours sit in a handful of
+//                  buckets: DPP rotations), then in an LDS hash table of the workgroup, one global atomic per (workgroup,
+//                  bucket) -- and STAGES the pre-formed record (slot word, position | class) in walking order;
+//   k_rev_scan     exclusive scan of the bucket counts (one workgroup);
+//   k_rev_scatter  streams the staged records (no second walk of the graph) into their buckets' regions as 6-byte records
+//                  (slot word, target's index in its bucket | class) -- ranks from the row groups and the LDS table, one
+//                  returning global atomic per (workgroup, bucket);
+//   k_rev_fill     one workgroup per bucket: its targets' slot banks live in LDS, the records are APPENDED (an LDS counter
+//                  per bank: no collision, no lost offer while a bank receives <= rcap offers; a bank that overflows is
+//                  redone with hashed atomicMin slots -- order independent, hubs only), the banks of active targets are
+//                  written to rbuf in whole 256-byte rows.
+// k_sample_select* read rbuf exactly as before (they never depended on WHICH slot an offer sits in).  The result is a
+// function of the graph and the seed alone: the set of appended words is the set of offers, the hashed fallback is a min.
+#define RV_TAB 1024  // entries of the per-workgroup hash table (bucket -> count); what does not fit goes straight to global
+#define RV_RPT 8     // row groups (of 256 / ksp rows) per workgroup = records per thread
+#define RV_NOHASH 0xFFFFu
+
+__device__ __forceinline__ uint32_t rv_tab_hash(uint32_t b) { return (b * 2654435761u) >> 22; }  // 10 bits
+
+// slot of bucket b in the workgroup's table (claimed on first use), or -1 when 24 probes found no room
+__device__ __forceinline__ int rv_tab_find(volatile uint32_t *hkey, uint32_t b) {
+    uint32_t h = rv_tab_hash(b);
+#pragma unroll 1
+    for (int p = 0; p < 24; p++) {
+        uint32_t cur = hkey[h];  // (a plain read first: after its first offer a bucket's slot is found without an atomic)
+        if (cur == 0xFFFFFFFFu) cur = atomicCAS((uint32_t *)&hkey[h], 0xFFFFFFFFu, b);
+        if (cur == 0xFFFFFFFFu || cur == b) return (int)h;
+        h = (h + 1) & (RV_TAB - 1);
+    }
+    return -1;
+}
+#define RV_NOKEY 0xFFFFFFFFu
+// Lanes of an aligned group of 16 (one k-list row when ks = 16) that hold the same key form a group: a row's neighbours
+// sit in a handful of buckets, and an LDS atomic per LANE on those few addresses is serialised lane by lane -- 15 M of them
+// made the first version of these kernels as slow as the global atomics they replace.  Fifteen DPP row rotations of
+// (key, lane): rank = members below this lane, size, leader = lowest member.  Every lane of the wave must be active.
+__device__ __forceinline__ void rv_row_groups(uint32_t key, int &rank, int &size, int &leader) {
+    // (the lane of the WAVE: these kernels run (ksp, rows)-shaped workgroups, threadIdx.x is the slot of a row there)
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    rank = 0;
+    size = 1;
+    leader = lane;
+#define RV_ROT(r)                                                                         \
+    {                                                                                     \
+        const uint32_t ok = (uint32_t)nnd_dpp_i32<NND_DPP_ROW_ROR(r)>((int)key);           \
+        const int ol = nnd_dpp_i32<NND_DPP_ROW_ROR(r)>(lane);                              \
+        const bool eq = ok == key;                                                        \
+        size += eq ? 1 : 0;                                                               \
+        rank += (eq && ol < lane) ? 1 : 0;                                                \
+        leader = (eq && ol < leader) ? ol : leader;                                       \
+    }
+    RV_ROT(1) RV_ROT(2) RV_ROT(3) RV_ROT(4) RV_ROT(5) RV_ROT(6) RV_ROT(7) RV_ROT(8)
+    RV_ROT(9) RV_ROT(10) RV_ROT(11) RV_ROT(12) RV_ROT(13) RV_ROT(14) RV_ROT(15)
+#undef RV_ROT
+}
+// word a bank stores for the offer v -> u: as k_sample_reverse (the slot word IS the source)
+__device__ __forceinline__ uint32_t rv_offer_word(uint32_t it_seed, uint32_t u, uint32_t v) { return nnd_mix32(v ^ nnd_offer_salt(it_seed, u)); }
+
+// late iterations (few new edges): the active flags first, so that k_rev_count can drop the offers nobody will read
+__global__ __launch_bounds__(256) void k_rev_mark(const uint32_t *__restrict__ knn_e, int64_t total, int ks, uint8_t *__restrict__ active) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    const u32x4 e = *(const u32x4 *)(knn_e + i);  // (rows are ks = 16 * m words: a vector never straddles two)
+    const int64_t v = i / ks;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t w = e[q];
+        if (w != NND_EMPTY_E && (w >> 31)) { active[v] = 1; active[w & NND_IDX_MASK] = 1; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rev_count(const uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, uint32_t it_seed,
+                                                   const int32_t *__restrict__ order, const int32_t *__restrict__ pos, int logB,
+                                                   uint8_t *__restrict__ active, int mark, uint32_t *__restrict__ bcount,
+                                                   uint2 *__restrict__ stage) {
+    __shared__ uint32_t hkey[RV_TAB], hcnt[RV_TAB];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int i = tid; i < RV_TAB; i += 256) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0; }
+    __syncthreads();
+    const int j = threadIdx.x;
+    uint32_t ev[RV_RPT], vv[RV_RPT];
+#pragma unroll
+    for (int it = 0; it < RV_RPT; it++) {  // all loads of the workgroup's rows first
+        const int64_t g = ((int64_t)blockIdx.x * RV_RPT + it) * blockDim.y + threadIdx.y;
+        ev[it] = NND_EMPTY_E;
+        vv[it] = 0;
+        if (g < n && j < k) {
+            vv[it] = (uint32_t)(order ? order[g] : (int32_t)g);
+            ev[it] = knn_e[(int64_t)vv[it] * ks + j];
+        }
+    }
+    uint32_t bb[RV_RPT];
+#pragma unroll
+    for (int it = 0; it < RV_RPT; it++) {
+        const int64_t g = ((int64_t)blockIdx.x * RV_RPT + it) * blockDim.y + threadIdx.y;
+        bb[it] = RV_NOKEY;
+        uint2 rec = make_uint2(0u, 0xFFFFFFFFu);
+        if (ev[it] != NND_EMPTY_E) {
+            const uint32_t u = ev[it] & NND_IDX_MASK, cls = ev[it] >> 31;
+            if (cls && mark == 1) { active[vv[it]] = 1; active[u] = 1; }  // a new edge: both endpoints will hold a new candidate
+            // mark == 2 (late iterations: few new edges, k_rev_mark has run): an old-class offer to a vertex that will not
+            // join is dropped here, before it costs a group, a record and a slot (utils.py:611-613: its old list is never read)
+            if (mark == 2 && !cls && !active[u]) { ev[it] = NND_EMPTY_E; }
+        }
+        if (ev[it] != NND_EMPTY_E) {
+            const uint32_t u = ev[it] & NND_IDX_MASK, cls = ev[it] >> 31;
+            const uint32_t p = (uint32_t)(pos ? pos[u] : (int32_t)u);
+            bb[it] = p >> logB;
+            rec = make_uint2(rv_offer_word(it_seed, u, vv[it]), p | (cls << 31));
+        }
+        if (g < n && j < ks) stage[g * ks + j] = rec;  // the scatter pass streams these: no second walk of the graph
+    }
+#pragma unroll
+    for (int it = 0; it < RV_RPT; it++) {
+        int rank, size, leader;
+        rv_row_groups(bb[it], rank, size, leader);
+        if (bb[it] != RV_NOKEY && rank == 0) {
+            const int h = rv_tab_find(hkey, bb[it]);
+            if (h >= 0) atomicAdd(&hcnt[h], (uint32_t)size);
+            else atomicAdd(&bcount[bb[it]], (uint32_t)size);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < RV_TAB; i += 256)
+        if (hcnt[i]) atomicAdd(&bcount[hkey[i]], hcnt[i]);
+}
+
+// exclusive scan of nb counts (one workgroup of 1024 threads; nb = n / 256: 4 k buckets at 1 M points, 40 k at 10 M);
+// out[nb] = the total
+__global__ __launch_bounds__(1024) void k_rev_scan(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int64_t nb) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 1024) {
+        const int64_t i = base + tid;
+        const uint32_t x = i < nb ? in[i] : 0u;
+        const uint32_t inc = (uint32_t)nnd_wave_incl_scan_i32((int)x);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (int q = 0; q < w; q++) before += wsum[q];
+        if (i < nb) out[i] = before + inc - x;
+        __syncthreads();
+        if (tid == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (tid == 0) out[nb] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void k_rev_scatter(const uint2 *__restrict__ stage, int64_t n, int ks, int logB, const uint32_t *__restrict__ bstart,
+                                                     uint32_t *__restrict__ bcursor, uint32_t *__restrict__ rec_w, uint16_t *__restrict__ rec_m) {
+    __shared__ uint32_t hkey[RV_TAB], hcnt[RV_TAB], hbase[RV_TAB];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int i = tid; i < RV_TAB; i += 256) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0; }
+    __syncthreads();
+    const int j = threadIdx.x;
+    const uint32_t bmask = (1u << logB) - 1u;
+    uint2 rec[RV_RPT];                 // slot word, position | class << 31
+    uint32_t at[RV_RPT];               // rank inside the (workgroup, bucket) group, or the final position
+    uint16_t hh[RV_RPT];               // table slot, RV_NOHASH: `at` is final, 0xFFFE: no record
+#pragma unroll
+    for (int it = 0; it < RV_RPT; it++) {
+        const int64_t g = ((int64_t)blockIdx.x * RV_RPT + it) * blockDim.y + threadIdx.y;
+        rec[it] = make_uint2(0u, 0xFFFFFFFFu);
+        if (g < n && j < ks) rec[it] = stage[g * ks + j];
+    }
+#pragma unroll
+    for (int it = 0; it < RV_RPT; it++) {
+        const uint32_t key = rec[it].y == 0xFFFFFFFFu ? RV_NOKEY : (rec[it].y & NND_IDX_MASK) >> logB;
+        int rank, size, leader;
+        rv_row_groups(key, rank, size, leader);
+        int h = -1;
+        uint32_t base = 0;
+        if (key != RV_NOKEY && rank == 0) {  // one LDS (or, table full, global) atomic per group
+            h = rv_tab_find(hkey, key);
+            base = h >= 0 ? atomicAdd(&hcnt[h], (uint32_t)size) : bstart[key] + atomicAdd(&bcursor[key], (uint32_t)size);
+        }
+        h = __shfl(h, leader, 64);
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        hh[it] = 0xFFFEu;
+        at[it] = 0;
+        if (key != RV_NOKEY) {
+            hh[it] = h >= 0 ? (uint16_t)h : RV_NOHASH;
+            at[it] = base + (uint32_t)rank;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < RV_TAB; i += 256)
+        if (hcnt[i]) hbase[i] = bstart[hkey[i]] + atomicAdd(&bcursor[hkey[i]], hcnt[i]);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RV_RPT; it++) {
+        if (hh[it] == 0xFFFEu) continue;
+        const uint32_t at_ = hh[it] == RV_NOHASH ? at[it] : hbase[hh[it]] + at[it];
+        rec_w[at_] = rec[it].x;
+        rec_m[at_] = (uint16_t)((rec[it].y & bmask) | ((rec[it].y >> 31) << 15));
+    }
+}
+
+// slot of a word in an overflowing bank: any fixed function of the word (itself a mixed value) will do
+__device__ __forceinline__ uint32_t rv_ovf_slot(uint32_t word, uint32_t cap) { return nnd_mix32(word ^ 0x68E31DA4u) & (cap - 1u); }
+
+// One workgroup per bucket.  RCAP slots per (target, class); WIDE: the first pass of a build, every offer is new-class and a
+// target's two banks form ONE bank of 2 * RCAP slots (nnd_offer_addr).  LDS: NB * 2 * RCAP words = 64 KB, two workgroups per CU.
+template <int RCAP, int NB, bool WIDE>
+__global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ rec_w, const uint16_t *__restrict__ rec_m,
+                                                   const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, int64_t n,
+                                                   const int32_t *__restrict__ order, const uint8_t *__restrict__ active,
+                                                   uint32_t *__restrict__ rbuf) {
+    constexpr int ROW = 2 * RCAP;                 // words per target
+    constexpr int CAP = WIDE ? 2 * RCAP : RCAP;   // slots per bank
+    constexpr int NBANK = WIDE ? NB : 2 * NB;
+    __shared__ uint32_t bank[NB * ROW];
+    __shared__ uint32_t cnt[NBANK];
+    __shared__ int any_ovf;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    for (int i = tid; i < NB * ROW; i += 1024) bank[i] = NND_EMPTY_SLOT;
+    for (int i = tid; i < NBANK; i += 1024) cnt[i] = 0;
+    if (tid == 0) any_ovf = 0;
+    __syncthreads();
+    const uint32_t base = bstart[b], nrec = bcursor[b];
+    for (uint32_t i = tid; i < nrec; i += 1024) {
+        const uint32_t w = rec_w[base + i];
+        const uint32_t m = rec_m[base + i];
+        const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));  // [old | new], as rbuf
+        const uint32_t s = atomicAdd(&cnt[bk], 1u);
+        if (s < (uint32_t)CAP) bank[bk * CAP + s] = w;
+    }
+    __syncthreads();
+    for (int i = tid; i < NBANK; i += 1024)
+        if (cnt[i] > (uint32_t)CAP) any_ovf = 1;
+    __syncthreads();
+    if (any_ovf) {  // (workgroup-uniform) a hub: more offers than slots -- those banks keep the smallest word per hashed slot
+        for (int i = tid; i < NBANK * CAP; i += 1024)
+            if (cnt[i / CAP] > (uint32_t)CAP) bank[i] = NND_EMPTY_SLOT;
+        __syncthreads();
+        for (uint32_t i = tid; i < nrec; i += 1024) {
+            const uint32_t m = rec_m[base + i];
+            const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));
+            if (cnt[bk] > (uint32_t)CAP) {
+                const uint32_t w = rec_w[base + i];
+                atomicMin(&bank[bk * CAP + rv_ovf_slot(w, CAP)], w);
+            }
+        }
+        __syncthreads();
+    }
+    // banks of the ACTIVE targets -> rbuf, whole rows (the selection reads no other; an inactive target's row stays EMPTY)
+    const int tl0 = tid / ROW, c = tid % ROW;
+    for (int tl = tl0; tl < NB; tl += 1024 / ROW) {
+        const int64_t p = b * NB + tl;
+        if (p >= n) break;
+        const int64_t v = order ? (int64_t)order[p] : p;
+        if (!active[v]) continue;
+        rbuf[v * ROW + c] = bank[tl * ROW + c];
+    }
+}
+
+// The BASELINE regime (k <= 32, 32 slots per bank, max_candidates <= 32): k_rev_fill and k_sample_select_h in ONE kernel --
+// the banks never leave LDS (rbuf is not touched: 256 B written, read and re-armed per vertex and iteration otherwise).
+// 512 threads per bucket of 128 targets: the records are appended to the banks as in k_rev_fill, then every half-wave
+// runs the selection (nnd_select_half) for 8 of the bucket's targets, whose k-list rows were requested before the fill
+// phase.  LDS: 32 KB banks + 16 KB selection lists: three workgroups per CU.
+template <bool WIDE>
+__global__ __launch_bounds__(512) void k_rev_select(const uint32_t *__restrict__ rec_w, const uint16_t *__restrict__ rec_m,
+                                                    const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, int64_t n,
+                                                    const int32_t *__restrict__ order, const uint8_t *__restrict__ active,
+                                                    uint32_t *__restrict__ knn_e, int k, int ks, int mc, int mcp, uint32_t it_seed,
+                                                    int32_t *__restrict__ cand) {
+    constexpr int RCAP = 32, NB = 128, ROW = 2 * RCAP, NHW = 16, PER = NB / NHW;
+    constexpr int CAP = WIDE ? 2 * RCAP : RCAP;
+    constexpr int NBANK = WIDE ? NB : 2 * NB;
+    __shared__ uint32_t bank[NB * ROW];
+    __shared__ uint32_t cnt[NBANK];
+    __shared__ uint64_t skey[NHW][2][64];
+    __shared__ int32_t vtx[NB];
+    __shared__ int any_ovf;
+    const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 5, j = lane & 31, hb = lane & 32;
+    const int64_t b = blockIdx.x;
+    // the bucket's vertices: v >= 0 active, -2 - v inactive, -1 beyond the last vertex
+    if (tid < NB) {
+        const int64_t p = b * NB + tid;
+        int32_t v = -1;
+        if (p < n) {
+            v = order ? order[p] : (int32_t)p;
+            if (!active[v]) v = -2 - v;
+        }
+        vtx[tid] = v;
+    }
+    for (int i = tid; i < NB * ROW; i += 512) bank[i] = NND_EMPTY_SLOT;
+    for (int i = tid; i < NBANK; i += 512) cnt[i] = 0;
+    if (tid == 0) any_ovf = 0;
+    __syncthreads();
+    // the k-list row of this half-wave's first target is requested now and lands during the fill phase; the next target's
+    // row is requested while the current one is ranked
+    uint32_t pre_e = NND_EMPTY_E;
+    {
+        const int32_t v0 = vtx[hw];
+        if (v0 >= 0 && j < k) pre_e = knn_e[(int64_t)v0 * ks + j];
+    }
+    const uint32_t base = bstart[b], nrec = bcursor[b];
+    for (uint32_t i = tid; i < nrec; i += 512) {
+        const uint32_t w = rec_w[base + i];
+        const uint32_t m = rec_m[base + i];
+        const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));  // [old | new], as rbuf
+        const uint32_t sl = atomicAdd(&cnt[bk], 1u);
+        if (sl < (uint32_t)CAP) bank[bk * CAP + sl] = w;
+    }
+    __syncthreads();
+    for (int i = tid; i < NBANK; i += 512)
+        if (cnt[i] > (uint32_t)CAP) any_ovf = 1;
+    __syncthreads();
+    if (any_ovf) {  // (workgroup-uniform) hubs: see k_rev_fill
+        for (int i = tid; i < NBANK * CAP; i += 512)
+            if (cnt[i / CAP] > (uint32_t)CAP) bank[i] = NND_EMPTY_SLOT;
+        __syncthreads();
+        for (uint32_t i = tid; i < nrec; i += 512) {
+            const uint32_t m = rec_m[base + i];
+            const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));
+            if (cnt[bk] > (uint32_t)CAP) {
+                const uint32_t w = rec_w[base + i];
+                atomicMin(&bank[bk * CAP + rv_ovf_slot(w, CAP)], w);
+            }
+        }
+        __syncthreads();
+    }
+    uint64_t(*sk)[64] = skey[hw];
+#pragma unroll 1
+    for (int r = 0; r < PER; r++) {
+        const int tl = r * NHW + hw;
+        const int32_t v = vtx[tl];
+        const bool act = v >= 0;
+        const uint32_t e = pre_e;
+        pre_e = NND_EMPTY_E;
+        if (r + 1 < PER) {
+            const int32_t vn = vtx[tl + NHW];
+            if (vn >= 0 && j < k) pre_e = knn_e[(int64_t)vn * ks + j];
+        }
+        if (v <= -2)  // no new candidate can reach the vertex: empty new list (its old list is never read)
+            for (int q = j; q < mcp; q += 32) cand[(int64_t)(-2 - v) * 2 * mcp + q] = -1;
+        if (!__ballot(act)) continue;  // wave-uniform
+        const uint32_t rw0 = act ? bank[tl * ROW + j] : NND_EMPTY_SLOT, rw1 = act ? bank[tl * ROW + RCAP + j] : NND_EMPTY_SLOT;
+        nnd_wave_lds_sync();  // the previous target's lists are done with
+        nnd_select_half<WIDE>(knn_e, k, ks, mc, mcp, it_seed, cand, act ? (int64_t)v : 0, act, e, rw0, rw1, sk, j, hb);
+    }
+}
+
+__global__ void k_rev_invert(const int32_t *__restrict__ order, int64_t n, int32_t *__restrict__ pos) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) pos[order[g]] = (int32_t)g;
+}
+
 // rows scanned for reverse offers: every row on a plain handle; the owned slice when shard bounds are set (row-sharded
 // build: offers to targets owned elsewhere travel as records, see k_offer_export)
 // both banks of a vertex for the new class while no old edge exists (nnd_offer_addr): 32 slots per class (the
@@ -489,12 +862,93 @@ static void launch_select(nnd_ctx *ctx, uint32_t it_seed, bool wide) {
     if (ctx->n_ranks <= 1) ctx->rbuf_clean = true;  // every bank that received an offer belongs to an active vertex and was re-armed
 }
 
+// grow-only tables of the bucketed reverse pass; the inverse of the visiting order once per forest
+template <typename T>
+static int rv_grow(nnd_ctx *ctx, T **p, size_t count) {
+    if (*p) NND_HIP_CHECK(hipFree(*p));
+    *p = nullptr;
+    NND_HIP_CHECK(hipMalloc((void **)p, sizeof(T) * count));
+    return 0;
+}
+static int rv_prepare(nnd_ctx *ctx, int logB, const int32_t *order) {
+    const int64_t nb = ((ctx->n - 1) >> logB) + 1, nrec = ctx->n * ctx->k;
+    if (nb + 1 > ctx->rv_cap_b) {
+        if (rv_grow(ctx, &ctx->rv_count, (size_t)nb + 1) || rv_grow(ctx, &ctx->rv_start, (size_t)nb + 1) || rv_grow(ctx, &ctx->rv_cursor, (size_t)nb + 1)) return 1;
+        ctx->rv_cap_b = nb + 1;
+    }
+    if (nrec > ctx->rv_cap_rec) {
+        if (rv_grow(ctx, &ctx->rv_word, (size_t)nrec) || rv_grow(ctx, &ctx->rv_meta, (size_t)nrec) || rv_grow(ctx, &ctx->rv_stage, (size_t)ctx->n * ctx->ks)) return 1;
+        ctx->rv_cap_rec = nrec;
+    }
+    if (order && (!ctx->rv_pos || ctx->rv_pos_gen != ctx->forest_gen)) {
+        if (!ctx->rv_pos && rv_grow(ctx, &ctx->rv_pos, (size_t)ctx->n)) return 1;
+        hipLaunchKernelGGL(k_rev_invert, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream, order, ctx->n, ctx->rv_pos);
+        ctx->rv_pos_gen = ctx->forest_gen;
+    }
+    return 0;
+}
+
+// the BASELINE regime: the fused kernel (k_rev_select) -- the conditions of k_sample_select_h
+static bool rv_fused(const nnd_ctx *ctx) {
+    return ctx->k <= 32 && ctx->rcap == 32 && ctx->mc <= 32 && !(ctx->p.flags & NND_FLAG_TEST_SELECT_WAVE);
+}
+// the reverse offers of this iteration by transposition (see above), then the selection; active[] is set on the way
+static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide) {
+    const bool fused = rv_fused(ctx);
+    const int logB = (fused || ctx->rcap != 32) ? 7 : 8;
+    const int32_t *order = (ctx->forest_built && ctx->p.n_trees > 0) ? ctx->perm[ctx->cur] : nullptr;
+    if (rv_prepare(ctx, logB, order)) return 1;
+    const int32_t *pos = order ? ctx->rv_pos : nullptr;
+    const int64_t nb = ((ctx->n - 1) >> logB) + 1;
+    int ksp = 16;
+    while (ksp < ctx->ks) ksp <<= 1;
+    const int rows = 256 / ksp;
+    const unsigned grid = (unsigned)((ctx->n + (int64_t)rows * RV_RPT - 1) / ((int64_t)rows * RV_RPT));
+    NND_HIP_CHECK(hipMemsetAsync(ctx->rv_count, 0, sizeof(uint32_t) * (size_t)(nb + 1), ctx->stream));
+    NND_HIP_CHECK(hipMemsetAsync(ctx->rv_cursor, 0, sizeof(uint32_t) * (size_t)(nb + 1), ctx->stream));
+    // the first pass of a build: every edge is new, every vertex with an edge is active -- one memset instead of n * k random byte stores
+    // (a vertex without any edge then "joins" with an empty new list, which is what an inactive one does)
+    NND_HIP_CHECK(hipMemsetAsync(ctx->active, ctx->all_new ? 1 : 0, (size_t)ctx->n, ctx->stream));
+    // how the active flags come about: 0 = the memset above, 1 = k_rev_count marks them while it counts, 2 = k_rev_mark first and
+    // k_rev_count filters by them -- once the previous iteration inserted into fewer than an eighth of the slots
+    int mark = ctx->all_new ? 0 : 1;
+    if (mark == 1 && ctx->last_updates >= 0 && ctx->last_updates * 8 < ctx->n * ctx->k) {
+        const int64_t total = ctx->n * ctx->ks;
+        hipLaunchKernelGGL(k_rev_mark, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e, total, ctx->ks, ctx->active);
+        mark = 2;
+    }
+    hipLaunchKernelGGL(k_rev_count, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->knn_e, ctx->n, ctx->k, ctx->ks, it_seed, order, pos, logB, ctx->active,
+                       mark, ctx->rv_count, ctx->rv_stage);
+    hipLaunchKernelGGL(k_rev_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->rv_count, ctx->rv_start, nb);
+    hipLaunchKernelGGL(k_rev_scatter, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->rv_stage, ctx->n, ctx->ks, logB, ctx->rv_start, ctx->rv_cursor,
+                       ctx->rv_word, ctx->rv_meta);
+    if (fused) {
+        auto kern = wide ? k_rev_select<true> : k_rev_select<false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), 0, ctx->stream, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, ctx->n, order,
+                           ctx->active, ctx->knn_e, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->cand);
+        return 0;
+    }
+    ctx->rbuf_clean = false;
+    auto fill = ctx->rcap == 32 ? (wide ? k_rev_fill<32, 256, true> : k_rev_fill<32, 256, false>) : k_rev_fill<64, 128, false>;
+    hipLaunchKernelGGL(fill, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, ctx->n, order,
+                       ctx->active, ctx->rbuf);
+    launch_select(ctx, it_seed, wide);
+    return 0;
+}
+
 int nnd_launch_sample(nnd_ctx *ctx) {
     if (ctx->n_ranks > 1) {
         ctx->set_error("nnd_launch_sample: this handle is one shard of a row-sharded build; use nnd_sample_begin / nnd_sample_finish");
         return 1;
     }
     const uint32_t it_seed = sample_seed(ctx);
+    if ((ctx->rcap == 32 || ctx->rcap == 64) && !(ctx->p.flags & NND_FLAG_TEST_SAMPLE_ATOMIC)) {
+        const bool wide_b = sample_wide(ctx);
+        if (launch_sample_bucketed(ctx, it_seed, wide_b)) return 1;
+        ctx->all_new = false;
+        NND_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     NND_HIP_CHECK(hipMemsetAsync(ctx->active, 0, (size_t)ctx->n, ctx->stream));
     // every edge still carries the "new" flag before the first sampling pass: there are no old edges to offer
     const int n_pass = ctx->all_new ? 1 : 2;

@@ -157,6 +157,17 @@ struct nnd_handle_s {
     std::vector<int64_t> tree_leaf_begin; // per tree: first leaf index (host)
     bool forest_built = false;
     bool all_new = false;  // every edge of the graph still carries the "new" flag (true from reset until the first sampling pass)
+    // bucketed reverse sampling (sample.hip; plain handles): the reverse offers of an iteration are counting-sorted by the
+    // target's BUCKET (a run of consecutive positions of the visiting order) and folded into the slot banks from LDS
+    int32_t *rv_pos = nullptr;                // (n) position of every vertex in the visiting order, grow-only
+    int rv_pos_gen = -1;                      // forest_gen the table was built for
+    int forest_gen = 0;                       // bumped whenever a forest (a visiting order) is finished
+    uint32_t *rv_count = nullptr, *rv_start = nullptr, *rv_cursor = nullptr;  // (n_buckets + 1) records per bucket / first record / fill
+    uint32_t *rv_word = nullptr;              // (n * k) record: the offer's slot word (invertible priority of the source)
+    uint16_t *rv_meta = nullptr;              // (n * k) record: target's index in its bucket | class << 15
+    uint2 *rv_stage = nullptr;                // (n, ks) pre-formed records in the order the graph is walked: (slot word, position | class << 31)
+    int64_t rv_cap_rec = 0, rv_cap_b = 0;
+    int64_t last_updates = -1;                // k-list insertions of the previous iteration (-1: unknown): picks the late-iteration form of the pass
     bool pbuf_clean = false, rbuf_clean = false;  // every proposal / reverse-offer slot is EMPTY (their consumers re-arm what they read): nnd_launch_reset_graph then skips the 2 x 512 MB memsets
 
     int32_t *out_idx = nullptr;           // finished graph of the host-buffer entry points (grow-only; capi.hip out_buffers)
