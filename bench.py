@@ -161,6 +161,23 @@ def other_config(_capi, name, device, local_rank):
         if rep_ > 0 and (best is None or dt < best):
             best = dt
     st = b.stats()
+    prune = None
+    if name == "c5":
+        # the graph diversification / prune pass of configs[4] on the handle that has just built the graph: the k-NN graph stays in
+        # HBM, every step between the kernels runs on the device (csrc/searchgraph.hip), ONE copy of indptr / indices comes back
+        from pynndescent_amd.search_graph import search_graph_on
+
+        bestp = sg = None
+        for rep_ in range(3):
+            t1 = time.perf_counter()
+            sg, stg = search_graph_on(b, oi.data_ptr(), od.data_ptr(), k, on_device=True, return_stages=True)
+            dtp = time.perf_counter() - t1
+            if rep_ > 0 and (bestp is None or dtp < bestp[0]):
+                bestp = (dtp, stg["ms_device"])
+        prune = {"ms": round(bestp[0] * 1e3, 2), "ms_device": round(bestp[1], 2), "edges_in": int((oi >= 0).sum().item()), "edges_out": int(sg.nnz),
+                 "max_degree": int(np.diff(sg.indptr).max()),
+                 "what": "diversify + reverse diversify + union + degree prune + binarise (pynndescent_.py:1451-1611) on the device, on the handle "
+                         "that built the graph: device arrays in, ONE device-to-host copy of the CSR pattern out (incl. the numpy / scipy wrap)"}
     b.close()
     rows = torch.from_numpy(np.random.RandomState(0).choice(n, 1000, replace=False)).to(device)
     rec = recall_at(exact_knn_cosine(x, rows, 10), oi[rows], 10)
@@ -174,11 +191,14 @@ def other_config(_capi, name, device, local_rank):
         from pynndescent_amd.search_graph import build_search_graph
 
         xh, gi, gd = x.cpu().numpy(), oi.cpu().numpy(), od.cpu().numpy()
+        build_search_graph(xh, gi, gd, "cosine", k)  # warm-up (handle allocation)
         t1 = time.perf_counter()
-        sg = build_search_graph(xh, gi, gd, "cosine", k)
-        out["prune_pass"] = {"ms": round((time.perf_counter() - t1) * 1e3, 2), "edges_in": int((gi >= 0).sum()), "edges_out": int(sg.nnz),
-                             "max_degree": int(np.diff(sg.indptr).max()),
-                             "what": "diversify + reverse diversify + degree prune (pynndescent_.py:1451-1611) on the GPU kernels, host arrays in / out"}
+        sg2 = build_search_graph(xh, gi, gd, "cosine", k)
+        prune["ms_host_arrays"] = round((time.perf_counter() - t1) * 1e3, 2)
+        prune["what_host_arrays"] = ("the same pass as a stand-alone call on HOST arrays (what NNDescent.prepare() runs): auxiliary handle, "
+                                     "H2D of the %d MB point set and of the graph, the pass, D2H of the pattern" % (xh.nbytes // 1000000))
+        assert sg2.nnz == prune["edges_out"]
+        out["prune_pass"] = prune
     return out
 
 
@@ -320,6 +340,64 @@ def builder_dp(d):
     return (d + 31) // 32 * 32
 
 
+class Watchdog:
+    """N > 1 only.  A scaling run must end with ONE JSON line whatever happens: when a phase (communicator creation, a
+    build, the one-GPU build of the same set) does not come back within its limit, when another rank dies (the launcher
+    sends SIGTERM) or when this rank raises, rank 0 prints a line with the contract's fields, `value` 0 and an `error`
+    that names the phase -- instead of a hang that the driver has to kill without a line."""
+
+    def __init__(self, rank, world, args):
+        import signal
+        import threading
+
+        self.rank, self.world, self.args = rank, world, args
+        self.name, self.deadline, self.done = "start", None, False
+        self.extra = {}
+        self._lock = threading.Lock()
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+        try:
+            signal.signal(signal.SIGTERM, lambda *_: self.fail("terminated by the launcher (another rank failed or the run was cancelled)"))
+        except ValueError:  # not the main thread
+            pass
+
+    def phase(self, name, seconds):
+        seconds *= float(os.environ.get("PYNND_BENCH_WATCHDOG_SCALE", "1"))  # (tests shrink the limits)
+        with self._lock:
+            self.name, self.deadline = name, time.monotonic() + seconds
+
+    def finish(self):
+        with self._lock:
+            self.done, self.deadline = True, None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self._lock:
+                late = (not self.done) and self.deadline is not None and time.monotonic() > self.deadline
+            if late:
+                self.fail("no progress: the phase did not finish within its limit")
+
+    def fail(self, why, code=3):
+        with self._lock:
+            if self.done:
+                return
+            self.done = True
+        msg = "%s [rank %d, phase: %s]" % (why, self.rank, self.name)
+        sys.stderr.write("bench.py: " + msg + "\n")
+        sys.stderr.flush()
+        if self.rank == 0:
+            line = {"metric": "index build: points indexed/sec (recall@10 vs brute force reported alongside)", "value": 0.0, "unit": "points/s",
+                    "n_gpus": self.world, "steps": self.args.steps, "warmup": self.args.warmup, "ms_per_step": None, "higher_is_better": True,
+                    "scaling": "strong" if self.args.n is None else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": "BASELINE configs[3] stand-in (row-sharded build over %d GPUs): NOT MEASURED, see error" % self.world},
+                    "error": msg}
+            line.update(self.extra)
+            print(json.dumps(line))
+            sys.stdout.flush()
+        os._exit(code)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,6 +430,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    wd = Watchdog(rank, world, args) if world > 1 else None
+    try:
+        run(args, world, rank, local_rank, share_gpu, wd)
+    except SystemExit:
+        raise
+    except BaseException as e:  # N > 1: the line with the error instead of a traceback only
+        if wd is None:
+            raise
+        import traceback
+
+        traceback.print_exc()
+        wd.fail("%s: %s" % (type(e).__name__, e), code=1)
+
+
+def run(args, world, rank, local_rank, share_gpu, wd):
+    def phase(name, seconds):
+        if wd is not None:
+            wd.phase(name, seconds)
+
+    phase("process group", 300)
     if world > 1:
         import torch.distributed as dist
 
@@ -422,7 +520,20 @@ def main():
     else:
         # the rank's communicator: RCCL (nccl backend; only the 128-byte unique id travels through torch) -- the exchanges
         # themselves are issued by libpynnd_amd.so (ncclGroupStart / ncclSend / ncclRecv) on the build's HIP stream
-        comm = sharded.make_comm(local_rank, allow_host_fallback=False)  # a scaling run never becomes a host-staged one silently
+        phase("communicator (RCCL: two channels, first exchange on each)", 300)
+        rccl_error = None
+        try:
+            comm = sharded.make_comm(local_rank, allow_host_fallback=False)  # a scaling run never becomes a host-staged one silently
+        except _capi.NNDError as e:  # (raised on EVERY rank: the ranks agree on the outcome, sharded.make_comm)
+            # ... but a LOUD host-staged number beats no line at all: config.comm.transport says "host", `degraded` says why
+            rccl_error = str(e)
+            if rank == 0:
+                sys.stderr.write("bench.py: %s -- falling back to the HOST transport (pinned staging + gloo): NOT a scaling number\n" % rccl_error)
+            comm = sharded.make_comm(local_rank, allow_host_fallback=True)
+        if wd is not None:
+            wd.extra["config"] = {"workload": "BASELINE configs[3] stand-in (row-sharded build over %d GPUs): NOT MEASURED, see error" % world,
+                                  "comm": comm.info()}
+        phase("shard allocation", 300)
         sb = sharded.ShardedBuilder(comm, shard_sizes, d, "euclidean", k, n_trees, seed=1234, device_index=local_rank)
         builder = None
         out_idx, out_dist = sb.out_idx, sb.out_dist
@@ -438,9 +549,14 @@ def main():
         if builder is not None:
             builder.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        phase("warm-up build %d" % i, 600)
+        if os.environ.get("PYNND_BENCH_TEST_STALL_RANK") == str(rank):  # test hook: this rank never enters its build
+            time.sleep(3600)
         step()
+    phase("barrier before the timed builds", 300)
     barrier()
+    phase("timed builds", 120 + 120 * args.steps)
     t0 = time.perf_counter()
     stage = {"forest": 0.0, "leaf_init": 0.0, "join": 0.0, "sample": 0.0, "merge": 0.0, "finalize": 0.0, "prep": 0.0,
              "random_init": 0.0}
@@ -467,6 +583,7 @@ def main():
         n_join_launches += st["n_iters_run"] * args.join_blocks
     barrier()
     elapsed = time.perf_counter() - t0
+    phase("recall / one-GPU build of the same set / extras", 1500)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -532,8 +649,8 @@ def main():
         forest_gbs = tree_bytes / (stage["forest"] * 1e-3) / 1e9 if stage["forest"] > 0 else 0.0
         # HBM traffic per launch from the committed PMC passes (tools/pmc_traffic.py; separate --pmc runs, FETCH_SIZE
         # corrected by the factor calibrated for this access pattern); null if no profile of this kernel is committed
-        traffic = None
-        for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        traffic = traffic_from = None
+        for tname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -541,6 +658,7 @@ def main():
                 for name, rec in tj.items():
                     if isinstance(rec, dict) and key in name:
                         traffic = rec["traffic_bytes_per_launch"]
+                        traffic_from = "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel; NOT measured in this run)" % tname
 
         # MFMA side (north_star: "MFMA utilisation reported against gfx950 peak"): instructions are counted by the
         # kernels themselves (v_mfma_f32_16x16x4_f32, 2048 flop each); algorithmic = 2*dp flop per evaluated pair
@@ -555,7 +673,7 @@ def main():
                 "k_local_join": mfma_rec(join_mfma, join_ms, join_pairs),
                 "k_leaf_join": mfma_rec(leaf_mfma, stage["leaf_init"], leaf_pairs)}
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_from": traffic_from,
                     "k_local_join": {"achieved": round(join_gbs, 2), "frac": round(join_gbs / HBM_PEAK_GBS, 5),
                                      "avg_launch_ms": round(join_ms / max(n_join_launches, 1), 4),
                                      "bytes_per_launch": round(join_bytes / max(n_join_launches, 1))},
@@ -709,8 +827,14 @@ def main():
             "workload_c5": c5,
             "cpu_baseline": cpu,
         }
+        if world > 1 and rccl_error is not None:
+            result["degraded"] = "RCCL unavailable (%s): exchanged through the HOST transport -- functional check, not a scaling number" % rccl_error
+        if wd is not None:
+            wd.finish()
         print(json.dumps(result))
         sys.stdout.flush()
+    if wd is not None:
+        wd.finish()
     if sb is not None:
         sb.close()
         comm.close()

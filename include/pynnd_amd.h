@@ -93,6 +93,12 @@ typedef struct nnd_params {
 /* test hook: the reverse offers of the candidate sampling through the round-1..4 kernel (one device-scope atomicMin per
  * edge into 32 hashed slots per bank) instead of the bucketed transposition (sample.hip): comparison / timing */
 #define NND_FLAG_TEST_SAMPLE_ATOMIC 256
+/* test hook (row-sharded build): a rank pretends that the forest sharded by cell cannot be built on this data -- at the
+ * tree tops (512), at the owners' shares (1024) or at the over-long cells (512 | 1024); the ranks must agree and build
+ * the forest split by tree instead (tests/test_gpu_sharded.py) */
+#define NND_FLAG_TEST_FOREST_FALLBACK_TOPS 512
+#define NND_FLAG_TEST_FOREST_FALLBACK_SHARE 1024
+#define NND_TEST_FALLBACK_AT(flags) ((((flags) & 512) ? 1 : 0) + (((flags) & 1024) ? 2 : 0))
 
 /* Run-time statistics for measurement (bench.py roofline). */
 typedef struct nnd_stats {
@@ -331,6 +337,31 @@ int32_t nnd_diversify_csr_host(nnd_handle_t h, const int32_t *indptr, const int3
                                const nnd_prune_opts *opts, const int32_t *degree);
 /* degree_prune_internal (pynndescent_.py:728-738): rows longer than max_degree keep entries <= sorted(row)[max_degree] */
 int32_t nnd_degree_prune_host(nnd_handle_t h, const int32_t *indptr, float *data, int64_t nnz, int32_t max_degree);
+
+/* The whole pruning pass of NNDescent._init_search_graph (pynndescent_.py:1451-1611) on the device (csrc/searchgraph.hip):
+ * forward diversify -> COO -> CSR -> "reverse" diversify_csr on the shared arrays -> union max(F', F'^T) -> diagonal and zeros
+ * dropped -> degree_prune to round(pruning_degree_multiplier * n_neighbors) -> binarise; ONE device-to-host copy at the end.
+ * Replaces, besides the three numba kernels above, the scipy glue between them (coo_matrix / tocsr 1527-1537, transpose 1549,
+ * maximum 1599, setdiag / eliminate_zeros 1602-1604, `!= 0` 1611).
+ * idx / dist: the (n, k) neighbour graph (k = the handle's n_neighbors; rows ascending in alt space, -1 / +inf padded), on the
+ * host (on_device = 0) or on the handle's device (1); not modified.  The handle must hold the point set (nnd_set_data_*): an
+ * NND_FLAG_NO_GRAPH handle, or the handle that built the graph (no second upload of the rows).  fwd_rows / fwd_dist: optional
+ * host (n, k) arrays that receive the graph after the forward pass (the `stages` view of the tests), or NULL. */
+typedef struct nnd_search_graph_stats {
+    int64_t forward_nnz;   /* edges after the forward pass */
+    int64_t reverse_nnz;   /* ... after the second pass (the reference's reverse_graph.nnz; = the forward matrix's, shared arrays) */
+    int64_t union_nnz;     /* entries of max(F', F'^T) without the diagonal */
+    int64_t final_nnz;     /* entries of the search graph */
+    float min_distance;    /* NNDescent._min_distance (pynndescent_.py:1539) */
+    int32_t max_degree_out;
+    float ms_device;       /* stream time of the pass, copies of the graph in included */
+    int32_t reserved[3];
+} nnd_search_graph_stats;
+int32_t nnd_search_graph(nnd_handle_t h, const int32_t *idx, const float *dist, int32_t on_device, int32_t n_neighbors,
+                         float pruning_degree_multiplier, float diversify_prob, int32_t degree_aware, float degree_prune_aggressiveness,
+                         uint32_t seed, int32_t *fwd_rows_host, float *fwd_dist_host, nnd_search_graph_stats *stats);
+/* the finished search graph of the last nnd_search_graph call: CSR pattern, indptr (n + 1), indices (final_nnz) sorted by column */
+int32_t nnd_search_graph_fetch(nnd_handle_t h, int32_t *indptr_host, int32_t *indices_host);
 
 /* ---- hub search tree of NNDescent.prepare() (reference rp_trees.py:714-1312 make_hub_tree and its splits,
  * rp_trees.py:2926-3049 convert_tree_format) ----

@@ -21,6 +21,8 @@ NND_FLAG_TEST_ROUTE_PLAIN = 16  # test hook: the forest's routing pass as one wa
 NND_FLAG_TEST_FOREST_BY_TREE = 32  # test hook (sharded build): forest split by tree where it would be sharded by cell
 NND_FLAG_TEST_FAIL = 64  # test hook (sharded build): this rank returns an error at the start of its second iteration
 NND_FLAG_TEST_VANISH = 128  # ... or returns there without telling anybody (a killed process)
+NND_FLAG_TEST_FOREST_FALLBACK_TOPS = 512  # test hook (sharded build): a rank reports that the by-cell forest cannot be built (at the tops)
+NND_FLAG_TEST_FOREST_FALLBACK_SHARE = 1024  # ... at the owners' shares; both flags: at the over-long cells
 NND_FLAG_TEST_SAMPLE_ATOMIC = 256  # test hook: reverse offers by one global atomicMin per edge (rounds 1-4) instead of the bucketed transposition
 
 
@@ -43,6 +45,11 @@ class NNDParams(C.Structure):
         ("flags", C.c_int32),
         ("reserved", C.c_int32 * 5),
     ]
+
+
+class NNDSearchGraphStats(C.Structure):
+    _fields_ = [("forward_nnz", C.c_int64), ("reverse_nnz", C.c_int64), ("union_nnz", C.c_int64), ("final_nnz", C.c_int64),
+                ("min_distance", C.c_float), ("max_degree_out", C.c_int32), ("ms_device", C.c_float), ("reserved", C.c_int32 * 3)]
 
 
 class NNDStats(C.Structure):
@@ -203,6 +210,9 @@ _SIGNATURES = [
     ("nnd_diversify_csr_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(NNDPruneOpts),
                                            C.c_void_p]),
     ("nnd_degree_prune_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    ("nnd_search_graph", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.POINTER(NNDSearchGraphStats)]),
+    ("nnd_search_graph_fetch", C.c_int32, [_H, C.c_void_p, C.c_void_p]),
     ("nnd_hub_tree_build", C.c_int32, [_H, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     ("nnd_hub_tree_fetch", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     ("nnd_searcher_create", C.c_int32, [C.POINTER(_H), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -421,6 +431,33 @@ class Builder:
         self._check(self.lib.nnd_diversify_csr_host(self._h, _ptr(indptr), _ptr(indices), _ptr(data), data.shape[0],
                                                     C.byref(o), _ptr(degree)))
         return data
+
+    def search_graph(self, idx, dist, n_neighbors, pruning_degree_multiplier=1.5, diversify_prob=1.0, degree_aware=False,
+                     degree_prune_aggressiveness=1.0, seed=0, on_device=False, want_forward=False):
+        """The whole pruning pass on the device (csrc/searchgraph.hip).  idx / dist: numpy (n, k) arrays, or device addresses
+        (ints) when ``on_device``.  Returns (indptr, indices, stats dict[, forward rows, forward distances])."""
+        st = NNDSearchGraphStats()
+        fr = fd = None
+        if want_forward:
+            fr = np.empty((self.n, self.k), np.int32)
+            fd = np.empty((self.n, self.k), np.float32)
+        if on_device:
+            pi, pd = C.c_void_p(int(idx)), C.c_void_p(int(dist))
+        else:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            dist = np.ascontiguousarray(dist, dtype=np.float32)
+            assert idx.shape == (self.n, self.k) and dist.shape == (self.n, self.k)
+            pi, pd = _ptr(idx), _ptr(dist)
+        self._check(self.lib.nnd_search_graph(self._h, pi, pd, 1 if on_device else 0, int(n_neighbors), float(pruning_degree_multiplier),
+                                              float(diversify_prob), 1 if degree_aware else 0, float(degree_prune_aggressiveness),
+                                              int(seed) & 0xFFFFFFFF, _ptr(fr) if want_forward else None, _ptr(fd) if want_forward else None,
+                                              C.byref(st)))
+        indptr = np.empty(self.n + 1, np.int32)
+        indices = np.empty(max(int(st.final_nnz), 1), np.int32)
+        self._check(self.lib.nnd_search_graph_fetch(self._h, _ptr(indptr), _ptr(indices)))
+        stats = {f: getattr(st, f) for f, _ in NNDSearchGraphStats._fields_ if f != "reserved"}
+        out = (indptr, indices[: int(st.final_nnz)], stats)
+        return out + (fr, fd) if want_forward else out
 
     def degree_prune(self, indptr, data, max_degree):
         indptr = np.ascontiguousarray(indptr, np.int32)

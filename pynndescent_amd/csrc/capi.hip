@@ -106,6 +106,7 @@ static void free_all(nnd_ctx *ctx) {
     ctx->tev.clear();
     F(ctx->shard_bounds); F(ctx->shard_cursors);
     nnd_hub_tree_free(ctx);
+    nnd_search_graph_free(ctx);
     if (ctx->stream && ctx->stream_owned) (void)hipStreamDestroy(ctx->stream);
 }
 
@@ -999,6 +1000,23 @@ extern "C" int32_t nnd_degree_prune_host(nnd_handle_t ctx, const int32_t *indptr
     API_HIP(hipMemcpyAsync(data, dd, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
     API_HIP(nnd_sync_spin(ctx));
     return 0;
+}
+
+// the whole pass on the device (searchgraph.hip)
+extern "C" int32_t nnd_search_graph(nnd_handle_t ctx, const int32_t *idx, const float *dist, int32_t on_device, int32_t n_neighbors,
+                                    float pruning_degree_multiplier, float diversify_prob, int32_t degree_aware, float degree_prune_aggressiveness,
+                                    uint32_t seed, int32_t *fwd_rows_host, float *fwd_dist_host, nnd_search_graph_stats *stats) {
+    ENTER(ctx);
+    if (ctx->p.flags & NND_FLAG_NO_PREP) { ctx->set_error("nnd_search_graph: this handle holds no prepared rows (NND_FLAG_NO_PREP)"); return 1; }
+    if (need_data(ctx)) return 1;
+    if (!idx || !dist || n_neighbors < 1) { ctx->set_error("nnd_search_graph: bad arguments"); return 1; }
+    return nnd_search_graph_impl(ctx, idx, dist, on_device != 0, n_neighbors, pruning_degree_multiplier, diversify_prob, degree_aware != 0,
+                                 degree_prune_aggressiveness, seed, fwd_rows_host, fwd_dist_host, stats);
+}
+extern "C" int32_t nnd_search_graph_fetch(nnd_handle_t ctx, int32_t *indptr_host, int32_t *indices_host) {
+    ENTER(ctx);
+    if (!indptr_host) { ctx->set_error("nnd_search_graph_fetch: null argument"); return 1; }
+    return nnd_search_graph_fetch_impl(ctx, indptr_host, indices_host);
 }
 
 // ---- hub search tree of NNDescent.prepare() (reference rp_trees.py:714-1312, 2926-3049; host glue: search_tree.py) ----

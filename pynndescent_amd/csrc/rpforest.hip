@@ -2429,7 +2429,9 @@ int nnd_forest_tops(nnd_ctx *ctx, int T_loc, int tree_bias, nnd_tops_info *out) 
     v.tree_bias = tree_bias;
     int32_t n_cells = 0;
     const int rc = forest_tops(ctx, v, &n_cells);
-    if (rc == 2) { ctx->set_error("rp-forest (sharded): the recorded tree tops outgrew their tables"); return 1; }
+    // rc 2: NOT an error of the build -- the single-GPU forest falls back to the whole-set passes here (nnd_launch_forest); the
+    // sharded build tells the other ranks and all of them switch to the forest split by tree (shard.hip)
+    if (rc == 2) { ctx->set_error("rp-forest (sharded): the recorded tree tops outgrew their tables"); return 2; }
     if (rc) return rc;
     // first cell of every local tree (cells are numbered tree-major): per-tree cell counts for the owner-major renumbering
     int32_t *tcb = ctx->route_roots + 2048;  // scratch words behind the root table
@@ -2542,7 +2544,7 @@ int nnd_forest_finish_owned(nnd_ctx *ctx, const int32_t *rec_cell, const int32_t
     if (n_rec > ctx->P || n_cells_own > ctx->cell_cap || n_cells_own + n_rec / (ctx->p.leaf_size + 1) > ctx->max_segs) {
         ctx->set_error("rp-forest (sharded): %lld point-trees / %d cells exceed this rank's forest tables (%lld positions)", (long long)n_rec, n_cells_own,
                        (long long)ctx->P);
-        return 1;
+        return 2;  // (as above: the ranks agree to build this forest split by tree)
     }
     if (n_cells_own <= 0 || n_rec <= 0) {  // (a rank that owns no cell: nothing to seed from)
         ctx->forest_built = true;
@@ -2569,7 +2571,7 @@ int nnd_forest_finish_owned(nnd_ctx *ctx, const int32_t *rec_cell, const int32_t
     tm.n_tree_begin = T_all;
     // (forest_place_finish scans the counts again: cheap, and it keeps one code path for the work lists)
     const int rc = forest_place_finish(ctx, n_cells_own, T_all, 0, 0, nullptr, nullptr, n_rec, tm);
-    if (rc == 2) { ctx->set_error("rp-forest (sharded): too many over-long cells"); return 1; }
+    if (rc == 2) { ctx->set_error("rp-forest (sharded): too many over-long cells"); return 2; }
     if (rc) return rc;
     ctx->stats.n_cells = n_cells_own;
     return forest_leaf_tables(ctx, n_rec, T_all, tpb);

@@ -170,6 +170,24 @@ static void shard_free(nnd_shard_s *s) {
     delete s;
 }
 
+// A shard whose forest was to be sharded by cell becomes one that builds its own trees (the round-3 scheme), IN PLACE: the
+// handle was created for ceil(1.25 T / G) + 1 trees' worth of positions, which holds the (t1 - t0) whole trees of the split by
+// tree; only the tree count, the position space and the tree seed change (every rank draws its own trees from a seed derived
+// from the global one and its first tree's number, as nnd_shard_create does for a by-tree shard).  Called on EVERY rank or on
+// none: at creation (the routing forest is not available on this geometry) or when the ranks have agreed that the by-cell
+// forest cannot be built on this data (forest_by_cell returns 2: tops / cell tables outgrown on some rank).
+static void shard_switch_to_by_tree(nnd_shard_s *s) {
+    nnd_ctx *h = s->h;
+    s->by_cell = false;
+    s->info.forest_by_cell = 0;
+    h->p.n_trees = s->t1 - s->t0;
+    h->P = (int64_t)h->p.n_trees * h->n;
+    h->p.tree_rng[1] = (int64_t)((uint64_t)s->gp.tree_rng[1] + 0x9E3779B97F4A7C15ull * (uint64_t)(s->t0 + 1));
+    h->tree_seed = nnd_mix32((uint32_t)h->p.tree_rng[0] ^ nnd_mix32((uint32_t)h->p.tree_rng[1] + 0x9E3779B9u) ^ nnd_mix32((uint32_t)h->p.tree_rng[2] + 0x7F4A7C15u));
+    h->own_order = nullptr;
+    h->forest_built = false;
+}
+
 extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, nnd_comm_t comm, const int64_t *shard_sizes) {
     auto fail = [&](const char *msg) {
         snprintf(g_serr2, sizeof(g_serr2), "nnd_shard_create: %s", msg);
@@ -224,6 +242,9 @@ extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, 
     }
     s->k = s->h->k;
     s->ks = s->h->ks;
+    // (the same on every rank: a function of the parameters) the handle has no routing forest after all -- a library built with
+    // the experiment knobs and NND_FOREST_WHOLE=1, or a future change of the condition in nnd_create_impl
+    if (s->by_cell && !(s->h->s_m > 0 && s->h->s_stride > 0)) shard_switch_to_by_tree(s);
     const int64_t n_own = s->hi - s->lo;
     std::lock_guard<std::recursive_mutex> lifecycle(nnd_lifecycle_mutex());
     bool ok = hipSetDevice(p.device) == hipSuccess;
@@ -496,29 +517,38 @@ static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t e
     }
     // ---- (b) tops of this rank's trees, counts to everybody ----
     nnd_tops_info ti;
+    bool tops_over = false;
     {
         section_timer sec(s);
         const int tf = t_begin(h);
-        S_CTX(nnd_forest_tops(h, T_loc, s->t0, &ti));
+        const int rc_t = nnd_forest_tops(h, T_loc, s->t0, &ti);
+        if (rc_t == 1) { s->set_error("%s", h->err); return 1; }
+        // rc 2: this rank's recorded tops outgrew their tables (duplicate-heavy / degenerate data).  One GPU falls back to the
+        // whole-set passes; here the word rides on the count vector every rank reads anyway and ALL ranks fall back together
+        tops_over = rc_t == 2 || (NND_TEST_FALLBACK_AT(s->gp.flags) == 1 && me == G - 1);
+        if (tops_over) ti = nnd_tops_info();
         t_end(h, tf, &h->stats.ms_forest, true);
         sec.end();
     }
     h->stats.tree_levels = ti.levels;
-    const int nv = 2 + 64;
+    const int nv = 3 + 64;
     std::vector<long long> cv(nv, 0), matrix((size_t)G * nv);
     cv[0] = ti.n_packed;
     cv[1] = ti.n_cells;
-    for (int t = 0; t < T_loc; t++) cv[2 + t] = ti.tree_cells[t];
+    cv[2] = tops_over ? 1 : 0;
+    for (int t = 0; t < T_loc; t++) cv[3 + t] = ti.tree_cells[t];
     S_HIP(hipMemcpyAsync(s->cvec, cv.data(), sizeof(long long) * nv, hipMemcpyHostToDevice, st));
     S_COMM(comm_gather_counts(c, st, s->cvec, nv, matrix.data()));
     t_flush(h);
+    for (int r = 0; r < G; r++)
+        if (matrix[(size_t)r * nv + 2]) return 2;  // (the same matrix on every rank: everybody leaves here)
     // ---- (c) the numbering of nodes and cells over the whole build (identical on every rank) ----
     std::vector<int64_t> node_base(G + 1, 0);
     std::vector<int32_t> C(T), lbase(G + 1, 0);  // cells per tree; first cell of every rank in tops-major order
     for (int r = 0; r < G; r++) {
         node_base[r + 1] = node_base[r] + matrix[(size_t)r * nv + 0];
         lbase[r + 1] = lbase[r] + (int32_t)matrix[(size_t)r * nv + 1];
-        for (int t = t0_of(r); t < t0_of(r + 1); t++) C[t] = (int32_t)matrix[(size_t)r * nv + 2 + (t - t0_of(r))];
+        for (int t = t0_of(r); t < t0_of(r + 1); t++) C[t] = (int32_t)matrix[(size_t)r * nv + 3 + (t - t0_of(r))];
     }
     const int64_t nodes_all = node_base[G];
     const int32_t cells_all = lbase[G];
@@ -646,6 +676,16 @@ static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t e
     std::vector<long long> m2((size_t)G * (G + 1));
     S_COMM(comm_gather_counts(c, st, s->cvec, G + 1, m2.data()));  // host wait: record offsets per destination, of every rank
     t_flush(h);
+    // Does every owner's share fit its forest tables (T n / G point-trees + 25 % + one tree)?  A skewed share (most rows in the
+    // cells of one owner) is not an error of the build either: every rank evaluates every rank's share from the same matrix, and
+    // all of them fall back to the split by tree together.  (The tables have the same size on every rank.)
+    for (int q = 0; q < G; q++) {
+        int64_t in_q = 0;
+        for (int r = 0; r < G; r++) in_q += (int64_t)(m2[(size_t)r * (G + 1) + q + 1] - m2[(size_t)r * (G + 1) + q]);
+        const int64_t cells_q = own_base[q + 1] - own_base[q];
+        if (in_q > h->P || cells_q > h->cell_cap || cells_q + in_q / (h->p.leaf_size + 1) > h->max_segs) return 2;
+        if (NND_TEST_FALLBACK_AT(s->gp.flags) == 2) return 2;
+    }
     int64_t n_in = 0;
     {
         size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
@@ -686,13 +726,23 @@ static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t e
         t_end(h, tp, &h->stats.ms_prep, true);
         // ---- (f) the cells this rank owns: rows placed, cells finished down to leaves, leaf tables ----
         const int tf = t_begin(h);
-        if (nnd_forest_finish_owned(h, s->in_t, (const int32_t *)s->in_k, n_in, own_base[me], cells_own, cnt_recv, G, cell_depth_all, s->maps + o_dmap,
-                                    s->maps + o_tfc, T)) {
+        const int rc_f = nnd_forest_finish_owned(h, s->in_t, (const int32_t *)s->in_k, n_in, own_base[me], cells_own, cnt_recv, G, cell_depth_all,
+                                                 s->maps + o_dmap, s->maps + o_tfc, T);
+        if (rc_f == 1) {
             s->set_error("nnd_forest_finish_owned: %s", h->err);
             return 1;
         }
         t_end(h, tf, &h->stats.ms_forest, true);
+        // too many over-long cells on SOME rank (rc 2; one GPU takes the whole-set passes then): one word per rank goes round --
+        // the leaf tables' read-back has just synchronised, the wait costs an exchange of G words
         sec.end();
+        std::vector<long long> agree((size_t)G, 0);
+        const long long mine = (rc_f == 2 || (NND_TEST_FALLBACK_AT(s->gp.flags) == 3 && me == 0)) ? 1 : 0;
+        S_HIP(hipMemcpyAsync(s->cvec, &mine, sizeof(long long), hipMemcpyHostToDevice, st));
+        S_COMM(comm_gather_counts(c, st, s->cvec, 1, agree.data()));
+        t_flush(h);
+        for (int r = 0; r < G; r++)
+            if (agree[r]) return 2;
     }
     s->info.forest_positions = n_in;
     return 0;
@@ -761,15 +811,32 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         }
         x_use = s->x_full;
     }
+    bool seeded = false;
     if (s->by_cell) {
-        if (forest_by_cell(s, x_local_dev, x_async ? s->ev_x : nullptr)) return 1;
-        if (x_async) (void)hipEventElapsedTime(&s->info.ms_allgather, e0, e1);  // (the stream has drained behind the leaf tables' read-back)
-        section_timer sec(s);
-        const int tl = t_begin(h);
-        S_CTX(nnd_launch_leaf_init(h));
-        t_end(h, tl, &h->stats.ms_leaf_init, false);
-        sec.end();
-    } else {
+        const int rc_c = forest_by_cell(s, x_local_dev, x_async ? s->ev_x : nullptr);
+        if (rc_c == 1) return 1;
+        if (rc_c == 2) {
+            // The ranks have AGREED (forest_by_cell: the word travels with counts they exchange anyway) that this forest cannot be
+            // sharded by cell on this data -- recorded tops or an owner's share outgrew their tables, too many over-long cells:
+            // conditions one GPU recovers from by its whole-set passes.  All of them switch to the split by tree, for this
+            // build and the later ones of this shard, and start over from the replicated point set.
+            shard_switch_to_by_tree(s);
+            if (x_async) {
+                S_HIP(hipStreamWaitEvent(st, s->ev_x, 0));
+                S_COMM(comm_wait(c, st, "point-set all-gather"));
+                (void)hipEventElapsedTime(&s->info.ms_allgather, e0, e1);
+            }
+        } else {
+            if (x_async) (void)hipEventElapsedTime(&s->info.ms_allgather, e0, e1);  // (the stream has drained behind the leaf tables' read-back)
+            section_timer sec(s);
+            const int tl = t_begin(h);
+            S_CTX(nnd_launch_leaf_init(h));
+            t_end(h, tl, &h->stats.ms_leaf_init, false);
+            sec.end();
+            seeded = true;
+        }
+    }
+    if (!seeded) {
     // ---- prep (all rows: 5 ms at 10 M points, cheaper than shipping the prepared copies over xGMI), reset ----
         section_timer sec(s);
         h->x_orig = x_use;
@@ -1081,7 +1148,10 @@ extern "C" int32_t nnd_build_multi(const nnd_params *params, const float *x, int
         if (use_rccl) {
             if (nnd_comm_create_rccl(&comms[r], id, G, r, dev[r])) bail(nnd_comm_last_error(nullptr));
             bar.wait();  // (1b) every rank has its first channel, or nobody asks for the second (its creation is collective too)
-            if (!failed.load() && nnd_comm_add_channel_rccl(comms[r], id2)) bail(nnd_comm_last_error(nullptr));
+            const bool go2 = !failed.load();
+            bar.wait();  // (1c) ... and every rank has READ that decision before anybody can change `failed` again: a rank whose
+                         // add_channel fails at once must not make a slower rank skip the collective the others already sit in
+            if (go2 && nnd_comm_add_channel_rccl(comms[r], id2)) bail(nnd_comm_last_error(nullptr));
             if (comms[r]) {
                 comms[r]->abort_flag = &abort_flag;
                 if (comms[r]->aux) comms[r]->aux->abort_flag = &abort_flag;
@@ -1120,6 +1190,19 @@ extern "C" int32_t nnd_build_multi(const nnd_params *params, const float *x, int
             (void)nnd_shard_get_stats(sh, &st[r]);
             (void)nnd_shard_get_info(sh, &inf[r]);
         }
+        // (3) nobody frees while a peer's stream may still hold a copy that reads this rank's buffers (LOCAL transport: peer
+        // copies queued on the OTHER rank's stream; a failed build returns with work still queued): every rank is out of its
+        // build -- the failing ones have aborted their communicators -- then every rank drains its own streams, bounded
+        bar.wait();
+        if (sh) {
+            nnd_handle_t hh = nnd_shard_handle(sh);
+            const auto t_dr = std::chrono::steady_clock::now();
+            while (hh && hh->stream && hipStreamQuery(hh->stream) == hipErrorNotReady &&
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dr).count() < 5.0) {
+            }
+            (void)hipGetLastError();
+        }
+        bar.wait();  // (4) ... and everybody has drained before the first hipFree
         if (dx) (void)hipFree(dx);
         if (di) (void)hipFree(di);
         if (dd) (void)hipFree(dd);

@@ -174,6 +174,7 @@ struct nnd_handle_s {
     float *out_dist = nullptr;
     size_t out_cap = 0;
     nnd_hub_result *hub = nullptr;
+    struct nnd_sg_state *sg = nullptr;    // searchgraph.hip: workspace and result of the device pruning pass
 
     long long *counters = nullptr;      // device NND_CNT_STRIPES x CNT_COUNT (stripe 0 doubles as scratch for single-block kernels)
     long long h_counters[CNT_COUNT] = {0};
@@ -257,6 +258,11 @@ int nnd_hub_tree_build_impl(nnd_ctx *ctx, const int32_t *rank_order_host, int le
 int nnd_hub_tree_fetch_impl(nnd_ctx *ctx, float *hyperplanes, float *offsets, int32_t *children, int32_t *indices, int32_t *max_leaf);
 int64_t nnd_hub_tree_nodes(const nnd_ctx *ctx);
 void nnd_hub_tree_free(nnd_ctx *ctx);
+void nnd_search_graph_free(nnd_ctx *ctx);
+int nnd_search_graph_impl(nnd_ctx *ctx, const int32_t *idx_src, const float *dist_src, bool src_on_device, int n_neighbors, float multiplier,
+                          float diversify_prob, bool aware, float aggressiveness, uint32_t seed, int32_t *fwd_rows_host, float *fwd_dist_host,
+                          nnd_search_graph_stats *st);
+int nnd_search_graph_fetch_impl(nnd_ctx *ctx, int32_t *indptr_host, int32_t *indices_host);
 int nnd_read_counters(nnd_ctx *ctx);  // device -> ctx->h_counters (synchronises the stream)
 int nnd_zero_counters(nnd_ctx *ctx);
 

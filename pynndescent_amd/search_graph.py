@@ -44,9 +44,65 @@ def compute_degrees_csr(indptr, indices):
     return deg.astype(np.int32)
 
 
+def search_graph_on(builder, indices, distances, n_neighbors=None, pruning_degree_multiplier=1.5, diversify_prob=1.0,
+                    diversify_method="standard", degree_prune_aggressiveness=1.0, seed=0, on_device=False, return_stages=False):
+    """The pass on a handle that already holds the point set (``_capi.Builder`` after ``set_data_*`` -- e.g. the one that has
+    just built the graph: no second upload of the rows).  ``indices`` / ``distances``: numpy (n, k) arrays, or device addresses
+    with ``on_device=True`` (the graph as ``build_device`` left it: it never visits the host).  Everything between the
+    kernels -- COO -> CSR, the transpose, the maximum, the diagonal, the zeros, the binarisation -- runs on the device
+    (csrc/searchgraph.hip); ONE copy of ``indptr`` / ``indices`` comes back."""
+    if diversify_method not in ("standard", "degree_aware"):
+        raise ValueError("diversify_method must be 'standard' or 'degree_aware'")
+    n, k = builder.n, builder.k
+    if k > 128:
+        raise NotImplementedError("the pruning pass (prepare / query) handles graphs of at most 128 neighbours per row (got %d)" % k)
+    n_neighbors = k if n_neighbors is None else n_neighbors
+    res = builder.search_graph(indices, distances, n_neighbors, pruning_degree_multiplier, diversify_prob,
+                               diversify_method == "degree_aware", degree_prune_aggressiveness, seed, on_device=on_device,
+                               want_forward=return_stages)
+    indptr, ind, st = res[:3]
+    graph = sp.csr_array((np.ones(ind.shape[0], np.uint8), ind, indptr), shape=(n, n))
+    graph.has_sorted_indices = True
+    if return_stages:
+        return graph, {"forward_rows": res[3], "forward_dist": res[4], "nnz_pre_diversify": None, "forward_nnz": int(st["forward_nnz"]),
+                       "reverse_nnz": int(st["reverse_nnz"]), "union_nnz": int(st["union_nnz"]), "final_nnz": int(st["final_nnz"]),
+                       "min_distance": float(st["min_distance"]), "ms_device": float(st["ms_device"])}
+    return graph
+
+
 def build_search_graph(data, indices, distances, metric="euclidean", n_neighbors=None, pruning_degree_multiplier=1.5,
                        diversify_prob=1.0, diversify_method="standard", degree_prune_aggressiveness=1.0, seed=0,
-                       device=0, return_stages=False):
+                       device=0, return_stages=False, host_glue=False):
+    """(data, indices int32 (n,k), alt-space distances float32 (n,k)) -> scipy CSR uint8 search graph (unordered): an auxiliary
+    handle for the point set, then ``search_graph_on``.  ``host_glue=True``: the rounds 2-4 form (the three kernels of
+    csrc/prune.hip with the reference's scipy calls between them), kept as the comparison for the device pass."""
+    if not host_glue:
+        if diversify_method not in ("standard", "degree_aware"):
+            raise ValueError("diversify_method must be 'standard' or 'degree_aware'")
+        if np.shape(indices)[1] > 128:
+            raise NotImplementedError("the pruning pass (prepare / query) handles graphs of at most 128 neighbours per row (got %d)"
+                                      % np.shape(indices)[1])
+        x = np.ascontiguousarray(data, dtype=np.float32)
+        n, d = x.shape
+        k = np.shape(indices)[1]
+        code = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN, "cosine": _capi.NND_METRIC_ALT_COSINE}[metric]
+        b = _capi.Builder(n, d, code, k, 0, 60, 200, min(60, k), 1, 0.001, [1, 2, 3], [4, 5, 6], device=device, flags=_capi.NND_FLAG_NO_GRAPH)
+        try:
+            b.set_data_host(x)
+            out = search_graph_on(b, indices, distances, n_neighbors, pruning_degree_multiplier, diversify_prob, diversify_method,
+                                  degree_prune_aggressiveness, seed, return_stages=return_stages)
+            if return_stages:
+                out[1]["nnz_pre_diversify"] = int((np.asarray(indices) >= 0).sum())
+            return out
+        finally:
+            b.close()
+    return _build_search_graph_host_glue(data, indices, distances, metric, n_neighbors, pruning_degree_multiplier, diversify_prob,
+                                         diversify_method, degree_prune_aggressiveness, seed, device, return_stages)
+
+
+def _build_search_graph_host_glue(data, indices, distances, metric="euclidean", n_neighbors=None, pruning_degree_multiplier=1.5,
+                                  diversify_prob=1.0, diversify_method="standard", degree_prune_aggressiveness=1.0, seed=0,
+                                  device=0, return_stages=False):
     """(indices int32 (n,k), alt-space distances float32 (n,k)) -> scipy CSR uint8 search graph (unordered).
 
     ``indices``/``distances`` are ``NNDescent._neighbor_graph`` (rows ascending, squared-L2 / log2-cosine)."""

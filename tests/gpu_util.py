@@ -68,3 +68,61 @@ def check_graph_invariants(x, metric, idx, dist, tol=2e-4, atol=1e-5, name=""):
         name, err.max(), (err / np.maximum(np.abs(true[m]), 1e-30)).max())
     assert np.all(dist[valid & big] > 1e30), name + ": FLT_MAX convention"
     assert np.all(np.isinf(dist[~valid])), name + ": empty slots must be +inf"
+
+
+# ---- full-size configurations: ONE generator and ONE oracle run per configuration and test SESSION, shared by the test
+# ---- modules (tests/test_gpu_fullsize.py, tests/test_gpu_sharded.py): the 10 M-point oracle build takes minutes
+def gen_fullsize(n, d, latent, seed, dev, nonneg):
+    """The full-size synthetic sets (SURVEY.md section 8d generator), generated ON the device: deterministic for a seed."""
+    import torch
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    centres = torch.randn(1024, latent, generator=g, device=dev) * 3.0
+    proj = torch.randn(latent, d, generator=g, device=dev) / latent ** 0.5
+    assign = torch.randint(0, 1024, (n,), generator=g, device=dev)
+    x = (centres[assign] + torch.randn(n, latent, generator=g, device=dev)) @ proj
+    x = x + 0.3 * torch.randn(n, d, generator=g, device=dev)
+    if nonneg:
+        x = (x + 12.0).clamp_min(0) * 9.0
+    return x.contiguous()
+
+
+# name -> (n, d, latent, generator seed, non-negative, metric, k, n_trees, oracle threads)
+FULLSIZE = {
+    "c2": (1_000_000, 128, 16, 1, True, "euclidean", 15, 8, 64),
+    "c3": (1_200_000, 100, 24, 2, False, "cosine", 15, 12, 64),
+    "c5": (290_000, 256, 32, 4, False, "cosine", 15, 11, 64),
+    "3m": (3_000_000, 128, 16, 3, True, "euclidean", 15, 12, 128),
+    "c4": (10_000_000, 128, 16, 3, True, "euclidean", 15, 12, 128),
+}
+_ORACLE_CACHE = {}
+
+
+def fullsize_points(name, dev):
+    n, d, latent, seed, nonneg = FULLSIZE[name][:5]
+    return gen_fullsize(n, d, latent, seed, dev, nonneg)
+
+
+def fullsize_oracle(name, x_host=None, dev=None):
+    """(indices, distances, seconds) of the CPU oracle (the reference algorithm, random_state 1) on configuration `name`; computed
+    once per session -- by whichever test asks first -- and kept."""
+    import time
+
+    if name not in _ORACLE_CACHE:
+        _, _, _, _, _, metric, k, n_trees, n_threads = FULLSIZE[name]
+        if x_host is None:
+            x_host = fullsize_points(name, dev).cpu().numpy()
+        t0 = time.perf_counter()
+        oi, od = O.build_index(x_host, metric, n_neighbors=k, n_trees=n_trees, random_state=1, n_threads=n_threads, kind="fast")
+        _ORACLE_CACHE[name] = (oi, od, time.perf_counter() - t0)
+    return _ORACLE_CACHE[name]
+
+
+def two_sided(x_host, metric, gpu_idx, oracle_idx, n_rows=1000, band=0.005, seed=5):
+    """recall@10 of both sides on the same sampled rows against exact brute force: |GPU - reference algorithm| <= band."""
+    rows = np.random.RandomState(seed).choice(x_host.shape[0], n_rows, replace=False)
+    ti, _ = O.brute_force_knn(x_host, 10, metric, rows=rows, kind="fast")
+    r_gpu, r_cpu = O.recall(ti, gpu_idx[rows]), O.recall(ti, oracle_idx[rows])
+    assert abs(r_gpu - r_cpu) <= band, (r_gpu, r_cpu)  # north star: within +-0.5 % of the reference algorithm
+    return r_gpu, r_cpu

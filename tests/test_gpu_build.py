@@ -228,6 +228,46 @@ def test_search_graph_pruning_pass_vs_reference_fixture(metric):
     assert sg.diagonal().sum() == 0
 
 
+@pytest.mark.parametrize("tag,metric,method,prob,aggr", [("euclidean", "euclidean", "standard", 1.0, 1.0), ("cosine", "cosine", "standard", 1.0, 1.0),
+                                                        ("prob_euclidean", "euclidean", "standard", 0.5, 1.0),
+                                                        ("aware_cosine", "cosine", "degree_aware", 1.0, 2.0),
+                                                        ("aware_euclidean", "euclidean", "degree_aware", 0.7, 1.0)])
+def test_device_search_graph_pass_equals_the_scipy_glued_pass(tag, metric, method, prob, aggr):
+    """Round 5: COO -> CSR, transpose, maximum, setdiag / eliminate_zeros, binarise (pynndescent_.py:1527-1611: scipy calls in the
+    reference, and in rounds 2-4 here) on the device (csrc/searchgraph.hip: keyed edges, radix sort, fold).  Same kernels for
+    the three numba functions, same coins: the search graph must be IDENTICAL to the scipy-glued pass, edge for edge, and the
+    stage counts with it -- on the reference-built graphs of the fixtures, in every mode."""
+    from pynndescent_amd.search_graph import build_search_graph
+
+    if tag in ("euclidean", "cosine"):
+        g = np.load(os.path.join(GOLDEN, "search_graph.npz"))
+    else:
+        g = np.load(os.path.join(GOLDEN, "search_graph_modes.npz"))
+    n, d, latent, ncl, seed = (int(v) for v in g[tag + "_gen"])
+    x = clustered(n, d, latent, ncl, seed)
+    kw = dict(diversify_prob=prob, diversify_method=method, degree_prune_aggressiveness=aggr, seed=77, return_stages=True)
+    a, sa = build_search_graph(x, g[tag + "_idx"], g[tag + "_dist"], metric, 15, **kw)
+    b, sb = build_search_graph(x, g[tag + "_idx"], g[tag + "_dist"], metric, 15, host_glue=True, **kw)
+    b.sort_indices()
+    assert np.array_equal(sa["forward_rows"], sb["forward_rows"])
+    np.testing.assert_array_equal(sa["forward_dist"], sb["forward_dist"])
+    for key in ("forward_nnz", "reverse_nnz", "union_nnz", "final_nnz"):
+        assert sa[key] == sb[key], (key, sa[key], sb[key])
+    assert sa["min_distance"] == np.float32(sb["min_distance"])
+    assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+    assert a.dtype == np.uint8 and (a.data == 1).all()
+    # a graph with holes and an exact duplicate point (distance 0 -> FLOAT32_EPS), rows of different lengths
+    idx2, dist2 = g[tag + "_idx"].copy(), g[tag + "_dist"].copy()
+    idx2[::7, 9:] = -1
+    dist2[::7, 9:] = np.inf
+    dist2[::5, 1] = 0.0
+    a2 = build_search_graph(x, idx2, dist2, metric, 15, diversify_prob=prob, diversify_method=method, degree_prune_aggressiveness=aggr, seed=5)
+    b2 = build_search_graph(x, idx2, dist2, metric, 15, diversify_prob=prob, diversify_method=method, degree_prune_aggressiveness=aggr, seed=5,
+                            host_glue=True)
+    b2.sort_indices()
+    assert np.array_equal(a2.indptr, b2.indptr) and np.array_equal(a2.indices, b2.indices)
+
+
 def test_search_graph_nytimes_like_cosine_d256():
     """Config-5 shape (angular, d=256, k=15) at reduced n: GPU build + GPU pruning pass vs the oracle's pass on the
     SAME neighbour graph (edge sets within 1 %), plus degree bound and symmetry of the union."""

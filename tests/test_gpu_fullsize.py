@@ -7,41 +7,23 @@ import torch
 
 from oracle import oracle as O
 from pynndescent_amd import _capi
+from tests.gpu_util import fullsize_oracle, gen_fullsize, two_sided
 from tests.util_data import clustered
 
 pytestmark = pytest.mark.gpu
 
 
 def _gen(n, d, latent, seed, dev, nonneg):
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    centres = torch.randn(1024, latent, generator=g, device=dev) * 3.0
-    proj = torch.randn(latent, d, generator=g, device=dev) / latent ** 0.5
-    assign = torch.randint(0, 1024, (n,), generator=g, device=dev)
-    x = (centres[assign] + torch.randn(n, latent, generator=g, device=dev)) @ proj
-    x = x + 0.3 * torch.randn(n, d, generator=g, device=dev)
-    if nonneg:
-        x = (x + 12.0).clamp_min(0) * 9.0
-    return x.contiguous()
+    return gen_fullsize(n, d, latent, seed, dev, nonneg)
 
 
-_ORACLE_CACHE = {}
+def _oracle(key, x_host, *unused, **unused_kw):
+    """The CPU oracle (reference algorithm) on the same points, once per configuration and test SESSION (tests/gpu_util.py)."""
+    oi, od, _ = fullsize_oracle(key, x_host=x_host)
+    return oi, od
 
 
-def _oracle(key, x_host, metric, k, n_trees, seed, n_threads=64):
-    """The CPU oracle (reference algorithm) on the same points, once per configuration and test session."""
-    if key not in _ORACLE_CACHE:
-        _ORACLE_CACHE[key] = O.build_index(x_host, metric, n_neighbors=k, n_trees=n_trees, random_state=seed,
-                                           n_threads=n_threads, kind="fast")
-    return _ORACLE_CACHE[key]
-
-
-def _two_sided(x_host, metric, gpu_idx, oracle_idx, n_rows=1000, band=0.005, seed=5):
-    rows = np.random.RandomState(seed).choice(x_host.shape[0], n_rows, replace=False)
-    ti, _ = O.brute_force_knn(x_host, 10, metric, rows=rows, kind="fast")
-    r_gpu, r_cpu = O.recall(ti, gpu_idx[rows]), O.recall(ti, oracle_idx[rows])
-    assert abs(r_gpu - r_cpu) <= band, (r_gpu, r_cpu)  # north star: within +-0.5 % of the reference algorithm
-    return r_gpu, r_cpu
+_two_sided = two_sided
 
 
 def _build(x, metric, k, n_trees, seed=1, join_blocks=1):
@@ -226,14 +208,10 @@ def test_config4_size_10m_on_one_gpu():
     # ... and two-sided against the reference algorithm at this size too (round 4: the oracle's candidate sampling and
     # update application no longer make every thread scan everything -- same results, pinned bit-exact -- so 10 M points
     # take it minutes instead of more than the box's budget)
-    import time
-
     xh = x.cpu().numpy()
     gi = idx.cpu().numpy()
     del idx, dist
-    t0 = time.perf_counter()
-    oidx, _ = _oracle("c4", xh, "euclidean", 15, 12, 1, n_threads=128)
-    t_or = time.perf_counter() - t0
+    oidx, _, t_or = fullsize_oracle("c4", x_host=xh)
     r_gpu, r_cpu = _two_sided(xh, "euclidean", gi, oidx, n_rows=1000)
     print("C4' 10 M two-sided: recall@10 gpu %.4f oracle %.4f (oracle: %.0f s on the host cores)" % (r_gpu, r_cpu, t_or))
 

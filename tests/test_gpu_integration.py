@@ -4,6 +4,7 @@ import json
 import os
 import re
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -100,6 +101,42 @@ def test_bench_two_processes_sharing_one_gpu():
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["recall_at_10"] >= 0.95
     assert sum(rec["exchanged_records_rank0"]) > 0
+
+
+def test_bench_eight_processes_rehearsal_of_the_drivers_scaling_run():
+    """What the driver runs for SCALE at N = 8 -- `bench.py --gpus 8`, eight processes, torch.distributed rendezvous, the
+    by-cell forest, every exchange of the sharded build, the watchdog armed -- rehearsed on this one-GPU box: all ranks on
+    GPU 0, the HOST transport over gloo (two RCCL ranks cannot share a GPU).  300 k points per rank (the configs[3] run is
+    1.25 M per rank; the eight thread-ranks of tests/test_gpu_sharded.py cover that size in one process)."""
+    env = dict(os.environ, PYNND_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--points-per-gpu", "300000", "--n-trees", "8",
+                          "--steps", "1", "--warmup", "1", "--no-one-gpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "error" not in rec, rec
+    assert rec["n_gpus"] == 8 and rec["value"] > 0 and rec["recall_at_10"] >= 0.95
+    assert rec["config"]["comm"]["transport"] == "host" and rec["shard_rank0"]["forest_by_cell"]
+    print("bench.py --gpus 8 (8 processes, one GPU, HOST transport): %.1f ms per build of %d points, recall@10 %.4f"
+          % (rec["ms_per_step"], 8 * 300000, rec["recall_at_10"]))
+
+
+def test_bench_watchdog_prints_a_line_when_a_rank_never_arrives():
+    """A rank that never enters its build (hook: it sleeps) must not leave the run hanging without a line: rank 0's
+    watchdog prints the contract's fields with `value` 0 and an `error` naming the phase, and the run ends."""
+    env = dict(os.environ, PYNND_BENCH_SHARE_GPU="1", PYNND_BENCH_TEST_STALL_RANK="1", PYNND_BENCH_WATCHDOG_SCALE="0.03")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--points-per-gpu", "60000", "--steps", "1", "--warmup", "1",
+                          "--no-one-gpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (out.stdout[-1000:], out.stderr[-2000:])
+    rec = json.loads(lines[-1])
+    assert rec["value"] == 0.0 and rec["n_gpus"] == 2 and "warm-up build" in rec["error"], rec
+    assert time.time() - t0 < 240
 
 
 def test_bench_refuses_more_gpus_than_visible():
