@@ -520,23 +520,38 @@ __device__ __forceinline__ void rv_row_groups(uint32_t key, int &rank, int &size
 // word a bank stores for the offer v -> u: as k_sample_reverse (the slot word IS the source)
 __device__ __forceinline__ uint32_t rv_offer_word(uint32_t it_seed, uint32_t u, uint32_t v) { return nnd_mix32(v ^ nnd_offer_salt(it_seed, u)); }
 
-// late iterations (few new edges): the active flags first, so that k_rev_count can drop the offers nobody will read
-__global__ __launch_bounds__(256) void k_rev_mark(const uint32_t *__restrict__ knn_e, int64_t total, int ks, uint8_t *__restrict__ active) {
+// late iterations (few new edges) and shards: the active flags first, so that k_rev_count can drop the offers nobody will read.
+// Rows [row0, row0 + n_rows) are walked; only targets inside that range are marked (a shard's other targets travel as records).
+__global__ __launch_bounds__(256) void k_rev_mark(const uint32_t *__restrict__ knn_e, int64_t row0, int64_t n_rows, int ks, uint8_t *__restrict__ active) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= total) return;
-    const u32x4 e = *(const u32x4 *)(knn_e + i);  // (rows are ks = 16 * m words: a vector never straddles two)
-    const int64_t v = i / ks;
+    if (i >= n_rows * ks) return;
+    const u32x4 e = *(const u32x4 *)(knn_e + row0 * ks + i);  // (rows are ks = 16 * m words: a vector never straddles two)
+    const int64_t v = row0 + i / ks;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t w = e[q];
-        if (w != NND_EMPTY_E && (w >> 31)) { active[v] = 1; active[w & NND_IDX_MASK] = 1; }
+        if (w != NND_EMPTY_E && (w >> 31)) {
+            active[v] = 1;
+            const uint32_t t = w & NND_IDX_MASK;
+            if ((uint32_t)(t - (uint32_t)row0) < (uint32_t)n_rows) active[t] = 1;
+        }
     }
 }
+// ... and the new-class offers a shard has received for its rows
+__global__ void k_rev_mark_records(const int32_t *__restrict__ targets, int64_t count, int64_t row0, int64_t n_rows, uint8_t *__restrict__ active) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t t = (uint32_t)targets[i];
+    const uint32_t u = t & NND_IDX_MASK;
+    if ((t >> 31) && (uint32_t)(u - (uint32_t)row0) < (uint32_t)n_rows) active[u] = 1;
+}
 
-__global__ __launch_bounds__(256) void k_rev_count(const uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, uint32_t it_seed,
+__global__ __launch_bounds__(256) void k_rev_count(const uint32_t *__restrict__ knn_e, int64_t row0, int64_t n, int k, int ks, uint32_t it_seed,
                                                    const int32_t *__restrict__ order, const int32_t *__restrict__ pos, int logB,
                                                    uint8_t *__restrict__ active, int mark, uint32_t *__restrict__ bcount,
                                                    uint2 *__restrict__ stage) {
+    // rows walked: the n vertices order[0 .. n) (or row0 .. row0 + n); targets outside [row0, row0 + n) are not this handle's
+    // (a shard: they have travelled as records, k_offer_export); positions are relative to row0
     __shared__ uint32_t hkey[RV_TAB], hcnt[RV_TAB];
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     for (int i = tid; i < RV_TAB; i += 256) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0; }
@@ -549,7 +564,7 @@ __global__ __launch_bounds__(256) void k_rev_count(const uint32_t *__restrict__ 
         ev[it] = NND_EMPTY_E;
         vv[it] = 0;
         if (g < n && j < k) {
-            vv[it] = (uint32_t)(order ? order[g] : (int32_t)g);
+            vv[it] = (uint32_t)(order ? order[g] : (int32_t)(row0 + g));
             ev[it] = knn_e[(int64_t)vv[it] * ks + j];
         }
     }
@@ -559,6 +574,10 @@ __global__ __launch_bounds__(256) void k_rev_count(const uint32_t *__restrict__ 
         const int64_t g = ((int64_t)blockIdx.x * RV_RPT + it) * blockDim.y + threadIdx.y;
         bb[it] = RV_NOKEY;
         uint2 rec = make_uint2(0u, 0xFFFFFFFFu);
+        if (ev[it] != NND_EMPTY_E && (uint32_t)((ev[it] & NND_IDX_MASK) - (uint32_t)row0) >= (uint32_t)n) {
+            if ((ev[it] >> 31) && mark == 1) active[vv[it]] = 1;
+            ev[it] = NND_EMPTY_E;  // the target is another rank's
+        }
         if (ev[it] != NND_EMPTY_E) {
             const uint32_t u = ev[it] & NND_IDX_MASK, cls = ev[it] >> 31;
             if (cls && mark == 1) { active[vv[it]] = 1; active[u] = 1; }  // a new edge: both endpoints will hold a new candidate
@@ -568,11 +587,53 @@ __global__ __launch_bounds__(256) void k_rev_count(const uint32_t *__restrict__ 
         }
         if (ev[it] != NND_EMPTY_E) {
             const uint32_t u = ev[it] & NND_IDX_MASK, cls = ev[it] >> 31;
-            const uint32_t p = (uint32_t)(pos ? pos[u] : (int32_t)u);
+            const uint32_t ul = u - (uint32_t)row0;
+            const uint32_t p = (uint32_t)(pos ? pos[ul] : (int32_t)ul);
             bb[it] = p >> logB;
             rec = make_uint2(rv_offer_word(it_seed, u, vv[it]), p | (cls << 31));
         }
         if (g < n && j < ks) stage[g * ks + j] = rec;  // the scatter pass streams these: no second walk of the graph
+    }
+#pragma unroll
+    for (int it = 0; it < RV_RPT; it++) {
+        int rank, size, leader;
+        rv_row_groups(bb[it], rank, size, leader);
+        if (bb[it] != RV_NOKEY && rank == 0) {
+            const int h = rv_tab_find(hkey, bb[it]);
+            if (h >= 0) atomicAdd(&hcnt[h], (uint32_t)size);
+            else atomicAdd(&bcount[bb[it]], (uint32_t)size);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < RV_TAB; i += 256)
+        if (hcnt[i]) atomicAdd(&bcount[hkey[i]], hcnt[i]);
+}
+
+// a shard's RECEIVED offers (target | class << 31, source; k_offer_export on the sender): staged and counted like the local ones
+__global__ __launch_bounds__(256) void k_rev_count_records(const int32_t *__restrict__ targets, const uint32_t *__restrict__ sources, int64_t count,
+                                                           uint32_t it_seed, int64_t row0, int64_t n, const int32_t *__restrict__ pos, int logB,
+                                                           const uint8_t *__restrict__ active, int filter, uint32_t *__restrict__ bcount,
+                                                           uint2 *__restrict__ stage) {
+    __shared__ uint32_t hkey[RV_TAB], hcnt[RV_TAB];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < RV_TAB; i += 256) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0; }
+    __syncthreads();
+    uint32_t bb[RV_RPT];
+#pragma unroll
+    for (int it = 0; it < RV_RPT; it++) {
+        const int64_t i = ((int64_t)blockIdx.x * RV_RPT + it) * 256 + tid;
+        bb[it] = RV_NOKEY;
+        uint2 rec = make_uint2(0u, 0xFFFFFFFFu);
+        if (i < count) {
+            const uint32_t t = (uint32_t)targets[i];
+            const uint32_t cls = t >> 31, u = t & NND_IDX_MASK, ul = u - (uint32_t)row0;
+            if (ul < (uint32_t)n && !(filter && !cls && !active[u])) {
+                const uint32_t p = (uint32_t)(pos ? pos[ul] : (int32_t)ul);
+                bb[it] = p >> logB;
+                rec = make_uint2(rv_offer_word(it_seed, u, sources[i]), p | (cls << 31));
+            }
+            stage[i] = rec;
+        }
     }
 #pragma unroll
     for (int it = 0; it < RV_RPT; it++) {
@@ -613,7 +674,7 @@ __global__ __launch_bounds__(1024) void k_rev_scan(const uint32_t *__restrict__ 
     if (tid == 0) out[nb] = carry_s;
 }
 
-__global__ __launch_bounds__(256) void k_rev_scatter(const uint2 *__restrict__ stage, int64_t n, int ks, int logB, const uint32_t *__restrict__ bstart,
+__global__ __launch_bounds__(256) void k_rev_scatter(const uint2 *__restrict__ stage, int64_t total, int ks, int logB, const uint32_t *__restrict__ bstart,
                                                      uint32_t *__restrict__ bcursor, uint32_t *__restrict__ rec_w, uint16_t *__restrict__ rec_m) {
     __shared__ uint32_t hkey[RV_TAB], hcnt[RV_TAB], hbase[RV_TAB];
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
@@ -628,7 +689,7 @@ __global__ __launch_bounds__(256) void k_rev_scatter(const uint2 *__restrict__ s
     for (int it = 0; it < RV_RPT; it++) {
         const int64_t g = ((int64_t)blockIdx.x * RV_RPT + it) * blockDim.y + threadIdx.y;
         rec[it] = make_uint2(0u, 0xFFFFFFFFu);
-        if (g < n && j < ks) rec[it] = stage[g * ks + j];
+        if (j < ks && g * ks + j < total) rec[it] = stage[g * ks + j];  // (`total` staged entries, rows of ks)
     }
 #pragma unroll
     for (int it = 0; it < RV_RPT; it++) {
@@ -670,7 +731,7 @@ __device__ __forceinline__ uint32_t rv_ovf_slot(uint32_t word, uint32_t cap) { r
 // target's two banks form ONE bank of 2 * RCAP slots (nnd_offer_addr).  LDS: NB * 2 * RCAP words = 64 KB, two workgroups per CU.
 template <int RCAP, int NB, bool WIDE>
 __global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ rec_w, const uint16_t *__restrict__ rec_m,
-                                                   const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, int64_t n,
+                                                   const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, int64_t row0, int64_t n,
                                                    const int32_t *__restrict__ order, const uint8_t *__restrict__ active,
                                                    uint32_t *__restrict__ rbuf) {
     constexpr int ROW = 2 * RCAP;                 // words per target
@@ -716,7 +777,7 @@ __global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ 
     for (int tl = tl0; tl < NB; tl += 1024 / ROW) {
         const int64_t p = b * NB + tl;
         if (p >= n) break;
-        const int64_t v = order ? (int64_t)order[p] : p;
+        const int64_t v = order ? (int64_t)order[p] : row0 + p;
         if (!active[v]) continue;
         rbuf[v * ROW + c] = bank[tl * ROW + c];
     }
@@ -729,7 +790,7 @@ __global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ 
 // phase.  LDS: 32 KB banks + 16 KB selection lists: three workgroups per CU.
 template <bool WIDE>
 __global__ __launch_bounds__(512) void k_rev_select(const uint32_t *__restrict__ rec_w, const uint16_t *__restrict__ rec_m,
-                                                    const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, int64_t n,
+                                                    const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, int64_t row0, int64_t n,
                                                     const int32_t *__restrict__ order, const uint8_t *__restrict__ active,
                                                     uint32_t *__restrict__ knn_e, int k, int ks, int mc, int mcp, uint32_t it_seed,
                                                     int32_t *__restrict__ cand) {
@@ -748,7 +809,7 @@ __global__ __launch_bounds__(512) void k_rev_select(const uint32_t *__restrict__
         const int64_t p = b * NB + tid;
         int32_t v = -1;
         if (p < n) {
-            v = order ? order[p] : (int32_t)p;
+            v = order ? order[p] : (int32_t)(row0 + p);
             if (!active[v]) v = -2 - v;
         }
         vtx[tid] = v;
@@ -811,9 +872,9 @@ __global__ __launch_bounds__(512) void k_rev_select(const uint32_t *__restrict__
     }
 }
 
-__global__ void k_rev_invert(const int32_t *__restrict__ order, int64_t n, int32_t *__restrict__ pos) {
+__global__ void k_rev_invert(const int32_t *__restrict__ order, int64_t row0, int64_t n, int32_t *__restrict__ pos) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n) pos[order[g]] = (int32_t)g;
+    if (g < n) pos[order[g] - row0] = (int32_t)g;
 }
 
 // rows scanned for reverse offers: every row on a plain handle; the owned slice when shard bounds are set (row-sharded
@@ -870,20 +931,31 @@ static int rv_grow(nnd_ctx *ctx, T **p, size_t count) {
     NND_HIP_CHECK(hipMalloc((void **)p, sizeof(T) * count));
     return 0;
 }
-static int rv_prepare(nnd_ctx *ctx, int logB, const int32_t *order) {
-    const int64_t nb = ((ctx->n - 1) >> logB) + 1, nrec = ctx->n * ctx->k;
+// rows [row0, row0 + n_rows) are walked (all rows; a shard: the owned slice), `extra` records arrive from elsewhere
+static int rv_prepare(nnd_ctx *ctx, int logB, const int32_t *order, int64_t row0, int64_t n_rows, int64_t extra) {
+    const int64_t nb = ((n_rows - 1) >> logB) + 1, nrec = n_rows * ctx->k + extra, nstage = n_rows * ctx->ks + extra;
     if (nb + 1 > ctx->rv_cap_b) {
         if (rv_grow(ctx, &ctx->rv_count, (size_t)nb + 1) || rv_grow(ctx, &ctx->rv_start, (size_t)nb + 1) || rv_grow(ctx, &ctx->rv_cursor, (size_t)nb + 1)) return 1;
         ctx->rv_cap_b = nb + 1;
     }
     if (nrec > ctx->rv_cap_rec) {
-        if (rv_grow(ctx, &ctx->rv_word, (size_t)nrec) || rv_grow(ctx, &ctx->rv_meta, (size_t)nrec) || rv_grow(ctx, &ctx->rv_stage, (size_t)ctx->n * ctx->ks)) return 1;
-        ctx->rv_cap_rec = nrec;
+        const int64_t cap = extra > 0 ? nrec + nrec / 4 : nrec;  // (a shard's inbox varies from iteration to iteration: head room)
+        if (rv_grow(ctx, &ctx->rv_word, (size_t)cap) || rv_grow(ctx, &ctx->rv_meta, (size_t)cap)) return 1;
+        ctx->rv_cap_rec = cap;
     }
-    if (order && (!ctx->rv_pos || ctx->rv_pos_gen != ctx->forest_gen)) {
-        if (!ctx->rv_pos && rv_grow(ctx, &ctx->rv_pos, (size_t)ctx->n)) return 1;
-        hipLaunchKernelGGL(k_rev_invert, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream, order, ctx->n, ctx->rv_pos);
+    if (nstage > ctx->rv_cap_stage) {
+        const int64_t cap = extra > 0 ? nstage + nstage / 4 : nstage;
+        if (rv_grow(ctx, &ctx->rv_stage, (size_t)cap)) return 1;
+        ctx->rv_cap_stage = cap;
+    }
+    if (order && (!ctx->rv_pos || ctx->rv_pos_gen != ctx->forest_gen || ctx->rv_pos_of != order)) {
+        if (n_rows > ctx->rv_cap_pos) {
+            if (rv_grow(ctx, &ctx->rv_pos, (size_t)n_rows)) return 1;
+            ctx->rv_cap_pos = n_rows;
+        }
+        hipLaunchKernelGGL(k_rev_invert, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream, order, row0, n_rows, ctx->rv_pos);
         ctx->rv_pos_gen = ctx->forest_gen;
+        ctx->rv_pos_of = order;
     }
     return 0;
 }
@@ -892,45 +964,59 @@ static int rv_prepare(nnd_ctx *ctx, int logB, const int32_t *order) {
 static bool rv_fused(const nnd_ctx *ctx) {
     return ctx->k <= 32 && ctx->rcap == 32 && ctx->mc <= 32 && !(ctx->p.flags & NND_FLAG_TEST_SELECT_WAVE);
 }
-// the reverse offers of this iteration by transposition (see above), then the selection; active[] is set on the way
-static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide) {
-    const bool fused = rv_fused(ctx);
+static bool rv_bucketed(const nnd_ctx *ctx) { return (ctx->rcap == 32 || ctx->rcap == 64) && !(ctx->p.flags & NND_FLAG_TEST_SAMPLE_ATOMIC); }
+// The reverse offers of this iteration by transposition (see above), then the selection; active[] is set on the way.  A shard
+// (n_ranks > 1) walks its owned rows and adds the `n_in` offers it has received (in_targets: target | class << 31, in_sources).
+static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide, const int32_t *in_targets, const uint32_t *in_sources, int64_t n_in) {
+    const bool fused = rv_fused(ctx), shard = ctx->n_ranks > 1;
     const int logB = (fused || ctx->rcap != 32) ? 7 : 8;
-    const int32_t *order = (ctx->forest_built && ctx->p.n_trees > 0) ? ctx->perm[ctx->cur] : nullptr;
-    if (rv_prepare(ctx, logB, order)) return 1;
+    const int64_t row0 = shard ? ctx->own_lo : 0, n_rows = shard ? ctx->own_hi - ctx->own_lo : ctx->n;
+    if (n_rows <= 0) return 0;
+    const int32_t *order = shard ? ctx->own_order : ((ctx->forest_built && ctx->p.n_trees > 0) ? ctx->perm[ctx->cur] : nullptr);
+    if (rv_prepare(ctx, logB, order, row0, n_rows, n_in)) return 1;
     const int32_t *pos = order ? ctx->rv_pos : nullptr;
-    const int64_t nb = ((ctx->n - 1) >> logB) + 1;
+    const int64_t nb = ((n_rows - 1) >> logB) + 1;
     int ksp = 16;
     while (ksp < ctx->ks) ksp <<= 1;
     const int rows = 256 / ksp;
-    const unsigned grid = (unsigned)((ctx->n + (int64_t)rows * RV_RPT - 1) / ((int64_t)rows * RV_RPT));
-    NND_HIP_CHECK(hipMemsetAsync(ctx->rv_count, 0, sizeof(uint32_t) * (size_t)(nb + 1), ctx->stream));
-    NND_HIP_CHECK(hipMemsetAsync(ctx->rv_cursor, 0, sizeof(uint32_t) * (size_t)(nb + 1), ctx->stream));
+    const unsigned grid = (unsigned)((n_rows + (int64_t)rows * RV_RPT - 1) / ((int64_t)rows * RV_RPT));
+    hipStream_t st = ctx->stream;
+    NND_HIP_CHECK(hipMemsetAsync(ctx->rv_count, 0, sizeof(uint32_t) * (size_t)(nb + 1), st));
+    NND_HIP_CHECK(hipMemsetAsync(ctx->rv_cursor, 0, sizeof(uint32_t) * (size_t)(nb + 1), st));
     // the first pass of a build: every edge is new, every vertex with an edge is active -- one memset instead of n * k random byte stores
     // (a vertex without any edge then "joins" with an empty new list, which is what an inactive one does)
-    NND_HIP_CHECK(hipMemsetAsync(ctx->active, ctx->all_new ? 1 : 0, (size_t)ctx->n, ctx->stream));
+    NND_HIP_CHECK(hipMemsetAsync(ctx->active + row0, ctx->all_new ? 1 : 0, (size_t)n_rows, st));
     // how the active flags come about: 0 = the memset above, 1 = k_rev_count marks them while it counts, 2 = k_rev_mark first and
-    // k_rev_count filters by them -- once the previous iteration inserted into fewer than an eighth of the slots
+    // k_rev_count filters by them -- once the previous iteration inserted into fewer than an eighth of the slots, and always on
+    // a shard (the received new-class offers mark too, before anything is filtered)
     int mark = ctx->all_new ? 0 : 1;
-    if (mark == 1 && ctx->last_updates >= 0 && ctx->last_updates * 8 < ctx->n * ctx->k) {
-        const int64_t total = ctx->n * ctx->ks;
-        hipLaunchKernelGGL(k_rev_mark, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->knn_e, total, ctx->ks, ctx->active);
+    if (mark == 1 && (shard || (ctx->last_updates >= 0 && ctx->last_updates * 8 < ctx->n * ctx->k))) {
+        hipLaunchKernelGGL(k_rev_mark, dim3((unsigned)((n_rows * ctx->ks / 4 + 255) / 256)), dim3(256), 0, st, ctx->knn_e, row0, n_rows, ctx->ks, ctx->active);
+        if (n_in > 0)
+            hipLaunchKernelGGL(k_rev_mark_records, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, in_targets, n_in, row0, n_rows, ctx->active);
         mark = 2;
     }
-    hipLaunchKernelGGL(k_rev_count, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->knn_e, ctx->n, ctx->k, ctx->ks, it_seed, order, pos, logB, ctx->active,
+    hipLaunchKernelGGL(k_rev_count, dim3(grid), dim3(ksp, rows), 0, st, ctx->knn_e, row0, n_rows, ctx->k, ctx->ks, it_seed, order, pos, logB, ctx->active,
                        mark, ctx->rv_count, ctx->rv_stage);
-    hipLaunchKernelGGL(k_rev_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->rv_count, ctx->rv_start, nb);
-    hipLaunchKernelGGL(k_rev_scatter, dim3(grid), dim3(ksp, rows), 0, ctx->stream, ctx->rv_stage, ctx->n, ctx->ks, logB, ctx->rv_start, ctx->rv_cursor,
+    uint2 *stage_in = ctx->rv_stage + (size_t)n_rows * ctx->ks;
+    const unsigned grid_in = (unsigned)((n_in + 256 * RV_RPT - 1) / (256 * RV_RPT));
+    if (n_in > 0)
+        hipLaunchKernelGGL(k_rev_count_records, dim3(grid_in), dim3(256), 0, st, in_targets, in_sources, n_in, it_seed, row0, n_rows, pos, logB, ctx->active,
+                           mark == 2 ? 1 : 0, ctx->rv_count, stage_in);
+    hipLaunchKernelGGL(k_rev_scan, dim3(1), dim3(1024), 0, st, ctx->rv_count, ctx->rv_start, nb);
+    hipLaunchKernelGGL(k_rev_scatter, dim3(grid), dim3(ksp, rows), 0, st, ctx->rv_stage, n_rows * ctx->ks, ctx->ks, logB, ctx->rv_start, ctx->rv_cursor,
                        ctx->rv_word, ctx->rv_meta);
+    if (n_in > 0)  // (the same kernel over the flat inbox stage: "rows" of 16 entries)
+        hipLaunchKernelGGL(k_rev_scatter, dim3(grid_in), dim3(16, 16), 0, st, stage_in, n_in, 16, logB, ctx->rv_start, ctx->rv_cursor, ctx->rv_word, ctx->rv_meta);
     if (fused) {
         auto kern = wide ? k_rev_select<true> : k_rev_select<false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), 0, ctx->stream, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, ctx->n, order,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), 0, st, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, row0, n_rows, order,
                            ctx->active, ctx->knn_e, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->cand);
         return 0;
     }
     ctx->rbuf_clean = false;
     auto fill = ctx->rcap == 32 ? (wide ? k_rev_fill<32, 256, true> : k_rev_fill<32, 256, false>) : k_rev_fill<64, 128, false>;
-    hipLaunchKernelGGL(fill, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, ctx->n, order,
+    hipLaunchKernelGGL(fill, dim3((unsigned)nb), dim3(1024), 0, st, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, row0, n_rows, order,
                        ctx->active, ctx->rbuf);
     launch_select(ctx, it_seed, wide);
     return 0;
@@ -942,9 +1028,9 @@ int nnd_launch_sample(nnd_ctx *ctx) {
         return 1;
     }
     const uint32_t it_seed = sample_seed(ctx);
-    if ((ctx->rcap == 32 || ctx->rcap == 64) && !(ctx->p.flags & NND_FLAG_TEST_SAMPLE_ATOMIC)) {
+    if (rv_bucketed(ctx)) {
         const bool wide_b = sample_wide(ctx);
-        if (launch_sample_bucketed(ctx, it_seed, wide_b)) return 1;
+        if (launch_sample_bucketed(ctx, it_seed, wide_b, nullptr, nullptr, 0)) return 1;
         ctx->all_new = false;
         NND_HIP_CHECK(hipGetLastError());
         return 0;
@@ -1051,9 +1137,11 @@ __global__ void k_offer_import(const int32_t *__restrict__ targets, const uint32
 int nnd_launch_sample_begin(nnd_ctx *ctx, int64_t cap, int32_t *targets_dev, uint32_t *sources_dev, long long *counts_dev) {
     if (ctx->n_ranks < 1 || !ctx->shard_bounds) { ctx->set_error("nnd_sample_begin: call nnd_set_shard_bounds first"); return 1; }
     const uint32_t it_seed = sample_seed(ctx);
-    NND_HIP_CHECK(hipMemsetAsync(ctx->active + ctx->slim_row0(), 0, (size_t)ctx->slim_rows(), ctx->stream));
     NND_HIP_CHECK(hipMemsetAsync(ctx->shard_cursors, 0, sizeof(long long) * 66, ctx->stream));
-    launch_reverse_pass(ctx, 0, it_seed);
+    if (!rv_bucketed(ctx)) {  // (the bucketed pass handles local and received offers together, in nnd_launch_sample_finish)
+        NND_HIP_CHECK(hipMemsetAsync(ctx->active + ctx->slim_row0(), 0, (size_t)ctx->slim_rows(), ctx->stream));
+        launch_reverse_pass(ctx, 0, it_seed);
+    }
     if (ctx->n_ranks > 1) {
         int ksp = 16;
         while (ksp < ctx->ks) ksp <<= 1;
@@ -1075,6 +1163,12 @@ int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uin
     const uint32_t it_seed = sample_seed(ctx);
     const unsigned grid = (unsigned)((count + 255) / 256);
     const bool wide = sample_wide(ctx);  // (all_new is still what it was when nnd_launch_sample_begin ran)
+    if (rv_bucketed(ctx)) {  // round 5: local edges and received records are transposed together (no hashed slots, no lost offers)
+        if (launch_sample_bucketed(ctx, it_seed, wide, targets_dev, sources_dev, count)) return 1;
+        ctx->all_new = false;
+        NND_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (count > 0) {
         ctx->rbuf_clean = false;
         hipLaunchKernelGGL(k_offer_import, dim3(grid), dim3(256), 0, ctx->stream, targets_dev, sources_dev, count, 1u, it_seed, ctx->rbuf,

@@ -166,7 +166,8 @@ struct nnd_handle_s {
     uint32_t *rv_word = nullptr;              // (n * k) record: the offer's slot word (invertible priority of the source)
     uint16_t *rv_meta = nullptr;              // (n * k) record: target's index in its bucket | class << 15
     uint2 *rv_stage = nullptr;                // (n, ks) pre-formed records in the order the graph is walked: (slot word, position | class << 31)
-    int64_t rv_cap_rec = 0, rv_cap_b = 0;
+    int64_t rv_cap_rec = 0, rv_cap_b = 0, rv_cap_stage = 0, rv_cap_pos = 0;
+    const int32_t *rv_pos_of = nullptr;       // the order rv_pos inverts
     int64_t last_updates = -1;                // k-list insertions of the previous iteration (-1: unknown): picks the late-iteration form of the pass
     bool pbuf_clean = false, rbuf_clean = false;  // every proposal / reverse-offer slot is EMPTY (their consumers re-arm what they read): nnd_launch_reset_graph then skips the 2 x 512 MB memsets
 
