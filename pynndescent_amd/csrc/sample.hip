@@ -609,45 +609,65 @@ __global__ __launch_bounds__(256) void k_rev_count(const uint32_t *__restrict__ 
         if (hcnt[i]) atomicAdd(&bcount[hkey[i]], hcnt[i]);
 }
 
-// a shard's RECEIVED offers (target | class << 31, source; k_offer_export on the sender): staged and counted like the local ones
-__global__ __launch_bounds__(256) void k_rev_count_records(const int32_t *__restrict__ targets, const uint32_t *__restrict__ sources, int64_t count,
-                                                           uint32_t it_seed, int64_t row0, int64_t n, const int32_t *__restrict__ pos, int logB,
-                                                           const uint8_t *__restrict__ active, int filter, uint32_t *__restrict__ bcount,
-                                                           uint2 *__restrict__ stage) {
-    __shared__ uint32_t hkey[RV_TAB], hcnt[RV_TAB];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < RV_TAB; i += 256) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0; }
-    __syncthreads();
-    uint32_t bb[RV_RPT];
-#pragma unroll
-    for (int it = 0; it < RV_RPT; it++) {
-        const int64_t i = ((int64_t)blockIdx.x * RV_RPT + it) * 256 + tid;
-        bb[it] = RV_NOKEY;
-        uint2 rec = make_uint2(0u, 0xFFFFFFFFu);
-        if (i < count) {
-            const uint32_t t = (uint32_t)targets[i];
-            const uint32_t cls = t >> 31, u = t & NND_IDX_MASK, ul = u - (uint32_t)row0;
-            if (ul < (uint32_t)n && !(filter && !cls && !active[u])) {
-                const uint32_t p = (uint32_t)(pos ? pos[ul] : (int32_t)ul);
-                bb[it] = p >> logB;
-                rec = make_uint2(rv_offer_word(it_seed, u, sources[i]), p | (cls << 31));
-            }
-            stage[i] = rec;
+// A shard's RECEIVED offers (target | class << 31, source; k_offer_export on the sender).  They arrive in the senders' row order:
+// their targets are spread over ALL of this rank's buckets (rows are owned by number, 7 of 8 of a vertex's neighbours live on
+// other ranks), so the row groups and the workgroup's LDS table have nothing to aggregate, and counting them first costs a
+// second pass over 16 M random records (8 x 1.25 M rows: 0.64 + 0.66 ms per iteration, measured).  They are PLACED in one pass
+// instead: every bucket has 8 fixed-capacity sub-regions (8 cursors: an eighth of the same-address contention), a record takes
+// the next slot of the sub-region its thread number picks; what does not fit a sub-region (hubs) goes to ONE overflow list
+// that only the buckets with a full sub-region read.  Nothing is dropped; the set of records a bucket sees is the set sent.
+struct rv_inbox {
+    const uint32_t *cursor = nullptr;  // (n_buckets, 8) records offered to every sub-region (beyond cap: on the overflow list)
+    const uint2 *rec = nullptr;        // (n_buckets, 8, cap): (word, target's index in the bucket | class << 15) -- one 8-byte store per record
+    int cap = 0;
+    const uint2 *ov = nullptr;         // overflow list: (word, bucket << 9 | class << 8 | target's index in the bucket)
+    const uint32_t *ov_count = nullptr;
+};
+__global__ __launch_bounds__(256) void k_rev_import(const int32_t *__restrict__ targets, const uint32_t *__restrict__ sources, int64_t count,
+                                                    uint32_t it_seed, int64_t row0, int64_t n, const int32_t *__restrict__ pos, int logB,
+                                                    const uint8_t *__restrict__ active, int filter, uint32_t *__restrict__ in_cursor,
+                                                    uint2 *__restrict__ in_rec, int cap, uint2 *__restrict__ ov, uint32_t *__restrict__ ov_count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t t = (uint32_t)targets[i];
+    const uint32_t cls = t >> 31, u = t & NND_IDX_MASK, ul = u - (uint32_t)row0;
+    if (ul >= (uint32_t)n || (filter && !cls && !active[u])) return;  // (old-class offer to a vertex that will not join: never read)
+    const uint32_t p = (uint32_t)(pos ? pos[ul] : (int32_t)ul);
+    const uint32_t b = p >> logB, tl = p & ((1u << logB) - 1u);
+    const uint32_t w = rv_offer_word(it_seed, u, sources[i]);
+    const size_t sr = (size_t)b * 8 + (threadIdx.x & 7);
+    const uint32_t at = atomicAdd(&in_cursor[sr], 1u);
+    if (at < (uint32_t)cap) {
+        in_rec[sr * cap + at] = make_uint2(w, tl | (cls << 15));
+    } else {
+        ov[atomicAdd(ov_count, 1u)] = make_uint2(w, (b << 9) | (cls << 8) | tl);
+    }
+}
+// f(word, meta) for every record of bucket b: the counting-sorted local records, then the inbox
+template <typename F>
+__device__ __forceinline__ void rv_each_record(const uint32_t *__restrict__ rec_w, const uint16_t *__restrict__ rec_m, uint32_t base, uint32_t nrec,
+                                               const rv_inbox &ib, int64_t b, int tid, int nthr, F f) {
+    for (uint32_t i = tid; i < nrec; i += nthr) f(rec_w[base + i], (uint32_t)rec_m[base + i]);
+    if (!ib.cursor) return;  // (kernel-uniform)
+    bool over = false;
+#pragma unroll 1
+    for (int sr = 0; sr < 8; sr++) {
+        const uint32_t c = ib.cursor[b * 8 + sr];
+        over = over || c > (uint32_t)ib.cap;
+        const uint32_t m = c < (uint32_t)ib.cap ? c : (uint32_t)ib.cap;
+        const size_t o = ((size_t)b * 8 + sr) * ib.cap;
+        for (uint32_t i = tid; i < m; i += nthr) {
+            const uint2 r = ib.rec[o + i];
+            f(r.x, r.y);
         }
     }
-#pragma unroll
-    for (int it = 0; it < RV_RPT; it++) {
-        int rank, size, leader;
-        rv_row_groups(bb[it], rank, size, leader);
-        if (bb[it] != RV_NOKEY && rank == 0) {
-            const int h = rv_tab_find(hkey, bb[it]);
-            if (h >= 0) atomicAdd(&hcnt[h], (uint32_t)size);
-            else atomicAdd(&bcount[bb[it]], (uint32_t)size);
+    if (over) {  // (workgroup-uniform) this bucket has records on the overflow list
+        const uint32_t M = *ib.ov_count;
+        for (uint32_t i = tid; i < M; i += nthr) {
+            const uint2 r = ib.ov[i];
+            if ((int64_t)(r.y >> 9) == b) f(r.x, (r.y & 0xFFu) | (((r.y >> 8) & 1u) << 15));
         }
     }
-    __syncthreads();
-    for (int i = tid; i < RV_TAB; i += 256)
-        if (hcnt[i]) atomicAdd(&bcount[hkey[i]], hcnt[i]);
 }
 
 // exclusive scan of nb counts (one workgroup of 1024 threads; nb = n / 256: 4 k buckets at 1 M points, 40 k at 10 M);
@@ -731,8 +751,8 @@ __device__ __forceinline__ uint32_t rv_ovf_slot(uint32_t word, uint32_t cap) { r
 // target's two banks form ONE bank of 2 * RCAP slots (nnd_offer_addr).  LDS: NB * 2 * RCAP words = 64 KB, two workgroups per CU.
 template <int RCAP, int NB, bool WIDE>
 __global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ rec_w, const uint16_t *__restrict__ rec_m,
-                                                   const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, int64_t row0, int64_t n,
-                                                   const int32_t *__restrict__ order, const uint8_t *__restrict__ active,
+                                                   const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, rv_inbox ib, int64_t row0,
+                                                   int64_t n, const int32_t *__restrict__ order, const uint8_t *__restrict__ active,
                                                    uint32_t *__restrict__ rbuf) {
     constexpr int ROW = 2 * RCAP;                 // words per target
     constexpr int CAP = WIDE ? 2 * RCAP : RCAP;   // slots per bank
@@ -747,13 +767,11 @@ __global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ 
     if (tid == 0) any_ovf = 0;
     __syncthreads();
     const uint32_t base = bstart[b], nrec = bcursor[b];
-    for (uint32_t i = tid; i < nrec; i += 1024) {
-        const uint32_t w = rec_w[base + i];
-        const uint32_t m = rec_m[base + i];
+    rv_each_record(rec_w, rec_m, base, nrec, ib, b, tid, 1024, [&](uint32_t w, uint32_t m) {
         const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));  // [old | new], as rbuf
         const uint32_t s = atomicAdd(&cnt[bk], 1u);
         if (s < (uint32_t)CAP) bank[bk * CAP + s] = w;
-    }
+    });
     __syncthreads();
     for (int i = tid; i < NBANK; i += 1024)
         if (cnt[i] > (uint32_t)CAP) any_ovf = 1;
@@ -762,14 +780,10 @@ __global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ 
         for (int i = tid; i < NBANK * CAP; i += 1024)
             if (cnt[i / CAP] > (uint32_t)CAP) bank[i] = NND_EMPTY_SLOT;
         __syncthreads();
-        for (uint32_t i = tid; i < nrec; i += 1024) {
-            const uint32_t m = rec_m[base + i];
+        rv_each_record(rec_w, rec_m, base, nrec, ib, b, tid, 1024, [&](uint32_t w, uint32_t m) {
             const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));
-            if (cnt[bk] > (uint32_t)CAP) {
-                const uint32_t w = rec_w[base + i];
-                atomicMin(&bank[bk * CAP + rv_ovf_slot(w, CAP)], w);
-            }
-        }
+            if (cnt[bk] > (uint32_t)CAP) atomicMin(&bank[bk * CAP + rv_ovf_slot(w, CAP)], w);
+        });
         __syncthreads();
     }
     // banks of the ACTIVE targets -> rbuf, whole rows (the selection reads no other; an inactive target's row stays EMPTY)
@@ -790,8 +804,8 @@ __global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ 
 // phase.  LDS: 32 KB banks + 16 KB selection lists: three workgroups per CU.
 template <bool WIDE>
 __global__ __launch_bounds__(512) void k_rev_select(const uint32_t *__restrict__ rec_w, const uint16_t *__restrict__ rec_m,
-                                                    const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, int64_t row0, int64_t n,
-                                                    const int32_t *__restrict__ order, const uint8_t *__restrict__ active,
+                                                    const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, rv_inbox ib, int64_t row0,
+                                                    int64_t n, const int32_t *__restrict__ order, const uint8_t *__restrict__ active,
                                                     uint32_t *__restrict__ knn_e, int k, int ks, int mc, int mcp, uint32_t it_seed,
                                                     int32_t *__restrict__ cand) {
     constexpr int RCAP = 32, NB = 128, ROW = 2 * RCAP, NHW = 16, PER = NB / NHW;
@@ -826,13 +840,11 @@ __global__ __launch_bounds__(512) void k_rev_select(const uint32_t *__restrict__
         if (v0 >= 0 && j < k) pre_e = knn_e[(int64_t)v0 * ks + j];
     }
     const uint32_t base = bstart[b], nrec = bcursor[b];
-    for (uint32_t i = tid; i < nrec; i += 512) {
-        const uint32_t w = rec_w[base + i];
-        const uint32_t m = rec_m[base + i];
+    rv_each_record(rec_w, rec_m, base, nrec, ib, b, tid, 512, [&](uint32_t w, uint32_t m) {
         const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));  // [old | new], as rbuf
         const uint32_t sl = atomicAdd(&cnt[bk], 1u);
         if (sl < (uint32_t)CAP) bank[bk * CAP + sl] = w;
-    }
+    });
     __syncthreads();
     for (int i = tid; i < NBANK; i += 512)
         if (cnt[i] > (uint32_t)CAP) any_ovf = 1;
@@ -841,14 +853,10 @@ __global__ __launch_bounds__(512) void k_rev_select(const uint32_t *__restrict__
         for (int i = tid; i < NBANK * CAP; i += 512)
             if (cnt[i / CAP] > (uint32_t)CAP) bank[i] = NND_EMPTY_SLOT;
         __syncthreads();
-        for (uint32_t i = tid; i < nrec; i += 512) {
-            const uint32_t m = rec_m[base + i];
+        rv_each_record(rec_w, rec_m, base, nrec, ib, b, tid, 512, [&](uint32_t w, uint32_t m) {
             const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));
-            if (cnt[bk] > (uint32_t)CAP) {
-                const uint32_t w = rec_w[base + i];
-                atomicMin(&bank[bk * CAP + rv_ovf_slot(w, CAP)], w);
-            }
-        }
+            if (cnt[bk] > (uint32_t)CAP) atomicMin(&bank[bk * CAP + rv_ovf_slot(w, CAP)], w);
+        });
         __syncthreads();
     }
     uint64_t(*sk)[64] = skey[hw];
@@ -998,25 +1006,40 @@ static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide, con
     }
     hipLaunchKernelGGL(k_rev_count, dim3(grid), dim3(ksp, rows), 0, st, ctx->knn_e, row0, n_rows, ctx->k, ctx->ks, it_seed, order, pos, logB, ctx->active,
                        mark, ctx->rv_count, ctx->rv_stage);
-    uint2 *stage_in = ctx->rv_stage + (size_t)n_rows * ctx->ks;
-    const unsigned grid_in = (unsigned)((n_in + 256 * RV_RPT - 1) / (256 * RV_RPT));
-    if (n_in > 0)
-        hipLaunchKernelGGL(k_rev_count_records, dim3(grid_in), dim3(256), 0, st, in_targets, in_sources, n_in, it_seed, row0, n_rows, pos, logB, ctx->active,
-                           mark == 2 ? 1 : 0, ctx->rv_count, stage_in);
+    // a shard's inbox: placed in one pass (k_rev_import); the overflow list lives behind the local stage (sized for n_in records)
+    rv_inbox ib;
+    if (n_in > 0) {
+        int cap = 64;
+        while (cap < 4 * (int)((n_rows * ctx->k / (nb * 8)) + 1)) cap <<= 1;  // 4 x the mean load of a sub-region if EVERY offer were remote
+        const int64_t need = nb * 8 * cap;
+        if (need > ctx->rv_cap_in || cap != ctx->rv_in_cap) {
+            if (rv_grow(ctx, &ctx->rv_in_cursor, (size_t)nb * 8 + 8) || rv_grow(ctx, &ctx->rv_in_rec, (size_t)need)) return 1;
+            ctx->rv_cap_in = need;
+            ctx->rv_in_cap = cap;
+        }
+        NND_HIP_CHECK(hipMemsetAsync(ctx->rv_in_cursor, 0, sizeof(uint32_t) * ((size_t)nb * 8 + 8), st));  // (+ the overflow count behind them)
+        uint2 *ov = ctx->rv_stage + (size_t)n_rows * ctx->ks;
+        uint32_t *ov_count = ctx->rv_in_cursor + (size_t)nb * 8;
+        hipLaunchKernelGGL(k_rev_import, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, in_targets, in_sources, n_in, it_seed, row0, n_rows, pos, logB,
+                           ctx->active, mark == 2 ? 1 : 0, ctx->rv_in_cursor, ctx->rv_in_rec, cap, ov, ov_count);
+        ib.cursor = ctx->rv_in_cursor;
+        ib.rec = ctx->rv_in_rec;
+        ib.cap = cap;
+        ib.ov = ov;
+        ib.ov_count = ov_count;
+    }
     hipLaunchKernelGGL(k_rev_scan, dim3(1), dim3(1024), 0, st, ctx->rv_count, ctx->rv_start, nb);
     hipLaunchKernelGGL(k_rev_scatter, dim3(grid), dim3(ksp, rows), 0, st, ctx->rv_stage, n_rows * ctx->ks, ctx->ks, logB, ctx->rv_start, ctx->rv_cursor,
                        ctx->rv_word, ctx->rv_meta);
-    if (n_in > 0)  // (the same kernel over the flat inbox stage: "rows" of 16 entries)
-        hipLaunchKernelGGL(k_rev_scatter, dim3(grid_in), dim3(16, 16), 0, st, stage_in, n_in, 16, logB, ctx->rv_start, ctx->rv_cursor, ctx->rv_word, ctx->rv_meta);
     if (fused) {
         auto kern = wide ? k_rev_select<true> : k_rev_select<false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), 0, st, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, row0, n_rows, order,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), 0, st, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, ib, row0, n_rows, order,
                            ctx->active, ctx->knn_e, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->cand);
         return 0;
     }
     ctx->rbuf_clean = false;
     auto fill = ctx->rcap == 32 ? (wide ? k_rev_fill<32, 256, true> : k_rev_fill<32, 256, false>) : k_rev_fill<64, 128, false>;
-    hipLaunchKernelGGL(fill, dim3((unsigned)nb), dim3(1024), 0, st, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, row0, n_rows, order,
+    hipLaunchKernelGGL(fill, dim3((unsigned)nb), dim3(1024), 0, st, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, ib, row0, n_rows, order,
                        ctx->active, ctx->rbuf);
     launch_select(ctx, it_seed, wide);
     return 0;

@@ -168,6 +168,10 @@ struct nnd_handle_s {
     uint2 *rv_stage = nullptr;                // (n, ks) pre-formed records in the order the graph is walked: (slot word, position | class << 31)
     int64_t rv_cap_rec = 0, rv_cap_b = 0, rv_cap_stage = 0, rv_cap_pos = 0;
     const int32_t *rv_pos_of = nullptr;       // the order rv_pos inverts
+    uint32_t *rv_in_cursor = nullptr;         // a shard's inbox: (n_buckets, 8) cursors (+ the overflow count)
+    uint2 *rv_in_rec = nullptr;               // ... (n_buckets, 8, cap) records (word, meta)
+    int64_t rv_cap_in = 0;
+    int rv_in_cap = 0;
     int64_t last_updates = -1;                // k-list insertions of the previous iteration (-1: unknown): picks the late-iteration form of the pass
     bool pbuf_clean = false, rbuf_clean = false;  // every proposal / reverse-offer slot is EMPTY (their consumers re-arm what they read): nnd_launch_reset_graph then skips the 2 x 512 MB memsets
 
