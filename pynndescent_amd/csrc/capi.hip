@@ -90,7 +90,7 @@ static void free_all(nnd_ctx *ctx) {
     for (void *&a : ctx->slim_alloc) { F(a); a = nullptr; }  // cand / rbuf / active (the working pointers may be biased)
     F(ctx->xp); F(ctx->nrm); F(ctx->nr2); F(ctx->xh); F(ctx->mean); F(ctx->knn_e); F(ctx->knn_d); F(ctx->th); F(ctx->pbuf_r);
     F(ctx->pdirty); F(ctx->out_idx); F(ctx->out_dist);
-    F(ctx->rv_pos); F(ctx->rv_count); F(ctx->rv_start); F(ctx->rv_cursor); F(ctx->rv_word); F(ctx->rv_meta); F(ctx->rv_stage); F(ctx->rv_in_cursor); F(ctx->rv_in_rec);
+    F(ctx->rv_pos); F(ctx->rv_in_cursor); F(ctx->rv_in_rec); F(ctx->rv_ov);
     for (int i = 0; i < 2; i++) { F(ctx->perm[i]); F(ctx->pos_seg[i]); F(ctx->seg_start[i]); F(ctx->seg_len[i]); }
     F(ctx->inv); F(ctx->side); F(ctx->side_pt); F(ctx->leaf_flag); F(ctx->scan_out); F(ctx->scan_blk); F(ctx->seg_nleft); F(ctx->seg_child);
     F(ctx->xs); F(ctx->xsh); F(ctx->nr2s); F(ctx->node_hf); F(ctx->node_hh); F(ctx->node_child); F(ctx->node_pack); F(ctx->node_hfc); F(ctx->route_roots); F(ctx->route_ws); F(ctx->s_leaf_depth);

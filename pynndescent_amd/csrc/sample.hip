@@ -454,27 +454,31 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Bucketed reverse pass (round 5; plain handles).  k_sample_reverse above is 15 M random device-scope atomicMin per launch:
+// Bucketed reverse pass (round 5).  k_sample_reverse above is 15 M random device-scope atomicMin per launch:
 // on this chip EVERY global atomic is executed at the memory side (per-XCD L2s are not coherent; workgroup- and agent-scope
 // atomics are the same instruction), 0.28 ms per launch whatever the traffic, and 32 hashed slots lose a fifth of the
 // offers of a bank to collisions -- the reference's heaps lose an offer only by priority (utils.py:277-306), and that loss
 // was the measured recall gap to the reference algorithm.  Here the reverse offers are TRANSPOSED
-// instead of scattered one atomic at a time:
-//   k_rev_count    one thread per edge: marks the endpoints of new edges active, looks the target's POSITION in the visiting
-//                  order up (the only random access per edge of the whole pass), counts the offers per target BUCKET
-//                  (128 or 256 consecutive positions) -- per 16-lane row first (a row's neighbours sit in a handful of
-//                  buckets: DPP rotations), then in an LDS hash table of the workgroup, one global atomic per (workgroup,
-//                  bucket) -- and STAGES the pre-formed record (slot word, position | class) in walking order;
-//   k_rev_scan     exclusive scan of the bucket counts (one workgroup);
-//   k_rev_scatter  streams the staged records (no second walk of the graph) into their buckets' regions as 6-byte records
-//                  (slot word, target's index in its bucket | class) -- ranks from the row groups and the LDS table, one
-//                  returning global atomic per (workgroup, bucket);
-//   k_rev_fill     one workgroup per bucket: its targets' slot banks live in LDS, the records are APPENDED (an LDS counter
-//                  per bank: no collision, no lost offer while a bank receives <= rcap offers; a bank that overflows is
-//                  redone with hashed atomicMin slots -- order independent, hubs only), the banks of active targets are
-//                  written to rbuf in whole 256-byte rows.
-// k_sample_select* read rbuf exactly as before (they never depended on WHICH slot an offer sits in).  The result is a
-// function of the graph and the seed alone: the set of appended words is the set of offers, the hashed fallback is a min.
+// instead of scattered one atomic at a time.  A BUCKET is 128 (256 in one regime) consecutive positions of the visiting
+// order; every bucket owns 8 fixed-capacity SUB-REGIONS of records (word, target's index in the bucket | class) and their
+// 8 cursors; what does not fit a sub-region (hubs) goes to ONE overflow list that only the buckets with a full sub-region
+// read -- nothing is dropped, and the set of records a bucket sees is the set of offers made to its vertices:
+//   k_rev_mark     (late iterations, shards) the endpoints of new edges are marked active first, so that the old-class offers
+//                  nobody will read are dropped before they cost anything;
+//   k_rev_place    one thread per edge: looks the target's POSITION in the visiting order up (the only random read per edge),
+//                  forms the record, and places it: the offers of a 16-lane row that share a bucket are grouped by DPP
+//                  rotations (a row's neighbours sit in a handful of buckets), the groups of a workgroup meet in an LDS hash
+//                  table, ONE returning global atomic per (workgroup, bucket) reserves their run in the sub-region the
+//                  workgroup's number picks, the records are written from registers -- the graph is walked ONCE (a first
+//                  version counted, scanned and scattered: two walks + 128 MB of staged records per iteration);
+//   k_rev_import   a shard's received offers, one atomic each (their targets are spread over all of the rank's buckets);
+//   k_rev_select   (k <= 32) one workgroup per bucket: its targets' slot banks live in LDS, the records are APPENDED (an LDS
+//                  counter per bank: no collision, no lost offer while a bank receives <= its slots; a bank that overflows is
+//                  redone with hashed atomicMin slots -- order independent, hubs only), then the selection of k_sample_select_h
+//                  runs on the banks where they are;  k_rev_fill: the other regimes -- the banks go to rbuf and
+//                  k_sample_select* read them exactly as before (they never depended on WHICH slot an offer sits in).
+// The result is a function of the graph and the seed alone: the set of appended words is the set of offers, the hashed
+// fallback is a min.
 #define RV_TAB 1024  // entries of the per-workgroup hash table (bucket -> count); what does not fit goes straight to global
 #define RV_RPT 8     // row groups (of 256 / ksp rows) per workgroup = records per thread
 #define RV_NOHASH 0xFFFFu
@@ -546,17 +550,27 @@ __global__ void k_rev_mark_records(const int32_t *__restrict__ targets, int64_t 
     if ((t >> 31) && (uint32_t)(u - (uint32_t)row0) < (uint32_t)n_rows) active[u] = 1;
 }
 
-__global__ __launch_bounds__(256) void k_rev_count(const uint32_t *__restrict__ knn_e, int64_t row0, int64_t n, int k, int ks, uint32_t it_seed,
+// The records of every bucket: 8 sub-regions of `cap` records + their cursors (a cursor may run past cap: the rest of its
+// records is on the overflow list).
+struct rv_inbox {
+    const uint32_t *cursor = nullptr;  // (n_buckets, 8) records offered to every sub-region (beyond cap: on the overflow list)
+    const uint2 *rec = nullptr;        // (n_buckets, 8, cap): (word, target's index in the bucket | class << 15) -- one 8-byte store per record
+    int cap = 0;
+    const uint2 *ov = nullptr;         // overflow list: (word, bucket << 9 | class << 8 | target's index in the bucket)
+    const uint32_t *ov_count = nullptr;
+};
+// the local edges: see the header of this section.  Rows walked: order[0 .. n) (or row0 .. row0 + n); targets outside
+// [row0, row0 + n) are not this handle's (a shard: they have travelled as records, k_offer_export); positions are relative to row0.
+__global__ __launch_bounds__(256) void k_rev_place(const uint32_t *__restrict__ knn_e, int64_t row0, int64_t n, int k, int ks, uint32_t it_seed,
                                                    const int32_t *__restrict__ order, const int32_t *__restrict__ pos, int logB,
-                                                   uint8_t *__restrict__ active, int mark, uint32_t *__restrict__ bcount,
-                                                   uint2 *__restrict__ stage) {
-    // rows walked: the n vertices order[0 .. n) (or row0 .. row0 + n); targets outside [row0, row0 + n) are not this handle's
-    // (a shard: they have travelled as records, k_offer_export); positions are relative to row0
-    __shared__ uint32_t hkey[RV_TAB], hcnt[RV_TAB];
+                                                   uint8_t *__restrict__ active, int mark, uint32_t *__restrict__ in_cursor,
+                                                   uint2 *__restrict__ in_rec, int cap, uint2 *__restrict__ ov, uint32_t *__restrict__ ov_count) {
+    __shared__ uint32_t hkey[RV_TAB], hcnt[RV_TAB], hbase[RV_TAB];
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     for (int i = tid; i < RV_TAB; i += 256) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0; }
     __syncthreads();
     const int j = threadIdx.x;
+    const uint32_t sub = blockIdx.x & 7u, bmask = (1u << logB) - 1u;
     uint32_t ev[RV_RPT], vv[RV_RPT];
 #pragma unroll
     for (int it = 0; it < RV_RPT; it++) {  // all loads of the workgroup's rows first
@@ -568,12 +582,14 @@ __global__ __launch_bounds__(256) void k_rev_count(const uint32_t *__restrict__ 
             ev[it] = knn_e[(int64_t)vv[it] * ks + j];
         }
     }
-    uint32_t bb[RV_RPT];
+    uint32_t bb[RV_RPT], w[RV_RPT], at[RV_RPT];  // bucket; slot word; rank inside the (workgroup, bucket) run, or the final place
+    uint16_t m[RV_RPT], hh[RV_RPT];              // target's index in the bucket | class << 15; table slot, RV_NOHASH: `at` is final
 #pragma unroll
     for (int it = 0; it < RV_RPT; it++) {
-        const int64_t g = ((int64_t)blockIdx.x * RV_RPT + it) * blockDim.y + threadIdx.y;
         bb[it] = RV_NOKEY;
-        uint2 rec = make_uint2(0u, 0xFFFFFFFFu);
+        w[it] = at[it] = 0;
+        m[it] = 0;
+        hh[it] = RV_NOHASH;
         if (ev[it] != NND_EMPTY_E && (uint32_t)((ev[it] & NND_IDX_MASK) - (uint32_t)row0) >= (uint32_t)n) {
             if ((ev[it] >> 31) && mark == 1) active[vv[it]] = 1;
             ev[it] = NND_EMPTY_E;  // the target is another rank's
@@ -581,48 +597,55 @@ __global__ __launch_bounds__(256) void k_rev_count(const uint32_t *__restrict__ 
         if (ev[it] != NND_EMPTY_E) {
             const uint32_t u = ev[it] & NND_IDX_MASK, cls = ev[it] >> 31;
             if (cls && mark == 1) { active[vv[it]] = 1; active[u] = 1; }  // a new edge: both endpoints will hold a new candidate
-            // mark == 2 (late iterations: few new edges, k_rev_mark has run): an old-class offer to a vertex that will not
-            // join is dropped here, before it costs a group, a record and a slot (utils.py:611-613: its old list is never read)
-            if (mark == 2 && !cls && !active[u]) { ev[it] = NND_EMPTY_E; }
+            // mark == 2 (k_rev_mark has run): an old-class offer to a vertex that will not join is dropped here, before it
+            // costs a group, a record and a slot (utils.py:611-613: its old list is never read)
+            if (mark == 2 && !cls && !active[u]) ev[it] = NND_EMPTY_E;
         }
         if (ev[it] != NND_EMPTY_E) {
             const uint32_t u = ev[it] & NND_IDX_MASK, cls = ev[it] >> 31;
             const uint32_t ul = u - (uint32_t)row0;
             const uint32_t p = (uint32_t)(pos ? pos[ul] : (int32_t)ul);
             bb[it] = p >> logB;
-            rec = make_uint2(rv_offer_word(it_seed, u, vv[it]), p | (cls << 31));
+            w[it] = rv_offer_word(it_seed, u, vv[it]);
+            m[it] = (uint16_t)((p & bmask) | (cls << 15));
         }
-        if (g < n && j < ks) stage[g * ks + j] = rec;  // the scatter pass streams these: no second walk of the graph
     }
 #pragma unroll
     for (int it = 0; it < RV_RPT; it++) {
         int rank, size, leader;
         rv_row_groups(bb[it], rank, size, leader);
-        if (bb[it] != RV_NOKEY && rank == 0) {
-            const int h = rv_tab_find(hkey, bb[it]);
-            if (h >= 0) atomicAdd(&hcnt[h], (uint32_t)size);
-            else atomicAdd(&bcount[bb[it]], (uint32_t)size);
+        int h = -1;
+        uint32_t base = 0;
+        if (bb[it] != RV_NOKEY && rank == 0) {  // one LDS (or, table full, global) atomic per group
+            h = rv_tab_find(hkey, bb[it]);
+            base = h >= 0 ? atomicAdd(&hcnt[h], (uint32_t)size) : atomicAdd(&in_cursor[(size_t)bb[it] * 8 + sub], (uint32_t)size);
+        }
+        h = __shfl(h, leader, 64);
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (bb[it] != RV_NOKEY) {
+            hh[it] = h >= 0 ? (uint16_t)h : RV_NOHASH;
+            at[it] = base + (uint32_t)rank;
         }
     }
     __syncthreads();
     for (int i = tid; i < RV_TAB; i += 256)
-        if (hcnt[i]) atomicAdd(&bcount[hkey[i]], hcnt[i]);
+        if (hcnt[i]) hbase[i] = atomicAdd(&in_cursor[(size_t)hkey[i] * 8 + sub], hcnt[i]);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RV_RPT; it++) {
+        if (bb[it] == RV_NOKEY) continue;
+        const uint32_t at_ = hh[it] == RV_NOHASH ? at[it] : hbase[hh[it]] + at[it];
+        if (at_ < (uint32_t)cap)
+            in_rec[((size_t)bb[it] * 8 + sub) * cap + at_] = make_uint2(w[it], (uint32_t)m[it]);
+        else
+            ov[atomicAdd(ov_count, 1u)] = make_uint2(w[it], (bb[it] << 9) | (((uint32_t)m[it] >> 15) << 8) | ((uint32_t)m[it] & 0xFFu));
+    }
 }
-
-// A shard's RECEIVED offers (target | class << 31, source; k_offer_export on the sender).  They arrive in the senders' row order:
-// their targets are spread over ALL of this rank's buckets (rows are owned by number, 7 of 8 of a vertex's neighbours live on
-// other ranks), so the row groups and the workgroup's LDS table have nothing to aggregate, and counting them first costs a
-// second pass over 16 M random records (8 x 1.25 M rows: 0.64 + 0.66 ms per iteration, measured).  They are PLACED in one pass
-// instead: every bucket has 8 fixed-capacity sub-regions (8 cursors: an eighth of the same-address contention), a record takes
-// the next slot of the sub-region its thread number picks; what does not fit a sub-region (hubs) goes to ONE overflow list
-// that only the buckets with a full sub-region read.  Nothing is dropped; the set of records a bucket sees is the set sent.
-struct rv_inbox {
-    const uint32_t *cursor = nullptr;  // (n_buckets, 8) records offered to every sub-region (beyond cap: on the overflow list)
-    const uint2 *rec = nullptr;        // (n_buckets, 8, cap): (word, target's index in the bucket | class << 15) -- one 8-byte store per record
-    int cap = 0;
-    const uint2 *ov = nullptr;         // overflow list: (word, bucket << 9 | class << 8 | target's index in the bucket)
-    const uint32_t *ov_count = nullptr;
-};
+// A shard's RECEIVED offers (target | class << 31, source; k_offer_export on the sender).  They arrive in the senders' row
+// order: their targets are spread over ALL of this rank's buckets (rows are owned by number, 7 of 8 of a vertex's neighbours
+// live on other ranks), so there is nothing for row groups or an LDS table to aggregate (measured: the same time with and
+// without, 0.64 ms per 16 M records at 8 x 1.25 M rows, and as much again when they were counted first and placed second):
+// one returning atomic and one 8-byte store per record; the thread number picks the sub-region.
 __global__ __launch_bounds__(256) void k_rev_import(const int32_t *__restrict__ targets, const uint32_t *__restrict__ sources, int64_t count,
                                                     uint32_t it_seed, int64_t row0, int64_t n, const int32_t *__restrict__ pos, int logB,
                                                     const uint8_t *__restrict__ active, int filter, uint32_t *__restrict__ in_cursor,
@@ -643,12 +666,9 @@ __global__ __launch_bounds__(256) void k_rev_import(const int32_t *__restrict__ 
         ov[atomicAdd(ov_count, 1u)] = make_uint2(w, (b << 9) | (cls << 8) | tl);
     }
 }
-// f(word, meta) for every record of bucket b: the counting-sorted local records, then the inbox
+// f(word, meta) for every record of bucket b
 template <typename F>
-__device__ __forceinline__ void rv_each_record(const uint32_t *__restrict__ rec_w, const uint16_t *__restrict__ rec_m, uint32_t base, uint32_t nrec,
-                                               const rv_inbox &ib, int64_t b, int tid, int nthr, F f) {
-    for (uint32_t i = tid; i < nrec; i += nthr) f(rec_w[base + i], (uint32_t)rec_m[base + i]);
-    if (!ib.cursor) return;  // (kernel-uniform)
+__device__ __forceinline__ void rv_each_record(const rv_inbox &ib, int64_t b, int tid, int nthr, F f) {
     bool over = false;
 #pragma unroll 1
     for (int sr = 0; sr < 8; sr++) {
@@ -670,90 +690,14 @@ __device__ __forceinline__ void rv_each_record(const uint32_t *__restrict__ rec_
     }
 }
 
-// exclusive scan of nb counts (one workgroup of 1024 threads; nb = n / 256: 4 k buckets at 1 M points, 40 k at 10 M);
-// out[nb] = the total
-__global__ __launch_bounds__(1024) void k_rev_scan(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int64_t nb) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < nb; base += 1024) {
-        const int64_t i = base + tid;
-        const uint32_t x = i < nb ? in[i] : 0u;
-        const uint32_t inc = (uint32_t)nnd_wave_incl_scan_i32((int)x);
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        uint32_t before = carry_s;
-        for (int q = 0; q < w; q++) before += wsum[q];
-        if (i < nb) out[i] = before + inc - x;
-        __syncthreads();
-        if (tid == 1023) carry_s = before + inc;
-        __syncthreads();
-    }
-    if (tid == 0) out[nb] = carry_s;
-}
-
-__global__ __launch_bounds__(256) void k_rev_scatter(const uint2 *__restrict__ stage, int64_t total, int ks, int logB, const uint32_t *__restrict__ bstart,
-                                                     uint32_t *__restrict__ bcursor, uint32_t *__restrict__ rec_w, uint16_t *__restrict__ rec_m) {
-    __shared__ uint32_t hkey[RV_TAB], hcnt[RV_TAB], hbase[RV_TAB];
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    for (int i = tid; i < RV_TAB; i += 256) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0; }
-    __syncthreads();
-    const int j = threadIdx.x;
-    const uint32_t bmask = (1u << logB) - 1u;
-    uint2 rec[RV_RPT];                 // slot word, position | class << 31
-    uint32_t at[RV_RPT];               // rank inside the (workgroup, bucket) group, or the final position
-    uint16_t hh[RV_RPT];               // table slot, RV_NOHASH: `at` is final, 0xFFFE: no record
-#pragma unroll
-    for (int it = 0; it < RV_RPT; it++) {
-        const int64_t g = ((int64_t)blockIdx.x * RV_RPT + it) * blockDim.y + threadIdx.y;
-        rec[it] = make_uint2(0u, 0xFFFFFFFFu);
-        if (j < ks && g * ks + j < total) rec[it] = stage[g * ks + j];  // (`total` staged entries, rows of ks)
-    }
-#pragma unroll
-    for (int it = 0; it < RV_RPT; it++) {
-        const uint32_t key = rec[it].y == 0xFFFFFFFFu ? RV_NOKEY : (rec[it].y & NND_IDX_MASK) >> logB;
-        int rank, size, leader;
-        rv_row_groups(key, rank, size, leader);
-        int h = -1;
-        uint32_t base = 0;
-        if (key != RV_NOKEY && rank == 0) {  // one LDS (or, table full, global) atomic per group
-            h = rv_tab_find(hkey, key);
-            base = h >= 0 ? atomicAdd(&hcnt[h], (uint32_t)size) : bstart[key] + atomicAdd(&bcursor[key], (uint32_t)size);
-        }
-        h = __shfl(h, leader, 64);
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        hh[it] = 0xFFFEu;
-        at[it] = 0;
-        if (key != RV_NOKEY) {
-            hh[it] = h >= 0 ? (uint16_t)h : RV_NOHASH;
-            at[it] = base + (uint32_t)rank;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < RV_TAB; i += 256)
-        if (hcnt[i]) hbase[i] = bstart[hkey[i]] + atomicAdd(&bcursor[hkey[i]], hcnt[i]);
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < RV_RPT; it++) {
-        if (hh[it] == 0xFFFEu) continue;
-        const uint32_t at_ = hh[it] == RV_NOHASH ? at[it] : hbase[hh[it]] + at[it];
-        rec_w[at_] = rec[it].x;
-        rec_m[at_] = (uint16_t)((rec[it].y & bmask) | ((rec[it].y >> 31) << 15));
-    }
-}
-
 // slot of a word in an overflowing bank: any fixed function of the word (itself a mixed value) will do
 __device__ __forceinline__ uint32_t rv_ovf_slot(uint32_t word, uint32_t cap) { return nnd_mix32(word ^ 0x68E31DA4u) & (cap - 1u); }
 
 // One workgroup per bucket.  RCAP slots per (target, class); WIDE: the first pass of a build, every offer is new-class and a
 // target's two banks form ONE bank of 2 * RCAP slots (nnd_offer_addr).  LDS: NB * 2 * RCAP words = 64 KB, two workgroups per CU.
 template <int RCAP, int NB, bool WIDE>
-__global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ rec_w, const uint16_t *__restrict__ rec_m,
-                                                   const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, rv_inbox ib, int64_t row0,
-                                                   int64_t n, const int32_t *__restrict__ order, const uint8_t *__restrict__ active,
-                                                   uint32_t *__restrict__ rbuf) {
+__global__ __launch_bounds__(1024) void k_rev_fill(rv_inbox ib, int64_t row0, int64_t n, const int32_t *__restrict__ order,
+                                                   const uint8_t *__restrict__ active, uint32_t *__restrict__ rbuf) {
     constexpr int ROW = 2 * RCAP;                 // words per target
     constexpr int CAP = WIDE ? 2 * RCAP : RCAP;   // slots per bank
     constexpr int NBANK = WIDE ? NB : 2 * NB;
@@ -766,8 +710,7 @@ __global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ 
     for (int i = tid; i < NBANK; i += 1024) cnt[i] = 0;
     if (tid == 0) any_ovf = 0;
     __syncthreads();
-    const uint32_t base = bstart[b], nrec = bcursor[b];
-    rv_each_record(rec_w, rec_m, base, nrec, ib, b, tid, 1024, [&](uint32_t w, uint32_t m) {
+    rv_each_record(ib, b, tid, 1024, [&](uint32_t w, uint32_t m) {
         const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));  // [old | new], as rbuf
         const uint32_t s = atomicAdd(&cnt[bk], 1u);
         if (s < (uint32_t)CAP) bank[bk * CAP + s] = w;
@@ -780,7 +723,7 @@ __global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ 
         for (int i = tid; i < NBANK * CAP; i += 1024)
             if (cnt[i / CAP] > (uint32_t)CAP) bank[i] = NND_EMPTY_SLOT;
         __syncthreads();
-        rv_each_record(rec_w, rec_m, base, nrec, ib, b, tid, 1024, [&](uint32_t w, uint32_t m) {
+        rv_each_record(ib, b, tid, 1024, [&](uint32_t w, uint32_t m) {
             const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));
             if (cnt[bk] > (uint32_t)CAP) atomicMin(&bank[bk * CAP + rv_ovf_slot(w, CAP)], w);
         });
@@ -803,9 +746,8 @@ __global__ __launch_bounds__(1024) void k_rev_fill(const uint32_t *__restrict__ 
 // runs the selection (nnd_select_half) for 8 of the bucket's targets, whose k-list rows were requested before the fill
 // phase.  LDS: 32 KB banks + 16 KB selection lists: three workgroups per CU.
 template <bool WIDE>
-__global__ __launch_bounds__(512) void k_rev_select(const uint32_t *__restrict__ rec_w, const uint16_t *__restrict__ rec_m,
-                                                    const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bcursor, rv_inbox ib, int64_t row0,
-                                                    int64_t n, const int32_t *__restrict__ order, const uint8_t *__restrict__ active,
+__global__ __launch_bounds__(512) void k_rev_select(rv_inbox ib, int64_t row0, int64_t n, const int32_t *__restrict__ order,
+                                                    const uint8_t *__restrict__ active,
                                                     uint32_t *__restrict__ knn_e, int k, int ks, int mc, int mcp, uint32_t it_seed,
                                                     int32_t *__restrict__ cand) {
     constexpr int RCAP = 32, NB = 128, ROW = 2 * RCAP, NHW = 16, PER = NB / NHW;
@@ -839,8 +781,7 @@ __global__ __launch_bounds__(512) void k_rev_select(const uint32_t *__restrict__
         const int32_t v0 = vtx[hw];
         if (v0 >= 0 && j < k) pre_e = knn_e[(int64_t)v0 * ks + j];
     }
-    const uint32_t base = bstart[b], nrec = bcursor[b];
-    rv_each_record(rec_w, rec_m, base, nrec, ib, b, tid, 512, [&](uint32_t w, uint32_t m) {
+    rv_each_record(ib, b, tid, 512, [&](uint32_t w, uint32_t m) {
         const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));  // [old | new], as rbuf
         const uint32_t sl = atomicAdd(&cnt[bk], 1u);
         if (sl < (uint32_t)CAP) bank[bk * CAP + sl] = w;
@@ -853,7 +794,7 @@ __global__ __launch_bounds__(512) void k_rev_select(const uint32_t *__restrict__
         for (int i = tid; i < NBANK * CAP; i += 512)
             if (cnt[i / CAP] > (uint32_t)CAP) bank[i] = NND_EMPTY_SLOT;
         __syncthreads();
-        rv_each_record(rec_w, rec_m, base, nrec, ib, b, tid, 512, [&](uint32_t w, uint32_t m) {
+        rv_each_record(ib, b, tid, 512, [&](uint32_t w, uint32_t m) {
             const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));
             if (cnt[bk] > (uint32_t)CAP) atomicMin(&bank[bk * CAP + rv_ovf_slot(w, CAP)], w);
         });
@@ -939,22 +880,24 @@ static int rv_grow(nnd_ctx *ctx, T **p, size_t count) {
     NND_HIP_CHECK(hipMalloc((void **)p, sizeof(T) * count));
     return 0;
 }
-// rows [row0, row0 + n_rows) are walked (all rows; a shard: the owned slice), `extra` records arrive from elsewhere
-static int rv_prepare(nnd_ctx *ctx, int logB, const int32_t *order, int64_t row0, int64_t n_rows, int64_t extra) {
-    const int64_t nb = ((n_rows - 1) >> logB) + 1, nrec = n_rows * ctx->k + extra, nstage = n_rows * ctx->ks + extra;
-    if (nb + 1 > ctx->rv_cap_b) {
-        if (rv_grow(ctx, &ctx->rv_count, (size_t)nb + 1) || rv_grow(ctx, &ctx->rv_start, (size_t)nb + 1) || rv_grow(ctx, &ctx->rv_cursor, (size_t)nb + 1)) return 1;
-        ctx->rv_cap_b = nb + 1;
+// rows [row0, row0 + n_rows) are walked (all rows; a shard: the owned slice), `extra` records arrive from elsewhere.  The
+// record regions: nb buckets x 8 sub-regions x cap records of 8 bytes (cap = 4 x the mean load of a sub-region when every offer
+// of a bucket's vertices is counted: 1024 at k = 15; 0.5 GB per million rows) + the overflow list, sized for every offer.
+static int rv_prepare(nnd_ctx *ctx, int logB, const int32_t *order, int64_t row0, int64_t n_rows, int64_t extra, int *cap_out) {
+    const int64_t nb = ((n_rows - 1) >> logB) + 1, nov = n_rows * ctx->k + extra;
+    int cap = 64;
+    while (cap < 4 * (int)((n_rows * ctx->k / (nb * 8)) + 1)) cap <<= 1;
+    *cap_out = cap;
+    const int64_t need = nb * 8 * cap;
+    if (need > ctx->rv_cap_in || cap != ctx->rv_in_cap) {
+        if (rv_grow(ctx, &ctx->rv_in_cursor, (size_t)nb * 8 + 8) || rv_grow(ctx, &ctx->rv_in_rec, (size_t)need)) return 1;
+        ctx->rv_cap_in = need;
+        ctx->rv_in_cap = cap;
     }
-    if (nrec > ctx->rv_cap_rec) {
-        const int64_t cap = extra > 0 ? nrec + nrec / 4 : nrec;  // (a shard's inbox varies from iteration to iteration: head room)
-        if (rv_grow(ctx, &ctx->rv_word, (size_t)cap) || rv_grow(ctx, &ctx->rv_meta, (size_t)cap)) return 1;
-        ctx->rv_cap_rec = cap;
-    }
-    if (nstage > ctx->rv_cap_stage) {
-        const int64_t cap = extra > 0 ? nstage + nstage / 4 : nstage;
-        if (rv_grow(ctx, &ctx->rv_stage, (size_t)cap)) return 1;
-        ctx->rv_cap_stage = cap;
+    if (nov > ctx->rv_cap_ov) {
+        const int64_t c = extra > 0 ? nov + nov / 4 : nov;  // (a shard's inbox varies from iteration to iteration: head room)
+        if (rv_grow(ctx, &ctx->rv_ov, (size_t)c)) return 1;
+        ctx->rv_cap_ov = c;
     }
     if (order && (!ctx->rv_pos || ctx->rv_pos_gen != ctx->forest_gen || ctx->rv_pos_of != order)) {
         if (n_rows > ctx->rv_cap_pos) {
@@ -981,7 +924,8 @@ static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide, con
     const int64_t row0 = shard ? ctx->own_lo : 0, n_rows = shard ? ctx->own_hi - ctx->own_lo : ctx->n;
     if (n_rows <= 0) return 0;
     const int32_t *order = shard ? ctx->own_order : ((ctx->forest_built && ctx->p.n_trees > 0) ? ctx->perm[ctx->cur] : nullptr);
-    if (rv_prepare(ctx, logB, order, row0, n_rows, n_in)) return 1;
+    int cap = 0;
+    if (rv_prepare(ctx, logB, order, row0, n_rows, n_in, &cap)) return 1;
     const int32_t *pos = order ? ctx->rv_pos : nullptr;
     const int64_t nb = ((n_rows - 1) >> logB) + 1;
     int ksp = 16;
@@ -989,13 +933,13 @@ static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide, con
     const int rows = 256 / ksp;
     const unsigned grid = (unsigned)((n_rows + (int64_t)rows * RV_RPT - 1) / ((int64_t)rows * RV_RPT));
     hipStream_t st = ctx->stream;
-    NND_HIP_CHECK(hipMemsetAsync(ctx->rv_count, 0, sizeof(uint32_t) * (size_t)(nb + 1), st));
-    NND_HIP_CHECK(hipMemsetAsync(ctx->rv_cursor, 0, sizeof(uint32_t) * (size_t)(nb + 1), st));
+    uint32_t *ov_count = ctx->rv_in_cursor + (size_t)nb * 8;
+    NND_HIP_CHECK(hipMemsetAsync(ctx->rv_in_cursor, 0, sizeof(uint32_t) * ((size_t)nb * 8 + 8), st));  // (+ the overflow count behind the cursors)
     // the first pass of a build: every edge is new, every vertex with an edge is active -- one memset instead of n * k random byte stores
     // (a vertex without any edge then "joins" with an empty new list, which is what an inactive one does)
     NND_HIP_CHECK(hipMemsetAsync(ctx->active + row0, ctx->all_new ? 1 : 0, (size_t)n_rows, st));
-    // how the active flags come about: 0 = the memset above, 1 = k_rev_count marks them while it counts, 2 = k_rev_mark first and
-    // k_rev_count filters by them -- once the previous iteration inserted into fewer than an eighth of the slots, and always on
+    // how the active flags come about: 0 = the memset above, 1 = k_rev_place marks them while it walks, 2 = k_rev_mark first and
+    // k_rev_place filters by them -- once the previous iteration inserted into fewer than an eighth of the slots, and always on
     // a shard (the received new-class offers mark too, before anything is filtered)
     int mark = ctx->all_new ? 0 : 1;
     if (mark == 1 && (shard || (ctx->last_updates >= 0 && ctx->last_updates * 8 < ctx->n * ctx->k))) {
@@ -1004,43 +948,26 @@ static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide, con
             hipLaunchKernelGGL(k_rev_mark_records, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, in_targets, n_in, row0, n_rows, ctx->active);
         mark = 2;
     }
-    hipLaunchKernelGGL(k_rev_count, dim3(grid), dim3(ksp, rows), 0, st, ctx->knn_e, row0, n_rows, ctx->k, ctx->ks, it_seed, order, pos, logB, ctx->active,
-                       mark, ctx->rv_count, ctx->rv_stage);
-    // a shard's inbox: placed in one pass (k_rev_import); the overflow list lives behind the local stage (sized for n_in records)
-    rv_inbox ib;
-    if (n_in > 0) {
-        int cap = 64;
-        while (cap < 4 * (int)((n_rows * ctx->k / (nb * 8)) + 1)) cap <<= 1;  // 4 x the mean load of a sub-region if EVERY offer were remote
-        const int64_t need = nb * 8 * cap;
-        if (need > ctx->rv_cap_in || cap != ctx->rv_in_cap) {
-            if (rv_grow(ctx, &ctx->rv_in_cursor, (size_t)nb * 8 + 8) || rv_grow(ctx, &ctx->rv_in_rec, (size_t)need)) return 1;
-            ctx->rv_cap_in = need;
-            ctx->rv_in_cap = cap;
-        }
-        NND_HIP_CHECK(hipMemsetAsync(ctx->rv_in_cursor, 0, sizeof(uint32_t) * ((size_t)nb * 8 + 8), st));  // (+ the overflow count behind them)
-        uint2 *ov = ctx->rv_stage + (size_t)n_rows * ctx->ks;
-        uint32_t *ov_count = ctx->rv_in_cursor + (size_t)nb * 8;
+    hipLaunchKernelGGL(k_rev_place, dim3(grid), dim3(ksp, rows), 0, st, ctx->knn_e, row0, n_rows, ctx->k, ctx->ks, it_seed, order, pos, logB, ctx->active,
+                       mark, ctx->rv_in_cursor, ctx->rv_in_rec, cap, ctx->rv_ov, ov_count);
+    if (n_in > 0)
         hipLaunchKernelGGL(k_rev_import, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, st, in_targets, in_sources, n_in, it_seed, row0, n_rows, pos, logB,
-                           ctx->active, mark == 2 ? 1 : 0, ctx->rv_in_cursor, ctx->rv_in_rec, cap, ov, ov_count);
-        ib.cursor = ctx->rv_in_cursor;
-        ib.rec = ctx->rv_in_rec;
-        ib.cap = cap;
-        ib.ov = ov;
-        ib.ov_count = ov_count;
-    }
-    hipLaunchKernelGGL(k_rev_scan, dim3(1), dim3(1024), 0, st, ctx->rv_count, ctx->rv_start, nb);
-    hipLaunchKernelGGL(k_rev_scatter, dim3(grid), dim3(ksp, rows), 0, st, ctx->rv_stage, n_rows * ctx->ks, ctx->ks, logB, ctx->rv_start, ctx->rv_cursor,
-                       ctx->rv_word, ctx->rv_meta);
+                           ctx->active, mark == 2 ? 1 : 0, ctx->rv_in_cursor, ctx->rv_in_rec, cap, ctx->rv_ov, ov_count);
+    rv_inbox ib;
+    ib.cursor = ctx->rv_in_cursor;
+    ib.rec = ctx->rv_in_rec;
+    ib.cap = cap;
+    ib.ov = ctx->rv_ov;
+    ib.ov_count = ov_count;
     if (fused) {
         auto kern = wide ? k_rev_select<true> : k_rev_select<false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), 0, st, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, ib, row0, n_rows, order,
-                           ctx->active, ctx->knn_e, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->cand);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), 0, st, ib, row0, n_rows, order, ctx->active, ctx->knn_e, ctx->k, ctx->ks, ctx->mc, ctx->mcp,
+                           it_seed, ctx->cand);
         return 0;
     }
     ctx->rbuf_clean = false;
     auto fill = ctx->rcap == 32 ? (wide ? k_rev_fill<32, 256, true> : k_rev_fill<32, 256, false>) : k_rev_fill<64, 128, false>;
-    hipLaunchKernelGGL(fill, dim3((unsigned)nb), dim3(1024), 0, st, ctx->rv_word, ctx->rv_meta, ctx->rv_start, ctx->rv_cursor, ib, row0, n_rows, order,
-                       ctx->active, ctx->rbuf);
+    hipLaunchKernelGGL(fill, dim3((unsigned)nb), dim3(1024), 0, st, ib, row0, n_rows, order, ctx->active, ctx->rbuf);
     launch_select(ctx, it_seed, wide);
     return 0;
 }

@@ -162,16 +162,12 @@ struct nnd_handle_s {
     int32_t *rv_pos = nullptr;                // (n) position of every vertex in the visiting order, grow-only
     int rv_pos_gen = -1;                      // forest_gen the table was built for
     int forest_gen = 0;                       // bumped whenever a forest (a visiting order) is finished
-    uint32_t *rv_count = nullptr, *rv_start = nullptr, *rv_cursor = nullptr;  // (n_buckets + 1) records per bucket / first record / fill
-    uint32_t *rv_word = nullptr;              // (n * k) record: the offer's slot word (invertible priority of the source)
-    uint16_t *rv_meta = nullptr;              // (n * k) record: target's index in its bucket | class << 15
-    uint2 *rv_stage = nullptr;                // (n, ks) pre-formed records in the order the graph is walked: (slot word, position | class << 31)
-    int64_t rv_cap_rec = 0, rv_cap_b = 0, rv_cap_stage = 0, rv_cap_pos = 0;
-    const int32_t *rv_pos_of = nullptr;       // the order rv_pos inverts
-    uint32_t *rv_in_cursor = nullptr;         // a shard's inbox: (n_buckets, 8) cursors (+ the overflow count)
-    uint2 *rv_in_rec = nullptr;               // ... (n_buckets, 8, cap) records (word, meta)
-    int64_t rv_cap_in = 0;
+    uint32_t *rv_in_cursor = nullptr;         // (n_buckets, 8) cursors of the record sub-regions (+ the overflow count behind them)
+    uint2 *rv_in_rec = nullptr;               // (n_buckets, 8, cap) records: (slot word = invertible priority of the source, target's index in its bucket | class << 15)
+    uint2 *rv_ov = nullptr;                   // overflow list (hubs): (word, bucket << 9 | class << 8 | index)
+    int64_t rv_cap_in = 0, rv_cap_ov = 0, rv_cap_pos = 0;
     int rv_in_cap = 0;
+    const int32_t *rv_pos_of = nullptr;       // the order rv_pos inverts
     int64_t last_updates = -1;                // k-list insertions of the previous iteration (-1: unknown): picks the late-iteration form of the pass
     bool pbuf_clean = false, rbuf_clean = false;  // every proposal / reverse-offer slot is EMPTY (their consumers re-arm what they read): nnd_launch_reset_graph then skips the 2 x 512 MB memsets
 
