@@ -482,6 +482,9 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
 #define RV_TAB 1024  // entries of the per-workgroup hash table (bucket -> count); what does not fit goes straight to global
 #define RV_RPT 8     // row groups (of 256 / ksp rows) per workgroup = records per thread
 #define RV_NOHASH 0xFFFFu
+#ifndef RV_SEL_THREADS
+#define RV_SEL_THREADS 512  // threads of the fused fill + select kernel (16 half-waves, 8 of the bucket's 128 targets each; 1024: 0.52 instead of 0.41 ms)
+#endif
 
 __device__ __forceinline__ uint32_t rv_tab_hash(uint32_t b) { return (b * 2654435761u) >> 22; }  // 10 bits
 
@@ -666,20 +669,30 @@ __global__ __launch_bounds__(256) void k_rev_import(const int32_t *__restrict__ 
         ov[atomicAdd(ov_count, 1u)] = make_uint2(w, (b << 9) | (cls << 8) | tl);
     }
 }
-// f(word, meta) for every record of bucket b
+// f(word, meta) for every record of bucket b.  The 8 cursors are read together and the sub-regions walked as ONE index space
+// (eight loops, each behind its own cursor load, were eight dependent round trips per workgroup).
 template <typename F>
 __device__ __forceinline__ void rv_each_record(const rv_inbox &ib, int64_t b, int tid, int nthr, F f) {
+    uint32_t c[8], pre[9];
     bool over = false;
-#pragma unroll 1
+#pragma unroll
+    for (int sr = 0; sr < 8; sr++) c[sr] = ib.cursor[b * 8 + sr];
+    pre[0] = 0;
+#pragma unroll
     for (int sr = 0; sr < 8; sr++) {
-        const uint32_t c = ib.cursor[b * 8 + sr];
-        over = over || c > (uint32_t)ib.cap;
-        const uint32_t m = c < (uint32_t)ib.cap ? c : (uint32_t)ib.cap;
-        const size_t o = ((size_t)b * 8 + sr) * ib.cap;
-        for (uint32_t i = tid; i < m; i += nthr) {
-            const uint2 r = ib.rec[o + i];
-            f(r.x, r.y);
-        }
+        over = over || c[sr] > (uint32_t)ib.cap;
+        pre[sr + 1] = pre[sr] + (c[sr] < (uint32_t)ib.cap ? c[sr] : (uint32_t)ib.cap);
+    }
+    const uint2 *base = ib.rec + (size_t)b * 8 * ib.cap;
+    for (uint32_t i = tid; i < pre[8]; i += nthr) {
+        int sr = 0;
+#pragma unroll
+        for (int q = 1; q < 8; q++) sr += i >= pre[q] ? 1 : 0;
+        uint32_t lo = pre[0];
+#pragma unroll
+        for (int q = 1; q < 8; q++) lo = sr >= q ? pre[q] : lo;
+        const uint2 r = base[(size_t)sr * ib.cap + (i - lo)];
+        f(r.x, r.y);
     }
     if (over) {  // (workgroup-uniform) this bucket has records on the overflow list
         const uint32_t M = *ib.ov_count;
@@ -742,15 +755,16 @@ __global__ __launch_bounds__(1024) void k_rev_fill(rv_inbox ib, int64_t row0, in
 
 // The BASELINE regime (k <= 32, 32 slots per bank, max_candidates <= 32): k_rev_fill and k_sample_select_h in ONE kernel --
 // the banks never leave LDS (rbuf is not touched: 256 B written, read and re-armed per vertex and iteration otherwise).
-// 512 threads per bucket of 128 targets: the records are appended to the banks as in k_rev_fill, then every half-wave
-// runs the selection (nnd_select_half) for 8 of the bucket's targets, whose k-list rows were requested before the fill
-// phase.  LDS: 32 KB banks + 16 KB selection lists: three workgroups per CU.
+// RV_SEL_THREADS threads per bucket of 128 targets: the records are appended to the banks as in k_rev_fill, then every half-wave
+// runs the selection (nnd_select_half) for 8 of the bucket's targets in turn, the next one's k-list row requested while the
+// current one is ranked.  LDS: 32 KB banks + 16 KB selection lists: three workgroups = 24 waves per CU (measured against 1024
+// threads -- 4 targets per half-wave, 32 KB of lists, two workgroups = 32 waves per CU: 0.52 instead of 0.41 ms per launch).
 template <bool WIDE>
-__global__ __launch_bounds__(512) void k_rev_select(rv_inbox ib, int64_t row0, int64_t n, const int32_t *__restrict__ order,
+__global__ __launch_bounds__(RV_SEL_THREADS) void k_rev_select(rv_inbox ib, int64_t row0, int64_t n, const int32_t *__restrict__ order,
                                                     const uint8_t *__restrict__ active,
                                                     uint32_t *__restrict__ knn_e, int k, int ks, int mc, int mcp, uint32_t it_seed,
                                                     int32_t *__restrict__ cand) {
-    constexpr int RCAP = 32, NB = 128, ROW = 2 * RCAP, NHW = 16, PER = NB / NHW;
+    constexpr int RCAP = 32, NB = 128, ROW = 2 * RCAP, NT = RV_SEL_THREADS, NHW = NT / 32, PER = NB / NHW;
     constexpr int CAP = WIDE ? 2 * RCAP : RCAP;
     constexpr int NBANK = WIDE ? NB : 2 * NB;
     __shared__ uint32_t bank[NB * ROW];
@@ -770,8 +784,8 @@ __global__ __launch_bounds__(512) void k_rev_select(rv_inbox ib, int64_t row0, i
         }
         vtx[tid] = v;
     }
-    for (int i = tid; i < NB * ROW; i += 512) bank[i] = NND_EMPTY_SLOT;
-    for (int i = tid; i < NBANK; i += 512) cnt[i] = 0;
+    for (int i = tid; i < NB * ROW; i += NT) bank[i] = NND_EMPTY_SLOT;
+    for (int i = tid; i < NBANK; i += NT) cnt[i] = 0;
     if (tid == 0) any_ovf = 0;
     __syncthreads();
     // the k-list row of this half-wave's first target is requested now and lands during the fill phase; the next target's
@@ -781,20 +795,20 @@ __global__ __launch_bounds__(512) void k_rev_select(rv_inbox ib, int64_t row0, i
         const int32_t v0 = vtx[hw];
         if (v0 >= 0 && j < k) pre_e = knn_e[(int64_t)v0 * ks + j];
     }
-    rv_each_record(ib, b, tid, 512, [&](uint32_t w, uint32_t m) {
+    rv_each_record(ib, b, tid, NT, [&](uint32_t w, uint32_t m) {
         const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));  // [old | new], as rbuf
         const uint32_t sl = atomicAdd(&cnt[bk], 1u);
         if (sl < (uint32_t)CAP) bank[bk * CAP + sl] = w;
     });
     __syncthreads();
-    for (int i = tid; i < NBANK; i += 512)
+    for (int i = tid; i < NBANK; i += NT)
         if (cnt[i] > (uint32_t)CAP) any_ovf = 1;
     __syncthreads();
     if (any_ovf) {  // (workgroup-uniform) hubs: see k_rev_fill
-        for (int i = tid; i < NBANK * CAP; i += 512)
+        for (int i = tid; i < NBANK * CAP; i += NT)
             if (cnt[i / CAP] > (uint32_t)CAP) bank[i] = NND_EMPTY_SLOT;
         __syncthreads();
-        rv_each_record(ib, b, tid, 512, [&](uint32_t w, uint32_t m) {
+        rv_each_record(ib, b, tid, NT, [&](uint32_t w, uint32_t m) {
             const uint32_t bk = WIDE ? (m & 0x7FFFu) : ((m & 0x7FFFu) * 2 + (m >> 15));
             if (cnt[bk] > (uint32_t)CAP) atomicMin(&bank[bk * CAP + rv_ovf_slot(w, CAP)], w);
         });
@@ -961,7 +975,7 @@ static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide, con
     ib.ov_count = ov_count;
     if (fused) {
         auto kern = wide ? k_rev_select<true> : k_rev_select<false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), 0, st, ib, row0, n_rows, order, ctx->active, ctx->knn_e, ctx->k, ctx->ks, ctx->mc, ctx->mcp,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(RV_SEL_THREADS), 0, st, ib, row0, n_rows, order, ctx->active, ctx->knn_e, ctx->k, ctx->ks, ctx->mc, ctx->mcp,
                            it_seed, ctx->cand);
         return 0;
     }
