@@ -523,13 +523,13 @@ def run(args, world, rank, local_rank, share_gpu, wd):
         phase("communicator (RCCL: two channels, first exchange on each)", 300)
         rccl_error = None
         try:
-            comm = sharded.make_comm(local_rank, allow_host_fallback=False)  # a scaling run never becomes a host-staged one silently
+            comm = sharded.make_comm(local_rank, allow_host_fallback=False, timeout_s=300)  # a scaling run never becomes a host-staged one silently
         except _capi.NNDError as e:  # (raised on EVERY rank: the ranks agree on the outcome, sharded.make_comm)
             # ... but a LOUD host-staged number beats no line at all: config.comm.transport says "host", `degraded` says why
             rccl_error = str(e)
             if rank == 0:
                 sys.stderr.write("bench.py: %s -- falling back to the HOST transport (pinned staging + gloo): NOT a scaling number\n" % rccl_error)
-            comm = sharded.make_comm(local_rank, allow_host_fallback=True)
+            comm = sharded.make_comm(local_rank, allow_host_fallback=True, timeout_s=300)
         if wd is not None:
             wd.extra["config"] = {"workload": "BASELINE configs[3] stand-in (row-sharded build over %d GPUs): NOT MEASURED, see error" % world,
                                   "comm": comm.info()}

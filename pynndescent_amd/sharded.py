@@ -138,8 +138,14 @@ def _host_callback(dist, group=None):
     return _capi.HOST_EXCHANGE_FN(exchange)
 
 
-def make_comm(device_index, group=None, allow_host_fallback=False):
-    """The rank's communicator under ``torch.distributed``: RCCL when the process group runs the nccl backend -- two unique
+def make_comm(device_index, group=None, allow_host_fallback=False, timeout_s=None):
+    """``timeout_s``: how long a host wait of a build may go without the peers before this rank gives up (default: the
+    library's 120 s).  Expiry is IRREVERSIBLE under RCCL -- the rank calls ``ncclCommAbort`` on both channels, the communicator is
+    dead and a new one has to be made -- so under one process per GPU set it no lower than the skew the ranks can have when they
+    ENTER a build (data loading, a first-call code-object load): e.g. the timeout of the torch process group.  The HOST transport
+    waits inside the caller's callback (gloo) and is bounded by THAT group's timeout, not by this one.
+
+    The rank's communicator under ``torch.distributed``: RCCL when the process group runs the nccl backend -- two unique
     ids (the build's channel and the second channel of the point-set all-gather) are broadcast through torch, the data
     path never touches torch again; HOST staging over gloo when the group itself is gloo (tests).  If the RCCL
     communicator cannot be created on some rank (all ranks agree on that through one all-reduce) the call RAISES on every
@@ -177,6 +183,8 @@ def make_comm(device_index, group=None, allow_host_fallback=False):
         if int(flag.item()) == 1:
             c = Comm(h, world, rank)
             c.transport = "rccl"
+            if timeout_s is not None:
+                c.set_timeout(timeout_s)
             return c
         if h.value:
             lib.nnd_comm_destroy(h)
@@ -194,6 +202,8 @@ def make_comm(device_index, group=None, allow_host_fallback=False):
         raise _capi.NNDError(lib.nnd_comm_last_error(None).decode())
     c = Comm(h, world, rank, keep=cb)
     c.transport = "host"
+    if timeout_s is not None:
+        c.set_timeout(timeout_s)
     return c
 
 
