@@ -1,6 +1,6 @@
 #!/bin/bash
 # recall / time of tools/bench_configs.py configurations under environment knobs (KNOBS variant of the library):
-#   tools/ab_cfg_env.sh <tag> <variant> "<configs>" "<ENV=..>" ["<ENV=..>" ...]
+#   tools/ab/ab_cfg_env.sh <tag> <variant> "<configs>" "<ENV=..>" ["<ENV=..>" ...]
 tag=$1; v=$2; cfgs=$3; shift; shift; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 lib=$R/pynndescent_amd/_exp/lib_$v.so

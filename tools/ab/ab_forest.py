@@ -1,7 +1,7 @@
 """Forest stage with the coherent routing passes vs the plain walk (NND_FLAG_TEST_ROUTE_PLAIN), same points, same seeds.
-usage: python tools/ab_forest.py [n] [n_trees] [reps]"""
+usage: python tools/ab/ab_forest.py [n] [n_trees] [reps]"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from pynndescent_amd import _capi

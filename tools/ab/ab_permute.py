@@ -1,8 +1,8 @@
 """What would renumbering the points into the first tree's leaf order buy?  The same set built as given and after a
 permutation into the leaf order of one RP tree (done here, outside the library: the best case for every gather).
-usage: python tools/ab_permute.py [n] [n_trees]"""
+usage: python tools/ab/ab_permute.py [n] [n_trees]"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import bench

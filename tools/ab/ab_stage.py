@@ -1,7 +1,7 @@
 """A/B helper: time the build stages for one library build (PYNND_AMD_LIB selects the .so) on the bench workload.
-usage: PYNND_AMD_LIB=... python tools/ab_stage.py [n_trees ...]"""
+usage: PYNND_AMD_LIB=... python tools/ab/ab_stage.py [n_trees ...]"""
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from pynndescent_amd import _capi

@@ -1,6 +1,6 @@
 #!/bin/bash
 # sample stride / cell size of the routing forest, sharded critical path + per-tree cost on one GPU:
-#   tools/ab_stride.sh <tag> <variant> "<ENV=.. ENV=..>" ["<...>" ...]     (variant: a KNOBS build of capi.hip)
+#   tools/ab/ab_stride.sh <tag> <variant> "<ENV=.. ENV=..>" ["<...>" ...]     (variant: a KNOBS build of capi.hip)
 tag=$1; v=$2; shift; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 lib=$R/pynndescent_amd/_exp/lib_$v.so
@@ -8,8 +8,8 @@ log=$O/${tag}_ab_stride.log
 for e in "$@"; do
   echo "== $e" >> $log
   ( cd $R && env $e PYNND_AMD_LIB=$lib timeout 400 python tools/rank_critical_path.py --world 8 --n 10000000 --trees 12 ${ONE_GPU:+--one-gpu} 2>&1 | grep '^{' >> $log )
-  ( cd $R && env $e PYNND_AMD_LIB=$lib timeout 300 python tools/ab_forest.py 10000000 2 2 2>&1 | grep route | head -1 >> $log )
-  ( cd $R && env $e PYNND_AMD_LIB=$lib timeout 300 python tools/ab_forest.py 1000000 8 4 2>&1 | grep route | head -1 >> $log )
+  ( cd $R && env $e PYNND_AMD_LIB=$lib timeout 300 python tools/ab/ab_forest.py 10000000 2 2 2>&1 | grep route | head -1 >> $log )
+  ( cd $R && env $e PYNND_AMD_LIB=$lib timeout 300 python tools/ab/ab_forest.py 1000000 8 4 2>&1 | grep route | head -1 >> $log )
 done
 python - <<PY
 import json

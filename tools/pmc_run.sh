@@ -3,5 +3,5 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$tag
-rocprofv3 --pmc $1 --output-format csv -d /tmp/pmc_$tag -- python $GRAFT_REPO_ROOT/tools/ab_stage.py 8 > /tmp/pmc_$tag.log 2>&1
+rocprofv3 --pmc $1 --output-format csv -d /tmp/pmc_$tag -- python $GRAFT_REPO_ROOT/tools/ab/ab_stage.py 8 > /tmp/pmc_$tag.log 2>&1
 python $GRAFT_REPO_ROOT/tools/prof_summary.py /tmp/pmc_$tag $GRAFT_REPO_ROOT/gpurun_out/$tag.txt
