@@ -480,7 +480,9 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
 // The result is a function of the graph and the seed alone: the set of appended words is the set of offers, the hashed
 // fallback is a min.
 #define RV_TAB 1024  // entries of the per-workgroup hash table (bucket -> count); what does not fit goes straight to global
+#ifndef RV_RPT
 #define RV_RPT 8     // row groups (of 256 / ksp rows) per workgroup = records per thread
+#endif
 #define RV_NOHASH 0xFFFFu
 #ifndef RV_SEL_THREADS
 #define RV_SEL_THREADS 512  // threads of the fused fill + select kernel (16 half-waves, 8 of the bucket's 128 targets each; 1024: 0.52 instead of 0.41 ms)
