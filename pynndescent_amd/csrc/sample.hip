@@ -944,6 +944,7 @@ static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide, con
     if (rv_prepare(ctx, logB, order, row0, n_rows, n_in, &cap)) return 1;
     const int32_t *pos = order ? ctx->rv_pos : nullptr;
     const int64_t nb = ((n_rows - 1) >> logB) + 1;
+    if (nb >= ((int64_t)1 << 23)) { ctx->set_error("candidate sampling: %lld buckets exceed the 2^23 bucket ids of an overflow record", (long long)nb); return 1; }
     int ksp = 16;
     while (ksp < ctx->ks) ksp <<= 1;
     const int rows = 256 / ksp;

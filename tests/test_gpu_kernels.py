@@ -266,6 +266,42 @@ def test_sampled_candidates_are_the_exact_priority_sample(n, k, mc):
     b.close()
 
 
+def test_sampling_with_hubs_uses_the_overflow_list_and_stays_exact_and_reproducible():
+    """An init graph in which EVERY row points at 15 of the same 30 vertices (no forest: positions = ids, the hubs share bucket 0):
+    each hub receives ~20 000 reverse offers, so (a) its banks overflow -- hashed minima over ALL of its offers, order independent --
+    and (b) the 8 sub-regions of bucket 0 (1 024 records each) overflow and 98 % of its records travel on the overflow list
+    (csrc/sample.hip k_rev_place / rv_each_record).  Every bank that did NOT overflow must still be the exact priority sample, the
+    hubs' lists must hold max_candidates distinct sources that really offered, and a second run must give the same lists (the
+    placement order of the records is not reproducible; the result has to be)."""
+    n, k, mc = 40_000, 15, 15
+    rs = np.random.RandomState(5)
+    x = clustered(n, 24, 6, 40, seed=17)
+    g = np.stack([rs.choice(30, k, replace=False) for _ in range(n)]).astype(np.int32)
+    rng_state, _, _ = O.draw_rng_states(1, 1)
+    runs = []
+    for rep in range(2):
+        b = make_builder(x, "euclidean", k=k, n_trees=0, mc=mc, seed=1)
+        b.init_from_graph(g)
+        idx0, _, fl0 = b.graph()
+        b.sample_candidates()
+        new, old = b.candidates()
+        runs.append((new.copy(), old.copy()))
+        if rep == 0:
+            indeg = np.bincount(idx0[idx0 >= 0].ravel(), minlength=n)
+            assert indeg[:30].min() > 8 * 1024  # more offers for ONE vertex than all sub-regions of its bucket hold
+            e_new, e_old, x_new, x_old = _expected_candidates(idx0, fl0, rng_state, 0, mc, 64, 32)
+            assert (~x_new[:30]).all() and x_new[30:].all()
+            np.testing.assert_array_equal(new[30:], e_new[30:])
+            src_of = [set(np.nonzero((idx0 == h).any(1))[0].tolist()) for h in range(30)]
+            for h in range(30):
+                row = new[h]
+                assert (row >= 0).all() and len(set(row.tolist())) == mc
+                fwd = set(idx0[h].tolist())
+                assert all((int(v) in src_of[h]) or (int(v) in fwd) for v in row)
+        b.close()
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+
+
 @pytest.mark.parametrize("metric,k", [("euclidean", 15), ("cosine", 15), ("euclidean", 30), ("euclidean", 50)])
 def test_descent_iterations_keep_invariants_and_improve(metric, k):
     x = clustered(4000, 24, 6, 30, seed=13)
