@@ -41,7 +41,7 @@ extern "C" {
 #define NND_METRIC_SQEUCLIDEAN 0 /* reference distances.py:63  squared_euclidean  */
 #define NND_METRIC_ALT_COSINE 1  /* reference distances.py:583 alternative_cosine */
 
-#define NND_ABI_VERSION 4
+#define NND_ABI_VERSION 5 /* 5: nnd_search_graph / nnd_search_graph_fetch (round 5); existing entry points unchanged */
 
 typedef struct nnd_handle_s *nnd_handle_t;
 
