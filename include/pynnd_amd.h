@@ -294,6 +294,10 @@ int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, nnd_comm_t 
  * x_stream, which the build then waits for).  Outputs: device buffers (n_local, k): GLOBAL neighbour ids, alt-space
  * distances, rows ascending.  Blocks until this rank's rows are final. */
 int32_t nnd_shard_build(nnd_shard_t s, const float *x_local_dev, void *x_stream, int32_t *out_idx_dev, float *out_dist_dev);
+/* ... from the rank's OWN rows of an init graph (device (n_own, init_width), global ids; init_dist_dev nullable); the shard must have been
+ * created with n_trees = 0 */
+int32_t nnd_shard_build_from_graph(nnd_shard_t s, const float *x_local_dev, void *x_stream, const int32_t *init_idx_dev,
+                                   const float *init_dist_dev, int32_t init_width, int32_t *out_idx_dev, float *out_dist_dev);
 int32_t nnd_shard_get_info(nnd_shard_t s, nnd_shard_info *out);
 int32_t nnd_shard_get_stats(nnd_shard_t s, nnd_stats *out); /* this rank's kernels */
 /* the rank's builder handle (tests: nnd_leaf_array_shape / nnd_get_leaf_array give the leaves this rank seeded from) */
@@ -307,6 +311,13 @@ const char *nnd_shard_last_error(nnd_shard_t s /* NULL: the error of a failed cr
  * uses the LOCAL transport.  Results depend on n_devices as the reference's depend on its thread count.  stats: rank 0's. */
 int32_t nnd_build_multi(const nnd_params *params, const float *x, int32_t n_devices, const int32_t *devices, int32_t *out_idx,
                         float *out_dist, nnd_stats *stats, nnd_shard_info *info_rank0 /* nullable */, char *err, int32_t errlen);
+/* ... from an init graph (ABI 5): the warm start of NNDescent(init_graph=, init_dist=), pynndescent_.py:1225-1242 /
+ * initalize_heap_from_graph_indices[_and_distances], utils.py:836-860 -- init_idx host (n, init_width) GLOBAL ids (-1: empty),
+ * init_dist nullable (alt-space distances; computed when NULL).  No forest (an init graph disables it, pynndescent_.py:1059-1062:
+ * params->n_trees is taken as 0), no random fill.  Every rank seeds ITS rows from its rows of the init graph. */
+int32_t nnd_build_multi_from_graph(const nnd_params *params, const float *x, int32_t n_devices, const int32_t *devices,
+                                   const int32_t *init_idx, const float *init_dist, int32_t init_width, int32_t *out_idx, float *out_dist,
+                                   nnd_stats *stats, nnd_shard_info *info_rank0 /* nullable */, char *err, int32_t errlen);
 
 /* Stream the handle runs on: the caller's HIP stream (e.g. the one that produces the point set) instead of the handle's
  * own, so the device-pointer entry points need no synchronisation with it.  NULL: the handle's own stream again. */
@@ -380,7 +391,7 @@ int32_t nnd_hub_tree_fetch(nnd_handle_t h, float *hyperplanes, float *offsets, i
  * closure of _init_search_function 1793-1883, select_side / search_flat_tree rp_trees.py:2662-2741, deheap_sort) ----
  * The searcher owns device copies of what the reference's closure captures: the (reordered) raw data, the CSR search
  * graph, the FlatTree of the search forest's first tree (n_nodes = 0: no tree, random starts only), min_distance and
- * n_neighbors.  All pointers are HOST pointers.  One wave per query; k <= 64 (the query's k, not the index's).  Output rows ascending in the
+ * n_neighbors.  All pointers are HOST pointers.  One wave per query; k <= 128 (the query's k, not the index's; above 64 the result list is two entries per lane).  Output rows ascending in the
  * alternative distance space, vertex numbers in the searcher's (reordered) numbering; unfilled slots (-1, +inf). */
 typedef struct nnd_searcher_s *nnd_searcher_t;
 int32_t nnd_searcher_create(nnd_searcher_t *out, int32_t device, int64_t n, int32_t dim, int32_t metric, const float *data,

@@ -258,12 +258,14 @@ int nnd_launch_random_init(nnd_ctx *ctx) {
 
 // utils.py:836-860: every valid (i, j=graph[i][c]) is pushed with distance metric(x_i, x_j) or the given one
 __global__ __launch_bounds__(256) void k_graph_init(const float *__restrict__ xp, int dp, const float *__restrict__ nrm,
-                                                    int metric, int64_t n, const int32_t *__restrict__ gidx,
+                                                    int metric, int64_t n, int64_t lo, int64_t hi, const int32_t *__restrict__ gidx,
                                                     const float *__restrict__ gdist, int width, int col0, int wchunk,
                                                     uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap) {
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
-    const int64_t v = (int64_t)blockIdx.x * 4 + w;
-    if (v >= n) return;
+    const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;  // the rows this handle owns; gidx / gdist hold THOSE rows (row v - lo)
+    if (v >= hi) return;
+    gidx += -lo * width;
+    if (gdist) gdist += -lo * width;
     // columns [col0, col0 + wchunk) of the row (wchunk <= 64 = the proposal slots; wider graphs come in several launches,
     // an id repeated across launches is dropped by the merge, utils.py:489-492)
     int32_t id = lane < wchunk ? gidx[v * width + col0 + lane] : -1;
@@ -284,12 +286,16 @@ __global__ __launch_bounds__(256) void k_graph_init(const float *__restrict__ xp
 
 int nnd_launch_init_from_graph(nnd_ctx *ctx, const int32_t *idx_dev, const float *dist_dev, int width) {
     if (ctx->pcap < 64) { ctx->set_error("init graphs need 64 proposal slots per row"); return 1; }
-    if (ctx->slim) { ctx->set_error("init graphs are not supported on a shard of a row-sharded build"); return 1; }
+    // (a shard: idx_dev / dist_dev hold the OWNED rows of the init graph, ids are global; every row of the point set is
+    // prepared on every rank, so the distances to neighbours owned elsewhere are computed here like any other)
+    const int64_t rows = ctx->own_hi - ctx->own_lo;
+    if (rows <= 0) return 0;
     for (int col0 = 0; col0 < width; col0 += 64) {
         const int wchunk = width - col0 < 64 ? width - col0 : 64;
         ctx->pbuf_clean = false;
-        hipLaunchKernelGGL(k_graph_init, dim3((unsigned)((ctx->n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, ctx->dp,
-                           ctx->nrm, ctx->p.metric, ctx->n, idx_dev, dist_dev, width, col0, wchunk, ctx->pbuf, ctx->pdirty, ctx->pcap);
+        hipLaunchKernelGGL(k_graph_init, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, ctx->xp, ctx->dp,
+                           ctx->nrm, ctx->p.metric, ctx->n, ctx->own_lo, ctx->own_hi, idx_dev, dist_dev, width, col0, wchunk, ctx->pbuf, ctx->pdirty,
+                           ctx->pcap);
         NND_HIP_CHECK(hipGetLastError());
         if (nnd_launch_merge(ctx)) return 1;
     }

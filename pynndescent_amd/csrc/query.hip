@@ -4,7 +4,7 @@
 // descent select_side / search_flat_tree (rp_trees.py:2662-2741) and the final deheap_sort (utils.py:189-218) for
 // dense float32 data with the euclidean / cosine metrics.  The reference walks one query at a time (optionally one
 // numba thread per query); here ONE WAVE owns one query:
-//   * result list: the k best (distance, vertex) pairs, sorted ascending, one entry per lane (k <= 64) -- the
+//   * result list: the k best (distance, vertex) pairs, sorted ascending, one entry per lane (k <= 64; two per lane up to k = 128) -- the
 //     reference's max-heap of size k (simple_heap_push, utils.py:352-406): a candidate enters iff it beats the worst
 //     entry, the worst leaves; insertion = one ballot (rank) + one lane shift;
 //   * frontier (`seed_set`, a heapq in the reference): (distance, vertex) pairs in LDS, pop-min by a wave reduction.
@@ -94,7 +94,8 @@ __device__ __forceinline__ float q_quad_dist(const float *__restrict__ x, const 
     return r > 1.0f ? log2f(r) : 0.0f;
 }
 
-template <bool BIG>
+// K2: 64 < k <= 128 -- the result list is two entries per lane (positions lane and 64 + lane)
+template <bool BIG, bool K2>
 __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, const float *__restrict__ xn2, int dp, int d, int metric,
                                                int64_t n, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                const float *__restrict__ hyper, const float *__restrict__ offsets,
@@ -161,9 +162,14 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
 
     float rd = INFINITY;   // result list: lane j < k holds the j-th best
     int32_t rv = -1;
+    float rd1 = INFINITY;  // K2: lane j holds the (64 + j)-th best
+    int32_t rv1 = -1;
     int fn = 0;            // frontier size (wave-uniform)
     float bound = INFINITY;
-    auto worst = [&]() -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rd), k - 1)); };
+    auto worst = [&]() -> float {
+        if (K2) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rd1), k - 65));
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rd), k - 1));
+    };
     auto update_bound = [&]() {
         const float wd = worst();
         bound = wd + epsilon * (wd - min_distance);  // inf while the list is not full
@@ -171,6 +177,25 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
     // simple_heap_push (utils.py:352-406) on the sorted list: enters iff it beats the worst entry
     auto result_push = [&](float dc, int32_t vc) {
         if (!(dc < worst())) return;
+        if (K2) {
+            const int p0 = __popcll(__ballot(rd <= dc)), p1 = __popcll(__ballot(64 + lane < k && rd1 <= dc));
+            const float dn = __shfl_up(rd, 1, 64), dn1 = __shfl_up(rd1, 1, 64);
+            const int32_t vn = __shfl_up(rv, 1, 64), vn1 = __shfl_up(rv1, 1, 64);
+            const float cd0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rd), 63));  // falls from the first half
+            const int32_t cv0 = __builtin_amdgcn_readlane(rv, 63);
+            if (p0 < 64) {  // lands in the first half: the whole second half moves up by one
+                if (lane > p0) { rd = dn; rv = vn; }
+                if (lane == p0) { rd = dc; rv = vc; }
+                if (64 + lane < k) {
+                    rd1 = lane == 0 ? cd0 : dn1;
+                    rv1 = lane == 0 ? cv0 : vn1;
+                }
+            } else {
+                if (lane > p1 && 64 + lane < k) { rd1 = dn1; rv1 = vn1; }
+                if (lane == p1) { rd1 = dc; rv1 = vc; }
+            }
+            return;
+        }
         const int pos = __popcll(__ballot(lane < k && rd <= dc));
         const float dn = __shfl_up(rd, 1, 64);
         const int32_t vn = __shfl_up(rv, 1, 64);
@@ -234,7 +259,10 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
         }
         nnd_wave_lds_sync();
     };
-    auto in_result = [&](int32_t vc) -> bool { return __ballot(lane < k && rv == vc) != 0ull; };
+    auto in_result = [&](int32_t vc) -> bool {
+        if (K2) return __ballot(rv == vc || (64 + lane < k && rv1 == vc)) != 0ull;
+        return __ballot(lane < k && rv == vc) != 0ull;
+    };
 
     if (!dead) {
         // ---- init from the tree (rp_trees.py:2732-2741): descend to a leaf ----
@@ -354,6 +382,10 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
     if (lane < k) {  // ascending, like deheap_sort; unfilled slots (-1, inf)
         out_idx[qi * k + lane] = rv;
         out_dist[qi * k + lane] = rd;
+    }
+    if (K2 && 64 + lane < k) {
+        out_idx[qi * k + 64 + lane] = rv1;
+        out_dist[qi * k + 64 + lane] = rd1;
     }
 }
 
@@ -478,7 +510,10 @@ extern "C" int32_t nnd_searcher_set_tier(nnd_searcher_t s, int32_t tier) {
 extern "C" int32_t nnd_searcher_query(nnd_searcher_t s, const float *queries, int64_t nq, int32_t k, float epsilon, int32_t *out_idx,
                                       float *out_dist) {
     if (!s) { snprintf(g_serr, sizeof(g_serr), "nnd_searcher_query: null searcher"); return 1; }
-    if (k < 1 || k > 64) { s->set_error("nnd_searcher_query: k must be in 1..64 (got %d)", k); return 1; }
+    if (k < 1 || k > 128) { s->set_error("nnd_searcher_query: k must be in 1..128 (got %d)", k); return 1; }
+    // (64 < k <= 128, round 5: the result list as two entries per lane; the reference takes any k, pynndescent_.py:2275-2379)
+    auto kq_lds = k > 64 ? k_query<false, true> : k_query<false, false>;
+    auto kq_big = k > 64 ? k_query<true, true> : k_query<true, false>;
     if (nq <= 0) return 0;
     if (nq >= (int64_t)0x7FFFFFF0) { s->set_error("nnd_searcher_query: too many queries in one call"); return 1; }
     S_HIP(hipSetDevice(s->device));
@@ -497,10 +532,10 @@ extern "C" int32_t nnd_searcher_query(nnd_searcher_t s, const float *queries, in
             hipMalloc((void **)&dd, sizeof(float) * (size_t)nq * k) != hipSuccess || hipMalloc((void **)&dov, (size_t)nq) != hipSuccess) { s->set_error("nnd_searcher_query: out of device memory"); rc = 1; break; }
         if (hipMemcpyAsync(dq, queries, sizeof(float) * (size_t)nq * s->d, hipMemcpyHostToDevice, s->stream) != hipSuccess) { s->set_error("H2D of the queries failed"); rc = 1; break; }
         if (!s->force_big) {
-            if (smem > 64 * 1024 && hipFuncSetAttribute((const void *)k_query<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+            if (smem > 64 * 1024 && hipFuncSetAttribute((const void *)kq_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
                 s->set_error("nnd_searcher_query: rows of %d floats need %zu bytes of LDS per workgroup", s->d, smem); rc = 1; break;
             }
-            hipLaunchKernelGGL(k_query<false>, dim3((unsigned)((nq + 3) / 4)), dim3(256), smem, s->stream, s->x, s->xn2, s->dp, s->d, s->metric, s->n,
+            hipLaunchKernelGGL(kq_lds, dim3((unsigned)((nq + 3) / 4)), dim3(256), smem, s->stream, s->x, s->xn2, s->dp, s->d, s->metric, s->n,
                                s->indptr, s->indices, s->hyper, s->offsets, s->children, s->tree_idx, s->n_nodes, dq, nq, k, epsilon,
                                s->min_distance, s->n_neighbors, s->seed, di, dd, dov, (const int32_t *)nullptr, 0, (unsigned char *)nullptr, (size_t)0);
             if (hipGetLastError() != hipSuccess) { s->set_error("k_query launch failed"); rc = 1; break; }
@@ -522,7 +557,7 @@ extern "C" int32_t nnd_searcher_query(nnd_searcher_t s, const float *queries, in
             if (hipMemcpyAsync(dlist, again.data(), sizeof(int32_t) * again.size(), hipMemcpyHostToDevice, s->stream) != hipSuccess) { s->set_error("H2D of the query list failed"); rc = 1; break; }
             for (size_t b0 = 0; b0 < again.size() && !rc; b0 += batch) {
                 const int nb = (int)(again.size() - b0 < batch ? again.size() - b0 : batch);
-                hipLaunchKernelGGL(k_query<true>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 4 * per_wave_big, s->stream, s->x, s->xn2, s->dp, s->d, s->metric,
+                hipLaunchKernelGGL(kq_big, dim3((unsigned)((nb + 3) / 4)), dim3(256), 4 * per_wave_big, s->stream, s->x, s->xn2, s->dp, s->d, s->metric,
                                    s->n, s->indptr, s->indices, s->hyper, s->offsets, s->children, s->tree_idx, s->n_nodes, dq, nq, k, epsilon,
                                    s->min_distance, s->n_neighbors, s->seed, di, dd, (uint8_t *)nullptr, (const int32_t *)(dlist + b0), nb, scratch, stride);
                 if (hipGetLastError() != hipSuccess) { s->set_error("k_query (global-memory tier) launch failed"); rc = 1; }

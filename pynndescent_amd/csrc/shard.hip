@@ -748,7 +748,10 @@ static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t e
     return 0;
 }
 
-static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream, int32_t *out_idx_dev, float *out_dist_dev) {
+// init_idx_dev (nullable): the owned rows of an init graph (n_own, init_width), global ids -- the warm start of
+// NNDescent(init_graph=...) (pynndescent_.py:1225-1242, utils.py:836-860): no forest, no random fill
+static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream, int32_t *out_idx_dev, float *out_dist_dev,
+                       const int32_t *init_idx_dev = nullptr, const float *init_dist_dev = nullptr, int init_width = 0) {
     nnd_ctx *h = s->h;
     nnd_comm_s *c = s->comm;
     const int G = s->world, me = s->rank, nv = G + 3;
@@ -890,6 +893,12 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         S_CTX(nnd_launch_merge_graph_rows(h, s->lo, s->hi, s->recv_e, s->recv_d, n_src, (int64_t)n_own * s->ks));
         const int tr = t_begin(h);
         S_CTX(nnd_launch_random_init(h));  // owned rows that are still not full (pynndescent_.py:188-203)
+        t_end(h, tr, &h->stats.ms_random_init, false);
+        sec.end();
+    } else if (init_idx_dev) {
+        section_timer sec(s);
+        const int tr = t_begin(h);
+        S_CTX(nnd_launch_init_from_graph(h, init_idx_dev, init_dist_dev, init_width));
         t_end(h, tr, &h->stats.ms_random_init, false);
         sec.end();
     } else {
@@ -1065,9 +1074,17 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
 }
 
 extern "C" int32_t nnd_shard_build(nnd_shard_t s, const float *x_local_dev, void *x_stream, int32_t *out_idx_dev, float *out_dist_dev) {
+    return nnd_shard_build_from_graph(s, x_local_dev, x_stream, nullptr, nullptr, 0, out_idx_dev, out_dist_dev);
+}
+extern "C" int32_t nnd_shard_build_from_graph(nnd_shard_t s, const float *x_local_dev, void *x_stream, const int32_t *init_idx_dev,
+                                              const float *init_dist_dev, int32_t init_width, int32_t *out_idx_dev, float *out_dist_dev) {
     if (!s) { snprintf(g_serr2, sizeof(g_serr2), "nnd_shard_build: null shard"); return 1; }
     if (!x_local_dev || !out_idx_dev || !out_dist_dev) { s->set_error("nnd_shard_build: null buffer"); return 1; }
-    const int rc = shard_build(s, x_local_dev, x_stream, out_idx_dev, out_dist_dev);
+    if (init_idx_dev && (s->gp.n_trees != 0 || init_width < 1 || init_width > 128)) {
+        s->set_error("nnd_shard_build_from_graph: an init graph needs a shard created with n_trees = 0 (pynndescent_.py:1059-1062) and a width in 1..128");
+        return 1;
+    }
+    const int rc = shard_build(s, x_local_dev, x_stream, out_idx_dev, out_dist_dev, init_idx_dev, init_dist_dev, init_width);
     s->h->wait_hook = nullptr;
     // a rank that fails tells the ranks of its process (shared flag, LOCAL barriers) and cancels its own collectives
     // (ncclCommAbort): nobody is left waiting in a collective.  (rc 2: the test hook of a rank that dies silently.)
@@ -1079,11 +1096,23 @@ extern "C" int32_t nnd_shard_build(nnd_shard_t s, const float *x_local_dev, void
 // nnd_build over several GPUs of this node: host buffers in, host buffers out, one host thread per GPU.
 extern "C" int32_t nnd_build_multi(const nnd_params *params, const float *x, int32_t n_devices, const int32_t *devices, int32_t *out_idx,
                                    float *out_dist, nnd_stats *stats, nnd_shard_info *info_rank0, char *err, int32_t errlen) {
+    return nnd_build_multi_from_graph(params, x, n_devices, devices, nullptr, nullptr, 0, out_idx, out_dist, stats, info_rank0, err, errlen);
+}
+// ... with the warm start of NNDescent(init_graph=..., init_dist=...) (pynndescent_.py:1225-1242): init_idx host (n, init_width) global
+// ids, init_dist nullable (distances are computed); params->n_trees is taken as 0 (an init graph disables the forest, 1059-1062)
+extern "C" int32_t nnd_build_multi_from_graph(const nnd_params *params_in, const float *x, int32_t n_devices, const int32_t *devices,
+                                              const int32_t *init_idx, const float *init_dist, int32_t init_width, int32_t *out_idx,
+                                              float *out_dist, nnd_stats *stats, nnd_shard_info *info_rank0, char *err, int32_t errlen) {
+    nnd_params params_v{};
+    if (params_in) params_v = *params_in;
+    if (init_idx) params_v.n_trees = 0;
+    const nnd_params *params = params_in ? &params_v : nullptr;
     auto fail = [&](const std::string &msg) {
         if (err && errlen > 0) { strncpy(err, msg.c_str(), (size_t)errlen - 1); err[errlen - 1] = 0; }
         return 1;
     };
     if (!params || !x || !out_idx || !out_dist) return fail("nnd_build_multi: null argument");
+    if (init_idx && (init_width < 1 || init_width > 128)) return fail("nnd_build_multi_from_graph: init_width must be in 1..128");
     if (n_devices < 1 || n_devices > NND_MAX_RANKS) return fail("nnd_build_multi: n_devices must be in 1..64");
     if (params->n < 1) return fail("nnd_build_multi: need n >= 1");
     const int G = (int64_t)n_devices <= params->n ? n_devices : (int)params->n;  // every rank owns at least one row: the first n devices build a set of n < n_devices points
@@ -1164,17 +1193,25 @@ extern "C" int32_t nnd_build_multi(const nnd_params *params, const float *x, int
         float *dx = nullptr;
         int32_t *di = nullptr;
         float *dd = nullptr;
+        int32_t *gi = nullptr;  // the owned rows of the init graph
+        float *gd = nullptr;
         if (!rcs[r] && nnd_shard_create(&sh, &p, comms[r], sizes.data())) bail(nnd_shard_last_error(nullptr));
         if (!rcs[r]) {
             bool ok = hipMalloc((void **)&dx, sizeof(float) * (nl ? nl : 1) * p.dim) == hipSuccess &&
                       hipMalloc((void **)&di, sizeof(int32_t) * (nl ? nl : 1) * p.n_neighbors) == hipSuccess &&
                       hipMalloc((void **)&dd, sizeof(float) * (nl ? nl : 1) * p.n_neighbors) == hipSuccess;
             if (ok && nl) ok = hipMemcpy(dx, x + (size_t)lo[r] * p.dim, sizeof(float) * nl * p.dim, hipMemcpyHostToDevice) == hipSuccess;
+            if (ok && init_idx) {
+                ok = hipMalloc((void **)&gi, sizeof(int32_t) * (nl ? nl : 1) * init_width) == hipSuccess &&
+                     (!init_dist || hipMalloc((void **)&gd, sizeof(float) * (nl ? nl : 1) * init_width) == hipSuccess);
+                if (ok && nl) ok = hipMemcpy(gi, init_idx + (size_t)lo[r] * init_width, sizeof(int32_t) * nl * init_width, hipMemcpyHostToDevice) == hipSuccess;
+                if (ok && nl && init_dist) ok = hipMemcpy(gd, init_dist + (size_t)lo[r] * init_width, sizeof(float) * nl * init_width, hipMemcpyHostToDevice) == hipSuccess;
+            }
             if (!ok) bail("allocation / H2D of the shard failed");
         }
         bar.wait();  // (2) every rank is ready, or nobody builds
         if (!failed.load()) {
-            if (nnd_shard_build(sh, dx, nullptr, di, dd)) {
+            if (nnd_shard_build_from_graph(sh, dx, nullptr, gi, gd, init_width, di, dd)) {
                 errs[r] = nnd_shard_last_error(sh);
                 rcs[r] = 1;
             } else if (nl && (hipMemcpy(out_idx + (size_t)lo[r] * p.n_neighbors, di, sizeof(int32_t) * nl * p.n_neighbors, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -1206,6 +1243,8 @@ extern "C" int32_t nnd_build_multi(const nnd_params *params, const float *x, int
         if (dx) (void)hipFree(dx);
         if (di) (void)hipFree(di);
         if (dd) (void)hipFree(dd);
+        if (gi) (void)hipFree(gi);
+        if (gd) (void)hipFree(gd);
         if (sh) (void)nnd_shard_destroy(sh);
     };
     std::vector<std::thread> th;

@@ -10,7 +10,7 @@ if the HIP library or a gfx950 device is missing, construction raises.
 Also on the GPU: ``update`` (warm start, pynndescent_.py:2381-2553), ``build_search_graph`` (the pruning
 pass of ``_init_search_graph``, all diversify methods), ``prepare`` (hub search tree + reordering) and
 ``query``.  Out of scope: sparse input, metrics other than euclidean / l2 / cosine, ``n_neighbors`` above 128 or
-``max_candidates`` above 64 (``query``: more than 64 results per query).  Those raise ``NotImplementedError`` naming the reference entry point to use
+``max_candidates`` above 64 (``query``: more than 128 results per query).  Those raise ``NotImplementedError`` naming the reference entry point to use
 instead; ``pynndescent_amd.make_index`` hands such inputs to ``pynndescent.NNDescent`` when it is importable.
 """
 import time
@@ -221,12 +221,9 @@ class NNDescent:
             if init_dist is not None and init_graph.shape != np.asarray(init_dist).shape:
                 raise ValueError("The shapes of init graph and init distances do not match!")  # pynndescent_.py:1236
 
-        if self.n_devices > 1 and init_graph is not None:
-            warn("pynndescent_amd: n_devices=%d is ignored for a build that starts from init_graph: the warm-start paths "
-                 "(init_graph, update()) run on one GPU (device %d)" % (self.n_devices, device))
-        if self.n_devices > 1 and init_graph is None:
+        if self.n_devices > 1:  # (round 5: a build that starts from init_graph is sharded too -- nnd_build_multi_from_graph)
             self._build_multi(data, metric, n_trees, eff_trees, eff_leaf_size, effective_max_candidates, n_iters, delta,
-                              max_rptree_depth, tree_states, verbose)
+                              max_rptree_depth, tree_states, verbose, init_graph, init_dist)
         else:
             self._build_single(data, metric, n_trees, eff_trees, eff_leaf_size, effective_max_candidates, n_iters, delta,
                                max_rptree_depth, tree_states, init_graph, init_dist, verbose, device)
@@ -241,7 +238,7 @@ class NNDescent:
             )
 
     def _build_multi(self, data, metric, n_trees, eff_trees, eff_leaf_size, effective_max_candidates, n_iters, delta,
-                     max_rptree_depth, tree_states, verbose):
+                     max_rptree_depth, tree_states, verbose, init_graph=None, init_dist=None):
         """Row-sharded build over several GPUs, one call into the library (include/pynnd_amd.h nnd_build_multi)."""
         from sklearn.utils import assert_all_finite
 
@@ -252,7 +249,8 @@ class NNDescent:
             print(ts(), "NN descent for", str(n_iters), "iterations on", self.n_devices, "GPUs")
         idx, dst, st, info = sharded.build_multi(
             data, self.n_devices, self.devices, metric, self.n_neighbors, eff_trees, eff_leaf_size, effective_max_candidates,
-            n_iters, delta, max_rptree_depth=max_rptree_depth, rng_state=self.rng_state, tree_state=tree_states[0])
+            n_iters, delta, max_rptree_depth=max_rptree_depth, rng_state=self.rng_state, tree_state=tree_states[0],
+            init_graph=init_graph, init_dist=init_dist)
         self._rp_forest = _DeviceForestSentinel(n_trees, st["n_leaves"], eff_leaf_size) if self.tree_init else None
         self._neighbor_graph = (idx, dst)
         self._build_stats = st
@@ -476,8 +474,8 @@ class NNDescent:
     def query(self, query_data, k=10, epsilon=0.1, proxy_beam_size=4):
         """``NNDescent.query`` (pynndescent_.py:2275-2379) on the GPU: one wave per query (csrc/query.hip).
         Returns (indices (n_queries, k) in the ORIGINAL numbering, true distances (n_queries, k))."""
-        if k > 64:
-            raise NotImplementedError("pynndescent_amd answers queries with k <= 64; use index.to_reference() for k = %d" % k)
+        if k > 128:
+            raise NotImplementedError("pynndescent_amd answers queries with k <= 128; use index.to_reference() for k = %d" % k)
         if not hasattr(self, "_search_graph") or getattr(self, "_searcher", None) is None:
             self.prepare()
         query_data = np.asarray(query_data).astype(np.float32, order="C")  # pynndescent_.py:2316

@@ -161,8 +161,8 @@ def test_query_without_tree_and_errors():
     qi, qd = index.query(x[:100] + 0.01, k=5)
     ti, _ = O.brute_force_knn(x, 5, "euclidean", rows=np.arange(100))
     assert O.recall(ti, qi) > 0.8  # random starts only (pynndescent_.py:1834-1848)
-    with pytest.raises(NotImplementedError, match="k <= 64"):
-        index.query(x[:3], k=100)
+    with pytest.raises(NotImplementedError, match="k <= 128"):
+        index.query(x[:3], k=200)
     with pytest.raises(ValueError, match="shape"):
         index.query(x[:3, :5], k=5)
 
@@ -194,3 +194,34 @@ def test_query_large_k_and_epsilon_two_tiers():
     # small searches stay on the LDS tier
     index.query(q[:50], k=10, epsilon=0.1)
     assert index._searcher.last_spilled() == 0
+
+
+@pytest.mark.parametrize("metric,k", [("euclidean", 100), ("cosine", 128), ("euclidean", 65)])
+def test_query_more_than_64_results(metric, k):
+    """Round 5: 64 < k <= 128 (the reference takes any k, pynndescent_.py:2275-2379): the result list is two entries per lane.
+    Rows ascending, ids unique, distances exact for the returned ids, the first 64 entries consistent with a k = 64 query of the
+    same index (same search, a longer list can only see MORE), recall against brute force as at k = 64."""
+    x = clustered(40_000, 24, 8, 40, seed=21, nonneg=(metric == "euclidean"))
+    q = clustered(300, 24, 8, 40, seed=21, nonneg=(metric == "euclidean"))[::-1].copy() + 0.01
+    index = NNDescent(x, metric, n_neighbors=30, random_state=6)
+    qi, qd = index.query(q, k=k, epsilon=0.3)
+    assert qi.shape == (300, k) and (qi >= 0).all()
+    assert np.all(np.diff(qd, axis=1) >= -1e-6)
+    for row in qi:
+        assert len(set(row.tolist())) == k
+    ti = _exact(x, q, k, metric)
+    r = O.recall(ti, qi)
+    qi64, qd64 = index.query(q, k=64, epsilon=0.3)
+    r64 = O.recall(_exact(x, q, 64, metric), qi64)
+    print("%s k=%d: recall@k %.4f (k = 64 on the same index: %.4f)" % (metric, k, r, r64))
+    assert r >= r64 - 0.03 and r >= 0.9
+    # returned distances are those of the returned ids
+    xi = x.astype(np.float64)
+    if metric == "euclidean":
+        true = np.sqrt(((q.astype(np.float64)[:, None, :] - xi[qi]) ** 2).sum(-1))
+    else:
+        a, b = q.astype(np.float64), xi[qi]
+        true = 1.0 - (a[:, None, :] * b).sum(-1) / (np.linalg.norm(a, axis=1)[:, None] * np.linalg.norm(b, axis=2))
+    np.testing.assert_allclose(qd, true, rtol=2e-4, atol=2e-6)
+    with pytest.raises(NotImplementedError):
+        index.query(q[:2], k=129)

@@ -369,6 +369,41 @@ def test_duplicate_heavy_rows_build_on_every_rank_count():
     print("duplicate-heavy rows: forest_by_cell per rank %s" % [i["forest_by_cell"] for i in infos])
 
 
+@pytest.mark.parametrize("metric,with_dist", [("euclidean", False), ("cosine", True)])
+def test_a_build_from_an_init_graph_is_sharded_too(metric, with_dist):
+    """Round 5: NNDescent(n_devices=G, init_graph=...) (pynndescent_.py:1225-1242; utils.py:836-860) no longer falls back to one GPU:
+    nnd_build_multi_from_graph -- every rank seeds its rows from its rows of the init graph (no forest, no random fill), then the
+    sharded iterations.  From a half-random graph it must reach the single-GPU build's recall, and say nothing about n_devices."""
+    import warnings
+
+    x = clustered(6000, 24, 6, 30, seed=14)
+    ti, td = O.brute_force_knn(x, 10, metric)
+    rs = np.random.RandomState(3)
+    noisy = np.where(rs.uniform(size=ti.shape) < 0.5, rs.randint(0, 6000, ti.shape), ti).astype(np.int32)
+    noisy[::9, 7:] = -1
+    kw = dict(n_neighbors=10, init_graph=noisy, random_state=1)
+    if with_dist:  # the caller's distances are taken as they are (alt space): give the true ones
+        from tests.gpu_util import alt_dist_matrix
+
+        d = np.empty(noisy.shape, np.float32)
+        for i in range(6000):
+            v = noisy[i] >= 0
+            d[i, v] = alt_dist_matrix(x, [i], noisy[i][v], metric)[0]
+            d[i, ~v] = np.inf
+        kw["init_dist"] = d
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        one = NNDescent(x, metric, **kw)._neighbor_graph[0]
+        two = NNDescent(x, metric, n_devices=3, devices=[0, 0, 0], **kw)
+    assert not [w for w in caught if "n_devices" in str(w.message)], [str(w.message) for w in caught]
+    assert two._shard_info["world"] == 3 and not two._shard_info["forest_by_cell"]
+    r1, r3 = O.recall(ti, one), O.recall(ti, two._neighbor_graph[0])
+    print("init graph (%s%s): recall@10 one GPU %.4f, 3 ranks %.4f" % (metric, ", init_dist" if with_dist else "", r1, r3))
+    assert r3 > 0.95 and abs(r1 - r3) <= 0.01
+    for row in two._neighbor_graph[0][::37]:
+        assert len(set(row[row >= 0].tolist())) == (row >= 0).sum()
+
+
 @pytest.mark.parametrize("hook,timeout_s", [("fail", 30.0), ("vanish", 3.0)])
 def test_a_failing_rank_ends_the_build_on_every_rank(hook, timeout_s):
     """One rank of eight dies at the start of its second iteration -- `fail`: it returns an error (the library tells the
