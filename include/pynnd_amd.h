@@ -298,6 +298,10 @@ int32_t nnd_shard_build(nnd_shard_t s, const float *x_local_dev, void *x_stream,
  * created with n_trees = 0 */
 int32_t nnd_shard_build_from_graph(nnd_shard_t s, const float *x_local_dev, void *x_stream, const int32_t *init_idx_dev,
                                    const float *init_dist_dev, int32_t init_width, int32_t *out_idx_dev, float *out_dist_dev);
+/* ... NNDescent.update() (pynndescent_.py:2498-2535): the rank's rows of the previous graph enter as OLD entries (alt-space distances
+ * required) before the fresh forest's leaves are joined; no random fill */
+int32_t nnd_shard_build_update(nnd_shard_t s, const float *x_local_dev, void *x_stream, const int32_t *old_idx_dev, const float *old_dist_dev,
+                               int32_t width, int32_t *out_idx_dev, float *out_dist_dev);
 int32_t nnd_shard_get_info(nnd_shard_t s, nnd_shard_info *out);
 int32_t nnd_shard_get_stats(nnd_shard_t s, nnd_stats *out); /* this rank's kernels */
 /* the rank's builder handle (tests: nnd_leaf_array_shape / nnd_get_leaf_array give the leaves this rank seeded from) */
@@ -318,6 +322,12 @@ int32_t nnd_build_multi(const nnd_params *params, const float *x, int32_t n_devi
 int32_t nnd_build_multi_from_graph(const nnd_params *params, const float *x, int32_t n_devices, const int32_t *devices,
                                    const int32_t *init_idx, const float *init_dist, int32_t init_width, int32_t *out_idx, float *out_dist,
                                    nnd_stats *stats, nnd_shard_info *info_rank0 /* nullable */, char *err, int32_t errlen);
+/* NNDescent.update() (pynndescent_.py:2381-2553, the rebuild at 2498-2535) over n_devices GPUs: a fresh forest of params->n_trees trees
+ * (n_trees_after_update) over the changed point set, the previous graph's surviving entries as OLD entries (init_from_neighbor_graph,
+ * pynndescent_.py:206-214; old_idx host (n, width) global ids, -1 where invalidated, old_dist their alt-space distances), no random fill */
+int32_t nnd_build_multi_update(const nnd_params *params, const float *x, int32_t n_devices, const int32_t *devices, const int32_t *old_idx,
+                               const float *old_dist, int32_t width, int32_t *out_idx, float *out_dist, nnd_stats *stats,
+                               nnd_shard_info *info_rank0 /* nullable */, char *err, int32_t errlen);
 
 /* Stream the handle runs on: the caller's HIP stream (e.g. the one that produces the point set) instead of the handle's
  * own, so the device-pointer entry points need no synchronisation with it.  NULL: the handle's own stream again. */

@@ -209,6 +209,9 @@ _SIGNATURES = [
     ("nnd_build_multi_from_graph", C.c_int32, [C.POINTER(NNDParams), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                C.c_void_p, C.c_void_p, C.POINTER(NNDStats), C.POINTER(NNDShardInfo), C.c_char_p, C.c_int32]),
     ("nnd_shard_build_from_graph", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("nnd_shard_build_update", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("nnd_build_multi_update", C.c_int32, [C.POINTER(NNDParams), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.POINTER(NNDStats), C.POINTER(NNDShardInfo), C.c_char_p, C.c_int32]),
     ("nnd_diversify_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.POINTER(NNDPruneOpts), C.c_void_p]),
     ("nnd_diversify_csr_host", C.c_int32, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(NNDPruneOpts),
                                            C.c_void_p]),

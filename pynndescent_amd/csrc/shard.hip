@@ -751,7 +751,16 @@ static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t e
 // init_idx_dev (nullable): the owned rows of an init graph (n_own, init_width), global ids -- the warm start of
 // NNDescent(init_graph=...) (pynndescent_.py:1225-1242, utils.py:836-860): no forest, no random fill
 static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream, int32_t *out_idx_dev, float *out_dist_dev,
-                       const int32_t *init_idx_dev = nullptr, const float *init_dist_dev = nullptr, int init_width = 0) {
+                       const int32_t *init_idx_dev = nullptr, const float *init_dist_dev = nullptr, int init_width = 0, int init_mode = 0) {
+    // init_mode 1: NNDescent(init_graph=...) -- entries enter as NEW, no forest (n_trees = 0), no random fill;
+    // init_mode 2: NNDescent.update() (pynndescent_.py:2498-2535) -- the previous graph's entries enter as OLD (init_from_neighbor_graph,
+    //              pynndescent_.py:206-214) BEFORE the fresh forest's leaves are joined, no random fill
+    auto seed_old = [&]() -> int {
+        if (init_mode != 2 || !init_idx_dev) return 0;
+        if (nnd_launch_init_from_graph(s->h, init_idx_dev, init_dist_dev, init_width) || nnd_launch_clear_new_flags(s->h)) { s->set_error("%s", s->h->err); return 1; }
+        s->h->all_new = false;
+        return 0;
+    };
     nnd_ctx *h = s->h;
     nnd_comm_s *c = s->comm;
     const int G = s->world, me = s->rank, nv = G + 3;
@@ -832,6 +841,7 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         } else {
             if (x_async) (void)hipEventElapsedTime(&s->info.ms_allgather, e0, e1);  // (the stream has drained behind the leaf tables' read-back)
             section_timer sec(s);
+            if (seed_old()) return 1;
             const int tl = t_begin(h);
             S_CTX(nnd_launch_leaf_init(h));
             t_end(h, tl, &h->stats.ms_leaf_init, false);
@@ -849,6 +859,7 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         S_CTX(nnd_launch_prep(h));
         S_CTX(nnd_launch_reset_graph(h));
         t_end(h, tp, &h->stats.ms_prep, false);
+        if (seed_old()) return 1;
         // ---- forest split by tree: this rank seeds ALL rows from its own trees ----
         if (h->p.n_trees > 0) {
             const int tf = t_begin(h);
@@ -892,9 +903,11 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         for (int r = 0; r < G; r++) n_src += rcnt[r] ? 1 : 0;
         S_CTX(nnd_launch_merge_graph_rows(h, s->lo, s->hi, s->recv_e, s->recv_d, n_src, (int64_t)n_own * s->ks));
         const int tr = t_begin(h);
-        S_CTX(nnd_launch_random_init(h));  // owned rows that are still not full (pynndescent_.py:188-203)
+        if (init_mode != 2) S_CTX(nnd_launch_random_init(h));  // owned rows that are still not full (pynndescent_.py:188-203)
         t_end(h, tr, &h->stats.ms_random_init, false);
         sec.end();
+    } else if (init_idx_dev && init_mode == 2) {
+        // (update() without a forest: the old entries are in, nothing else to seed from)
     } else if (init_idx_dev) {
         section_timer sec(s);
         const int tr = t_begin(h);
@@ -1076,15 +1089,26 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
 extern "C" int32_t nnd_shard_build(nnd_shard_t s, const float *x_local_dev, void *x_stream, int32_t *out_idx_dev, float *out_dist_dev) {
     return nnd_shard_build_from_graph(s, x_local_dev, x_stream, nullptr, nullptr, 0, out_idx_dev, out_dist_dev);
 }
+static int32_t shard_build_entry(nnd_shard_t s, const float *x_local_dev, void *x_stream, const int32_t *init_idx_dev, const float *init_dist_dev,
+                                 int32_t init_width, int init_mode, int32_t *out_idx_dev, float *out_dist_dev);
 extern "C" int32_t nnd_shard_build_from_graph(nnd_shard_t s, const float *x_local_dev, void *x_stream, const int32_t *init_idx_dev,
                                               const float *init_dist_dev, int32_t init_width, int32_t *out_idx_dev, float *out_dist_dev) {
+    return shard_build_entry(s, x_local_dev, x_stream, init_idx_dev, init_dist_dev, init_width, init_idx_dev ? 1 : 0, out_idx_dev, out_dist_dev);
+}
+extern "C" int32_t nnd_shard_build_update(nnd_shard_t s, const float *x_local_dev, void *x_stream, const int32_t *old_idx_dev,
+                                          const float *old_dist_dev, int32_t width, int32_t *out_idx_dev, float *out_dist_dev) {
+    if (s && (!old_idx_dev || !old_dist_dev)) { s->set_error("nnd_shard_build_update: the previous graph (ids and alt-space distances) is required"); return 1; }
+    return shard_build_entry(s, x_local_dev, x_stream, old_idx_dev, old_dist_dev, width, 2, out_idx_dev, out_dist_dev);
+}
+static int32_t shard_build_entry(nnd_shard_t s, const float *x_local_dev, void *x_stream, const int32_t *init_idx_dev, const float *init_dist_dev,
+                                 int32_t init_width, int init_mode, int32_t *out_idx_dev, float *out_dist_dev) {
     if (!s) { snprintf(g_serr2, sizeof(g_serr2), "nnd_shard_build: null shard"); return 1; }
     if (!x_local_dev || !out_idx_dev || !out_dist_dev) { s->set_error("nnd_shard_build: null buffer"); return 1; }
-    if (init_idx_dev && (s->gp.n_trees != 0 || init_width < 1 || init_width > 128)) {
+    if (init_idx_dev && ((init_mode == 1 && s->gp.n_trees != 0) || init_width < 1 || init_width > 128)) {
         s->set_error("nnd_shard_build_from_graph: an init graph needs a shard created with n_trees = 0 (pynndescent_.py:1059-1062) and a width in 1..128");
         return 1;
     }
-    const int rc = shard_build(s, x_local_dev, x_stream, out_idx_dev, out_dist_dev, init_idx_dev, init_dist_dev, init_width);
+    const int rc = shard_build(s, x_local_dev, x_stream, out_idx_dev, out_dist_dev, init_idx_dev, init_dist_dev, init_width, init_mode);
     s->h->wait_hook = nullptr;
     // a rank that fails tells the ranks of its process (shared flag, LOCAL barriers) and cancels its own collectives
     // (ncclCommAbort): nobody is left waiting in a collective.  (rc 2: the test hook of a rank that dies silently.)
@@ -1100,12 +1124,32 @@ extern "C" int32_t nnd_build_multi(const nnd_params *params, const float *x, int
 }
 // ... with the warm start of NNDescent(init_graph=..., init_dist=...) (pynndescent_.py:1225-1242): init_idx host (n, init_width) global
 // ids, init_dist nullable (distances are computed); params->n_trees is taken as 0 (an init graph disables the forest, 1059-1062)
+static int32_t build_multi_impl(const nnd_params *params_in, const float *x, int32_t n_devices, const int32_t *devices, const int32_t *init_idx,
+                                const float *init_dist, int32_t init_width, int init_mode, int32_t *out_idx, float *out_dist, nnd_stats *stats,
+                                nnd_shard_info *info_rank0, char *err, int32_t errlen);
 extern "C" int32_t nnd_build_multi_from_graph(const nnd_params *params_in, const float *x, int32_t n_devices, const int32_t *devices,
                                               const int32_t *init_idx, const float *init_dist, int32_t init_width, int32_t *out_idx,
                                               float *out_dist, nnd_stats *stats, nnd_shard_info *info_rank0, char *err, int32_t errlen) {
+    return build_multi_impl(params_in, x, n_devices, devices, init_idx, init_dist, init_width, init_idx ? 1 : 0, out_idx, out_dist, stats, info_rank0, err, errlen);
+}
+// NNDescent.update() (pynndescent_.py:2498-2535) over n_devices GPUs: a fresh forest of params->n_trees trees over the (changed) point
+// set, the previous graph's surviving entries as OLD entries (old_idx (n, width) global ids, -1 where an entry was invalidated;
+// old_dist: their alt-space distances), no random fill
+extern "C" int32_t nnd_build_multi_update(const nnd_params *params_in, const float *x, int32_t n_devices, const int32_t *devices,
+                                          const int32_t *old_idx, const float *old_dist, int32_t width, int32_t *out_idx, float *out_dist,
+                                          nnd_stats *stats, nnd_shard_info *info_rank0, char *err, int32_t errlen) {
+    if (!old_idx || !old_dist) {
+        if (err && errlen > 0) snprintf(err, (size_t)errlen, "nnd_build_multi_update: the previous graph (ids and alt-space distances) is required");
+        return 1;
+    }
+    return build_multi_impl(params_in, x, n_devices, devices, old_idx, old_dist, width, 2, out_idx, out_dist, stats, info_rank0, err, errlen);
+}
+static int32_t build_multi_impl(const nnd_params *params_in, const float *x, int32_t n_devices, const int32_t *devices, const int32_t *init_idx,
+                                const float *init_dist, int32_t init_width, int init_mode, int32_t *out_idx, float *out_dist, nnd_stats *stats,
+                                nnd_shard_info *info_rank0, char *err, int32_t errlen) {
     nnd_params params_v{};
     if (params_in) params_v = *params_in;
-    if (init_idx) params_v.n_trees = 0;
+    if (init_idx && init_mode == 1) params_v.n_trees = 0;
     const nnd_params *params = params_in ? &params_v : nullptr;
     auto fail = [&](const std::string &msg) {
         if (err && errlen > 0) { strncpy(err, msg.c_str(), (size_t)errlen - 1); err[errlen - 1] = 0; }
@@ -1211,7 +1255,7 @@ extern "C" int32_t nnd_build_multi_from_graph(const nnd_params *params_in, const
         }
         bar.wait();  // (2) every rank is ready, or nobody builds
         if (!failed.load()) {
-            if (nnd_shard_build_from_graph(sh, dx, nullptr, gi, gd, init_width, di, dd)) {
+            if (shard_build_entry(sh, dx, nullptr, gi, gd, init_width, init_mode, di, dd)) {
                 errs[r] = nnd_shard_last_error(sh);
                 rcs[r] = 1;
             } else if (nl && (hipMemcpy(out_idx + (size_t)lo[r] * p.n_neighbors, di, sizeof(int32_t) * nl * p.n_neighbors, hipMemcpyDeviceToHost) != hipSuccess ||

@@ -574,9 +574,27 @@ class NNDescent:
             effective_max_candidates = min(60, self.n_neighbors)
         else:
             effective_max_candidates = self.max_candidates
-        if getattr(self, "n_devices", 1) > 1:
-            warn("pynndescent_amd: update() rebuilds on one GPU (device %d); n_devices=%d applies to fresh builds only"
-                 % (self.device, self.n_devices))
+        if getattr(self, "n_devices", 1) > 1:  # round 5: the rebuild is sharded like the build was (nnd_build_multi_update)
+            from sklearn.utils import assert_all_finite
+
+            from . import sharded
+
+            assert_all_finite(raw)
+            idx, dst, st, info = sharded.build_multi(
+                raw, self.n_devices, self.devices, self.metric, self.n_neighbors, self.n_trees, eff_leaf_size, effective_max_candidates,
+                self.n_iters, self.delta, max_rptree_depth=self.max_rptree_depth, rng_state=self.rng_state, tree_state=tree_states[0],
+                old_graph=(pad_i, pad_d))
+            self._rp_forest = _DeviceForestSentinel(self.n_trees, st["n_leaves"], eff_leaf_size)
+            self._neighbor_graph = (idx, dst)
+            self._build_stats = st
+            self._shard_info = info
+            self._raw_data = raw
+            if hasattr(self, "_search_graph"):
+                for name in ("_search_graph", "_search_forest", "_vertex_order", "_searcher"):
+                    if hasattr(self, name):
+                        delattr(self, name)
+                self.prepare()
+            return
         builder = _capi.Builder(
             n, raw.shape[1], _METRIC_CODES[self.metric], self.n_neighbors, self.n_trees, eff_leaf_size,
             self.max_rptree_depth, effective_max_candidates, self.n_iters, self.delta, self.rng_state, tree_states[0],

@@ -319,12 +319,14 @@ def sharded_build(comm, x_local, shard_sizes, metric="euclidean", n_neighbors=15
 
 def build_multi(x, n_devices, devices=None, metric="euclidean", n_neighbors=15, n_trees=8, leaf_size=None, max_candidates=None,
                 n_iters=None, delta=0.001, seed=0, max_rptree_depth=200, rng_state=None, tree_state=None, init_graph=None,
-                init_dist=None):
+                init_dist=None, old_graph=None):
     """``nnd_build_multi``: the whole build over ``n_devices`` GPUs of this node in ONE call -- host array in, host arrays
     out, one host thread per GPU inside the library, RCCL between distinct GPUs (LOCAL copies when ``devices`` repeats an
     ordinal).  Returns (idx int32 (n, k), alt-space dist float32 (n, k), stats of rank 0, shard info of rank 0).
     ``init_graph`` (n, width) / ``init_dist``: the warm start of ``NNDescent(init_graph=...)`` (``nnd_build_multi_from_graph``:
-    no forest, no random fill; every rank seeds its rows from its rows of the graph)."""
+    no forest, no random fill; every rank seeds its rows from its rows of the graph).  ``old_graph`` = (ids (n, width), alt-space
+    distances): the rebuild of ``NNDescent.update()`` (``nnd_build_multi_update``: a fresh forest + the previous graph's surviving
+    entries as OLD entries, no random fill)."""
     lib = _capi.load_library()
     x = np.ascontiguousarray(x, np.float32)
     n, d = x.shape
@@ -340,7 +342,14 @@ def build_multi(x, n_devices, devices=None, metric="euclidean", n_neighbors=15, 
     dist = np.empty((n, int(n_neighbors)), np.float32)
     st, inf = _capi.NNDStats(), _capi.NNDShardInfo()
     err = C.create_string_buffer(1024)
-    if init_graph is not None:
+    if old_graph is not None:
+        g = np.ascontiguousarray(old_graph[0], np.int32)
+        gd = np.ascontiguousarray(old_graph[1], np.float32)
+        if g.shape[0] != n or gd.shape != g.shape:
+            raise ValueError("the previous graph does not match the data")
+        rc = lib.nnd_build_multi_update(C.byref(p), _capi._ptr(x), int(n_devices), _capi._ptr(dev), _capi._ptr(g), _capi._ptr(gd), int(g.shape[1]),
+                                        _capi._ptr(idx), _capi._ptr(dist), C.byref(st), C.byref(inf), err, 1024)
+    elif init_graph is not None:
         g = np.ascontiguousarray(init_graph, np.int32)
         gd = None if init_dist is None else np.ascontiguousarray(init_dist, np.float32)
         if g.shape[0] != n or (gd is not None and gd.shape != g.shape):

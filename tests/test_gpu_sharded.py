@@ -404,6 +404,51 @@ def test_a_build_from_an_init_graph_is_sharded_too(metric, with_dist):
         assert len(set(row[row >= 0].tolist())) == (row >= 0).sum()
 
 
+@pytest.mark.parametrize("metric,n", [("euclidean", 1500), ("cosine", 140_000)])
+def test_update_of_a_sharded_index_rebuilds_sharded(metric, n):
+    """Round 5: NNDescent.update() (pynndescent_.py:2381-2553) of an index built with n_devices > 1 is sharded too
+    (nnd_build_multi_update: fresh forest -- split by tree at the small size, by cell at the large one -- + the previous graph's
+    surviving entries as OLD entries on their owners, no random fill), without the round-4 warning: the updated graph reaches the
+    single-GPU update's recall on the NEW data, holds exact distances, no stale edge, and the warm start shows (untouched rows
+    keep most of their old neighbours)."""
+    import warnings
+
+    rs = np.random.RandomState(8)
+    x = clustered(n, 20, 6, 30, seed=19)
+    n_upd, n_fresh = n // 20, n // 25
+    upd_idx = rs.choice(n, n_upd, replace=False)
+    upd = clustered(n_upd, 20, 6, 30, seed=20)
+    fresh = clustered(n_fresh, 20, 6, 30, seed=21)
+    out = {}
+    for G in (1, 3):
+        kw = dict(n_devices=3, devices=[0, 0, 0]) if G > 1 else {}
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            index = NNDescent(x.copy(), metric, n_neighbors=12, n_trees=4, random_state=np.random.RandomState(5), **kw)
+            before = index._neighbor_graph[0].copy()
+            index.update(xs_fresh=fresh, xs_updated=upd, updated_indices=upd_idx)
+        assert not [w for w in caught if "n_devices" in str(w.message)], [str(w.message) for w in caught]
+        out[G] = (index._neighbor_graph[0], index._neighbor_graph[1], before, index._raw_data)
+    raw = out[3][3]
+    np.testing.assert_array_equal(raw, out[1][3])
+    assert raw.shape[0] == n + n_fresh
+    rows = rs.choice(raw.shape[0], 1500, replace=False)
+    ti, _ = O.brute_force_knn(raw, 10, metric, rows=rows, kind="fast")
+    r1, r3 = O.recall(ti, out[1][0][rows]), O.recall(ti, out[3][0][rows])
+    print("update (%s, n = %d): recall@10 one GPU %.4f, 3 ranks %.4f" % (metric, n, r1, r3))
+    assert r3 > 0.95 and abs(r1 - r3) <= 0.01
+    idx3, d3 = out[3][0], out[3][1]
+    from tests.gpu_util import alt_dist_matrix
+
+    for r in rows[:200]:  # the stored (alt-space) distances are those of the stored ids, rows ascending, ids unique
+        want = alt_dist_matrix(raw, [r], idx3[r], metric)[0]
+        np.testing.assert_allclose(d3[r], want, rtol=2e-4, atol=1e-6 * max(1.0, float(want.max())))
+        assert np.all(np.diff(d3[r]) >= 0) and len(set(idx3[r].tolist())) == idx3.shape[1]
+    keep = np.setdiff1d(np.arange(n), upd_idx)[::11]
+    same = np.mean([len(np.intersect1d(out[3][2][i], idx3[i])) / idx3.shape[1] for i in keep])
+    assert same > 0.75, same
+
+
 @pytest.mark.parametrize("hook,timeout_s", [("fail", 30.0), ("vanish", 3.0)])
 def test_a_failing_rank_ends_the_build_on_every_rank(hook, timeout_s):
     """One rank of eight dies at the start of its second iteration -- `fail`: it returns an error (the library tells the
