@@ -7,20 +7,20 @@
 // Afterwards every forward new edge whose target made it into new[v] has its flag cleared
 // (utils.py:311-318).
 //
-// The reference makes every thread scan all n*k edges and push into the heaps of the vertices it
-// owns.  Here:
-//   k_sample_reverse : one thread per edge scatters the reverse offer into a bank of RCAP hashed
-//                      slots per (target, class) with a 32-bit atomicMin on the offer's priority
-//                      -- order independent, so the sample is deterministic for a given seed.  The
-//                      priority of the offer v -> u is mix32(v ^ salt(u)): mix32 is a bijection, so
-//                      the 4-byte slot IS the source (v = unmix32(slot) ^ salt(u)) and its order is
-//                      a fresh pseudo-random order of the sources for every target and iteration;
-//   k_sample_select  : one wave per vertex gathers its k forward offers and its reverse slots,
-//                      drops reverse offers that duplicate a forward id, ranks by priority and
-//                      writes the max_candidates smallest of each class, clears the flags of the
-//                      sampled forward-new edges and re-arms the reverse slots.
-// Forward priorities are hash(seed, iteration, v, u); both kinds are uniform 32-bit words, ranked together.
-// (Until round 3 a slot held priority << 32 | source, 8 bytes: the table was the largest stream of the phase.)
+// The reference makes every thread scan all n*k edges and push into the heaps of the vertices it owns.  Here, since round 5,
+// the reverse offers are TRANSPOSED (second half of this file: k_rev_place / k_rev_import / k_rev_select / k_rev_fill) -- placed
+// by target bucket and appended to the targets' slot banks in LDS: a bank that receives no more offers than it has slots keeps
+// every one of them, which is what the reference's heaps do.  The priority of the offer v -> u is mix32(v ^ salt(u)): mix32 is a
+// bijection, so a 4-byte slot word IS the source (v = unmix32(word) ^ salt(u)) and its order is a fresh pseudo-random order of the
+// sources for every target and iteration.  Forward priorities are hash(seed, iteration, v, u); both kinds are uniform 32-bit words,
+// ranked together by k_rev_select (k <= 32) or by k_sample_select / _h / _wide on banks k_rev_fill wrote to rbuf.
+//
+// The first half is the form of rounds 1-4, kept behind NND_FLAG_TEST_SAMPLE_ATOMIC (comparison, A/B timing):
+//   k_sample_reverse : one thread per edge scatters the reverse offer into a bank of RCAP hashed slots per (target, class) with a
+//                      32-bit atomicMin on the offer's priority -- order independent, but two offers that share a slot lose one;
+//   k_sample_select  : one wave per vertex gathers its k forward offers and its reverse slots, drops reverse offers that duplicate
+//                      a forward id, ranks by priority and writes the max_candidates smallest of each class, clears the flags of
+//                      the sampled forward-new edges and re-arms the reverse slots.
 #include "common.h"
 #include "state.h"
 

@@ -157,8 +157,8 @@ struct nnd_handle_s {
     std::vector<int64_t> tree_leaf_begin; // per tree: first leaf index (host)
     bool forest_built = false;
     bool all_new = false;  // every edge of the graph still carries the "new" flag (true from reset until the first sampling pass)
-    // bucketed reverse sampling (sample.hip; plain handles): the reverse offers of an iteration are counting-sorted by the
-    // target's BUCKET (a run of consecutive positions of the visiting order) and folded into the slot banks from LDS
+    // candidate sampling by transposition (sample.hip): the reverse offers of an iteration are placed by the target's BUCKET (a run
+    // of consecutive positions of the visiting order) and appended to the targets' slot banks in LDS
     int32_t *rv_pos = nullptr;                // (n) position of every vertex in the visiting order, grow-only
     int rv_pos_gen = -1;                      // forest_gen the table was built for
     int forest_gen = 0;                       // bumped whenever a forest (a visiting order) is finished
