@@ -52,7 +52,7 @@ typedef struct nnd_params {
     int64_t n;              /* points */
     int32_t dim;            /* features */
     int32_t metric;         /* NND_METRIC_* */
-    int32_t n_neighbors;    /* k, 1..128 (rows above 64 entries are merged through LDS: correct, not tuned) */
+    int32_t n_neighbors;    /* k, 1..256 (rows above 64 entries are merged through LDS: correct, not tuned) */
     int32_t n_trees;        /* 0 = no RP-forest initialisation */
     int32_t leaf_size;      /* > 0 */
     int32_t max_depth;      /* max_rptree_depth (pynndescent_.py:1000) */
@@ -62,7 +62,8 @@ typedef struct nnd_params {
     int64_t rng_state[3];   /* NNDescent.rng_state (pynndescent_.py:1105-1107) */
     int64_t tree_rng[3];    /* first row of make_forest's per-tree draw (rp_trees.py:2850) */
     int32_t device;         /* HIP device ordinal */
-    int32_t join_blocks;    /* descent sub-steps per iteration (>=1); reference blocks by 16384 vertices (pynndescent_.py:279) */
+    int32_t join_blocks;    /* descent sub-steps per iteration; reference blocks by 16384 vertices (pynndescent_.py:279).  0 = chosen by the
+                             * library: 1 up to 64 neighbours, ceil(k / 32) above (a row takes at most 64 updates per sub-step) */
     int32_t flags;          /* NND_FLAG_*; 0 for a build handle */
     int32_t reserved[5];
 } nnd_params;
@@ -170,7 +171,7 @@ int32_t nnd_init_from_leaf_array(nnd_handle_t h, const int32_t *leaf_array, int6
 /* init_random (pynndescent_.py:188-203): top up rows that are not full with random points. */
 int32_t nnd_init_random(nnd_handle_t h);
 /* initalize_heap_from_graph_indices[_and_distances] (utils.py:836-860), used for init_graph /
- * init_dist (pynndescent_.py:1225-1242).  init_dist may be NULL. Host pointers, (n, width), width <= 128. */
+ * init_dist (pynndescent_.py:1225-1242).  init_dist may be NULL. Host pointers, (n, width), width <= 256. */
 int32_t nnd_init_from_graph(nnd_handle_t h, const int32_t *init_idx, const float *init_dist, int32_t width);
 /* init_from_neighbor_graph (pynndescent_.py:206-214), the warm start of NNDescent.update
  * (pynndescent_.py:2512-2517): the entries of an existing graph -- host (n, width) indices (-1 = none) and

@@ -266,7 +266,7 @@ class Builder:
     """Thin object wrapper over an ``nnd_handle_t`` (one GPU, one stream)."""
 
     def __init__(self, n, dim, metric, n_neighbors, n_trees, leaf_size, max_depth, max_candidates, n_iters, delta,
-                 rng_state, tree_rng, device=0, join_blocks=1, flags=0):
+                 rng_state, tree_rng, device=0, join_blocks=0, flags=0):
         self.lib = load_library()
         p = NNDParams()
         p.n, p.dim, p.metric = int(n), int(dim), int(metric)

@@ -113,12 +113,18 @@ static void free_all(nnd_ctx *ctx) {
 static nnd_ctx *take_parked(const nnd_params *p);
 extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) { return nnd_create_impl(out, p, nullptr, 0, 0); }
 
+// join_blocks = 0: chosen here.  A row takes at most 64 updates per merge (its proposal slots); rows of more than 64 neighbours
+// change by more than that per iteration while the graph is poor (the reference's heaps have no such bound, utils.py:459-500), so
+// their iterations are cut into sub-steps (join a part of the vertices, merge, ...: pynndescent_.py:239-261 does the same in
+// blocks of 16384 vertices) until the slots of an iteration add up to 2 k.
+static int auto_join_blocks(int k) { return k <= 64 ? 1 : (k + 31) / 32; }
+
 int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bounds_host, int n_ranks, int rank) {
     if (!out || !p) { gerr("nnd_create: null argument"); return 1; }
     *out = nullptr;
     if (p->n < 1 || p->dim < 1) { gerr("nnd_create: need n >= 1 and dim >= 1 (got n=%lld dim=%d)", (long long)p->n, p->dim); return 1; }
     if (p->metric != NND_METRIC_SQEUCLIDEAN && p->metric != NND_METRIC_ALT_COSINE) { gerr("nnd_create: unknown metric %d", p->metric); return 1; }
-    if (p->n_neighbors < 1 || p->n_neighbors > 128) { gerr("nnd_create: n_neighbors must be in 1..128 (got %d)", p->n_neighbors); return 1; }
+    if (p->n_neighbors < 1 || p->n_neighbors > NND_WIDE_K) { gerr("nnd_create: n_neighbors must be in 1..%d (got %d)", NND_WIDE_K, p->n_neighbors); return 1; }
     if (p->max_candidates < 1 || p->max_candidates > 64) { gerr("nnd_create: max_candidates must be in 1..64 (got %d)", p->max_candidates); return 1; }
     if (p->n_trees < 0 || p->n_trees > 4096 || p->leaf_size < 1) { gerr("nnd_create: bad n_trees (0..4096) / leaf_size"); return 1; }
     if (p->n >= (int64_t)0x7FFFFFF0) { gerr("nnd_create: n too large for int32 ids"); return 1; }
@@ -179,7 +185,7 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
         const int r = atoi(pc_env);
         if (r == 16 || r == 32 || r == 64) ctx->pcap = r;
     }
-    if (ctx->p.join_blocks < 1) ctx->p.join_blocks = 1;
+    if (ctx->p.join_blocks < 1) ctx->p.join_blocks = auto_join_blocks(ctx->p.n_neighbors);
     ctx->seed = nnd_mix32((uint32_t)p->rng_state[0] ^ nnd_mix32((uint32_t)p->rng_state[1] + 0x9E3779B9u) ^
                           nnd_mix32((uint32_t)p->rng_state[2] + 0x7F4A7C15u));
     ctx->tree_seed = nnd_mix32((uint32_t)p->tree_rng[0] ^ nnd_mix32((uint32_t)p->tree_rng[1] + 0x9E3779B9u) ^
@@ -353,7 +359,7 @@ static nnd_ctx *take_parked(const nnd_params *p) {
     if (!ctx) return nullptr;
     (void)hipSetDevice(p->device);
     ctx->p = *p;
-    if (ctx->p.join_blocks < 1) ctx->p.join_blocks = 1;
+    if (ctx->p.join_blocks < 1) ctx->p.join_blocks = auto_join_blocks(ctx->p.n_neighbors);
     ctx->seed = nnd_mix32((uint32_t)p->rng_state[0] ^ nnd_mix32((uint32_t)p->rng_state[1] + 0x9E3779B9u) ^ nnd_mix32((uint32_t)p->rng_state[2] + 0x7F4A7C15u));
     ctx->tree_seed = nnd_mix32((uint32_t)p->tree_rng[0] ^ nnd_mix32((uint32_t)p->tree_rng[1] + 0x9E3779B9u) ^ nnd_mix32((uint32_t)p->tree_rng[2] + 0x7F4A7C15u));
     ctx->iter = 0;
@@ -542,7 +548,7 @@ extern "C" int32_t nnd_init_from_graph(nnd_handle_t ctx, const int32_t *init_idx
     ENTER(ctx);
     if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
-    if (!init_idx || width < 1 || width > 128) { ctx->set_error("nnd_init_from_graph: width must be in 1..128"); return 1; }
+    if (!init_idx || width < 1 || width > NND_WIDE_K) { ctx->set_error("nnd_init_from_graph: width must be in 1..%d", NND_WIDE_K); return 1; }
     size_t cnt = (size_t)ctx->n * width;
     nnd_scratch tmp;
     int32_t *di = tmp.get<int32_t>(ctx, cnt);

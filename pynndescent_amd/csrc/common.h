@@ -11,6 +11,9 @@
 #define NND_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define NND_EMPTY_SLOT 0xFFFFFFFFu  // an unarmed reverse-offer slot (sample.hip)
 #define NND_FLT_MAX 3.402823466e+38f
+// rows of more than 64 neighbours (n_neighbors up to NND_WIDE_K): a lane holds entries lane, 64 + lane, ...; merged through LDS (merge.h)
+#define NND_WIDE_K 256
+#define NND_WIDE_U (NND_WIDE_K / 64)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -119,13 +119,13 @@ __global__ __launch_bounds__(256, METRIC == 0 ? 6 : 4) void k_finalize(const flo
     }
 }
 
-// 64 < k <= 128: one wave per row, ids / exact distances through LDS, four neighbours at a time (16 lanes each), ranks by
+// 64 < k <= NND_WIDE_K: one wave per row, ids / exact distances through LDS, four neighbours at a time (16 lanes each), ranks by
 // counting over the LDS copy.  Same arithmetic as k_finalize (float64 accumulation of the reference's formulas).
 __global__ __launch_bounds__(256) void k_finalize_wide(const float *__restrict__ x, int d, int64_t lo, int64_t n, int k, int ks, int metric,
                                                        const uint32_t *__restrict__ knn_e, int32_t *__restrict__ out_idx,
                                                        float *__restrict__ out_dist) {
-    __shared__ uint32_t sid[4][128];
-    __shared__ float sdist[4][128];
+    __shared__ uint32_t sid[4][NND_WIDE_K];
+    __shared__ float sdist[4][NND_WIDE_K];
     const int lane = nnd_lane(), w = threadIdx.x >> 6, grp = lane >> 4, l16 = lane & 15;
     const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;
     if (v >= n) return;

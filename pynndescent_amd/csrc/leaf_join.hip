@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_leaf_join_rb(const float *__rest
     __shared__ __attribute__((aligned(16))) float big[BIG];           // row tile, then the 32 x m distance block
     __shared__ int32_t ids[MP];
     __shared__ float nrs[MP];
-    __shared__ uint64_t wide_scr[WIDE ? NW : 1][WIDE ? NND_WIDE_SCRATCH_WORDS : 1];  // 64 < k <= 128: rows merged through LDS
+    __shared__ uint64_t wide_scr[WIDE ? NW : 1][WIDE ? NND_WIDE_SCRATCH_WORDS : 1];  // 64 < k <= NND_WIDE_K: rows merged through LDS
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
     const int64_t leaf = leaf0 + blockIdx.x;
     if (leaf >= n_leaves) return;

@@ -295,13 +295,13 @@ __device__ __forceinline__ int nnd_merge_rows_q16(bool row_on, uint32_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Wide rows, 64 < k <= 128 (the reference has no bound on n_neighbors, utils.py:130-158): the row does not fit one entry
-// per lane, so it is merged through LDS -- same result as nnd_merge_row_regs (the k smallest keys of row U {candidates
+// Wide rows, 64 < k <= NND_WIDE_K = 256 (the reference has no bound on n_neighbors, utils.py:130-158; 256 is also the cap of its
+// default leaf size, rp_trees.py:2845): the row does not fit one entry per lane -- a lane holds entries lane, 64 + lane, ... --
+// so it is merged through LDS -- same result as nnd_merge_row_regs (the k smallest keys of row U {candidates
 // that beat the row's worst distance as it was at the start and are not in the row}), same return value, by the same
 // rank counting; the loops read LDS broadcasts instead of v_readlane.  `scr`: NND_WIDE_SCRATCH_WORDS 64-bit words of
 // LDS private to this wave.  The row is read from and written to global memory here (every row is merged at most once
 // per launch by its callers).  Not tuned: k > 64 builds instead of raising; the k <= 64 paths are the fast ones.
-#define NND_WIDE_K 128
 #define NND_WIDE_MAXC 256
 #define NND_WIDE_SCRATCH_WORDS (NND_WIDE_K + NND_WIDE_MAXC)
 template <int NCHUNK, typename CandFn>
@@ -311,11 +311,11 @@ __device__ __forceinline__ int nnd_merge_row_lds(uint64_t *scr, uint32_t *__rest
     const int lane = nnd_lane();
     uint64_t *rkey = scr;               // [k] the row's keys (dist_bits << 32 | idx | flag kept apart below)
     uint64_t *ckey = scr + NND_WIDE_K;  // [nv] surviving candidates' keys, compacted
-    uint32_t me[2];
-    float md[2];
+    uint32_t me[NND_WIDE_U];
+    float md[NND_WIDE_U];
     int nlist = 0;
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < NND_WIDE_U; u++) {
         const int j = lane + 64 * u;
         me[u] = j < k ? row_e[j] : NND_EMPTY_E;
         md[u] = j < k ? row_d[j] : INFINITY;
@@ -346,11 +346,13 @@ __device__ __forceinline__ int nnd_merge_row_lds(uint64_t *scr, uint32_t *__rest
     if (nv == 0) return 0;
     nnd_wave_lds_sync();
     // list entries: new position = old position + #{candidates before it}
-    int shift[2] = {0, 0};
+    int shift[NND_WIDE_U];
+#pragma unroll
+    for (int u = 0; u < NND_WIDE_U; u++) shift[u] = 0;
     for (int c = 0; c < nv; c++) {
         const uint64_t kc = ckey[c];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < NND_WIDE_U; u++) {
             const uint64_t rk = me[u] == NND_EMPTY_E ? NND_EMPTY_KEY : nnd_make_key(md[u], me[u]);
             shift[u] += kc < rk ? 1 : 0;
         }
@@ -371,7 +373,7 @@ __device__ __forceinline__ int nnd_merge_row_lds(uint64_t *scr, uint32_t *__rest
     }
     nnd_wave_lds_sync();  // every lane has read what it needs from the LDS copies (the caller may reuse them)
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < NND_WIDE_U; u++) {
         const int j = lane + 64 * u;
         if (j < nlist && shift[u] > 0 && j + shift[u] < k) {
             row_e[j + shift[u]] = me[u];

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_merge_q(uint64_t *__restrict__ pbuf, ui
     }
 }
 
-// 64 < k <= 128: the same walk over the dirty rows, one at a time, merged through LDS (merge.h nnd_merge_row_lds)
+// 64 < k <= NND_WIDE_K: the same walk over the dirty rows, one at a time, merged through LDS (merge.h nnd_merge_row_lds)
 __global__ __launch_bounds__(256) void k_merge_wide(uint64_t *__restrict__ pbuf, uint8_t *__restrict__ pdirty, int pcap, int64_t lo, int64_t n,
                                                     int k, int ks, uint32_t *__restrict__ knn_e, float *__restrict__ knn_d,
                                                     float *__restrict__ th, long long *__restrict__ counters) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_random_init(const float *__restrict__ x
     const int64_t v = lo + (int64_t)blockIdx.x * 4 + w;
     if (v >= hi) return;
     int filled = 0;
-    for (int j0 = 0; j0 < k; j0 += 64) {  // (k <= 128: up to two entries per lane)
+    for (int j0 = 0; j0 < k; j0 += 64) {  // (wide rows: several entries per lane)
         const uint32_t e = j0 + lane < k ? knn_e[v * ks + j0 + lane] : NND_EMPTY_E;
         filled += __popcll(__ballot(e != NND_EMPTY_E));
     }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_merge_graph_rows(int64_t lo, int64_t hi
     };
     if (k > NND_MAX_K) {
         __shared__ uint64_t scr[4][NND_WIDE_SCRATCH_WORDS];
-        nnd_merge_row_lds<2>(scr[w], knn_e + v * ks, knn_d + v * ks, th + v, k, k, cf);
+        nnd_merge_row_lds<NND_WIDE_U>(scr[w], knn_e + v * ks, knn_d + v * ks, th + v, k, k, cf);
     } else {
         nnd_merge_row<1>(v, k, ks, knn_e, knn_d, th, k, cf);
     }

@@ -170,10 +170,10 @@ __global__ __launch_bounds__(256) void k_diversify_csr(const float *__restrict__
 }
 
 
-// ---- rows of 65 .. 128 entries (n_neighbors up to 128: the reference has no bound, utils.py:130-158).  The same walks with
+// ---- rows of 65 .. 256 entries (n_neighbors up to NND_WIDE_K: the reference has no bound, utils.py:130-158).  The same walks with
 // the row in LDS (indices, distances / weights, factors, kept flags per wave) instead of one entry per lane: LDS
 // broadcasts take the place of v_readlane.  Same decisions as the kernels above on rows that fit both (tests).
-#define PRUNE_WIDE 128
+#define PRUNE_WIDE NND_WIDE_K
 struct prune_wide_row {
     int32_t idx[PRUNE_WIDE];
     float w[PRUNE_WIDE];
@@ -364,7 +364,7 @@ int nnd_launch_diversify_rows(nnd_ctx *ctx, int32_t *idx_dev, float *dist_dev, c
 int nnd_launch_diversify_csr(nnd_ctx *ctx, const int32_t *indptr_dev, const int32_t *indices_dev, float *data_dev,
                              int *too_long_dev, const nnd_prune_opts *o, const int32_t *degree_dev) {
     const dim3 grid((unsigned)((ctx->n + 3) / 4));
-    if (ctx->k > 64) {  // rows of up to 128 entries: the LDS variants
+    if (ctx->k > 64) {  // rows of up to PRUNE_WIDE entries: the LDS variants
         if (o->degree_aware)
             hipLaunchKernelGGL(k_diversify_csr_wide<true>, grid, dim3(256), 0, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->n, indptr_dev,
                                indices_dev, data_dev, too_long_dev, o->prune_probability, o->seed ^ 0x51ED270Bu, degree_dev, o->max_degree, o->aggressiveness);

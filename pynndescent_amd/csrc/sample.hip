@@ -190,16 +190,17 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
     if (valid && cls == 1u && my_rank < mc) knn_e[v * ks + lane] = u;
 }
 
-// 64 < k <= 128: the same selection with up to two forward edges per lane (the reference has no bound on n_neighbors).
+// 64 < k <= NND_WIDE_K (256): the same selection with up to NND_WIDE_U forward edges per lane (the reference has no bound on
+// n_neighbors).
 // Items of a class: <= k forward + rcap reverse offers; ranks by counting over the LDS copy; the rank of every forward
 // new edge goes through LDS (rank_new) to the lane that holds the edge, which clears its flag when it was sampled.
 __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict__ knn_e, int64_t n, int k, int ks, int mc,
                                                             int mcp, uint32_t it_seed, uint32_t *__restrict__ rbuf, int rcap,
                                                             int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
                                                             const uint8_t *__restrict__ active) {
-    constexpr int MAXI = 128 + 64;
+    constexpr int MAXI = NND_WIDE_K + 64;
     __shared__ uint64_t skey[4][2][MAXI];
-    __shared__ int srank[4][128];  // rank among the new offers of forward item i (class new)
+    __shared__ int srank[4][NND_WIDE_K];  // rank among the new offers of forward item i (class new)
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
     const int64_t v = own_lo + (int64_t)blockIdx.x * 4 + w;
     if (v >= own_hi) return;
@@ -208,11 +209,11 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
         return;
     }
     uint64_t(*key)[MAXI] = skey[w];
-    uint32_t e[2];
-    int item[2];  // index of my forward edge among its class's items, or -1
+    uint32_t e[NND_WIDE_U];
+    int item[NND_WIDE_U];  // index of my forward edge among its class's items, or -1
     int cnt[2] = {0, 0};
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < NND_WIDE_U; u++) {
         const int j = lane + 64 * u;
         e[u] = j < k ? knn_e[v * ks + j] : NND_EMPTY_E;
         item[u] = -1;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
 #pragma unroll
     for (int c = 0; c < 2; c++) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < NND_WIDE_U; u++) {
             const bool mine = e[u] != NND_EMPTY_E && (e[u] >> 31) == (uint32_t)c;
             const unsigned long long m = __ballot(mine);
             if (mine) {
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
     nnd_wave_lds_sync();
     // flag reset (utils.py:311-318): a forward new edge that was sampled becomes old
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < NND_WIDE_U; u++) {
         const int j = lane + 64 * u;
         if (e[u] != NND_EMPTY_E && (e[u] >> 31) == 1u && item[u] >= 0 && srank[w][item[u]] < mc) knn_e[v * ks + j] = e[u] & NND_IDX_MASK;
     }

@@ -1104,8 +1104,8 @@ static int32_t shard_build_entry(nnd_shard_t s, const float *x_local_dev, void *
                                  int32_t init_width, int init_mode, int32_t *out_idx_dev, float *out_dist_dev) {
     if (!s) { snprintf(g_serr2, sizeof(g_serr2), "nnd_shard_build: null shard"); return 1; }
     if (!x_local_dev || !out_idx_dev || !out_dist_dev) { s->set_error("nnd_shard_build: null buffer"); return 1; }
-    if (init_idx_dev && ((init_mode == 1 && s->gp.n_trees != 0) || init_width < 1 || init_width > 128)) {
-        s->set_error("nnd_shard_build_from_graph: an init graph needs a shard created with n_trees = 0 (pynndescent_.py:1059-1062) and a width in 1..128");
+    if (init_idx_dev && ((init_mode == 1 && s->gp.n_trees != 0) || init_width < 1 || init_width > NND_WIDE_K)) {
+        s->set_error("nnd_shard_build_from_graph: an init graph needs a shard created with n_trees = 0 (pynndescent_.py:1059-1062) and a width in 1..%d", NND_WIDE_K);
         return 1;
     }
     const int rc = shard_build(s, x_local_dev, x_stream, out_idx_dev, out_dist_dev, init_idx_dev, init_dist_dev, init_width, init_mode);
@@ -1156,7 +1156,7 @@ static int32_t build_multi_impl(const nnd_params *params_in, const float *x, int
         return 1;
     };
     if (!params || !x || !out_idx || !out_dist) return fail("nnd_build_multi: null argument");
-    if (init_idx && (init_width < 1 || init_width > 128)) return fail("nnd_build_multi_from_graph: init_width must be in 1..128");
+    if (init_idx && (init_width < 1 || init_width > NND_WIDE_K)) return fail("nnd_build_multi_from_graph: init_width must be in 1..256");
     if (n_devices < 1 || n_devices > NND_MAX_RANKS) return fail("nnd_build_multi: n_devices must be in 1..64");
     if (params->n < 1) return fail("nnd_build_multi: need n >= 1");
     const int G = (int64_t)n_devices <= params->n ? n_devices : (int)params->n;  // every rank owns at least one row: the first n devices build a set of n < n_devices points

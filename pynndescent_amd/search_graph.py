@@ -54,8 +54,8 @@ def search_graph_on(builder, indices, distances, n_neighbors=None, pruning_degre
     if diversify_method not in ("standard", "degree_aware"):
         raise ValueError("diversify_method must be 'standard' or 'degree_aware'")
     n, k = builder.n, builder.k
-    if k > 128:
-        raise NotImplementedError("the pruning pass (prepare / query) handles graphs of at most 128 neighbours per row (got %d)" % k)
+    if k > 256:
+        raise NotImplementedError("the pruning pass (prepare / query) handles graphs of at most 256 neighbours per row (got %d)" % k)
     n_neighbors = k if n_neighbors is None else n_neighbors
     res = builder.search_graph(indices, distances, n_neighbors, pruning_degree_multiplier, diversify_prob,
                                diversify_method == "degree_aware", degree_prune_aggressiveness, seed, on_device=on_device,
@@ -79,8 +79,8 @@ def build_search_graph(data, indices, distances, metric="euclidean", n_neighbors
     if not host_glue:
         if diversify_method not in ("standard", "degree_aware"):
             raise ValueError("diversify_method must be 'standard' or 'degree_aware'")
-        if np.shape(indices)[1] > 128:
-            raise NotImplementedError("the pruning pass (prepare / query) handles graphs of at most 128 neighbours per row (got %d)"
+        if np.shape(indices)[1] > 256:
+            raise NotImplementedError("the pruning pass (prepare / query) handles graphs of at most 256 neighbours per row (got %d)"
                                       % np.shape(indices)[1])
         x = np.ascontiguousarray(data, dtype=np.float32)
         n, d = x.shape
@@ -108,8 +108,8 @@ def _build_search_graph_host_glue(data, indices, distances, metric="euclidean", 
     ``indices``/``distances`` are ``NNDescent._neighbor_graph`` (rows ascending, squared-L2 / log2-cosine)."""
     if diversify_method not in ("standard", "degree_aware"):
         raise ValueError("diversify_method must be 'standard' or 'degree_aware'")
-    if np.shape(indices)[1] > 128:
-        raise NotImplementedError("the pruning pass (prepare / query) handles graphs of at most 128 neighbours per row (got %d)"
+    if np.shape(indices)[1] > 256:
+        raise NotImplementedError("the pruning pass (prepare / query) handles graphs of at most 256 neighbours per row (got %d)"
                                   % np.shape(indices)[1])
     aware = diversify_method == "degree_aware"
     x = np.ascontiguousarray(data, dtype=np.float32)

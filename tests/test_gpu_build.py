@@ -372,8 +372,8 @@ def test_search_graph_non_default_modes_vs_reference_fixture(tag, metric, method
 
 def test_unsupported_sizes_are_reported_up_front():
     x = clustered(500, 8, 4, 5, seed=1)
-    with pytest.raises(NotImplementedError, match="n_neighbors <= 128"):
-        NNDescent(x, n_neighbors=200)
+    with pytest.raises(NotImplementedError, match="n_neighbors <= 256"):
+        NNDescent(x, n_neighbors=300)
     with pytest.raises(NotImplementedError, match="max_candidates <= 64"):
         NNDescent(x, n_neighbors=10, max_candidates=80)
     with pytest.raises(NotImplementedError, match="manhattan"):
@@ -413,8 +413,28 @@ def test_nn_descent_function_with_reference_leaf_array(metric, dist):
     assert abs(O.recall(ti, gi2) - ro) <= 0.005
 
 
-@pytest.mark.parametrize("metric,k,n_trees", [("euclidean", 100, 4), ("cosine", 80, 3), ("euclidean", 128, 2)])
-def test_wide_rows_up_to_128_neighbours(metric, k, n_trees):
+def test_wide_rows_on_unclustered_data_converge_like_the_oracle():
+    """k = 160 on 20 000 Gaussian points in 32 dimensions, ONE tree: the start is poor (recall@k 0.08 after one iteration of the
+    reference algorithm) and a row takes far more than 64 updates on the way -- more than the 64 proposal slots of a row hold
+    per pass, so the device build may need more passes than the reference; where it stops it must be as good (0.5 %)."""
+    n, k = 20000, 160
+    x = np.random.RandomState(5).normal(0, 1, (n, 32)).astype(np.float32)
+    rows = np.arange(0, n, 13)
+    ti, _ = O.brute_force_knn(x, k, "euclidean", rows=rows, kind="fast")
+    index = NNDescent(x, "euclidean", n_neighbors=k, n_trees=1, random_state=3)
+    idx, dist = index._neighbor_graph
+    check_graph_invariants(x, "euclidean", idx, dist, tol=2e-4, name="wide-hard")
+    oi, _ = O.build_index(x, "euclidean", n_neighbors=k, n_trees=1, random_state=3, n_threads=8, kind="fast")
+    rg, ro = O.recall(ti, idx[rows]), O.recall(ti, oi[rows])
+    i3, _ = NNDescent(x, "euclidean", n_neighbors=k, n_trees=1, random_state=3, n_iters=3)._neighbor_graph
+    o3, _ = O.build_index(x, "euclidean", n_neighbors=k, n_trees=1, n_iters=3, random_state=3, n_threads=8, kind="fast")
+    print("k=160 gaussian: recall@k GPU %.4f (%d iterations) oracle %.4f; after 3 iterations GPU %.4f oracle %.4f" % (
+        rg, index._build_stats["n_iters_run"], ro, O.recall(ti, i3[rows]), O.recall(ti, o3[rows])))
+    assert rg >= ro - 0.005
+
+
+@pytest.mark.parametrize("metric,k,n_trees", [("euclidean", 100, 4), ("cosine", 80, 3), ("euclidean", 128, 2), ("euclidean", 200, 2), ("cosine", 256, 2)])
+def test_wide_rows_up_to_256_neighbours(metric, k, n_trees):
     """The reference has no bound on n_neighbors (utils.py:130-158); rows above 64 entries take the LDS-merge kernels
     (merge.h nnd_merge_row_lds): same invariants, same parity bar against the reference algorithm (oracle)."""
     n, d = 12000, 24
@@ -449,5 +469,5 @@ def test_wide_rows_up_to_128_neighbours(metric, k, n_trees):
     tq, _ = O.brute_force_knn(np.vstack([x, q]), 330, metric, rows=np.arange(n, n + 300), kind="fast")  # (the other queries are points of that set too)
     tq = np.array([[v for v in row if v < n][:10] for row in tq])
     assert O.recall(tq, qi) >= 0.9, O.recall(tq, qi)
-    with pytest.raises(NotImplementedError, match="n_neighbors <= 128"):
-        NNDescent(x, metric, n_neighbors=129)
+    with pytest.raises(NotImplementedError, match="n_neighbors <= 256"):
+        NNDescent(x, metric, n_neighbors=257)

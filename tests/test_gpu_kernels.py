@@ -230,7 +230,7 @@ def _expected_candidates(idx, fl, rng_state, it, mc, cap_new, cap_old):
     return out[:, 1], out[:, 0], recv[:, 1] <= cap_new, recv[:, 0] <= cap_old
 
 
-@pytest.mark.parametrize("n,k,mc", [(20000, 15, 15), (70000, 15, 15), (20000, 30, 30), (9000, 60, 60), (9000, 20, 40), (6000, 100, 50)])
+@pytest.mark.parametrize("n,k,mc", [(20000, 15, 15), (70000, 15, 15), (20000, 30, 30), (9000, 60, 60), (9000, 20, 40), (6000, 100, 50), (5000, 200, 60)])
 def test_sampled_candidates_are_the_exact_priority_sample(n, k, mc):
     """The bucketed reverse pass (round 5) keeps EVERY reverse offer of a bank that receives no more offers than it has
     slots, as the reference's heaps do (utils.py:277-306): the candidate lists must equal, entry for entry, the
@@ -259,8 +259,10 @@ def test_sampled_candidates_are_the_exact_priority_sample(n, k, mc):
         np.testing.assert_array_equal(old[rows], e_old[rows])
         # how many banks are exact depends on the in-degrees (mean = k) against the slots per bank: nearly all at k = 15
         # with 32 slots; at k >= 30 a good part overflows into the hashed-minimum form (order independent, not compared)
-        assert x_new.mean() > (0.97 if k <= 15 else 0.1) and x_old.mean() > (0.9 if k <= 15 else 0.1), (x_new.mean(), x_old.mean())
-        checked += int(x_new.sum())
+        # (k = 200 against 64 slots: hardly any new-class bank is exact; the old-class banks of the first passes are)
+        floor = 0.0 if k > 128 else 0.1
+        assert x_new.mean() > (0.97 if k <= 15 else floor) and x_old.mean() > (0.9 if k <= 15 else floor), (x_new.mean(), x_old.mean())
+        checked += int(x_new.sum()) + (int((x_old & act).sum()) if k > 128 else 0)
         b.descent_iter()  # (samples again from the state the call above left, joins, merges: the next state to test)
     assert checked > n
     b.close()
