@@ -907,17 +907,20 @@ static int rv_prepare(nnd_ctx *ctx, int logB, const int32_t *order, int64_t row0
     *cap_out = cap;
     const int64_t need = nb * 8 * cap;
     if (need > ctx->rv_cap_in || cap != ctx->rv_in_cap) {
+        ctx->rv_cap_in = 0;  // (a failed allocation leaves no stale capacity behind)
         if (rv_grow(ctx, &ctx->rv_in_cursor, (size_t)nb * 8 + 8) || rv_grow(ctx, &ctx->rv_in_rec, (size_t)need)) return 1;
         ctx->rv_cap_in = need;
         ctx->rv_in_cap = cap;
     }
     if (nov > ctx->rv_cap_ov) {
         const int64_t c = extra > 0 ? nov + nov / 4 : nov;  // (a shard's inbox varies from iteration to iteration: head room)
+        ctx->rv_cap_ov = 0;
         if (rv_grow(ctx, &ctx->rv_ov, (size_t)c)) return 1;
         ctx->rv_cap_ov = c;
     }
     if (order && (!ctx->rv_pos || ctx->rv_pos_gen != ctx->forest_gen || ctx->rv_pos_of != order)) {
         if (n_rows > ctx->rv_cap_pos) {
+            ctx->rv_cap_pos = 0;
             if (rv_grow(ctx, &ctx->rv_pos, (size_t)n_rows)) return 1;
             ctx->rv_cap_pos = n_rows;
         }

@@ -1015,8 +1015,16 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
             t_end(h, ts, ms_s, true);
             // (3) local join of the owned vertices
             S_CTX(nnd_zero_counters(h));
+            // (rows of more than 64 neighbours: join_blocks sub-steps as in the one-GPU build, capi.hip auto_join_blocks -- the
+            // owned rows are merged between the sub-steps, the proposals for rows owned elsewhere keep collecting in their narrow
+            // table and travel once, below)
             const int tj = t_begin(h);
-            S_CTX(nnd_launch_join(h, s->lo, s->hi));
+            const int nsub = h->p.join_blocks > 1 ? h->p.join_blocks : 1;
+            for (int b = 0; b < nsub; b++) {
+                const int64_t v0 = s->lo + (int64_t)n_own * b / nsub, v1 = s->lo + (int64_t)n_own * (b + 1) / nsub;
+                S_CTX(nnd_launch_join(h, v0, v1));
+                if (b + 1 < nsub) S_CTX(nnd_launch_merge(h));
+            }
             t_end(h, tj, ms_j, false);
             // (4) proposals for vertices owned elsewhere -> their owners' regions
             if (G > 1) {

@@ -227,7 +227,7 @@ def _global_params(n_total, dim, metric, n_neighbors, n_trees, leaf_size, max_ca
     p = _capi.NNDParams()
     p.n, p.dim, p.metric, p.n_neighbors, p.n_trees, p.leaf_size = int(n_total), int(dim), metric_code, k, int(n_trees), leaf_size
     p.max_depth, p.max_candidates, p.n_iters, p.delta = int(max_rptree_depth), mc, n_iters, float(delta)
-    p.device, p.join_blocks = int(device), 1
+    p.device, p.join_blocks = int(device), 0  # (0: the library's choice -- 1 up to 64 neighbours, sub-steps for wider rows)
     for i in range(3):
         p.rng_state[i], p.tree_rng[i] = int(rng_state[i]), int(tree_states[0][i])
     return p

@@ -154,6 +154,22 @@ def test_sharded_wide_rows_cosine_and_no_trees(n, world, k, metric, trees):
     assert abs(r_m - r_1) <= 0.005
 
 
+def test_sharded_wide_rows_on_unclustered_data_take_the_substeps_too():
+    """k = 160 on 20 000 Gaussian points (tests/test_gpu_build.py has the one-GPU form against the oracle): rows change by more
+    than their 64 proposal slots per pass while the graph is poor, so the shards cut their joins into sub-steps like the one-GPU
+    build (shard.hip step 3).  Three ranks: the same end point as one GPU, in about as many iterations."""
+    n, k = 20000, 160
+    x = np.random.RandomState(5).normal(0, 1, (n, 32)).astype(np.float32)
+    rows = np.arange(0, n, 13)
+    ti, _ = O.brute_force_knn(x, k, "euclidean", rows=rows, kind="fast")
+    idx, dist, st, info = sharded.build_multi(x, 3, devices=[0] * 3, metric="euclidean", n_neighbors=k, n_trees=3, seed=3)
+    one = NNDescent(x, "euclidean", n_neighbors=k, n_trees=1, random_state=3)
+    r_m, r_1 = O.recall(ti, idx[rows]), O.recall(ti, one._neighbor_graph[0][rows])
+    print("k=160 gaussian, 3 ranks: recall@k %.4f in %d iterations; one GPU %.4f in %d" % (r_m, info["iters"], r_1, one._build_stats["n_iters_run"]))
+    assert (idx >= 0).all() and np.all(np.diff(dist, axis=1) >= 0)
+    assert abs(r_m - r_1) <= 0.005 and info["iters"] <= one._build_stats["n_iters_run"] + 2
+
+
 def test_build_multi_and_class_api_two_ranks_on_one_gpu():
     """The drop-in boundary reaches the sharded build: nnd_build_multi (host arrays in / out, one host thread per rank
     inside the library) and NNDescent(..., n_devices=2).  devices=[0, 0]: both ranks on this box's one GPU."""
