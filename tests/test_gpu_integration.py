@@ -83,7 +83,7 @@ def test_integration_md_stub_init_graph_and_error():
     idx, _ = gpu_nn_descent(x, 10, rng_state, tree_states, 10, "euclidean", 12, 0.001, 4, 60, 200, init_graph=noisy)
     assert O.recall(ti, idx) > 0.95
     with pytest.raises(RuntimeError, match="n_neighbors"):  # no silent fallback: the library's message surfaces
-        gpu_nn_descent(x, 200, rng_state, tree_states, 60, "euclidean", 12, 0.001, 4, 60, 200)
+        gpu_nn_descent(x, 300, rng_state, tree_states, 60, "euclidean", 12, 0.001, 4, 60, 200)
 
 
 def test_bench_two_processes_sharing_one_gpu():
