@@ -402,7 +402,7 @@ int32_t nnd_hub_tree_fetch(nnd_handle_t h, float *hyperplanes, float *offsets, i
  * closure of _init_search_function 1793-1883, select_side / search_flat_tree rp_trees.py:2662-2741, deheap_sort) ----
  * The searcher owns device copies of what the reference's closure captures: the (reordered) raw data, the CSR search
  * graph, the FlatTree of the search forest's first tree (n_nodes = 0: no tree, random starts only), min_distance and
- * n_neighbors.  All pointers are HOST pointers.  One wave per query; k <= 128 (the query's k, not the index's; above 64 the result list is two entries per lane).  Output rows ascending in the
+ * n_neighbors.  All pointers are HOST pointers.  One wave per query; k <= 256 (the query's k, not the index's; above 64 the result list is two or four entries per lane).  Output rows ascending in the
  * alternative distance space, vertex numbers in the searcher's (reordered) numbering; unfilled slots (-1, +inf). */
 typedef struct nnd_searcher_s *nnd_searcher_t;
 int32_t nnd_searcher_create(nnd_searcher_t *out, int32_t device, int64_t n, int32_t dim, int32_t metric, const float *data,

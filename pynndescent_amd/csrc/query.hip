@@ -94,8 +94,8 @@ __device__ __forceinline__ float q_quad_dist(const float *__restrict__ x, const 
     return r > 1.0f ? log2f(r) : 0.0f;
 }
 
-// K2: 64 < k <= 128 -- the result list is two entries per lane (positions lane and 64 + lane)
-template <bool BIG, bool K2>
+// KU: result entries per lane -- entry u of lane j is position 64 u + j of the list (k <= 64 KU: 1, 2 or 4)
+template <bool BIG, int KU>
 __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, const float *__restrict__ xn2, int dp, int d, int metric,
                                                int64_t n, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                const float *__restrict__ hyper, const float *__restrict__ offsets,
@@ -160,15 +160,20 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
     }
     nnd_wave_lds_sync();
 
-    float rd = INFINITY;   // result list: lane j < k holds the j-th best
-    int32_t rv = -1;
-    float rd1 = INFINITY;  // K2: lane j holds the (64 + j)-th best
-    int32_t rv1 = -1;
+    float rd[KU];    // result list, ascending: entry u of lane j holds the (64 u + j)-th best
+    int32_t rv[KU];
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+        rd[u] = INFINITY;
+        rv[u] = -1;
+    }
     int fn = 0;            // frontier size (wave-uniform)
     float bound = INFINITY;
     auto worst = [&]() -> float {
-        if (K2) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rd1), k - 65));
-        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rd), k - 1));
+        float w = rd[0];
+#pragma unroll
+        for (int u = 1; u < KU; u++) w = ((k - 1) >> 6) == u ? rd[u] : w;  // (wave-uniform)
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), (k - 1) & 63));
     };
     auto update_bound = [&]() {
         const float wd = worst();
@@ -177,30 +182,31 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
     // simple_heap_push (utils.py:352-406) on the sorted list: enters iff it beats the worst entry
     auto result_push = [&](float dc, int32_t vc) {
         if (!(dc < worst())) return;
-        if (K2) {
-            const int p0 = __popcll(__ballot(rd <= dc)), p1 = __popcll(__ballot(64 + lane < k && rd1 <= dc));
-            const float dn = __shfl_up(rd, 1, 64), dn1 = __shfl_up(rd1, 1, 64);
-            const int32_t vn = __shfl_up(rv, 1, 64), vn1 = __shfl_up(rv1, 1, 64);
-            const float cd0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rd), 63));  // falls from the first half
-            const int32_t cv0 = __builtin_amdgcn_readlane(rv, 63);
-            if (p0 < 64) {  // lands in the first half: the whole second half moves up by one
-                if (lane > p0) { rd = dn; rv = vn; }
-                if (lane == p0) { rd = dc; rv = vc; }
-                if (64 + lane < k) {
-                    rd1 = lane == 0 ? cd0 : dn1;
-                    rv1 = lane == 0 ? cv0 : vn1;
+        int pos = 0;  // entries that stay in front of the new one
+        float cd[KU];  // what falls from the end of every 64-entry segment when the entries behind `pos` move up by one
+        int32_t cv[KU];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            pos += __popcll(__ballot(64 * u + lane < k && rd[u] <= dc));
+            cd[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rd[u]), 63));
+            cv[u] = __builtin_amdgcn_readlane(rv[u], 63);
+        }
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int p = pos - 64 * u;  // where the new entry lands, seen from this segment (wave-uniform)
+            if (p >= 64) continue;       // behind this segment: nothing moves here
+            const float dn = __shfl_up(rd[u], 1, 64);
+            const int32_t vn = __shfl_up(rv[u], 1, 64);
+            if (p < 0) {  // in an earlier segment: the whole segment moves up, its first lane takes what fell from the one before
+                if (64 * u + lane < k) {
+                    rd[u] = lane == 0 ? cd[u > 0 ? u - 1 : 0] : dn;
+                    rv[u] = lane == 0 ? cv[u > 0 ? u - 1 : 0] : vn;
                 }
             } else {
-                if (lane > p1 && 64 + lane < k) { rd1 = dn1; rv1 = vn1; }
-                if (lane == p1) { rd1 = dc; rv1 = vc; }
+                if (lane > p && 64 * u + lane < k) { rd[u] = dn; rv[u] = vn; }
+                if (lane == p) { rd[u] = dc; rv[u] = vc; }
             }
-            return;
         }
-        const int pos = __popcll(__ballot(lane < k && rd <= dc));
-        const float dn = __shfl_up(rd, 1, 64);
-        const int32_t vn = __shfl_up(rv, 1, 64);
-        if (lane > pos && lane < k) { rd = dn; rv = vn; }
-        if (lane == pos) { rd = dc; rv = vc; }
     };
     auto frontier_push = [&](float dc, int32_t vc) {
         if (fn == FCAP) {  // drop what can never be expanded any more (the bound only shrinks)
@@ -260,8 +266,10 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
         nnd_wave_lds_sync();
     };
     auto in_result = [&](int32_t vc) -> bool {
-        if (K2) return __ballot(rv == vc || (64 + lane < k && rv1 == vc)) != 0ull;
-        return __ballot(lane < k && rv == vc) != 0ull;
+        bool hit = false;
+#pragma unroll
+        for (int u = 0; u < KU; u++) hit = hit || (64 * u + lane < k && rv[u] == vc);
+        return __ballot(hit) != 0ull;
     };
 
     if (!dead) {
@@ -379,14 +387,12 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ x, cons
         }
     }
     if (!BIG && lane == 0) overflow[qi] = spilled ? 1 : 0;  // the host re-runs flagged queries on the big tier
-    if (lane < k) {  // ascending, like deheap_sort; unfilled slots (-1, inf)
-        out_idx[qi * k + lane] = rv;
-        out_dist[qi * k + lane] = rd;
-    }
-    if (K2 && 64 + lane < k) {
-        out_idx[qi * k + 64 + lane] = rv1;
-        out_dist[qi * k + 64 + lane] = rd1;
-    }
+#pragma unroll
+    for (int u = 0; u < KU; u++)
+        if (64 * u + lane < k) {  // ascending, like deheap_sort; unfilled slots (-1, inf)
+            out_idx[qi * k + 64 * u + lane] = rv[u];
+            out_dist[qi * k + 64 * u + lane] = rd[u];
+        }
 }
 
 // squared norms of the padded rows (alternative_cosine recomputes them per call, distances.py:617-620)
@@ -510,10 +516,10 @@ extern "C" int32_t nnd_searcher_set_tier(nnd_searcher_t s, int32_t tier) {
 extern "C" int32_t nnd_searcher_query(nnd_searcher_t s, const float *queries, int64_t nq, int32_t k, float epsilon, int32_t *out_idx,
                                       float *out_dist) {
     if (!s) { snprintf(g_serr, sizeof(g_serr), "nnd_searcher_query: null searcher"); return 1; }
-    if (k < 1 || k > 128) { s->set_error("nnd_searcher_query: k must be in 1..128 (got %d)", k); return 1; }
-    // (64 < k <= 128, round 5: the result list as two entries per lane; the reference takes any k, pynndescent_.py:2275-2379)
-    auto kq_lds = k > 64 ? k_query<false, true> : k_query<false, false>;
-    auto kq_big = k > 64 ? k_query<true, true> : k_query<true, false>;
+    if (k < 1 || k > 256) { s->set_error("nnd_searcher_query: k must be in 1..256 (got %d)", k); return 1; }
+    // (k > 64, round 5: the result list as two or four entries per lane; the reference takes any k, pynndescent_.py:2275-2379)
+    auto kq_lds = k > 128 ? k_query<false, 4> : (k > 64 ? k_query<false, 2> : k_query<false, 1>);
+    auto kq_big = k > 128 ? k_query<true, 4> : (k > 64 ? k_query<true, 2> : k_query<true, 1>);
     if (nq <= 0) return 0;
     if (nq >= (int64_t)0x7FFFFFF0) { s->set_error("nnd_searcher_query: too many queries in one call"); return 1; }
     S_HIP(hipSetDevice(s->device));

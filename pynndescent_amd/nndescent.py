@@ -10,7 +10,7 @@ if the HIP library or a gfx950 device is missing, construction raises.
 Also on the GPU: ``update`` (warm start, pynndescent_.py:2381-2553), ``build_search_graph`` (the pruning
 pass of ``_init_search_graph``, all diversify methods), ``prepare`` (hub search tree + reordering) and
 ``query``.  Out of scope: sparse input, metrics other than euclidean / l2 / cosine, ``n_neighbors`` above 256 or
-``max_candidates`` above 64 (``query``: more than 128 results per query).  Those raise ``NotImplementedError`` naming the reference entry point to use
+``max_candidates`` above 64 (``query``: more than 256 results per query).  Those raise ``NotImplementedError`` naming the reference entry point to use
 instead; ``pynndescent_amd.make_index`` hands such inputs to ``pynndescent.NNDescent`` when it is importable.
 """
 import time
@@ -474,8 +474,8 @@ class NNDescent:
     def query(self, query_data, k=10, epsilon=0.1, proxy_beam_size=4):
         """``NNDescent.query`` (pynndescent_.py:2275-2379) on the GPU: one wave per query (csrc/query.hip).
         Returns (indices (n_queries, k) in the ORIGINAL numbering, true distances (n_queries, k))."""
-        if k > 128:
-            raise NotImplementedError("pynndescent_amd answers queries with k <= 128; use index.to_reference() for k = %d" % k)
+        if k > 256:
+            raise NotImplementedError("pynndescent_amd answers queries with k <= 256; use index.to_reference() for k = %d" % k)
         if not hasattr(self, "_search_graph") or getattr(self, "_searcher", None) is None:
             self.prepare()
         query_data = np.asarray(query_data).astype(np.float32, order="C")  # pynndescent_.py:2316

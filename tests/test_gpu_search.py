@@ -161,8 +161,8 @@ def test_query_without_tree_and_errors():
     qi, qd = index.query(x[:100] + 0.01, k=5)
     ti, _ = O.brute_force_knn(x, 5, "euclidean", rows=np.arange(100))
     assert O.recall(ti, qi) > 0.8  # random starts only (pynndescent_.py:1834-1848)
-    with pytest.raises(NotImplementedError, match="k <= 128"):
-        index.query(x[:3], k=200)
+    with pytest.raises(NotImplementedError, match="k <= 256"):
+        index.query(x[:3], k=300)
     with pytest.raises(ValueError, match="shape"):
         index.query(x[:3, :5], k=5)
 
@@ -196,9 +196,9 @@ def test_query_large_k_and_epsilon_two_tiers():
     assert index._searcher.last_spilled() == 0
 
 
-@pytest.mark.parametrize("metric,k", [("euclidean", 100), ("cosine", 128), ("euclidean", 65)])
+@pytest.mark.parametrize("metric,k", [("euclidean", 100), ("cosine", 128), ("euclidean", 65), ("euclidean", 129), ("cosine", 200), ("euclidean", 256)])
 def test_query_more_than_64_results(metric, k):
-    """Round 5: 64 < k <= 128 (the reference takes any k, pynndescent_.py:2275-2379): the result list is two entries per lane.
+    """Round 5: 64 < k <= 256 (the reference takes any k, pynndescent_.py:2275-2379): the result list is two or four entries per lane.
     Rows ascending, ids unique, distances exact for the returned ids, the first 64 entries consistent with a k = 64 query of the
     same index (same search, a longer list can only see MORE), recall against brute force as at k = 64."""
     x = clustered(40_000, 24, 8, 40, seed=21, nonneg=(metric == "euclidean"))
@@ -224,4 +224,4 @@ def test_query_more_than_64_results(metric, k):
         true = 1.0 - (a[:, None, :] * b).sum(-1) / (np.linalg.norm(a, axis=1)[:, None] * np.linalg.norm(b, axis=2))
     np.testing.assert_allclose(qd, true, rtol=2e-4, atol=2e-6)
     with pytest.raises(NotImplementedError):
-        index.query(q[:2], k=129)
+        index.query(q[:2], k=257)
