@@ -56,7 +56,7 @@ typedef struct nnd_params {
     int32_t n_trees;        /* 0 = no RP-forest initialisation */
     int32_t leaf_size;      /* > 0 */
     int32_t max_depth;      /* max_rptree_depth (pynndescent_.py:1000) */
-    int32_t max_candidates; /* 1..64 */
+    int32_t max_candidates; /* 1..128 (above 64: five passes of the 64-slot join over blocks of the candidate lists) */
     int32_t n_iters;
     float delta;            /* stop when c <= delta*k*n (pynndescent_.py:317) */
     int64_t rng_state[3];   /* NNDescent.rng_state (pynndescent_.py:1105-1107) */

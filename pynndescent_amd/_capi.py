@@ -382,10 +382,12 @@ class Builder:
         self._check(self.lib.nnd_synchronize(self._h))
 
     # -- introspection --------------------------------------------------------------------------
-    def stats(self):
+    def stats(self, raw=False):
+        """The handle's statistics block; ``raw``: the ctypes structure itself (per-iteration arrays beyond ``n_iters_run`` too:
+        ``descent_join`` leaves the counters of a join that no finished iteration owns yet at index ``n_iters_run``)."""
         s = NNDStats()
         self._check(self.lib.nnd_get_stats(self._h, C.byref(s)))
-        return s.as_dict()
+        return s if raw else s.as_dict()
 
     def graph(self):
         idx = np.empty((self.n, self.k), np.int32)

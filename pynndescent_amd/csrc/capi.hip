@@ -125,7 +125,7 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
     if (p->n < 1 || p->dim < 1) { gerr("nnd_create: need n >= 1 and dim >= 1 (got n=%lld dim=%d)", (long long)p->n, p->dim); return 1; }
     if (p->metric != NND_METRIC_SQEUCLIDEAN && p->metric != NND_METRIC_ALT_COSINE) { gerr("nnd_create: unknown metric %d", p->metric); return 1; }
     if (p->n_neighbors < 1 || p->n_neighbors > NND_WIDE_K) { gerr("nnd_create: n_neighbors must be in 1..%d (got %d)", NND_WIDE_K, p->n_neighbors); return 1; }
-    if (p->max_candidates < 1 || p->max_candidates > 64) { gerr("nnd_create: max_candidates must be in 1..64 (got %d)", p->max_candidates); return 1; }
+    if (p->max_candidates < 1 || p->max_candidates > 128) { gerr("nnd_create: max_candidates must be in 1..128 (got %d)", p->max_candidates); return 1; }
     if (p->n_trees < 0 || p->n_trees > 4096 || p->leaf_size < 1) { gerr("nnd_create: bad n_trees (0..4096) / leaf_size"); return 1; }
     if (p->n >= (int64_t)0x7FFFFFF0) { gerr("nnd_create: n too large for int32 ids"); return 1; }
     if (p->n_trees > 0 && (int64_t)p->n_trees * p->n >= (int64_t)0x7FFFFFF0) {
@@ -171,11 +171,11 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
     ctx->k = p->n_neighbors;
     ctx->ks = (p->n_neighbors + 15) & ~15;
     ctx->mc = p->max_candidates;
-    ctx->mcp = p->max_candidates <= 16 ? 16 : (p->max_candidates <= 32 ? 32 : 64);
+    ctx->mcp = p->max_candidates <= 16 ? 16 : (p->max_candidates <= 32 ? 32 : (p->max_candidates <= 64 ? 64 : 128));  // (128: the blocked passes of join.hip)
     if (ctx->ks > 64 && ctx->mcp < 32) ctx->mcp = 32;  // wide rows: the join that reads neighbour lists from global memory (join.hip k_local_join_w)
     // reverse-offer slots per (vertex, class): at least max_candidates rounded up to a power of two, so that a vertex
     // can fill its list from reverse offers alone, as the reference's max_candidates-deep heaps can (utils.py:277-306)
-    ctx->rcap = p->max_candidates <= 32 ? 32 : 64;
+    ctx->rcap = p->max_candidates <= 32 ? 32 : (p->max_candidates <= 64 ? 64 : 128);  // (128: hashed slots, the bucketed pass stops at 64)
     if (const char *rc_env = nnd_knob("NND_RCAP")) {  // experiments: reverse-offer slots per (vertex, class), a power of two
         const int r = atoi(rc_env);
         if (r == 16 || r == 32 || r == 64) ctx->rcap = r;
@@ -925,6 +925,14 @@ extern "C" int32_t nnd_descent_join(nnd_handle_t ctx) {
     const int t_ = t_begin(ctx);
     if (nnd_launch_join(ctx, ctx->own_lo, ctx->own_hi)) return 1;
     t_end(ctx, t_, ctx->iter < 64 ? &ctx->stats.ms_join[ctx->iter] : &sink, false);
+    if (nnd_read_counters(ctx)) return 1;  // (a test / profiling entry point: the join's counters are in the stats when it returns)
+    t_flush(ctx);
+    if (ctx->iter < 64) {
+        ctx->stats.join_pairs[ctx->iter] = ctx->h_counters[CNT_PAIRS];
+        ctx->stats.join_rows[ctx->iter] = ctx->h_counters[CNT_ROWS];
+        ctx->stats.join_active[ctx->iter] = ctx->h_counters[CNT_ACTIVE];
+        ctx->stats.proposals[ctx->iter] = ctx->h_counters[CNT_PROPOSALS];
+    }
     return 0;
 }
 

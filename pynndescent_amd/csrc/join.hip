@@ -453,7 +453,11 @@ static int launch_join16_ks(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
 #ifndef NND_JW_DCW
 #define NND_JW_DCW 32
 #endif
-template <int MCP, int DC, bool SHARD>
+// BLOCKED (max_candidates 65..128, candidate lists of [new(128) | old(128)] slots): the MCP = 64 kernel run over 64-slot blocks of
+// the lists -- `new` rows from slots [new_off, new_off + 64), `old` rows from [old_off, old_off + 64) of a vertex's cstride slots;
+// SKIP_TRI leaves the new x new triangle out (the passes that meet a `new` block a second time, and the pass whose "old" block is
+// the second block of new candidates: every pair of the reference's join exactly once, pynndescent_.py:228-258).
+template <int MCP, int DC, bool SHARD, bool BLOCKED = false, bool SKIP_TRI = false>
 __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_join_w(const float *__restrict__ xp, int dp,
                                                                        const float *__restrict__ nrm, int metric,
                                                                        const int32_t *__restrict__ cand,
@@ -463,7 +467,9 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
                                                                        const float *__restrict__ th, uint64_t *__restrict__ pbuf,
                                                                        uint8_t *__restrict__ pdirty, int pcap, uint32_t slot_seed,
                                                                        long long *__restrict__ counters, int64_t own_lo, int64_t own_hi,
-                                                                       uint64_t *__restrict__ pbuf_r, int pcap_r, int64_t rt_lo, int64_t rt_hi) {
+                                                                       uint64_t *__restrict__ pbuf_r, int pcap_r, int64_t rt_lo, int64_t rt_hi,
+                                                                       int cstride, int new_off, int old_off) {
+    static_assert(!BLOCKED || MCP == 64, "the blocked passes run the 64-slot kernel");
     constexpr int NA = MCP / 16, NB = 2 * NA, RV = 2 * MCP;
     constexpr int NT = DC / 16;                       // 16-byte chunks per lane, row and K block
     constexpr int RPL = RV / 64;                      // candidate slots per lane (1 or 2)
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
         const int64_t v = order ? (int64_t)order[v_begin + gg] : v_begin + gg;
 #pragma unroll
         for (int u = 0; u < RPL; u++) {
-            const int cc = cand[v * RV + lane + 64 * u];
+            const int cc = BLOCKED ? cand[v * cstride + (u == 0 ? new_off : old_off) + lane] : cand[v * RV + lane + 64 * u];
             c[u] = ok ? cc : -1;
         }
     };
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
                 for (int a = 0; a < NA; a++) {
                     if (!tile_live(a, nn, no)) continue;
 #pragma unroll
-                    for (int b = a; b < NB; b++) {  // new x new from the diagonal tile up, then new x old
+                    for (int b = SKIP_TRI ? NA : a; b < NB; b++) {  // new x new from the diagonal tile up, then new x old
                         if (!tile_live(b, nn, no)) continue;
                         if (c0 == 0) tot_tiles++;  // wave-uniform
 #pragma unroll
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
                     pth4[r] = cth[16 * a + 4 * gq + r];
                 }
 #pragma unroll
-                for (int b = a; b < NB; b++) {
+                for (int b = SKIP_TRI ? NA : a; b < NB; b++) {
                     if (!tile_live(b, nn, no)) continue;
                     const int jj = 16 * b + r16;  // index inside [new | old]
                     const int qid = cid[jj];
@@ -735,12 +741,12 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
     }
 }
 
-template <int MCP, int DC, bool SHARD>
-static int launch_join_w_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
+template <int MCP, int DC, bool SHARD, bool BLOCKED = false, bool SKIP_TRI = false>
+static int launch_join_w_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end, int cstride = 0, int new_off = 0, int old_off = 0) {
     constexpr int RV = 2 * MCP;
     constexpr int WAVE_BYTES = 512 * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + 8;
     size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
-    auto kern = k_local_join_w<MCP, DC, SHARD>;
+    auto kern = k_local_join_w<MCP, DC, SHARD, BLOCKED, SKIP_TRI>;
     // function attributes and occupancy are per DEVICE: cached per device ordinal, not per process
     static int wg_per_cu_dev[64] = {0}, n_cu_dev[64] = {0};
     int &wg_per_cu = wg_per_cu_dev[ctx->p.device & 63], &n_cu = n_cu_dev[ctx->p.device & 63];
@@ -763,7 +769,8 @@ static int launch_join_w_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     const int32_t *order = join_order(ctx, v_begin, v_end);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, ctx->xp, ctx->dp, ctx->nrm, ctx->p.metric, ctx->cand,
                        order, v_begin, v_end, ctx->k, ctx->ks, ctx->knn_e, ctx->th, ctx->pbuf, ctx->pdirty,
-                       ctx->pcap, slot_seed, ctx->counters, nnd_list_lo(ctx), nnd_list_hi(ctx), ctx->pbuf_r, ctx->pcap_r, ctx->own_lo, ctx->own_hi);
+                       ctx->pcap, slot_seed, ctx->counters, nnd_list_lo(ctx), nnd_list_hi(ctx), ctx->pbuf_r, ctx->pcap_r, ctx->own_lo, ctx->own_hi,
+                       cstride, new_off, old_off);
     NND_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -771,6 +778,18 @@ static int launch_join_w_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
 template <int MCP, int DC>
 static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
     return ctx->pbuf_r ? launch_join_w_t<MCP, DC, true>(ctx, v_begin, v_end) : launch_join_w_t<MCP, DC, false>(ctx, v_begin, v_end);
+}
+
+// max_candidates 65..128: candidate lists [newA(64) newB(64) | oldA(64) oldB(64)] (filled from the front: the B blocks are empty
+// unless a class has more than 64 candidates, and a pass whose `new` block is empty does nothing).  Five passes of the 64-slot
+// kernel cover every pair once: A x A + A x oldA, A x oldB, B x B + B x oldA, B x oldB, A x B.
+template <bool SHARD>
+static int launch_join_blocked(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
+    if (launch_join_w_t<64, 32, SHARD, true, false>(ctx, v_begin, v_end, 256, 0, 128)) return 1;
+    if (launch_join_w_t<64, 32, SHARD, true, true>(ctx, v_begin, v_end, 256, 0, 192)) return 1;
+    if (launch_join_w_t<64, 32, SHARD, true, false>(ctx, v_begin, v_end, 256, 64, 128)) return 1;
+    if (launch_join_w_t<64, 32, SHARD, true, true>(ctx, v_begin, v_end, 256, 64, 192)) return 1;
+    return launch_join_w_t<64, 32, SHARD, true, true>(ctx, v_begin, v_end, 256, 0, 64);
 }
 
 int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
@@ -783,6 +802,7 @@ int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
         case 16: return wide ? launch_join16_ks<NND_J16_DCW>(ctx, v_begin, v_end) : launch_join16_ks<32>(ctx, v_begin, v_end);
         case 32: return wide ? launch_join_w<32, NND_JW_DCW>(ctx, v_begin, v_end) : launch_join_w<32, 32>(ctx, v_begin, v_end);
         case 64: return launch_join_w<64, 32>(ctx, v_begin, v_end);
+        case 128: return ctx->pbuf_r ? launch_join_blocked<true>(ctx, v_begin, v_end) : launch_join_blocked<false>(ctx, v_begin, v_end);
     }
     ctx->set_error("unsupported padded max_candidates %d", ctx->mcp);
     return 1;

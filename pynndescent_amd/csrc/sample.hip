@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
                                                             int mcp, uint32_t it_seed, uint32_t *__restrict__ rbuf, int rcap,
                                                             int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
                                                             const uint8_t *__restrict__ active) {
-    constexpr int MAXI = NND_WIDE_K + 64;
+    constexpr int MAXI = NND_WIDE_K + 128;  // k forward edges + rcap <= 128 reverse offers per class
     __shared__ uint64_t skey[4][2][MAXI];
     __shared__ int srank[4][NND_WIDE_K];  // rank among the new offers of forward item i (class new)
     const int lane = nnd_lane(), w = threadIdx.x >> 6;
@@ -867,7 +867,7 @@ static void launch_reverse_pass(nnd_ctx *ctx, int pass, uint32_t it_seed) {
 static uint32_t sample_seed(const nnd_ctx *ctx) { return nnd_hash2(ctx->seed ^ 0x9E3779B9u, (uint32_t)ctx->iter + 1u); }
 
 static void launch_select(nnd_ctx *ctx, uint32_t it_seed, bool wide) {
-    if (ctx->k > 64) {
+    if (ctx->k > 64 || ctx->mc > 64) {  // rows, or candidate lists, of more than one entry per lane
         hipLaunchKernelGGL(k_sample_select_wide, dim3((unsigned)((ctx->own_hi - ctx->own_lo + 3) / 4)), dim3(256), 0, ctx->stream,
                            ctx->knn_e, ctx->n, ctx->k, ctx->ks, ctx->mc, ctx->mcp, it_seed, ctx->rbuf, ctx->rcap, ctx->cand, ctx->own_lo,
                            ctx->own_hi, ctx->active);

@@ -10,7 +10,7 @@ if the HIP library or a gfx950 device is missing, construction raises.
 Also on the GPU: ``update`` (warm start, pynndescent_.py:2381-2553), ``build_search_graph`` (the pruning
 pass of ``_init_search_graph``, all diversify methods), ``prepare`` (hub search tree + reordering) and
 ``query``.  Out of scope: sparse input, metrics other than euclidean / l2 / cosine, ``n_neighbors`` above 256 or
-``max_candidates`` above 64 (``query``: more than 256 results per query).  Those raise ``NotImplementedError`` naming the reference entry point to use
+``max_candidates`` above 128 (``query``: more than 256 results per query).  Those raise ``NotImplementedError`` naming the reference entry point to use
 instead; ``pynndescent_amd.make_index`` hands such inputs to ``pynndescent.NNDescent`` when it is importable.
 """
 import time
@@ -705,11 +705,11 @@ def _raise_if_nonfinite(builder, data):
 
 def _check_supported_sizes(n_neighbors, max_candidates, init_graph):
     """The GPU k-lists hold at most 256 entries (four per lane of a wave; rows above 64 take the LDS-merge kernels) and the
-    candidate lists at most 64; the reference has no such bounds (pynndescent_.py:976-982), so the limits are reported up
+    candidate lists at most 128 (above 64: five passes of the 64-slot join over blocks of the lists); the reference has no such bounds (pynndescent_.py:976-982), so the limits are reported up
     front and by name."""
-    if int(n_neighbors) > 256 or (max_candidates is not None and int(max_candidates) > 64):
+    if int(n_neighbors) > 256 or (max_candidates is not None and int(max_candidates) > 128):
         raise NotImplementedError(
-            "pynndescent_amd supports n_neighbors <= 256 and max_candidates <= 64 (got n_neighbors=%s, max_candidates=%s); "
+            "pynndescent_amd supports n_neighbors <= 256 and max_candidates <= 128 (got n_neighbors=%s, max_candidates=%s); "
             "use pynndescent.NNDescent (or pynndescent_amd.make_index) for wider graphs" % (n_neighbors, max_candidates))
     if init_graph is not None and np.ndim(init_graph) == 2 and np.shape(init_graph)[1] > 256:
         raise NotImplementedError("pynndescent_amd supports init_graph with at most 256 columns (got %d); use "

@@ -326,9 +326,10 @@ def test_update_errors_and_plain_refresh():
     assert index.neighbor_graph[0].shape == (650, 8)
 
 
-@pytest.mark.parametrize("k,mc", [(40, None), (64, None), (20, 50)])
+@pytest.mark.parametrize("k,mc", [(40, None), (64, None), (20, 50), (40, 100), (100, 128)])
 def test_wide_candidate_lists_against_oracle(k, mc):
-    """max_candidates 33..64 (k_local_join_w<64,...>): recall parity with the CPU oracle on the same inputs."""
+    """max_candidates 33..64 (k_local_join_w<64,...>) and 65..128 (the same kernel over blocks of the lists): recall parity with
+    the CPU oracle on the same inputs."""
     x = clustered(6000, 24, 8, 30, seed=9)
     idx, _ = NNDescent(x, "euclidean", n_neighbors=k, max_candidates=mc, random_state=7)._neighbor_graph
     oidx, _ = O.build_index(x, "euclidean", n_neighbors=k, max_candidates=mc, random_state=7, n_threads=8, kind="fast")
@@ -374,8 +375,8 @@ def test_unsupported_sizes_are_reported_up_front():
     x = clustered(500, 8, 4, 5, seed=1)
     with pytest.raises(NotImplementedError, match="n_neighbors <= 256"):
         NNDescent(x, n_neighbors=300)
-    with pytest.raises(NotImplementedError, match="max_candidates <= 64"):
-        NNDescent(x, n_neighbors=10, max_candidates=80)
+    with pytest.raises(NotImplementedError, match="max_candidates <= 128"):
+        NNDescent(x, n_neighbors=10, max_candidates=200)
     with pytest.raises(NotImplementedError, match="manhattan"):
         NNDescent(x, metric="manhattan")
 
@@ -411,6 +412,24 @@ def test_nn_descent_function_with_reference_leaf_array(metric, dist):
     hi, hd, hf = O.init_rp_tree(x, k, metric, la)
     gi2, _ = pynndescent_amd.nn_descent(x, k, rng_state, max_candidates=k, dist=dist, n_iters=n_iters, init_graph=(hi, hd, hf))
     assert abs(O.recall(ti, gi2) - ro) <= 0.005
+
+
+def test_more_than_64_candidates_progress_like_the_oracle():
+    """max_candidates = 128 on 20 000 Gaussian points, k = 80, one tree, THREE iterations: where a build stands then depends on
+    how many pairs an iteration evaluates (reference algorithm: recall@80 0.63-0.73 with 60 candidates, 0.93-0.97 with 128,
+    depending on the seed) -- a join that lost a block of the candidate lists would fall back towards the 60-candidate figure.
+    (tests/test_gpu_kernels.py counts the pairs exactly.)"""
+    n, k = 20000, 80
+    x = np.random.RandomState(7).normal(0, 1, (n, 32)).astype(np.float32)
+    rows = np.arange(0, n, 13)
+    ti, _ = O.brute_force_knn(x, k, "euclidean", rows=rows, kind="fast")
+    rec = {}
+    for mc in (60, 128):
+        gi, _ = NNDescent(x, "euclidean", n_neighbors=k, n_trees=1, max_candidates=mc, n_iters=3, random_state=3)._neighbor_graph
+        oi, _ = O.build_index(x, "euclidean", n_neighbors=k, n_trees=1, max_candidates=mc, n_iters=3, random_state=3, n_threads=8, kind="fast")
+        rec[mc] = (O.recall(ti, gi[rows]), O.recall(ti, oi[rows]))
+        print("max_candidates %d, 3 iterations: recall@%d GPU %.4f oracle %.4f" % (mc, k, rec[mc][0], rec[mc][1]))
+    assert rec[128][0] >= rec[128][1] - 0.08 and rec[128][0] >= rec[60][0] + 0.1
 
 
 def test_wide_rows_on_unclustered_data_converge_like_the_oracle():

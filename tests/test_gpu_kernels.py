@@ -304,6 +304,32 @@ def test_sampling_with_hubs_uses_the_overflow_list_and_stays_exact_and_reproduci
     np.testing.assert_array_equal(runs[0][0], runs[1][0])
 
 
+@pytest.mark.parametrize("k,mc", [(15, 15), (30, 30), (40, 50), (70, 65), (40, 100), (100, 128)])
+def test_join_evaluates_every_candidate_pair_once(k, mc):
+    """The pair set of the local join (pynndescent_.py:228-258): every new candidate against the new candidates from itself on
+    (the kernels count the self pair) and against every old candidate.  The join's pair counter must equal that number computed
+    from the candidate lists -- in particular for max_candidates > 64, where five passes of the 64-slot kernel walk blocks of
+    the lists (join.hip launch_join_blocked): no block pair left out, none taken twice."""
+    x = clustered(5000, 24, 6, 30, seed=31)
+    b = make_builder(x, "euclidean", k=k, n_trees=2, mc=mc)
+    b.make_forest()
+    b.init_from_leaves()
+    b.init_random()
+    b.descent_iter()  # a mix of new and old entries
+    b.descent_sample()
+    new, old = b.candidates()
+    b.descent_join()
+    st = b.stats(raw=True)
+    nn, no = (new >= 0).sum(1).astype(np.int64), (old >= 0).sum(1).astype(np.int64)
+    expect = int((nn * (nn + 1) // 2 + nn * no)[nn > 0].sum())
+    got = int(st.join_pairs[int(st.n_iters_run)])
+    print("k=%d mc=%d: %d pairs, longest lists %d new / %d old" % (k, mc, got, nn.max(), no.max()))
+    assert got == expect, (got, expect)
+    if mc > 64:
+        assert max(nn.max(), no.max()) > 64  # the second blocks are in use
+    b.close()
+
+
 @pytest.mark.parametrize("metric,k", [("euclidean", 15), ("cosine", 15), ("euclidean", 30), ("euclidean", 50)])
 def test_descent_iterations_keep_invariants_and_improve(metric, k):
     x = clustered(4000, 24, 6, 30, seed=13)

@@ -170,6 +170,22 @@ def test_sharded_wide_rows_on_unclustered_data_take_the_substeps_too():
     assert abs(r_m - r_1) <= 0.005 and info["iters"] <= one._build_stats["n_iters_run"] + 2
 
 
+def test_sharded_more_than_64_candidates():
+    """max_candidates = 100 on shards: 128 hashed reverse-offer slots per class (records imported by k_offer_import), the blocked
+    passes of the join with the narrow table for rows owned elsewhere.  20 000 Gaussian points, k = 80, three trees, two iterations: the
+    three-rank build stands where the one-GPU build stands (both far ahead of 60 candidates, tests/test_gpu_build.py)."""
+    n, k = 20000, 80
+    x = np.random.RandomState(7).normal(0, 1, (n, 32)).astype(np.float32)
+    rows = np.arange(0, n, 13)
+    ti, _ = O.brute_force_knn(x, k, "euclidean", rows=rows, kind="fast")
+    idx, dist, st, info = sharded.build_multi(x, 3, devices=[0] * 3, metric="euclidean", n_neighbors=k, n_trees=3, max_candidates=128, n_iters=2, seed=3)
+    one, _ = NNDescent(x, "euclidean", n_neighbors=k, n_trees=3, max_candidates=128, n_iters=2, random_state=3)._neighbor_graph
+    r_m, r_1 = O.recall(ti, idx[rows]), O.recall(ti, one[rows])
+    print("max_candidates 128, 2 iterations, 3 trees, 3 ranks: recall@80 %.4f, one GPU %.4f" % (r_m, r_1))
+    assert (idx >= 0).all() and np.all(np.diff(dist, axis=1) >= 0) and info["dropped_offers"] == 0
+    assert abs(r_m - r_1) <= 0.06 and r_m >= 0.6  # (two iterations in: seeds of the reference algorithm differ by as much)
+
+
 def test_build_multi_and_class_api_two_ranks_on_one_gpu():
     """The drop-in boundary reaches the sharded build: nnd_build_multi (host arrays in / out, one host thread per rank
     inside the library) and NNDescent(..., n_devices=2).  devices=[0, 0]: both ranks on this box's one GPU."""
