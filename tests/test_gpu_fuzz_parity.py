@@ -21,3 +21,10 @@ def test_structural_stress():
     import fuzz_structural
 
     assert fuzz_structural.main(60, 11) == 0
+
+
+def test_structural_stress_wide_rows_and_candidate_lists():
+    """The same sweep over rows of 65..256 neighbours and candidate lists of 65..128 (round 5's bounds): 16 configurations."""
+    import fuzz_structural
+
+    assert fuzz_structural.main(16, 5, wide=True) == 0

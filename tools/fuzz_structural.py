@@ -1,5 +1,5 @@
 """GPU-only stress: many random configurations (shapes, k, trees, leaf sizes, candidate counts, metrics), structural
-invariants of the result; the share of rows whose k-th distance is exact is printed for information.  usage: fuzz_structural.py [N] [seed]"""
+invariants of the result; the share of rows whose k-th distance is exact is printed for information.  usage: fuzz_structural.py [N] [seed] [wide]"""
 import os
 import sys
 import warnings
@@ -11,19 +11,20 @@ import torch
 from pynndescent_amd import NNDescent
 
 
-def main(count, seed):
+def main(count, seed, wide=False):
+    """``wide``: rows of 65..256 neighbours and candidate lists of 65..128 (the LDS-merge kernels, the blocked join) on smaller sets."""
     rs = np.random.RandomState(seed)
     bad = 0
     for t in range(count):
-        n = int(rs.choice([65, 257, 1000, 4097, 20000, 70000]))
+        n = int(rs.choice([300, 1000, 4097, 20000] if wide else [65, 257, 1000, 4097, 20000, 70000]))
         d = int(rs.choice([1, 2, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 255, 256, 300, 513]))
-        k = int(min(rs.choice([1, 2, 3, 7, 15, 16, 17, 31, 32, 33, 50, 64]), n - 1))
+        k = int(min(rs.choice([20, 65, 100, 128, 129, 200, 255, 256] if wide else [1, 2, 3, 7, 15, 16, 17, 31, 32, 33, 50, 64]), n - 1))
         metric = str(rs.choice(["euclidean", "cosine"]))
         n_trees = rs.choice([None, 0, 1, 2, 5, 16])
         n_trees = None if n_trees is None else int(n_trees)
         leaf = rs.choice([None, None, 2, 17, 64, 65, 96, 129, 200, 300])
         leaf = None if leaf is None else int(leaf)
-        mc = rs.choice([None, None, 1, 2, 16, 17, 33, 64])
+        mc = rs.choice([None, 20, 65, 100, 128] if wide else [None, None, 1, 2, 16, 17, 33, 64])
         mc = None if mc is None else int(mc)
         kind = rs.randint(4)
         if kind == 0:
@@ -74,4 +75,4 @@ def main(count, seed):
 
 
 if __name__ == "__main__":
-    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0, len(sys.argv) > 3) else 0)
