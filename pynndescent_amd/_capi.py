@@ -13,6 +13,10 @@ LIB_PATH = os.environ.get("PYNND_AMD_LIB", os.path.join(_HERE, "libpynnd_amd.so"
 
 NND_METRIC_SQEUCLIDEAN = 0
 NND_METRIC_ALT_COSINE = 1
+# the reference's metric names on this path -> the space the kernels work in ("sqeuclidean" is that space itself: no correction,
+# distances.py named_distances / fast_distance_alternatives)
+METRIC_CODES = {"euclidean": NND_METRIC_SQEUCLIDEAN, "l2": NND_METRIC_SQEUCLIDEAN, "sqeuclidean": NND_METRIC_SQEUCLIDEAN,
+                "cosine": NND_METRIC_ALT_COSINE}
 NND_FLAG_NO_GRAPH = 1  # auxiliary handle: no k-lists / candidate / proposal tables (pruning pass, hub tree)
 NND_FLAG_NO_PREP = 2   # ... and no prepared copy of the rows (hub tree only)
 NND_FLAG_TEST_SELECT_WAVE = 4  # test hook: the one-wave-per-vertex selection kernel

@@ -9,7 +9,7 @@ if the HIP library or a gfx950 device is missing, construction raises.
 
 Also on the GPU: ``update`` (warm start, pynndescent_.py:2381-2553), ``build_search_graph`` (the pruning
 pass of ``_init_search_graph``, all diversify methods), ``prepare`` (hub search tree + reordering) and
-``query``.  Out of scope: sparse input, metrics other than euclidean / l2 / cosine, ``n_neighbors`` above 256 or
+``query``.  Out of scope: sparse input, metrics other than euclidean / l2 / sqeuclidean / cosine, ``n_neighbors`` above 256 or
 ``max_candidates`` above 128 (``query``: more than 256 results per query).  Those raise ``NotImplementedError`` naming the reference entry point to use
 instead; ``pynndescent_amd.make_index`` hands such inputs to ``pynndescent.NNDescent`` when it is importable.
 """
@@ -24,8 +24,7 @@ from . import _capi
 INT32_MIN = np.iinfo(np.int32).min + 1  # pynndescent_.py:62
 INT32_MAX = np.iinfo(np.int32).max - 1  # pynndescent_.py:63
 
-_METRIC_CODES = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN,
-                 "cosine": _capi.NND_METRIC_ALT_COSINE}
+_METRIC_CODES = _capi.METRIC_CODES
 # metrics whose trees are angular in the reference (pynndescent_.py:1075-1086)
 _ANGULAR_METRICS = ("cosine", "dot", "correlation", "dice", "jaccard", "hellinger", "hamming", "bit_hamming",
                     "bit_jaccard")
@@ -53,7 +52,8 @@ def correct_alternative_cosine(d):
 
 
 # (numpy.sqrt; large float32 arrays go through the library's threaded sqrtf -- the same bits, the fresh pages touched in parallel)
-_DISTANCE_CORRECTIONS = {"euclidean": _capi.host_sqrt, "l2": _capi.host_sqrt, "cosine": correct_alternative_cosine}
+# ("sqeuclidean": the reference applies no correction, pynndescent_.py:1271-1298; neighbor_graph still hands out a copy)
+_DISTANCE_CORRECTIONS = {"euclidean": _capi.host_sqrt, "l2": _capi.host_sqrt, "sqeuclidean": _capi.host_copy, "cosine": correct_alternative_cosine}
 
 
 class _DeviceForestSentinel:
@@ -150,7 +150,7 @@ class NNDescent:
         if callable(metric) or metric not in _METRIC_CODES:
             if callable(metric) or metric in _KNOWN_REFERENCE_METRICS:
                 raise NotImplementedError(
-                    "pynndescent_amd accelerates the dense euclidean / l2 / cosine build only; "
+                    "pynndescent_amd accelerates the dense euclidean / l2 / sqeuclidean / cosine build only; "
                     "use pynndescent.NNDescent for metric %r" % (metric,)
                 )
             raise ValueError("Metric is neither callable, " + "nor a recognised string")  # pynndescent_.py:1292
@@ -717,7 +717,7 @@ def _check_supported_sizes(n_neighbors, max_candidates, init_graph):
 
 
 def make_index(data, *args, **kwargs):
-    """``NNDescent(data, ...)`` on the GPU when the input is in scope (dense data, euclidean / l2 / cosine, k <= 256);
+    """``NNDescent(data, ...)`` on the GPU when the input is in scope (dense data, euclidean / l2 / sqeuclidean / cosine, k <= 256);
     otherwise -- and only then -- the reference ``pynndescent.NNDescent`` on the CPU when that package is importable
     (SURVEY.md section 8b), with a warning.  A missing HIP library or GPU is never papered over: that still raises."""
     device = kwargs.pop("device", 0)

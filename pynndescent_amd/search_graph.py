@@ -85,7 +85,7 @@ def build_search_graph(data, indices, distances, metric="euclidean", n_neighbors
         x = np.ascontiguousarray(data, dtype=np.float32)
         n, d = x.shape
         k = np.shape(indices)[1]
-        code = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN, "cosine": _capi.NND_METRIC_ALT_COSINE}[metric]
+        code = _capi.METRIC_CODES[metric]
         b = _capi.Builder(n, d, code, k, 0, 60, 200, min(60, k), 1, 0.001, [1, 2, 3], [4, 5, 6], device=device, flags=_capi.NND_FLAG_NO_GRAPH)
         try:
             b.set_data_host(x)
@@ -116,7 +116,7 @@ def _build_search_graph_host_glue(data, indices, distances, metric="euclidean", 
     n, d = x.shape
     k = indices.shape[1]
     n_neighbors = k if n_neighbors is None else n_neighbors
-    code = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN, "cosine": _capi.NND_METRIC_ALT_COSINE}[metric]
+    code = _capi.METRIC_CODES[metric]
     b = _capi.Builder(n, d, code, k, 0, 60, 200, min(60, k), 1, 0.001, [1, 2, 3], [4, 5, 6], device=device,
                       flags=_capi.NND_FLAG_NO_GRAPH)  # the pass reads rows and norms only: no k-lists / proposal tables
     try:

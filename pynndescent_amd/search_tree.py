@@ -33,7 +33,7 @@ def make_hub_tree(data, neighbor_indices, metric="euclidean", leaf_size=30, max_
     n, d = x.shape
     deg = compute_global_degrees(neighbor_indices)
     rank_order = np.argsort(-deg.astype(np.int64), kind="stable").astype(np.int32)
-    code = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN, "cosine": _capi.NND_METRIC_ALT_COSINE}[metric]
+    code = _capi.METRIC_CODES[metric]
     b = _capi.Builder(n, d, code, 1, 1, max(int(leaf_size), 1), max_depth, 1, 1, 0.001, [seed, 2, 3], [4, 5, 6], device=device,
                       flags=_capi.NND_FLAG_NO_GRAPH | _capi.NND_FLAG_NO_PREP)  # original rows + the forest's scan / scatter buffers
     try:

@@ -222,8 +222,7 @@ def _global_params(n_total, dim, metric, n_neighbors, n_trees, leaf_size, max_ca
     rng_state = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
     _search = rs.randint(lim.min + 1, lim.max - 1, 3).astype(np.int64)
     tree_states = rs.randint(lim.min + 1, lim.max - 1, size=(max(int(n_trees), 1), 3)).astype(np.int64)
-    metric_code = {"euclidean": _capi.NND_METRIC_SQEUCLIDEAN, "l2": _capi.NND_METRIC_SQEUCLIDEAN,
-                   "cosine": _capi.NND_METRIC_ALT_COSINE}[metric]
+    metric_code = _capi.METRIC_CODES[metric]
     p = _capi.NNDParams()
     p.n, p.dim, p.metric, p.n_neighbors, p.n_trees, p.leaf_size = int(n_total), int(dim), metric_code, k, int(n_trees), leaf_size
     p.max_depth, p.max_candidates, p.n_iters, p.delta = int(max_rptree_depth), mc, n_iters, float(delta)

@@ -371,6 +371,24 @@ def test_search_graph_non_default_modes_vs_reference_fixture(tag, metric, method
     assert sg.dtype == np.uint8 and sg.diagonal().sum() == 0
 
 
+def test_sqeuclidean_is_the_euclidean_build_without_the_square_root():
+    """metric="sqeuclidean" (distances.py named_distances: squared_euclidean itself, no fast alternative, no correction,
+    euclidean trees): the same build as "euclidean" -- same seed, same ids -- with squared distances out of neighbor_graph and
+    query()."""
+    x = clustered(5000, 20, 6, 25, seed=12)
+    a = NNDescent(x, "euclidean", n_neighbors=12, random_state=5)
+    b = NNDescent(x, "sqeuclidean", n_neighbors=12, random_state=5)
+    (ia, da), (ib, db) = a.neighbor_graph, b.neighbor_graph
+    np.testing.assert_array_equal(ia, ib)
+    np.testing.assert_allclose(db, da.astype(np.float64) ** 2, rtol=1e-5, atol=1e-7)
+    xi = x.astype(np.float64)
+    np.testing.assert_allclose(db, ((xi[:, None, :] - xi[ib]) ** 2).sum(-1), rtol=1e-5, atol=1e-6)
+    q = x[:200] + 0.01
+    (qa, ea), (qb, eb) = a.query(q, k=5), b.query(q, k=5)
+    np.testing.assert_array_equal(qa, qb)
+    np.testing.assert_allclose(eb, ea.astype(np.float64) ** 2, rtol=1e-5, atol=1e-7)
+
+
 def test_unsupported_sizes_are_reported_up_front():
     x = clustered(500, 8, 4, 5, seed=1)
     with pytest.raises(NotImplementedError, match="n_neighbors <= 256"):
