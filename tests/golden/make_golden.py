@@ -320,6 +320,17 @@ def gen_build_clustered(ref):
          n_iters=np.int32(11), n_threads=np.int32(4), **r)
 
 
+def gen_build_wide(ref):
+    """Rows of more than 64 neighbours and candidate lists of more than 64 entries (round 5 lifted the GPU path's bounds to 256 / 128;
+    the reference has none, utils.py:130-158, pynndescent_.py:1135-1138)."""
+    x = clustered(400, 10, 4, 8, seed=33)
+    t0 = time.time()
+    r = _staged_build(ref, x, "euclidean", 70, 2, None, 9, 4, 2, max_candidates=80)
+    print("wide rows / lists %.1fs" % (time.time() - t0), "c:", r["c"])
+    save("build_wide_euclidean_T2", gen=np.array([400, 10, 4, 8, 33]), seed=np.int64(9), k=np.int32(70), n_trees=np.int32(2),
+         n_iters=np.int32(4), n_threads=np.int32(2), max_candidates=np.int32(80), **r)
+
+
 def gen_build_c1(ref):
     """BASELINE.json configs[0]: 10k x 64 float32 random, euclidean, k=10, n_iters=5."""
     x = np.random.RandomState(0).standard_normal((10000, 64)).astype(np.float32)
@@ -535,6 +546,7 @@ GENERATORS = {
     "build_small": gen_build_small,
     "build_clustered": gen_build_clustered,
     "build_c1": gen_build_c1,
+    "build_wide": gen_build_wide,
     "reference_testdata": gen_reference_testdata,
     "search_graph": gen_search_graph,
     "search_graph_modes": gen_search_graph_modes,

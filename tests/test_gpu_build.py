@@ -77,6 +77,19 @@ def test_iid_cosine_against_reference_fixture():
     np.testing.assert_allclose(dist, truth, rtol=1e-5, atol=2e-7)
 
 
+def test_wide_rows_and_candidate_lists_against_reference_fixture():
+    """The reference itself at k = 70, max_candidates = 80 (un-jitted run, tests/golden/make_golden.py gen_build_wide; the oracle
+    reproduces it bit for bit): 400 points, 4 iterations -- recall@70 of the GPU build against the reference's, distances exact."""
+    g = np.load(os.path.join(GOLDEN, "build_wide_euclidean_T2.npz"))
+    n, d, latent, ncl, seed = (int(v) for v in g["gen"])
+    x = clustered(n, d, latent, ncl, seed)
+    index = NNDescent(x, "euclidean", n_neighbors=70, n_trees=2, max_candidates=80, n_iters=4, random_state=9)
+    idx, dist = index.neighbor_graph
+    r_gpu, r_ref = _parity(x, "euclidean", 70, idx, g["idx"], k_true=70, two_sided=False)
+    assert abs(r_gpu - r_ref) <= 0.01
+    np.testing.assert_allclose(dist, _true_alt_to_corrected(x, idx, "euclidean"), rtol=1e-5, atol=1e-7)
+
+
 def test_baseline_config1_plumbing():
     """BASELINE.json configs[0]: 10k x 64 random, euclidean, k=10, n_iters=5 (reference fixture, recall ~0.49)."""
     g = np.load(os.path.join(GOLDEN, "build_c1_T8.npz"))

@@ -62,6 +62,20 @@ def test_clustered_euclidean_bit_exact(golden_dir):
     np.testing.assert_array_equal(dist, g["dist"])
 
 
+def test_wide_rows_and_candidate_lists_bit_exact(golden_dir):
+    """k = 70 with max_candidates = 80 (the reference has no bound on either; the GPU path takes them since round 5 and is
+    compared with this oracle): reference run un-jitted at 2 threads, reproduced bit for bit."""
+    g = _g(golden_dir, "build_wide_euclidean_T2")
+    n, d, latent, ncl, seed = (int(v) for v in g["gen"])
+    x = clustered(n, d, latent, ncl, seed)
+    idx, dist, tr = O.build_index(x, metric="euclidean", n_neighbors=int(g["k"]), n_trees=int(g["n_trees"]), random_state=int(g["seed"]),
+                                  n_iters=int(g["n_iters"]), n_threads=int(g["n_threads"]), max_candidates=int(g["max_candidates"]),
+                                  return_trace=True)
+    np.testing.assert_array_equal(tr["c"], g["c"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(dist, g["dist"])
+
+
 @pytest.mark.slow
 def test_c1_plumbing_config_bit_exact(golden_dir):
     """BASELINE.json configs[0]: 10k x 64 random, euclidean, k=10, n_iters=5 (reference run, 8 threads)."""
