@@ -21,7 +21,7 @@
 #include "state.h"
 
 #ifndef NND_LEAF_QW_OCC
-#define NND_LEAF_QW_OCC 6
+#define NND_LEAF_QW_OCC 7
 #endif
 template <int NT, int NW, int DC, bool QW = false>
 struct leaf_cfg {
@@ -51,12 +51,17 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : (QW && NT <= 5 
                                                        const int32_t *__restrict__ wl_len, int64_t leaf0,
                                                        int64_t n_leaves, int k, int ks, uint32_t *__restrict__ knn_e,
                                                        float *__restrict__ knn_d, float *__restrict__ th,
-                                                       long long *__restrict__ counters) {
+                                                       long long *__restrict__ counters, int m_lo) {
     using C = leaf_cfg<NT, NW, DC, QW>;
     static_assert(!QW || C::FULLD, "quarter-wave merges read the whole distance block from LDS");
     __shared__ __attribute__((aligned(16))) float big[C::BIG_FLOATS];
     __shared__ int32_t ids[C::MP];
     __shared__ float nrs[C::MP];
+    __shared__ uint2 qscr[QW ? NW * 4 * NND_Q16B_CAP : 1];  // QW: per wave, the four rows' queues of surviving candidates (merge.h)
+#ifdef NND_LEAF_PAD_LDS  // occupancy experiment: fewer workgroups per CU
+    __shared__ float lds_pad[NND_LEAF_PAD_LDS];
+    if (dp < 0) lds_pad[threadIdx.x] = 1.0f, counters[0] = (long long)lds_pad[(threadIdx.x + 1) & 63];
+#endif
 
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
     const int64_t leaf = leaf0 + blockIdx.x;
@@ -64,6 +69,7 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : (QW && NT <= 5 
     const int start = wl_start[leaf];
     const int m = wl_len[leaf];
     if (m < 2) return;  // no pairs
+    if (m <= m_lo || m > C::MP) return;  // a launch takes the leaves of ITS size class (run_leaf_rounds)
     const int nt = (m + 15) >> 4;
     const int mp = nt << 4;
 
@@ -262,12 +268,21 @@ __global__ __launch_bounds__(NW * 64, (NT <= 5 && NW == 8) ? 8 : (QW && NT <= 5 
                 if (qe[q] == 12345u && qd[q] == 3.0f && Drow[lane] == 7.0f) accepted++;
                 if (false)
 #endif
+#ifdef NND_LEAF_OLD_MERGE  // A/B: the one-candidate-per-step insertion of rounds 2-5
                 accepted += nnd_merge_rows_q16<NT>(on, knn_e + v * ks, knn_d + v * ks, th + v, qe[q], qd[q], k, m,
                                                    [&](int c, uint32_t &id, float &dc) {
                                                        id = (uint32_t)ids[c];
                                                        dc = Drow[c];
                                                        return c != i;  // pynndescent_.py:97: p != q
                                                    });
+#else
+                accepted += nnd_merge_rows_q16b<NT>(on, knn_e + v * ks, knn_d + v * ks, th + v, qe[q], qd[q], k, m,
+                                                    [&](int c, uint32_t &id, float &dc) {
+                                                        id = (uint32_t)ids[c];
+                                                        dc = Drow[c];
+                                                        return c != i;  // pynndescent_.py:97: p != q
+                                                    }, qscr + w * 4 * NND_Q16B_CAP);
+#endif
             }
         } else
         for (int i = w; i < m; i += NW) {  // rows dealt round-robin: every wave gets ~m/NW merges
@@ -545,21 +560,27 @@ static int run_leaf_rounds(nnd_ctx *ctx, const int32_t *perm, const int32_t *d_w
             else
                 hipLaunchKernelGGL((k_leaf_join_rb<16, 8, true>), dim3((unsigned)cnt, 4), dim3(512), 0, ctx->stream, LEAF_ARGS);
         } else if (maxlen <= 64 && qw)
-            hipLaunchKernelGGL((k_leaf_join<4, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+            hipLaunchKernelGGL((k_leaf_join<4, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 0);
         else if (maxlen <= 64)
-            hipLaunchKernelGGL((k_leaf_join<4, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
-        else if (maxlen <= 80 && qw)  // the default leaf_size (<= 75 points) with k <= 16
-#ifdef NND_LEAF_QW_NW4
-            hipLaunchKernelGGL((k_leaf_join<5, 4, 64, true>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS);
+            hipLaunchKernelGGL((k_leaf_join<4, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 0);
+        else if (maxlen <= 80 && qw) {  // the default leaf_size (<= 75 points) with k <= 16
+            // Two size classes, two launches over the tree's leaf table (a workgroup whose leaf belongs to the other class
+            // leaves at once): leaves of <= 64 points -- 85 % of the leaves, 3/4 of the points -- get FOUR waves and 21 KB of LDS,
+            // so that 7 of them are in flight per CU instead of 4.  The kernel is bound by exposed latency, not by a pipe
+            // (profiles/r06_leaf_occupancy.log: 375 / 425 / 535 us per tree with 4 / 3 / 2 workgroups per CU).
+#ifdef NND_LEAF_ONE_CLASS
+            hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 0);
 #else
-            hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+            hipLaunchKernelGGL((k_leaf_join<4, 4, 64, true>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS, 0);
+            hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 64);
 #endif
+        }
         else if (maxlen <= 80)
-            hipLaunchKernelGGL((k_leaf_join<5, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+            hipLaunchKernelGGL((k_leaf_join<5, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 0);
         else if (maxlen <= 96 && qw)
-            hipLaunchKernelGGL((k_leaf_join<6, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+            hipLaunchKernelGGL((k_leaf_join<6, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 0);
         else if (maxlen <= 96)
-            hipLaunchKernelGGL((k_leaf_join<6, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS);
+            hipLaunchKernelGGL((k_leaf_join<6, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 0);
         else if (maxlen <= 128)  // larger leaves: a workgroup per block of 32 rows (k_leaf_join_rb)
             hipLaunchKernelGGL((k_leaf_join_rb<8, 8>), dim3((unsigned)cnt, 2), dim3(512), 0, ctx->stream, LEAF_ARGS);
         else if (maxlen <= 160)  // k = 30 (leaf_size 150)

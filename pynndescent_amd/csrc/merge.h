@@ -295,6 +295,158 @@ __device__ __forceinline__ int nnd_merge_rows_q16(bool row_on, uint32_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Quarter-wave merge of MANY candidates per row (the leaf kernel: 40..80 leaf-mates against a row of k <= 16), round 6.
+// nnd_merge_rows_q16 above inserts one candidate per step and a step serves the UNION of the candidate positions that
+// are live in any of the wave's four rows: ~20 steps of ~15 VALU instructions per block-of-16 pass on a later tree, 41 on
+// the first (profiles/r05_pmc_sq.txt: 200 M VALU wave-instructions per launch against 5.5 M MFMA).  Here the candidates
+// that beat the row's CURRENT worst distance are first COMPACTED, row by row, into a wave-private LDS queue (32 entries
+// per row), and a queue is folded into its row by a sorting network over the row's 16 lanes, all four rows of the wave
+// at once, whatever the number of survivors: bitonic sort of the <= 16 queued keys (10 compare-exchange stages, partners
+// by DPP quad_perm / row_half_mirror / row_mirror), elementwise min against the mirrored row (the 16 smallest of the
+// union, a bitonic sequence), four half-cleaner stages.  Duplicates (utils.py:489-492) are screened against the row's ids
+// after the compaction (16 row rotations per batch instead of 16 per block of candidates).  The threshold tightens after
+// every batch -- the reference's sequential pushes compare with the heap's current root too (utils.py:484) -- so a row
+// that starts empty keeps ~k + 12 of 41 leaf-mates instead of inserting all of them.
+// Result: the k smallest keys of row U candidates, rows sorted by (dist, idx) -- what nnd_merge_rows_q16 leaves.
+// Return value: candidates that entered a batch (beat the current threshold, not in the row); statistics only.
+#define NND_Q16B_CAP 32  // queue entries per row: a batch is flushed before a block of 16 could overflow it
+#define NND_DPP_QUAD_XOR1 0xB1         // quad_perm [1,0,3,2]
+#define NND_DPP_QUAD_XOR2 0x4E         // quad_perm [2,3,0,1]
+#define NND_DPP_QUAD_MIRROR 0x1B       // quad_perm [3,2,1,0]
+#define NND_DPP_ROW_MIRROR 0x140
+#define NND_DPP_ROW_HALF_MIRROR 0x141
+#define NND_DPP_ROW_SHL(n) (0x100 + (n))
+
+// partner value of a compare-exchange stage.  Every lane of a row has a valid source lane in these patterns, so the DPP
+// moves are issued with bound_ctrl (no `old` operand to initialise, and the compiler may fold the move into its consumer).
+// CTRL < 0: lane j ^ 4 of the row = half-row mirror of the quad mirror (no single DPP pattern)
+template <int CTRL>
+__device__ __forceinline__ uint32_t nnd_q16_partner(uint32_t v) {
+    if constexpr (CTRL >= 0) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+    } else {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, NND_DPP_QUAD_MIRROR, 0xF, 0xF, true);  // j ^ 3
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, t, NND_DPP_ROW_HALF_MIRROR, 0xF, 0xF, true);  // (j ^ 3) ^ 7
+    }
+}
+// one compare-exchange stage on 64-bit keys hi:lo; keep_max lanes end up with the larger key of the pair
+template <int CTRL>
+__device__ __forceinline__ void nnd_q16_cx(uint32_t &lo, uint32_t &hi, bool keep_max) {
+    const uint32_t plo = nnd_q16_partner<CTRL>(lo), phi = nnd_q16_partner<CTRL>(hi);
+    const bool less = (((uint64_t)phi << 32) | plo) < (((uint64_t)hi << 32) | lo);
+    const bool take = less != keep_max;
+    lo = take ? plo : lo;
+    hi = take ? phi : hi;
+}
+template <int CTRL>
+__device__ __forceinline__ void nnd_q16_cx(uint32_t &lo, uint32_t &hi, uint32_t &fl, bool keep_max) {
+    const uint32_t plo = nnd_q16_partner<CTRL>(lo), phi = nnd_q16_partner<CTRL>(hi), pfl = nnd_q16_partner<CTRL>(fl);
+    const bool less = (((uint64_t)phi << 32) | plo) < (((uint64_t)hi << 32) | lo);
+    const bool take = less != keep_max;
+    lo = take ? plo : lo;
+    hi = take ? phi : hi;
+    fl = take ? pfl : fl;
+}
+template <int T>
+__device__ __forceinline__ bool nnd_q16_any_eq(uint32_t ids, uint32_t x) {  // does x equal any of the 16 ids of my row?
+    if constexpr (T == 0) return ids == x;
+    else return ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)ids, NND_DPP_ROW_ROR(T), 0xF, 0xF, true) == x) | nnd_q16_any_eq<T - 1>(ids, x);
+}
+
+template <int NBLK, typename CandFn>
+__device__ __forceinline__ int nnd_merge_rows_q16b(bool row_on, uint32_t *__restrict__ row_e, float *__restrict__ row_d,
+                                                   float *__restrict__ th_slot, uint32_t e, float d, int k, int ncand,
+                                                   CandFn cand, uint2 *wave_scr) {
+    const int lane = nnd_lane(), j = lane & 15, gbase = lane & 48;
+    uint2 *my = wave_scr + (lane >> 4) * NND_Q16B_CAP;
+    const uint32_t e_in = e;
+    const float d_in = d;
+    uint32_t klo = e & NND_IDX_MASK, khi = __float_as_uint(d), flag = e & NND_NEW_BIT;  // key = khi:klo
+    if (e == NND_EMPTY_E) { klo = 0xFFFFFFFFu; khi = 0xFFFFFFFFu; flag = 0u; }
+    const bool any_list = __ballot(e != NND_EMPTY_E) != 0;  // first tree: every row of the wave is still empty
+    // worst distance of my row as it is now (+inf while the row is not full: d is +inf in empty slots)
+    float th_cur = __int_as_float(__builtin_amdgcn_ds_bpermute((gbase + k - 1) << 2, __float_as_int(d)));
+    const bool b0 = (j & 1) != 0, b1 = (j & 2) != 0, b2 = (j & 4) != 0, b3 = (j & 8) != 0;
+    int fill = 0, pushed = 0;
+
+    // ONE copy of the batch code per call site (the loops are kept rolled: the leaf kernel inlines this routine once per
+    // pass over its rows, and a sorting network is ~150 instructions)
+    const int nblk = (ncand + 15) >> 4;
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; blk++) {
+        const int c = blk * 16 + j;
+        uint32_t cid = 0;
+        float dc = 0.0f;
+        bool ok = row_on && c < ncand && cand(c, cid, dc);
+        ok = ok && (dc < th_cur);  // strict, utils.py:484
+        const unsigned long long cmask = __ballot(ok);
+        if (cmask) {
+            const uint32_t m16 = (uint32_t)(cmask >> gbase) & 0xFFFFu;
+            if (ok) my[fill + __popc(m16 & ((1u << j) - 1u))] = make_uint2(cid, __float_as_uint(dc));
+            fill += __popc(m16);
+        }
+        // fold the queues into the rows when a queue could overflow with the next block, at the last block, and while a
+        // row is not full (it accepts everything: fold what it has so that the next block meets a threshold)
+        const bool last = blk + 1 >= nblk;
+        if (!__ballot(fill > 16 || (fill > 0 && (last || th_cur == INFINITY)))) continue;
+        nnd_wave_lds_sync();
+#pragma unroll 1
+        for (int b = 0; b < NND_Q16B_CAP / 16; b++) {
+            if (!__ballot(fill > 16 * b)) break;  // wave-uniform
+            const uint2 s = my[16 * b + j];
+            bool sok = 16 * b + j < fill && __uint_as_float(s.y) < th_cur;  // queued against an older threshold: test again
+            if (any_list && __ballot(sok)) {  // utils.py:489-492 (ids of this leaf are unique)
+                // every lane evaluates the rotations: a DPP source lane that is masked off reads as zero
+                const bool dup = nnd_q16_any_eq<15>(klo, s.x);
+                sok = sok && !dup;
+            }
+            const unsigned long long mask = __ballot(sok);
+            if (!mask) continue;
+            pushed += __popcll(mask);
+            uint32_t slo = sok ? s.x : 0xFFFFFFFFu, shi = sok ? s.y : 0xFFFFFFFFu;
+            // bitonic sort of the batch, ascending over the row's lanes
+            nnd_q16_cx<NND_DPP_QUAD_XOR1>(slo, shi, b0);
+            nnd_q16_cx<NND_DPP_QUAD_MIRROR>(slo, shi, b1);
+            nnd_q16_cx<NND_DPP_QUAD_XOR1>(slo, shi, b0);
+            nnd_q16_cx<NND_DPP_ROW_HALF_MIRROR>(slo, shi, b2);
+            nnd_q16_cx<NND_DPP_QUAD_XOR2>(slo, shi, b1);
+            nnd_q16_cx<NND_DPP_QUAD_XOR1>(slo, shi, b0);
+            nnd_q16_cx<NND_DPP_ROW_MIRROR>(slo, shi, b3);
+            nnd_q16_cx<-1>(slo, shi, b2);
+            nnd_q16_cx<NND_DPP_QUAD_XOR2>(slo, shi, b1);
+            nnd_q16_cx<NND_DPP_QUAD_XOR1>(slo, shi, b0);
+            // the 16 smallest of row U batch: min(row[j], batch[15 - j]) is bitonic; four half-cleaners sort it
+            {
+                const uint32_t tlo = nnd_q16_partner<NND_DPP_ROW_MIRROR>(slo), thi = nnd_q16_partner<NND_DPP_ROW_MIRROR>(shi);
+                const bool take = (((uint64_t)thi << 32) | tlo) < (((uint64_t)khi << 32) | klo);
+                klo = take ? tlo : klo;
+                khi = take ? thi : khi;
+                flag = take ? NND_NEW_BIT : flag;
+            }
+            nnd_q16_cx<NND_DPP_ROW_ROR(8)>(klo, khi, flag, b3);
+            nnd_q16_cx<-1>(klo, khi, flag, b2);
+            nnd_q16_cx<NND_DPP_QUAD_XOR2>(klo, khi, flag, b1);
+            nnd_q16_cx<NND_DPP_QUAD_XOR1>(klo, khi, flag, b0);
+            if (j >= k) { klo = 0xFFFFFFFFu; khi = 0xFFFFFFFFu; flag = 0u; }  // k < 16: the row ends at slot k - 1
+            const uint32_t wk = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + k - 1) << 2, (int)khi);
+            th_cur = wk == 0xFFFFFFFFu ? INFINITY : __uint_as_float(wk);
+        }
+        fill = 0;
+        nnd_wave_lds_sync();  // the queue is read: the next block may overwrite it
+    }
+    if (pushed == 0) return 0;
+    const bool empty = (klo & khi) == 0xFFFFFFFFu;
+    e = empty ? NND_EMPTY_E : (klo | flag);
+    d = empty ? INFINITY : __uint_as_float(khi);
+    if (row_on && j < k && (e != e_in || d != d_in)) {
+        row_e[j] = e;
+        row_d[j] = d;
+        if (j == k - 1) *th_slot = d;  // new worst distance of the row
+    }
+    return pushed;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Wide rows, 64 < k <= NND_WIDE_K = 256 (the reference has no bound on n_neighbors, utils.py:130-158; 256 is also the cap of its
 // default leaf size, rp_trees.py:2845): the row does not fit one entry per lane -- a lane holds entries lane, 64 + lane, ... --
 // so it is merged through LDS -- same result as nnd_merge_row_regs (the k smallest keys of row U {candidates
