@@ -41,7 +41,7 @@ extern "C" {
 #define NND_METRIC_SQEUCLIDEAN 0 /* reference distances.py:63  squared_euclidean  */
 #define NND_METRIC_ALT_COSINE 1  /* reference distances.py:583 alternative_cosine */
 
-#define NND_ABI_VERSION 5 /* 5: nnd_search_graph / nnd_search_graph_fetch (round 5); existing entry points unchanged */
+#define NND_ABI_VERSION 6 /* 6 (round 6): nnd_stats grew join_substeps[] at its end; nnd_host_alloc / nnd_host_free; 5: nnd_search_graph / nnd_search_graph_fetch */
 
 typedef struct nnd_handle_s *nnd_handle_t;
 
@@ -100,6 +100,9 @@ typedef struct nnd_params {
 #define NND_FLAG_TEST_FOREST_FALLBACK_TOPS 512
 #define NND_FLAG_TEST_FOREST_FALLBACK_SHARE 1024
 #define NND_TEST_FALLBACK_AT(flags) ((((flags) & 512) ? 1 : 0) + (((flags) & 1024) ? 2 : 0))
+/* test hook: the candidate sampling behaves as if the record regions of the bucketed transposition could not be allocated
+ * (wide rows on a full device): the handle must switch to the hashed slots and build, not fail (tests/test_gpu_kernels.py) */
+#define NND_FLAG_TEST_SAMPLE_NOMEM 2048
 
 /* Run-time statistics for measurement (bench.py roofline). */
 typedef struct nnd_stats {
@@ -118,6 +121,7 @@ typedef struct nnd_stats {
     int64_t join_mfma[64];       /* v_mfma_f32_16x16x4_f32 instructions issued by the join (2048 flop each), per iteration */
     int64_t leaf_mfma;           /* the same for the leaf-seeding kernel, whole stage */
     int64_t n_cells;             /* rp forest: cells of the routing pass (0 = whole-set level-synchronous build) */
+    int64_t join_substeps[64];   /* ABI 6: join + merge sub-steps of every iteration (join_blocks, or the library's schedule when join_blocks = 0) */
 } nnd_stats;
 
 int32_t nnd_abi_version(void);
@@ -139,6 +143,13 @@ int32_t nnd_release_pending(void);
  * host threads.  nnd_host_sqrt_f32 is IEEE sqrtf per element: bit-identical to numpy.sqrt on float32. */
 int32_t nnd_host_copy(void *dst, const void *src, int64_t bytes);
 int32_t nnd_host_sqrt_f32(float *dst, const float *src, int64_t count);
+/* Pinned host memory for result arrays (round 6).  The reference returns freshly allocated numpy arrays
+ * (pynndescent_.py:2145-2158, 1247-1260); at 1 M x 15 their first touch cost more than the device-to-host copy itself.  The host
+ * side of the drop-in class keeps a small pool of these buffers (pynndescent_amd/_capi.py HostPool): a buffer goes back to the
+ * pool when the last numpy view of it dies.  nnd_host_alloc returns NULL without a device or without memory (callers fall back
+ * to ordinary allocations); the finalize / build entry points recognise a pinned destination and copy into it with one DMA. */
+void *nnd_host_alloc(int64_t bytes);
+int32_t nnd_host_free(void *p);
 
 /* Point set, float32 C-contiguous (n, dim) -- NNDescent._raw_data (pynndescent_.py:1054-1057).
  * Host variant copies H2D; device variant BORROWS the pointer (it must outlive the handle's

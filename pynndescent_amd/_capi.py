@@ -27,6 +27,7 @@ NND_FLAG_TEST_FAIL = 64  # test hook (sharded build): this rank returns an error
 NND_FLAG_TEST_VANISH = 128  # ... or returns there without telling anybody (a killed process)
 NND_FLAG_TEST_FOREST_FALLBACK_TOPS = 512  # test hook (sharded build): a rank reports that the by-cell forest cannot be built (at the tops)
 NND_FLAG_TEST_FOREST_FALLBACK_SHARE = 1024  # ... at the owners' shares; both flags: at the over-long cells
+NND_FLAG_TEST_SAMPLE_NOMEM = 2048  # test hook: the sampler's record regions "cannot be allocated": the handle must fall back to the hashed slots
 NND_FLAG_TEST_SAMPLE_ATOMIC = 256  # test hook: reverse offers by one global atomicMin per edge (rounds 1-4) instead of the bucketed transposition
 
 
@@ -80,6 +81,7 @@ class NNDStats(C.Structure):
         ("join_mfma", C.c_int64 * 64),
         ("leaf_mfma", C.c_int64),
         ("n_cells", C.c_int64),
+        ("join_substeps", C.c_int64 * 64),
     ]
 
     def as_dict(self):
@@ -89,7 +91,7 @@ class NNDStats(C.Structure):
             "n_iters_run": it, "n_leaves": int(self.n_leaves), "tree_levels": int(self.tree_levels),
             "leaf_pairs": int(self.leaf_pairs), "leaf_rows": int(self.leaf_rows), "leaf_mfma": int(self.leaf_mfma), "n_cells": int(self.n_cells),
         }
-        for name in ("join_pairs", "join_rows", "join_active", "proposals", "updates", "join_mfma"):
+        for name in ("join_pairs", "join_rows", "join_active", "proposals", "updates", "join_mfma", "join_substeps"):
             out[name] = [int(v) for v in getattr(self, name)[:m]]
         for name in ("ms_prep", "ms_forest", "ms_leaf_init", "ms_random_init", "ms_descent", "ms_finalize"):
             out[name] = float(getattr(self, name))
@@ -164,6 +166,8 @@ _SIGNATURES = [
     ("nnd_release_pending", C.c_int32, []),
     ("nnd_host_copy", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
     ("nnd_host_sqrt_f32", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("nnd_host_alloc", C.c_void_p, [C.c_int64]),
+    ("nnd_host_free", C.c_int32, [C.c_void_p]),
     ("nnd_make_forest", C.c_int32, [_H]),
     ("nnd_leaf_array_shape", C.c_int32, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     ("nnd_get_leaf_array", C.c_int32, [_H, C.c_void_p]),
@@ -371,8 +375,8 @@ class Builder:
         self._check(self.lib.nnd_sample_candidates(self._h))
 
     def finalize(self):
-        idx = np.empty((self.n, self.k), np.int32)
-        dist = np.empty((self.n, self.k), np.float32)
+        idx = host_pool.empty((self.n, self.k), np.int32)
+        dist = host_pool.empty((self.n, self.k), np.float32)
         self._check(self.lib.nnd_finalize_host(self._h, _ptr(idx), _ptr(dist)))
         return idx, dist
 
@@ -555,11 +559,80 @@ class Searcher:
             pass
 
 
+class HostPool:
+    """Result arrays in pinned host memory, recycled (round 6; include/pynnd_amd.h nnd_host_alloc).
+
+    ``empty(shape, dtype)`` is ``numpy.empty`` for arrays of 4 MB and more, backed by a pinned buffer: the pages are resident (a
+    fresh 60 MB numpy array costs ~15 k page faults on first touch: 12 of the 57 ms of ``NNDescent(x).neighbor_graph`` at
+    1 M x 15) and the library copies a finished graph into it with one DMA.  A buffer returns to the pool when the last numpy
+    view of it is garbage-collected and serves the next request of the same size: a process that builds index after index
+    allocates its result arrays once.  Without a device, or beyond ``max_bytes`` of pinned memory, ``numpy.empty``."""
+
+    def __init__(self, min_bytes=4 << 20, max_bytes=4 << 30, keep_per_size=6):
+        import threading
+
+        self.min_bytes, self.max_bytes, self.keep = min_bytes, max_bytes, keep_per_size
+        self._free, self._held, self._lock = {}, 0, threading.Lock()
+
+    def _release(self, ptr, nbytes):
+        with self._lock:
+            lst = self._free.setdefault(nbytes, [])
+            if len(lst) < self.keep:
+                lst.append(ptr)
+                return
+            self._held -= nbytes
+        try:
+            load_library().nnd_host_free(C.c_void_p(ptr))
+        except Exception:  # (interpreter shutdown)
+            pass
+
+    def empty(self, shape, dtype):
+        import weakref
+
+        dtype = np.dtype(dtype)
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if nbytes < self.min_bytes:
+            return np.empty(shape, dtype)
+        ptr = None
+        with self._lock:
+            lst = self._free.get(nbytes)
+            if lst:
+                ptr = lst.pop()
+            elif self._held + nbytes <= self.max_bytes:
+                self._held += nbytes
+                ptr = 0
+        if ptr == 0:
+            ptr = load_library().nnd_host_alloc(nbytes)
+            if not ptr:
+                with self._lock:
+                    self._held -= nbytes
+                ptr = None
+        if ptr is None:
+            return np.empty(shape, dtype)
+        buf = (C.c_char * nbytes).from_address(ptr)
+        fin = weakref.finalize(buf, self._release, ptr, nbytes)
+        fin.atexit = False  # (process exit releases the memory)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def trim(self):
+        """Give the idle buffers back."""
+        with self._lock:
+            items = [(p, nb) for nb, lst in self._free.items() for p in lst]
+            self._free.clear()
+            self._held -= sum(nb for _, nb in items)
+        for p, _ in items:
+            load_library().nnd_host_free(C.c_void_p(p))
+
+
+host_pool = HostPool()
+
+
 def host_copy(a):
     """``a.copy()`` for a C-contiguous array, the pages of the fresh destination touched by several host threads."""
     if not a.flags.c_contiguous or a.nbytes < (4 << 20):
         return a.copy()
-    out = np.empty_like(a)
+    out = host_pool.empty(a.shape, a.dtype)
     if load_library().nnd_host_copy(_ptr(out), _ptr(a), a.nbytes) != 0:
         raise NNDError(load_library().nnd_last_global_error().decode())
     return out
@@ -569,7 +642,7 @@ def host_sqrt(a):
     """``numpy.sqrt(a)`` for a C-contiguous float32 array (IEEE sqrtf per element: the same bits), several host threads."""
     if a.dtype != np.float32 or not a.flags.c_contiguous or a.nbytes < (4 << 20):
         return np.sqrt(a)
-    out = np.empty_like(a)
+    out = host_pool.empty(a.shape, a.dtype)
     if load_library().nnd_host_sqrt_f32(_ptr(out), _ptr(a), a.size) != 0:
         raise NNDError(load_library().nnd_last_global_error().decode())
     return out

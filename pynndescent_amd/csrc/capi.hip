@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -117,7 +118,14 @@ extern "C" int32_t nnd_create(nnd_handle_t *out, const nnd_params *p) { return n
 // change by more than that per iteration while the graph is poor (the reference's heaps have no such bound, utils.py:459-500), so
 // their iterations are cut into sub-steps (join a part of the vertices, merge, ...: pynndescent_.py:239-261 does the same in
 // blocks of 16384 vertices) until the slots of an iteration add up to 2 k.
-static int auto_join_blocks(int k) { return k <= 64 ? 1 : (k + 31) / 32; }
+// More than 64 candidates per class run as five passes of the 64-slot join (join.hip launch_join_blocked) that all deposit into
+// the same 64 proposal slots of a row: twice the sub-steps, so that a merge empties the slots between them (round-5 advisor item).
+static void jb_knobs(nnd_ctx *ctx) {  // experiments (KNOBS builds only): the schedule of nnd_join_substeps
+    if (const char *e = nnd_knob("NND_JB_MAX")) ctx->jb_max = atoi(e) < 1 ? 1 : atoi(e);
+    if (const char *e = nnd_knob("NND_JB_DIV")) ctx->jb_div = atoi(e) < 1 ? 1 : atoi(e);
+    if (const char *e = nnd_knob("NND_JB_FIRST")) ctx->jb_first = atoi(e) < 0 ? 0 : atoi(e);
+}
+static int auto_join_blocks(int k, int mc) { return (k <= 64 ? 1 : (k + 31) / 32) * (mc > 64 ? 2 : 1); }
 
 int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bounds_host, int n_ranks, int rank) {
     if (!out || !p) { gerr("nnd_create: null argument"); return 1; }
@@ -185,7 +193,9 @@ int nnd_create_impl(nnd_handle_t *out, const nnd_params *p, const int64_t *bound
         const int r = atoi(pc_env);
         if (r == 16 || r == 32 || r == 64) ctx->pcap = r;
     }
-    if (ctx->p.join_blocks < 1) ctx->p.join_blocks = auto_join_blocks(ctx->p.n_neighbors);
+    ctx->jb_auto = ctx->p.join_blocks < 1;
+    if (ctx->p.join_blocks < 1) ctx->p.join_blocks = auto_join_blocks(ctx->p.n_neighbors, ctx->p.max_candidates);
+    jb_knobs(ctx);
     ctx->seed = nnd_mix32((uint32_t)p->rng_state[0] ^ nnd_mix32((uint32_t)p->rng_state[1] + 0x9E3779B9u) ^
                           nnd_mix32((uint32_t)p->rng_state[2] + 0x7F4A7C15u));
     ctx->tree_seed = nnd_mix32((uint32_t)p->tree_rng[0] ^ nnd_mix32((uint32_t)p->tree_rng[1] + 0x9E3779B9u) ^
@@ -359,7 +369,9 @@ static nnd_ctx *take_parked(const nnd_params *p) {
     if (!ctx) return nullptr;
     (void)hipSetDevice(p->device);
     ctx->p = *p;
-    if (ctx->p.join_blocks < 1) ctx->p.join_blocks = auto_join_blocks(ctx->p.n_neighbors);
+    jb_knobs(ctx);
+    ctx->jb_auto = ctx->p.join_blocks < 1;
+    if (ctx->p.join_blocks < 1) ctx->p.join_blocks = auto_join_blocks(ctx->p.n_neighbors, ctx->p.max_candidates);
     ctx->seed = nnd_mix32((uint32_t)p->rng_state[0] ^ nnd_mix32((uint32_t)p->rng_state[1] + 0x9E3779B9u) ^ nnd_mix32((uint32_t)p->rng_state[2] + 0x7F4A7C15u));
     ctx->tree_seed = nnd_mix32((uint32_t)p->tree_rng[0] ^ nnd_mix32((uint32_t)p->tree_rng[1] + 0x9E3779B9u) ^ nnd_mix32((uint32_t)p->tree_rng[2] + 0x7F4A7C15u));
     ctx->iter = 0;
@@ -429,6 +441,62 @@ static int after_data(nnd_ctx *ctx) {
     return 0;
 }
 
+// Pageable host memory -> device.  The runtime stages such a copy through its own pinned buffers; how fast depends on the box
+// (one staging thread, the NUMA node of the caller's pages): the same 488 MB took 9.7 ms on one MI355X host and visibly more on
+// another (round-5 review: 32.9 vs 42.2 ms for the whole nnd_build call).  Here: eight pinned 8 MB buffers per device (allocated
+// once per process), eight host threads -- thread t copies chunks t, t + 8, ... into ITS buffer and queues the DMA of each on the
+// handle's stream itself (the chunks are independent; what follows on the stream is ordered behind all of them).  A pinned
+// source is copied directly.
+static std::mutex g_up_mu[64];  // per device: the ranks of nnd_build_multi upload side by side
+static char *g_up_stage[64][8] = {};
+static hipEvent_t g_up_ev[64][8] = {};
+static int h2d_parallel(nnd_ctx *ctx, void *dst_dev, const void *src, size_t bytes) {
+    constexpr size_t STAGE = (size_t)8 << 20;
+    constexpr int P = 8;
+    bool direct = bytes < (size_t)(16u << 20) || ctx->p.device < 0 || ctx->p.device >= 64;
+    if (!direct) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost) direct = true;
+        else (void)hipGetLastError();
+    }
+    if (direct) {
+        API_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+    }
+    const int dev = ctx->p.device;
+    std::lock_guard<std::mutex> lk(g_up_mu[dev]);
+    API_HIP(hipSetDevice(dev));
+    for (int b = 0; b < P; b++) {
+        if (!g_up_stage[dev][b]) API_HIP(hipHostMalloc((void **)&g_up_stage[dev][b], STAGE, hipHostMallocDefault));
+        if (!g_up_ev[dev][b]) {
+            API_HIP(hipEventCreateWithFlags(&g_up_ev[dev][b], hipEventDisableTiming));
+        } else {
+            API_HIP(hipEventSynchronize(g_up_ev[dev][b]));  // (a previous call's last DMA out of this buffer)
+        }
+    }
+    const size_t nchunks = (bytes + STAGE - 1) / STAGE;
+    std::atomic<int> failed{0};
+    hipStream_t st = ctx->stream;
+    auto work = [&](int t) {
+        if (hipSetDevice(dev) != hipSuccess) { failed = 1; return; }
+        bool first = true;
+        for (size_t c = (size_t)t; c < nchunks && !failed; c += P) {
+            const size_t o = c * STAGE, len = bytes - o < STAGE ? bytes - o : STAGE;
+            if (!first && hipEventSynchronize(g_up_ev[dev][t]) != hipSuccess) { failed = 1; return; }
+            first = false;
+            memcpy(g_up_stage[dev][t], (const char *)src + o, len);
+            if (hipMemcpyAsync((char *)dst_dev + o, g_up_stage[dev][t], len, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipEventRecord(g_up_ev[dev][t], st) != hipSuccess) { failed = 1; return; }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < P; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &t : th) t.join();
+    if (failed) { (void)hipGetLastError(); ctx->set_error("nnd_set_data_host: staged host-to-device copy failed"); return 1; }
+    return 0;
+}
+
 extern "C" int32_t nnd_set_data_host(nnd_handle_t ctx, const float *x) {
     ENTER(ctx);
     if (!x) { ctx->set_error("nnd_set_data_host: null data"); return 1; }
@@ -438,7 +506,7 @@ extern "C" int32_t nnd_set_data_host(nnd_handle_t ctx, const float *x) {
         ctx->x_orig = dx;
         ctx->x_owned = true;
     }
-    API_HIP(hipMemcpyAsync((void *)ctx->x_orig, x, sizeof(float) * (size_t)ctx->n * ctx->d, hipMemcpyHostToDevice, ctx->stream));
+    if (h2d_parallel(ctx, (void *)ctx->x_orig, x, sizeof(float) * (size_t)ctx->n * ctx->d)) return 1;
     ctx->x_valid = true;
     return after_data(ctx);
 }
@@ -549,13 +617,17 @@ extern "C" int32_t nnd_init_from_graph(nnd_handle_t ctx, const int32_t *init_idx
     if (need_graph(ctx)) return 1;
     if (need_data(ctx)) return 1;
     if (!init_idx || width < 1 || width > NND_WIDE_K) { ctx->set_error("nnd_init_from_graph: width must be in 1..%d", NND_WIDE_K); return 1; }
-    size_t cnt = (size_t)ctx->n * width;
+    // the caller's arrays are the FULL (n, width) graph; the launcher takes the rows this handle OWNS (all of them, or a
+    // shard's slice -- nnd_shard_handle exposes such handles): upload exactly those
+    const int64_t rows = ctx->own_hi - ctx->own_lo;
+    if (rows <= 0) return 0;
+    const size_t cnt = (size_t)rows * width, off = (size_t)ctx->own_lo * width;
     nnd_scratch tmp;
     int32_t *di = tmp.get<int32_t>(ctx, cnt);
     float *dd = init_dist ? tmp.get<float>(ctx, cnt) : nullptr;
     if (!di || (init_dist && !dd)) return 1;
-    API_HIP(hipMemcpyAsync(di, init_idx, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, ctx->stream));
-    if (init_dist) API_HIP(hipMemcpyAsync(dd, init_dist, sizeof(float) * cnt, hipMemcpyHostToDevice, ctx->stream));
+    API_HIP(hipMemcpyAsync(di, init_idx + off, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, ctx->stream));
+    if (init_dist) API_HIP(hipMemcpyAsync(dd, init_dist + off, sizeof(float) * cnt, hipMemcpyHostToDevice, ctx->stream));
     int rc = nnd_launch_init_from_graph(ctx, di, dd, width);
     (void)hipStreamSynchronize(ctx->stream);  // the scratch buffers are released on return
     return rc;
@@ -579,6 +651,25 @@ extern "C" int32_t nnd_sample_candidates(nnd_handle_t ctx) {
     return nnd_launch_sample(ctx);
 }
 
+// Sub-steps of an iteration (join a part of the vertices, merge, ...).  The reference applies the updates of every block of 16384
+// vertices before it generates the next block's (pynndescent_.py:239-261): thresholds tighten INSIDE an iteration, and a row
+// never has more than a block's worth of pushes pending.  One launch per iteration (rounds 1-5) leaves a row's 64 hashed
+// proposal slots to take a whole iteration's proposals -- 23 per row in the first iteration of the 1 M bench set, more where
+// convergence is slow -- and what collides is lost: measured on 200 000 iid Gaussian points x 32 (the reference algorithm
+// reaches recall@10 0.613 there, tools/mid_regime_study.py): 0.6094 with one launch, 0.6108 / 0.6112 / 0.6125 with 2 / 4 / 12
+// sub-steps (12 = the reference's blocking at that size).  When join_blocks is left to the library the sub-steps of an iteration
+// follow the insertions per row the previous iteration made (halving is the slowest decay seen), so that late iterations --
+// few updates, nothing to collide -- stay single launches.  An explicit join_blocks is taken as given.
+int nnd_join_substeps(const nnd_ctx *ctx) {
+    int nb = ctx->p.join_blocks;
+    if (!ctx->jb_auto || ctx->k > 64) return nb;  // (wide rows: auto_join_blocks has cut their iterations already)
+    const double rows = (double)(ctx->own_hi - ctx->own_lo);
+    const double per_row = (ctx->iter == 0 || ctx->last_updates < 0 || rows <= 0) ? (double)ctx->jb_first : (double)ctx->last_updates / rows;
+    int m = 1;
+    while (m < ctx->jb_max && (double)(m * ctx->jb_div) < per_row) m <<= 1;
+    return nb * m;
+}
+
 // one iteration of nn_descent_internal (pynndescent_.py:296-320)
 static int descent_iter(nnd_ctx *ctx, int64_t *c_out, bool timed) {
     const int it = ctx->iter;
@@ -591,8 +682,11 @@ static int descent_iter(nnd_ctx *ctx, int64_t *c_out, bool timed) {
     if (nnd_zero_counters(ctx)) return 1;
     // The reference joins vertices in blocks of 16384 and applies updates between blocks
     // (pynndescent_.py:239-261) so thresholds tighten inside an iteration; join_blocks sub-steps do the same.
-    const int nb = ctx->p.join_blocks;
-    if (it < 64) ctx->stats.ms_join[it] = ctx->stats.ms_merge[it] = 0.f;
+    const int nb = nnd_join_substeps(ctx);
+    if (it < 64) {
+        ctx->stats.ms_join[it] = ctx->stats.ms_merge[it] = 0.f;
+        ctx->stats.join_substeps[it] = nb;
+    }
     for (int b = 0; b < nb; b++) {
         const int64_t span = ctx->own_hi - ctx->own_lo;
         int64_t v0 = ctx->own_lo + span * b / nb, v1 = ctx->own_lo + span * (b + 1) / nb;
@@ -681,6 +775,15 @@ static int d2h_parallel(nnd_ctx *ctx, void *dst, const void *src, size_t bytes, 
         API_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
         return 0;
     }
+    {   // a pinned destination (nnd_host_alloc: the result arrays of the drop-in class) takes the DMA directly
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeHost) {
+            API_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            API_HIP(hipStreamSynchronize(ctx->stream));
+            return 0;
+        }
+        (void)hipGetLastError();  // (an ordinary host pointer is "invalid value" to the query)
+    }
     std::lock_guard<std::mutex> lk(g_stage_mu);
     char **g_stage = g_stage_dev[ctx->p.device];
     hipEvent_t *g_stage_ev = g_stage_ev_dev[ctx->p.device];
@@ -733,6 +836,22 @@ static void host_parallel(size_t bytes, size_t unit, F fn) {  // fn(offset_units
     }
     fn(0, total < per ? total : per);
     for (auto &t : th) t.join();
+}
+// Pinned (page-locked, resident) host memory for result arrays: no first-touch page faults when the graph lands in it, and the
+// device-to-host copy is one DMA at the link rate instead of a staged copy.  NULL when there is no device or no memory: the
+// caller then uses ordinary memory.
+extern "C" void *nnd_host_alloc(int64_t bytes) {
+    void *p = nullptr;
+    if (bytes <= 0) return nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+extern "C" int32_t nnd_host_free(void *p) {
+    if (p && hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); gerr("nnd_host_free: not a pointer of nnd_host_alloc"); return 1; }
+    return 0;
 }
 extern "C" int32_t nnd_host_copy(void *dst, const void *src, int64_t bytes) {
     if (bytes < 0 || (bytes > 0 && (!dst || !src))) { gerr("nnd_host_copy: bad arguments"); return 1; }

@@ -24,6 +24,17 @@
 #include "common.h"
 #include "state.h"
 
+// A reverse offer that repeats a forward edge of the same class (v and u are each other's neighbours).  The reference pushes both
+// into the same heap with independent random priorities and its duplicate check rejects whichever push comes second
+// (utils.py:277-306, checked_heap_push: 427-430) -- a mutual neighbour has TWO draws at a place in the list.  Rounds 1-5 dropped
+// the reverse offer and kept the forward draw alone: the forward share of the lists came out 2 points below the reference
+// algorithm's (0.757 vs 0.779 on the first pass, tests/test_gpu_kernels.py::test_candidate_lists_have_the_reference_algorithms_
+// distribution).  Here the item keeps the SMALLER of the two keys -- the order-independent form of "two draws".  The keys differ
+// only in their priority word (same id below it), so lanes that read the id of the slot meanwhile read the same id.
+__device__ __forceinline__ void nnd_dup_min(uint64_t *item, uint64_t offer_key) {
+    if (offer_key < *item) *item = offer_key;
+}
+
 // per-target, per-iteration salt of the reverse priorities
 __device__ __forceinline__ uint32_t nnd_offer_salt(uint32_t it_seed, uint32_t u) { return nnd_hash2(it_seed ^ 0x3C6EF372u, u); }
 
@@ -124,10 +135,11 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
         }
         bool ok = rw != NND_EMPTY_SLOT;
         const uint64_t rk = nnd_offer_key(rw, salt);
-        if (ok) {  // utils.py:427-430: an id already in the list is not pushed again
+        if (ok) {  // utils.py:427-430: an id already in the list is not pushed again (nnd_dup_min: it keeps the better draw)
             const uint32_t src = (uint32_t)rk;
             const int nf = c ? nfwd[1] : nfwd[0];
-            for (int j = 0; j < nf; j++) ok &= ((uint32_t)sc.key[c][j] != src);
+            for (int j = 0; j < nf; j++)
+                if ((uint32_t)sc.key[c][j] == src) { ok = false; nnd_dup_min(&sc.key[c][j], rk); }
         }
 #pragma unroll
         for (int cc = 0; cc < 2; cc++) {
@@ -151,7 +163,8 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
                 const uint64_t rk = nnd_offer_key(rw, salt);
                 if (ok) {  // utils.py:427-430: an id already in the list is not pushed again
                     uint32_t src = (uint32_t)rk;
-                    for (int j = 0; j < nfwd[c]; j++) ok &= ((uint32_t)sc.key[c][j] != src);
+                    for (int j = 0; j < nfwd[c]; j++)
+                        if ((uint32_t)sc.key[c][j] == src) { ok = false; nnd_dup_min(&sc.key[c][j], rk); }
                 }
                 unsigned long long m = __ballot(ok);
                 if (ok) sc.key[c][cnt[c] + nnd_prefix_popc(m)] = rk;
@@ -249,7 +262,8 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
             const uint64_t rk = nnd_offer_key(rw, salt);
             if (__ballot(ok)) {  // utils.py:427-430: an id already in the list is not pushed again
                 const uint32_t src = (uint32_t)rk;
-                for (int j = 0; j < nfwd[c]; j++) ok = ok && ((uint32_t)key[c][j] != src);
+                for (int j = 0; j < nfwd[c]; j++)
+                    if (ok && (uint32_t)key[c][j] == src) { ok = false; nnd_dup_min(&key[c][j], rk); }
             }
             const unsigned long long m = __ballot(ok);
             if (ok) key[c][cnt[c] + nnd_prefix_popc(m)] = rk;
@@ -335,8 +349,8 @@ __device__ __forceinline__ void nnd_select_half(uint32_t *__restrict__ knn_e, in
             const uint32_t s0 = (uint32_t)rk0, s1 = (uint32_t)rk1;
             for (int q = 0; q < nfm; q++) {
                 const uint32_t f = (uint32_t)fl[q];
-                ok0 = ok0 && !(q < nf1 && f == s0);
-                ok1 = ok1 && !(q < nf1 && f == s1);
+                if (ok0 && q < nf1 && f == s0) { ok0 = false; nnd_dup_min(&fl[q], rk0); }
+                if (ok1 && q < nf1 && f == s1) { ok1 = false; nnd_dup_min(&fl[q], rk1); }
             }
         }
         int M = nf1;
@@ -382,8 +396,8 @@ __device__ __forceinline__ void nnd_select_half(uint32_t *__restrict__ knn_e, in
         const uint32_t s0 = (uint32_t)rk0, s1 = (uint32_t)rk1;
         for (int q = 0; q < nfm; q++) {
             const uint32_t f0 = (uint32_t)sk[0][q], f1 = (uint32_t)sk[1][q];
-            ok0 = ok0 && !(q < nf0 && f0 == s0);
-            ok1 = ok1 && !(q < nf1 && f1 == s1);
+            if (ok0 && q < nf0 && f0 == s0) { ok0 = false; nnd_dup_min(&sk[0][q], rk0); }
+            if (ok1 && q < nf1 && f1 == s1) { ok1 = false; nnd_dup_min(&sk[1][q], rk1); }
         }
     }
     {
@@ -889,44 +903,72 @@ static void launch_select(nnd_ctx *ctx, uint32_t it_seed, bool wide) {
     if (ctx->n_ranks <= 1) ctx->rbuf_clean = true;  // every bank that received an offer belongs to an active vertex and was re-armed
 }
 
-// grow-only tables of the bucketed reverse pass; the inverse of the visiting order once per forest
+// grow-only tables of the bucketed reverse pass; the inverse of the visiting order once per forest.  An allocation that fails is
+// NOT a build error (returns false, nothing left behind): the caller falls back to the hashed slots, which need 8 * rcap bytes a row
 template <typename T>
-static int rv_grow(nnd_ctx *ctx, T **p, size_t count) {
-    if (*p) NND_HIP_CHECK(hipFree(*p));
+static bool rv_grow(T **p, size_t count) {
+    if (*p) (void)hipFree(*p);
     *p = nullptr;
-    NND_HIP_CHECK(hipMalloc((void **)p, sizeof(T) * count));
-    return 0;
+    if (hipMalloc((void **)p, sizeof(T) * count) != hipSuccess) {
+        (void)hipGetLastError();  // (the error is handled here: do not let a later hipGetLastError() report it)
+        *p = nullptr;
+        return false;
+    }
+    return true;
 }
 // rows [row0, row0 + n_rows) are walked (all rows; a shard: the owned slice), `extra` records arrive from elsewhere.  The
-// record regions: nb buckets x 8 sub-regions x cap records of 8 bytes (cap = 4 x the mean load of a sub-region when every offer
-// of a bucket's vertices is counted: 1024 at k = 15; 0.5 GB per million rows) + the overflow list, sized for every offer.
+// record regions: nb buckets x 8 sub-regions x cap records of 8 bytes + the overflow list, sized for every offer.  cap = 4 x the
+// mean load of a sub-region when every offer of a bucket's vertices is counted (1024 at k = 15: 0.5 GB per million rows) for
+// k <= 32 -- the regime that is tuned: a sub-region that overflows sends its bucket to the overflow list -- and 2 x beyond (wide
+// rows: the regions would be 4 .. 16 GB per million rows at k = 64 .. 256 with the factor 4 and a power-of-two capacity; round-5
+// advisor item).  Returns 0, 1 (error) or 2: the tables could not be allocated -- the caller samples through the hashed slots.
 static int rv_prepare(nnd_ctx *ctx, int logB, const int32_t *order, int64_t row0, int64_t n_rows, int64_t extra, int *cap_out) {
     const int64_t nb = ((n_rows - 1) >> logB) + 1, nov = n_rows * ctx->k + extra;
-    int cap = 64;
-    while (cap < 4 * (int)((n_rows * ctx->k / (nb * 8)) + 1)) cap <<= 1;
+    const int64_t mean = n_rows * ctx->k / (nb * 8) + 1;
+    int64_t cap64 = (ctx->k <= 32 ? 4 : 2) * mean;
+    cap64 = cap64 < 64 ? 64 : ((cap64 + 63) / 64) * 64;
+    const int cap = (int)cap64;
     *cap_out = cap;
     const int64_t need = nb * 8 * cap;
-    if (need > ctx->rv_cap_in || cap != ctx->rv_in_cap) {
+    bool ok = !(ctx->p.flags & NND_FLAG_TEST_SAMPLE_NOMEM);  // test hook: behave as if the first allocation had failed
+    if (ok && (need > ctx->rv_cap_in || cap != ctx->rv_in_cap)) {
         ctx->rv_cap_in = 0;  // (a failed allocation leaves no stale capacity behind)
-        if (rv_grow(ctx, &ctx->rv_in_cursor, (size_t)nb * 8 + 8) || rv_grow(ctx, &ctx->rv_in_rec, (size_t)need)) return 1;
-        ctx->rv_cap_in = need;
-        ctx->rv_in_cap = cap;
+        ok = rv_grow(&ctx->rv_in_cursor, (size_t)nb * 8 + 8) && rv_grow(&ctx->rv_in_rec, (size_t)need);
+        if (ok) {
+            ctx->rv_cap_in = need;
+            ctx->rv_in_cap = cap;
+        }
     }
-    if (nov > ctx->rv_cap_ov) {
+    if (ok && nov > ctx->rv_cap_ov) {
         const int64_t c = extra > 0 ? nov + nov / 4 : nov;  // (a shard's inbox varies from iteration to iteration: head room)
         ctx->rv_cap_ov = 0;
-        if (rv_grow(ctx, &ctx->rv_ov, (size_t)c)) return 1;
-        ctx->rv_cap_ov = c;
+        ok = rv_grow(&ctx->rv_ov, (size_t)c);
+        if (ok) ctx->rv_cap_ov = c;
     }
-    if (order && (!ctx->rv_pos || ctx->rv_pos_gen != ctx->forest_gen || ctx->rv_pos_of != order)) {
+    if (ok && order && (!ctx->rv_pos || ctx->rv_pos_gen != ctx->forest_gen || ctx->rv_pos_of != order)) {
         if (n_rows > ctx->rv_cap_pos) {
             ctx->rv_cap_pos = 0;
-            if (rv_grow(ctx, &ctx->rv_pos, (size_t)n_rows)) return 1;
-            ctx->rv_cap_pos = n_rows;
+            ok = rv_grow(&ctx->rv_pos, (size_t)n_rows);
+            if (ok) ctx->rv_cap_pos = n_rows;
         }
-        hipLaunchKernelGGL(k_rev_invert, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream, order, row0, n_rows, ctx->rv_pos);
-        ctx->rv_pos_gen = ctx->forest_gen;
-        ctx->rv_pos_of = order;
+        if (ok) {
+            hipLaunchKernelGGL(k_rev_invert, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream, order, row0, n_rows, ctx->rv_pos);
+            ctx->rv_pos_gen = ctx->forest_gen;
+            ctx->rv_pos_of = order;
+        }
+    }
+    if (!ok) {
+        // give the memory back and switch this handle to the hashed-slot form of the pass for good: the banks (rbuf) exist on
+        // every handle; they are re-armed here because the bucketed fill (k_rev_fill) leaves them in its own state
+        if (ctx->rv_in_cursor) { (void)hipFree(ctx->rv_in_cursor); ctx->rv_in_cursor = nullptr; }
+        if (ctx->rv_in_rec) { (void)hipFree(ctx->rv_in_rec); ctx->rv_in_rec = nullptr; }
+        if (ctx->rv_ov) { (void)hipFree(ctx->rv_ov); ctx->rv_ov = nullptr; }
+        ctx->rv_cap_in = ctx->rv_cap_ov = 0;
+        ctx->rv_in_cap = 0;
+        ctx->rv_off = true;
+        NND_HIP_CHECK(hipMemsetAsync(ctx->rbuf + (size_t)ctx->slim_row0() * 2 * ctx->rcap, 0xFF, sizeof(uint32_t) * (size_t)ctx->slim_rows() * 2 * ctx->rcap, ctx->stream));
+        ctx->rbuf_clean = true;
+        return 2;
     }
     return 0;
 }
@@ -935,7 +977,7 @@ static int rv_prepare(nnd_ctx *ctx, int logB, const int32_t *order, int64_t row0
 static bool rv_fused(const nnd_ctx *ctx) {
     return ctx->k <= 32 && ctx->rcap == 32 && ctx->mc <= 32 && !(ctx->p.flags & NND_FLAG_TEST_SELECT_WAVE);
 }
-static bool rv_bucketed(const nnd_ctx *ctx) { return (ctx->rcap == 32 || ctx->rcap == 64) && !(ctx->p.flags & NND_FLAG_TEST_SAMPLE_ATOMIC); }
+static bool rv_bucketed(const nnd_ctx *ctx) { return (ctx->rcap == 32 || ctx->rcap == 64) && !ctx->rv_off && !(ctx->p.flags & NND_FLAG_TEST_SAMPLE_ATOMIC); }
 // The reverse offers of this iteration by transposition (see above), then the selection; active[] is set on the way.  A shard
 // (n_ranks > 1) walks its owned rows and adds the `n_in` offers it has received (in_targets: target | class << 31, in_sources).
 static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide, const int32_t *in_targets, const uint32_t *in_sources, int64_t n_in) {
@@ -945,7 +987,7 @@ static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide, con
     if (n_rows <= 0) return 0;
     const int32_t *order = shard ? ctx->own_order : ((ctx->forest_built && ctx->p.n_trees > 0) ? ctx->perm[ctx->cur] : nullptr);
     int cap = 0;
-    if (rv_prepare(ctx, logB, order, row0, n_rows, n_in, &cap)) return 1;
+    if (const int prc = rv_prepare(ctx, logB, order, row0, n_rows, n_in, &cap)) return prc;  // 2: no memory for the regions (rv_off is set)
     const int32_t *pos = order ? ctx->rv_pos : nullptr;
     const int64_t nb = ((n_rows - 1) >> logB) + 1;
     if (nb >= ((int64_t)1 << 23)) { ctx->set_error("candidate sampling: %lld buckets exceed the 2^23 bucket ids of an overflow record", (long long)nb); return 1; }
@@ -1001,10 +1043,14 @@ int nnd_launch_sample(nnd_ctx *ctx) {
     const uint32_t it_seed = sample_seed(ctx);
     if (rv_bucketed(ctx)) {
         const bool wide_b = sample_wide(ctx);
-        if (launch_sample_bucketed(ctx, it_seed, wide_b, nullptr, nullptr, 0)) return 1;
-        ctx->all_new = false;
-        NND_HIP_CHECK(hipGetLastError());
-        return 0;
+        const int brc = launch_sample_bucketed(ctx, it_seed, wide_b, nullptr, nullptr, 0);
+        if (brc == 1) return 1;
+        if (brc == 0) {
+            ctx->all_new = false;
+            NND_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+        // brc == 2: the record regions do not fit the device -- this and every later pass of the handle: hashed slots (below)
     }
     NND_HIP_CHECK(hipMemsetAsync(ctx->active, 0, (size_t)ctx->n, ctx->stream));
     // every edge still carries the "new" flag before the first sampling pass: there are no old edges to offer
@@ -1135,10 +1181,17 @@ int nnd_launch_sample_finish(nnd_ctx *ctx, const int32_t *targets_dev, const uin
     const unsigned grid = (unsigned)((count + 255) / 256);
     const bool wide = sample_wide(ctx);  // (all_new is still what it was when nnd_launch_sample_begin ran)
     if (rv_bucketed(ctx)) {  // round 5: local edges and received records are transposed together (no hashed slots, no lost offers)
-        if (launch_sample_bucketed(ctx, it_seed, wide, targets_dev, sources_dev, count)) return 1;
-        ctx->all_new = false;
-        NND_HIP_CHECK(hipGetLastError());
-        return 0;
+        const int brc = launch_sample_bucketed(ctx, it_seed, wide, targets_dev, sources_dev, count);
+        if (brc == 1) return 1;
+        if (brc == 0) {
+            ctx->all_new = false;
+            NND_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+        // brc == 2: no memory for the record regions.  nnd_launch_sample_begin left the local new-class pass to the bucketed form:
+        // run it now, then go on with the hashed slots (every rank decides for itself: the exchange does not depend on the form)
+        NND_HIP_CHECK(hipMemsetAsync(ctx->active + ctx->slim_row0(), 0, (size_t)ctx->slim_rows(), ctx->stream));
+        launch_reverse_pass(ctx, 0, it_seed);
     }
     if (count > 0) {
         ctx->rbuf_clean = false;

@@ -669,6 +669,7 @@ static int forest_by_cell(nnd_shard_s *s, const float *x_local_dev, hipEvent_t e
             hipLaunchKernelGGL(k_order_from_records, dim3(256), dim3(256), 0, st, rec_row, cell_count_all, s->maps + o_oseg, G, cells_all,
                                (const int32_t *)(h->counters + CNT_SCRATCH), s->own_order);
             h->own_order = s->own_order;
+            h->forest_gen++;  // the buffer is rewritten in place: the sampler's inverse of the visiting order (rv_pos) is stale
         }
         t_end(h, tf, &h->stats.ms_forest, true);
         sec.end();
@@ -873,6 +874,7 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
                 hipLaunchKernelGGL(k_compact_owned, dim3((unsigned)((h->n + 4095) / 4096)), dim3(256), 0, st, h->perm[h->cur], h->n, s->lo, s->hi,
                                    s->own_order, s->order_cursor);
                 h->own_order = s->own_order;
+                h->forest_gen++;  // (as above: own_order is one buffer rewritten by every build)
             }
         }
         sec.end();
@@ -1020,6 +1022,7 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
             // table and travel once, below)
             const int tj = t_begin(h);
             const int nsub = h->p.join_blocks > 1 ? h->p.join_blocks : 1;
+            if (h->iter < 64) h->stats.join_substeps[h->iter] = nsub;
             for (int b = 0; b < nsub; b++) {
                 const int64_t v0 = s->lo + (int64_t)n_own * b / nsub, v1 = s->lo + (int64_t)n_own * (b + 1) / nsub;
                 S_CTX(nnd_launch_join(h, v0, v1));

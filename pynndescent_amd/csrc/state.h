@@ -168,6 +168,9 @@ struct nnd_handle_s {
     int64_t rv_cap_in = 0, rv_cap_ov = 0, rv_cap_pos = 0;
     int rv_in_cap = 0;
     const int32_t *rv_pos_of = nullptr;       // the order rv_pos inverts
+    bool rv_off = false;                      // the record regions could not be allocated: this handle samples through the hashed atomicMin slots (rbuf) from now on
+    bool jb_auto = false;                     // join_blocks was left to the library: sub-steps per iteration follow the update volume (capi.hip descent_iter)
+    int jb_max = 8, jb_div = 2, jb_first = 8; // the schedule: sub-steps = pow2ceil(expected insertions per row / jb_div), at most jb_max; first iteration: as if jb_first per row
     int64_t last_updates = -1;                // k-list insertions of the previous iteration (-1: unknown): picks the late-iteration form of the pass
     bool pbuf_clean = false, rbuf_clean = false;  // every proposal / reverse-offer slot is EMPTY (their consumers re-arm what they read): nnd_launch_reset_graph then skips the 2 x 512 MB memsets
 

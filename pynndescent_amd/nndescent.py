@@ -283,15 +283,16 @@ class NNDescent:
                 builder.init_random()
             else:
                 builder.init_from_graph(init_graph, init_dist)
-            # nn_descent_internal (pynndescent_.py:296-320), driven from here so verbose output matches
-            for it in range(n_iters):
-                if verbose:
+            if verbose:
+                # nn_descent_internal (pynndescent_.py:296-320), driven from here so that the output matches the reference's
+                for it in range(n_iters):
                     print("\t", it + 1, " / ", n_iters)
-                c = builder.descent_iter()
-                if c <= delta * n_neighbors * n:
-                    if verbose:
+                    c = builder.descent_iter()
+                    if c <= delta * n_neighbors * n:
                         print("\tStopping threshold met -- exiting after", it + 1, "iterations")
-                    break
+                        break
+            else:
+                builder.descent()  # the same loop inside the library (nnd_descent): no host round trip per iteration
             self._neighbor_graph = builder.finalize()
             self._build_stats = builder.stats()
         finally:

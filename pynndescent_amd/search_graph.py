@@ -23,6 +23,7 @@ import scipy.sparse as sp
 from . import _capi
 
 FLOAT32_EPS = np.finfo(np.float32).eps  # pynndescent_.py:65
+DEVICE_PASS_MAX_EDGES = 0x7FFFFFF0      # csrc/searchgraph.hip: 2 n k keyed edges, int32 positions
 
 
 def compute_degrees(indices):
@@ -86,16 +87,29 @@ def build_search_graph(data, indices, distances, metric="euclidean", n_neighbors
         n, d = x.shape
         k = np.shape(indices)[1]
         code = _capi.METRIC_CODES[metric]
-        b = _capi.Builder(n, d, code, k, 0, 60, 200, min(60, k), 1, 0.001, [1, 2, 3], [4, 5, 6], device=device, flags=_capi.NND_FLAG_NO_GRAPH)
+        # The device pass keeps 2 n k keyed edges with int32 positions and ~104 bytes of workspace per edge; a graph beyond that
+        # (or a device too full for the workspace) goes through the kernels with the reference's scipy calls between them --
+        # the rounds 2-4 form, same edges (tests/test_gpu_build.py), n k < 2^31 -- instead of failing prepare().
+        fits = 2 * n * k < DEVICE_PASS_MAX_EDGES
+        b = _capi.Builder(n, d, code, k, 0, 60, 200, min(60, k), 1, 0.001, [1, 2, 3], [4, 5, 6], device=device, flags=_capi.NND_FLAG_NO_GRAPH) if fits else None
         try:
-            b.set_data_host(x)
-            out = search_graph_on(b, indices, distances, n_neighbors, pruning_degree_multiplier, diversify_prob, diversify_method,
-                                  degree_prune_aggressiveness, seed, return_stages=return_stages)
-            if return_stages:
-                out[1]["nnz_pre_diversify"] = int((np.asarray(indices) >= 0).sum())
-            return out
+            if fits:
+                b.set_data_host(x)
+                try:
+                    out = search_graph_on(b, indices, distances, n_neighbors, pruning_degree_multiplier, diversify_prob, diversify_method,
+                                          degree_prune_aggressiveness, seed, return_stages=return_stages)
+                    if return_stages:
+                        out[1]["nnz_pre_diversify"] = int((np.asarray(indices) >= 0).sum())
+                    return out
+                except _capi.NNDError as e:
+                    if "memory" not in str(e).lower():
+                        raise
+                    import warnings
+
+                    warnings.warn("the search-graph pass does not fit the device (%s): running it with host-side sparse-matrix steps" % e)
         finally:
-            b.close()
+            if b is not None:
+                b.close()
     return _build_search_graph_host_glue(data, indices, distances, metric, n_neighbors, pruning_degree_multiplier, diversify_prob,
                                          diversify_method, degree_prune_aggressiveness, seed, device, return_stages)
 

@@ -95,6 +95,9 @@ FULLSIZE = {
     "c5": (290_000, 256, 32, 4, False, "cosine", 15, 11, 64),
     "3m": (3_000_000, 128, 16, 3, True, "euclidean", 15, 12, 128),
     "c4": (10_000_000, 128, 16, 3, True, "euclidean", 15, 12, 128),
+    # round 6: the other workloads of the bench line -- the slow-converging set (latent dimension 48) and the reference's default k = 30
+    "hard": (1_000_000, 128, 48, 1, True, "euclidean", 15, 8, 64),
+    "k30": (1_000_000, 128, 16, 1, True, "euclidean", 30, 8, 64),
 }
 _ORACLE_CACHE = {}
 

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), "libpynnd_amd.so does not export %s" % name
     assert sorted(_capi.EXPORTED_SYMBOLS) == declared
-    assert lib.nnd_abi_version() == 5
+    assert lib.nnd_abi_version() == 6
 
 
 def test_no_cpu_fallback_without_a_device():

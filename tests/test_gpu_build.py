@@ -95,8 +95,9 @@ def test_baseline_config1_plumbing():
     g = np.load(os.path.join(GOLDEN, "build_c1_T8.npz"))
     x = np.random.RandomState(0).standard_normal((10000, 64)).astype(np.float32)
     idx, _ = NNDescent(x, "euclidean", n_neighbors=10, n_trees=8, n_iters=5, random_state=0)._neighbor_graph
-    r_gpu, r_ref = _parity(x, "euclidean", 10, idx, g["idx"], band=0.02, two_sided=False)
-    assert abs(r_gpu - r_ref) < 0.08  # same regime, not merely "at least as good"
+    # round 6: two-sided +-0.01 against the REFERENCE'S OWN graph (the fixture is the unmodified reference at 8 threads;
+    # recall ~0.48: a regime where nothing saturates -- 0.4840 vs 0.4835 at the end of round 5)
+    r_gpu, r_ref = _parity(x, "euclidean", 10, idx, g["idx"], band=0.01, two_sided=True)
 
 
 def test_sift_like_medium_vs_oracle():

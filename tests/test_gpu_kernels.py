@@ -195,7 +195,8 @@ def _hash3(seed, a, b):
 def _expected_candidates(idx, fl, rng_state, it, mc, cap_new, cap_old):
     """Host model of new_build_candidates (utils.py:221-320) with the library's counter hashes as priorities
     (csrc/sample.hip): per (vertex, class) the max_candidates smallest (priority, id) keys of its forward edges and of
-    the reverse offers it receives (a reverse offer that repeats a forward id of the list is not pushed, utils.py:427-430).
+    the reverse offers it receives (a reverse offer that repeats a forward id of the list is not pushed, utils.py:427-430;
+    the forward item then takes the smaller of the two priorities).
     Returns (new, old, exact_new, exact_old): exact_* is False where a bank received more offers than it has slots."""
     n, k = idx.shape
     r = [np.uint32(int(v) & 0xFFFFFFFF) for v in rng_state]
@@ -215,6 +216,13 @@ def _expected_candidates(idx, fl, rng_state, it, mc, cap_new, cap_old):
     fwd_code = (vv.astype(np.int64) * n + uu) * 2 + cc
     rev_code = (uu * n + vv.astype(np.int64)) * 2 + cc
     keep = ~np.isin(rev_code, fwd_code)
+    # ... and the forward item keeps the better of the two draws (sample.hip nnd_dup_min: the reference pushes both, its duplicate
+    # check rejects the second)
+    order_f = np.argsort(fwd_code)
+    pos = np.searchsorted(fwd_code[order_f], rev_code[~keep])
+    tgt = order_f[pos]
+    fkey = fkey.copy()
+    np.minimum.at(fkey, tgt, rkey[~keep])
     owner = np.concatenate([vv.astype(np.int64), uu[keep]])
     cls = np.concatenate([cc, cc[keep]])
     key = np.concatenate([fkey, rkey[keep]])
@@ -561,3 +569,80 @@ def test_leaf_init_recall_gpu_forest_vs_reference_forest(metric):
     print("recall@10 after leaf seeding (%s, %d trees): GPU forest %.4f, reference forest %.4f" % (metric, T, rg, ro))
     assert abs(rg - ro) <= 0.015
     b.close()
+
+
+@pytest.mark.parametrize("k,mc", [(15, 15), (40, 40), (100, 60)])
+def test_sampling_falls_back_to_hashed_slots_when_the_record_regions_cannot_be_allocated(k, mc):
+    """Round-5 advisor item: the record regions of the bucketed transposition take 0.5 GB per million rows at k = 15 and
+    several GB at wide rows; an allocation failure there must not fail the build.  NND_FLAG_TEST_SAMPLE_NOMEM makes the
+    first allocation "fail": the handle switches to the hashed atomicMin slots (round 1-4 form) for good and builds a graph
+    of the same quality as the default path (reference: new_build_candidates, utils.py:222-320)."""
+    from pynndescent_amd import _capi
+
+    x = clustered(20000, 32, 8, 64, seed=21)
+    rows = np.random.RandomState(3).choice(x.shape[0], 1500, replace=False)
+    ti, _ = O.brute_force_knn(x, 10, "euclidean", rows=rows)
+    rec = []
+    for flags in (0, _capi.NND_FLAG_TEST_SAMPLE_NOMEM):
+        b = make_builder(x, "euclidean", k=k, n_trees=4, mc=mc, flags=flags)
+        for _ in range(2):  # (a second build on the same handle: the switch is permanent)
+            b.reset_graph()
+            b.make_forest()
+            b.init_from_leaves()
+            b.init_random()
+            b.descent()
+            idx, dist = b.finalize()
+        if k <= 15:
+            check_graph_invariants(x, "euclidean", idx, dist, name="nomem flags=%d" % flags)
+        assert (idx >= 0).all()
+        rec.append(O.recall(ti, idx[rows]))
+        b.close()
+    print("k=%d mc=%d recall@10: default %.4f, hashed-slot fallback %.4f" % (k, mc, rec[0], rec[1]))
+    assert abs(rec[0] - rec[1]) <= 0.01 and rec[1] >= 0.9
+
+
+@pytest.mark.parametrize("k,mc,stage", [(15, 15, "first"), (15, 15, "mixed"), (30, 30, "mixed"), (20, 10, "mixed")])
+def test_candidate_lists_have_the_reference_algorithms_distribution(k, mc, stage):
+    """Round-5 review: the exact-sample test above checks the kernel against a host model of the LIBRARY'S OWN hashes; this one
+    compares the lists with what the REFERENCE ALGORITHM (the oracle's new_build_candidates, pinned bit-exact to utils.py:222-320)
+    builds from the SAME graph state -- as distributions, the priorities being random on both sides: per-vertex fill of the new
+    and old lists, the share of forward (own-row) entries in them, the histogram of the fills."""
+    n = 60000
+    x = clustered(n, 32, 8, 64, seed=5)
+    b = make_builder(x, "euclidean", k=k, n_trees=4, mc=mc)
+    b.make_forest()
+    b.init_from_leaves()
+    b.init_random()
+    if stage == "mixed":
+        b.descent_iter()  # a mix of old and new entries, some vertices without any new edge
+    idx0, _, fl0 = b.graph()
+    b.sample_candidates()
+    new, old = b.candidates()
+    b.close()
+    lib = O.load("strict")
+    onew = np.empty((n, mc), np.int32)
+    oold = np.empty((n, mc), np.int32)
+    lib.orc_new_build_candidates(idx0.copy(), fl0.copy(), n, k, mc, np.array([11, 22, 33], np.int64), 8, onew, oold)
+
+    def stats(lists, rows):
+        fill = (lists[rows] >= 0).sum(1)
+        fwd = (lists[rows][:, :, None] == idx0[rows][:, None, :]).any(2) & (lists[rows] >= 0)
+        hist = np.bincount(fill, minlength=mc + 1) / float(len(rows))
+        return fill.mean(), fwd.sum() / max(1, (lists[rows] >= 0).sum()), hist
+
+    every = np.arange(n)
+    # the join skips a vertex without new candidates, and the library does not build its old list: compare the old lists
+    # where both sides have new candidates
+    joined = np.nonzero((new[:, 0] >= 0) & (onew[:, 0] >= 0))[0]
+    assert len(joined) > 2000, len(joined)
+    for name, g_l, o_l, rows in (("new", new, onew, every), ("old", old, oold, joined)):
+        gm, gf, gh = stats(g_l, rows)
+        om, of, oh = stats(o_l, rows)
+        tv = 0.5 * np.abs(gh - oh).sum()
+        print("%s lists (k=%d mc=%d %s): mean fill gpu %.3f reference %.3f; forward share gpu %.4f reference %.4f; fill histogram TV %.4f"
+              % (name, k, mc, stage, gm, om, gf, of, tv))
+        assert abs(gm - om) <= 0.01 * max(om, 1.0) + 0.02, (name, gm, om)
+        assert abs(gf - of) <= 0.015, (name, gf, of)
+        assert tv <= 0.03, (name, tv)
+    # the same vertices take part in the join (a vertex is active iff it has a new candidate)
+    assert abs(int((new[:, 0] >= 0).sum()) - int((onew[:, 0] >= 0).sum())) <= 0.002 * n
