@@ -24,17 +24,15 @@
 #include "common.h"
 #include "state.h"
 
-// A reverse offer that repeats a forward edge of the same class (v and u are each other's neighbours).  The reference pushes both
-// into the same heap with independent random priorities and its duplicate check rejects whichever push comes second
-// (utils.py:277-306, checked_heap_push: 427-430) -- a mutual neighbour has TWO draws at a place in the list.  Rounds 1-5 dropped
-// the reverse offer and kept the forward draw alone: the forward share of the lists came out 2 points below the reference
-// algorithm's (0.757 vs 0.779 on the first pass, tests/test_gpu_kernels.py::test_candidate_lists_have_the_reference_algorithms_
-// distribution).  Here the item keeps the SMALLER of the two keys -- the order-independent form of "two draws".  The keys differ
-// only in their priority word (same id below it), so lanes that read the id of the slot meanwhile read the same id.
-__device__ __forceinline__ void nnd_dup_min(uint64_t *item, uint64_t offer_key) {
-    if (offer_key < *item) *item = offer_key;
-}
-
+// A reverse offer that repeats a forward edge of the same class (v and u are each other's neighbours) is dropped: the item keeps
+// its forward draw.  The reference pushes both into the same heap with ONE shared priority per edge and its duplicate check
+// rejects whichever push comes second while the first is still in the heap (utils.py:277-306, 427-430): a mutual neighbour gets
+// a second draw only if the first was evicted before the second edge is scanned -- an order-dependent rule.  Measured (round 6,
+// tests/test_gpu_kernels.py::test_candidate_lists_have_the_reference_algorithms_distribution): share of forward (own-row)
+// entries in the new lists of a first pass 0.757 here, 0.779 in the reference, and 0.799 when the item keeps the SMALLER of the
+// two draws (built and measured: recall@10 0.6099 -> 0.6090 on 200 000 iid Gaussian points x 32, 0.9944 -> 0.9938 at the 1 M
+// bench set, +0.3 ms of sampling: dropped).  The reference sits between the two order-independent rules; the one kept is the one
+// with the better graph.
 // per-target, per-iteration salt of the reverse priorities
 __device__ __forceinline__ uint32_t nnd_offer_salt(uint32_t it_seed, uint32_t u) { return nnd_hash2(it_seed ^ 0x3C6EF372u, u); }
 
@@ -135,11 +133,10 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
         }
         bool ok = rw != NND_EMPTY_SLOT;
         const uint64_t rk = nnd_offer_key(rw, salt);
-        if (ok) {  // utils.py:427-430: an id already in the list is not pushed again (nnd_dup_min: it keeps the better draw)
+        if (ok) {  // utils.py:427-430: an id already in the list is not pushed again
             const uint32_t src = (uint32_t)rk;
             const int nf = c ? nfwd[1] : nfwd[0];
-            for (int j = 0; j < nf; j++)
-                if ((uint32_t)sc.key[c][j] == src) { ok = false; nnd_dup_min(&sc.key[c][j], rk); }
+            for (int j = 0; j < nf; j++) ok &= ((uint32_t)sc.key[c][j] != src);
         }
 #pragma unroll
         for (int cc = 0; cc < 2; cc++) {
@@ -163,8 +160,7 @@ __global__ __launch_bounds__(256) void k_sample_select(uint32_t *__restrict__ kn
                 const uint64_t rk = nnd_offer_key(rw, salt);
                 if (ok) {  // utils.py:427-430: an id already in the list is not pushed again
                     uint32_t src = (uint32_t)rk;
-                    for (int j = 0; j < nfwd[c]; j++)
-                        if ((uint32_t)sc.key[c][j] == src) { ok = false; nnd_dup_min(&sc.key[c][j], rk); }
+                    for (int j = 0; j < nfwd[c]; j++) ok &= ((uint32_t)sc.key[c][j] != src);
                 }
                 unsigned long long m = __ballot(ok);
                 if (ok) sc.key[c][cnt[c] + nnd_prefix_popc(m)] = rk;
@@ -262,8 +258,7 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
             const uint64_t rk = nnd_offer_key(rw, salt);
             if (__ballot(ok)) {  // utils.py:427-430: an id already in the list is not pushed again
                 const uint32_t src = (uint32_t)rk;
-                for (int j = 0; j < nfwd[c]; j++)
-                    if (ok && (uint32_t)key[c][j] == src) { ok = false; nnd_dup_min(&key[c][j], rk); }
+                for (int j = 0; j < nfwd[c]; j++) ok = ok && ((uint32_t)key[c][j] != src);
             }
             const unsigned long long m = __ballot(ok);
             if (ok) key[c][cnt[c] + nnd_prefix_popc(m)] = rk;
@@ -349,8 +344,8 @@ __device__ __forceinline__ void nnd_select_half(uint32_t *__restrict__ knn_e, in
             const uint32_t s0 = (uint32_t)rk0, s1 = (uint32_t)rk1;
             for (int q = 0; q < nfm; q++) {
                 const uint32_t f = (uint32_t)fl[q];
-                if (ok0 && q < nf1 && f == s0) { ok0 = false; nnd_dup_min(&fl[q], rk0); }
-                if (ok1 && q < nf1 && f == s1) { ok1 = false; nnd_dup_min(&fl[q], rk1); }
+                ok0 = ok0 && !(q < nf1 && f == s0);
+                ok1 = ok1 && !(q < nf1 && f == s1);
             }
         }
         int M = nf1;
@@ -396,8 +391,8 @@ __device__ __forceinline__ void nnd_select_half(uint32_t *__restrict__ knn_e, in
         const uint32_t s0 = (uint32_t)rk0, s1 = (uint32_t)rk1;
         for (int q = 0; q < nfm; q++) {
             const uint32_t f0 = (uint32_t)sk[0][q], f1 = (uint32_t)sk[1][q];
-            if (ok0 && q < nf0 && f0 == s0) { ok0 = false; nnd_dup_min(&sk[0][q], rk0); }
-            if (ok1 && q < nf1 && f1 == s1) { ok1 = false; nnd_dup_min(&sk[1][q], rk1); }
+            ok0 = ok0 && !(q < nf0 && f0 == s0);
+            ok1 = ok1 && !(q < nf1 && f1 == s1);
         }
     }
     {
@@ -848,6 +843,10 @@ __global__ __launch_bounds__(RV_SEL_THREADS) void k_rev_select(rv_inbox ib, int6
         if (!__ballot(act)) continue;  // wave-uniform
         const uint32_t rw0 = act ? bank[tl * ROW + j] : NND_EMPTY_SLOT, rw1 = act ? bank[tl * ROW + RCAP + j] : NND_EMPTY_SLOT;
         nnd_wave_lds_sync();  // the previous target's lists are done with
+#ifdef NND_RV_NOSELECT  // timing experiments only: the kernel without the per-target selection
+        if (e == 0x12345u && rw0 == 7u && rw1 == 9u) cand[0] = 1;
+        continue;
+#endif
         nnd_select_half<WIDE>(knn_e, k, ks, mc, mcp, it_seed, cand, act ? (int64_t)v : 0, act, e, rw0, rw1, sk, j, hb);
     }
 }
