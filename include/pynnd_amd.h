@@ -103,6 +103,9 @@ typedef struct nnd_params {
 /* test hook: the candidate sampling behaves as if the record regions of the bucketed transposition could not be allocated
  * (wide rows on a full device): the handle must switch to the hashed slots and build, not fail (tests/test_gpu_kernels.py) */
 #define NND_FLAG_TEST_SAMPLE_NOMEM 2048
+/* test hook: the fused candidate selection with 32 lanes per vertex where rows and candidate lists of at most 16 entries would
+ * take 16 (four vertices per wave): the two forms must write identical lists (tests/test_gpu_kernels.py) */
+#define NND_FLAG_TEST_SELECT_HALF 4096
 
 /* Run-time statistics for measurement (bench.py roofline). */
 typedef struct nnd_stats {

@@ -303,131 +303,178 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
 // The selection for one vertex per half-wave (both halves of the wave at once): forward edge word `e` of lane j, reverse slot
 // words rw0 (old-class bank, slot j) and rw1 (new-class bank) however the caller obtained them -- from rbuf
 // (k_sample_select_h) or from the LDS banks of the bucketed reverse pass (k_rev_select).  `sk`: the half-wave's LDS lists.
-template <bool WIDE>
-__device__ __forceinline__ void nnd_select_half(uint32_t *__restrict__ knn_e, int k, int ks, int mc, int mcp, uint32_t it_seed,
-                                                int32_t *__restrict__ cand, int64_t vv, bool act, uint32_t e, uint32_t rw0, uint32_t rw1,
-                                                uint64_t (*sk)[64], int j, int hb) {
+// One class of one vertex per GROUP of LW lanes (round 6; LW = 32: two vertices per wave, LW = 16: four -- rows of up to 16
+// neighbours with up to 16 candidates per class, the BASELINE regime).  Rounds 2-5 ranked EVERY item of a class against every
+// other one -- k forward edges + up to 32 (first pass: 64) reverse offers, two or three items per lane of a half-wave, a loop of
+// up to 47 (79) LDS broadcasts with a 64-bit compare per item: 400 of the 500 us of k_rev_select
+// (profiles/r06_sample_select_floor.log).  Only the max_candidates smallest keys matter, and the keys' priority words are
+// uniform 32-bit hashes: the items whose priority lies under a threshold tau -- chosen so that ~max_candidates + 10 pass -- are
+// compacted (at most two per lane), the reverse offers among THEM are screened against the forward ids, and only they are
+// ranked.  An item's rank among the survivors is its rank among all items (every smaller key passed too), so the lists are the
+// ones the full ranking writes, entry for entry (tests/test_gpu_kernels.py: exact-sample test, half-wave = wave test).  tau
+// moves (bisection) in the few per cent of the cases where fewer than max_candidates or more than 2 LW items pass.
+//   F = list[0 .. LW): the class's forward keys (the ids the duplicate screen reads); C = list[LW .. 3 LW): the survivors.
+// Returns the rank of this lane's forward item (1 << 30: not sampled).
+template <int LW>
+__device__ __forceinline__ int nnd_group_max(int v) {  // the largest v over the wave's groups (v is uniform inside a group)
+    int m = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+    for (int g = LW; g < 64; g += LW) {
+        const int o = __builtin_amdgcn_readlane(v, g);
+        m = o > m ? o : m;
+    }
+    return m;
+}
+template <int LW, int NR>
+__device__ __forceinline__ int nnd_select_class(bool act, bool fvalid, uint64_t fkey, const bool (&rvalid)[NR], const uint64_t (&rkey)[NR], int mc,
+                                                int mcp, int32_t *dst, uint64_t *list, int j, int gb) {
+    constexpr uint32_t GM = LW == 32 ? 0xFFFFFFFFu : ((1u << (LW & 31)) - 1u);
+    constexpr int CAP = 2 * LW;
+    uint64_t *F = list, *C = list + LW;
+    const uint32_t below = (1u << j) - 1u;
+    const uint32_t fmask = (uint32_t)(__ballot(fvalid) >> gb) & GM;
+    const int nf = __popc(fmask);
+    if (fvalid) F[__popc(fmask & below)] = fkey;
+    int M = nf;
+#pragma unroll
+    for (int i = 0; i < NR; i++) M += __popc((uint32_t)(__ballot(rvalid[i]) >> gb) & GM);
+    const uint32_t fp = (uint32_t)(fkey >> 32);
+    uint32_t rp[NR];
+#pragma unroll
+    for (int i = 0; i < NR; i++) rp[i] = (uint32_t)(rkey[i] >> 32);
+    uint32_t tau = 0xFFFFFFFFu, lo = 0u, hi = 0xFFFFFFFFu;
+    if (M > CAP || M > mc + 12) {
+        const float t = (float)(mc + 10) * 4294967296.0f / (float)M;
+        tau = t >= 4294967040.0f ? 0xFFFFFFFFu : (uint32_t)t;
+    }
+    const int nfm = nnd_group_max<LW>(nf);  // wave-uniform trip count of the screen
+    int count = 0, cv = 0, tpos = -1, cn = 0;
+    uint64_t key0 = NND_EMPTY_KEY, key1 = NND_EMPTY_KEY;
+    bool dup0 = false, dup1 = false;
+#pragma unroll 1
+    for (int iter = 0; iter < 30; iter++) {
+        nnd_wave_lds_sync();  // F is written / the previous round's reads of C are done
+        const bool fpass = fvalid && fp <= tau;
+        const uint32_t pm = (uint32_t)(__ballot(fpass) >> gb) & GM;
+        const int npf = __popc(pm);
+        tpos = fpass ? __popc(pm & below) : -1;
+        if (fpass) C[tpos] = fkey;  // (npf <= nf <= LW)
+        int pos = npf;
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const bool rpass = rvalid[i] && rp[i] <= tau;
+            const uint32_t m = (uint32_t)(__ballot(rpass) >> gb) & GM;
+            const int p = pos + __popc(m & below);
+            if (rpass && p < CAP) C[p] = rkey[i];
+            pos += __popc(m);
+        }
+        count = pos;
+        nnd_wave_lds_sync();
+        cn = count < CAP ? count : CAP;
+        const bool two = nnd_group_max<LW>(cn) > LW;  // wave-uniform: some group holds a second survivor per lane
+        key0 = j < cn ? C[j] : NND_EMPTY_KEY;
+        key1 = (two && LW + j < cn) ? C[LW + j] : NND_EMPTY_KEY;
+        // utils.py:427-430: an id already in the list is not pushed again (a reverse offer that repeats a forward edge of the class)
+        const bool rev0 = j >= npf && j < cn, rev1 = two && LW + j < cn;  // (survivors LW .. are reverse offers: npf <= LW)
+        dup0 = dup1 = false;
+        if (__ballot(rev0 || rev1)) {
+            const uint32_t s0 = (uint32_t)key0, s1 = (uint32_t)key1;
+            if (two) {
+#pragma unroll 4
+                for (int q = 0; q < nfm; q++) {
+                    const uint32_t f = (uint32_t)F[q];
+                    dup0 = dup0 || (rev0 && q < nf && f == s0);
+                    dup1 = dup1 || (rev1 && q < nf && f == s1);
+                }
+            } else {
+#pragma unroll 4
+                for (int q = 0; q < nfm; q++) dup0 = dup0 || (rev0 && q < nf && (uint32_t)F[q] == s0);
+            }
+        }
+        cv = cn - __popc((uint32_t)(__ballot(dup0) >> gb) & GM) - __popc((uint32_t)(__ballot(dup1) >> gb) & GM);
+        const bool ok = count <= CAP && (cv >= mc || tau == 0xFFFFFFFFu);
+        if (!__ballot(!ok)) break;  // every vertex of the wave is settled
+        if (!ok) {
+            if (count > CAP) {
+                hi = tau;
+                tau = lo + (hi - lo) / 2;
+            } else {
+                lo = tau;
+                const uint64_t up = (uint64_t)tau + (tau >> 1) + 1u;
+                tau = hi == 0xFFFFFFFFu ? (up >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)up) : lo + (hi - lo) / 2 + 1u;
+            }
+        }
+    }
+    if (dup0) key0 = NND_EMPTY_KEY;
+    if (dup1) key1 = NND_EMPTY_KEY;
+    const int cmax = nnd_group_max<LW>(cn);  // wave-uniform trip count
+    nnd_wave_lds_sync();  // every lane holds its survivors: C is rewritten with the screened keys
+    C[j] = key0;
+    if (cmax > LW) C[LW + j] = key1;
+    nnd_wave_lds_sync();
+    int r0 = 0, r1 = 0;
+    if (cmax > LW) {
+#pragma unroll 4
+        for (int q = 0; q < cmax; q++) {
+            const uint64_t kq = C[q];
+            const bool in = q < cn;
+            r0 += (in && kq < key0) ? 1 : 0;
+            r1 += (in && kq < key1) ? 1 : 0;
+        }
+    } else {
+#pragma unroll 4
+        for (int q = 0; q < cmax; q++) r0 += (q < cn && C[q] < key0) ? 1 : 0;
+    }
+    if (act) {
+        if (key0 != NND_EMPTY_KEY && r0 < mc) dst[r0] = (int32_t)(uint32_t)key0;
+        if (key1 != NND_EMPTY_KEY && r1 < mc) dst[r1] = (int32_t)(uint32_t)key1;
+        const int filled = cv < mc ? cv : mc;
+        for (int q = filled + j; q < mcp; q += LW) dst[q] = -1;
+    }
+    const int got = __builtin_amdgcn_ds_bpermute((gb + (tpos >= 0 ? tpos : 0)) << 2, r0);
+    return tpos >= 0 ? got : (1 << 30);
+}
+
+// The selection for one vertex per group of LW lanes: forward edge word `e` of lane j of the group, the lane's NRC reverse slot
+// words per class (rwo: old-class bank, rwn: new-class bank; slot i * LW + j) however the caller obtained them -- from rbuf
+// (k_sample_select_h) or from the LDS banks of the bucketed reverse pass (k_rev_select).  `list`: 3 LW keys of LDS per group.
+// WIDE (the first pass of a build: every edge new, both banks hold new-class offers, nnd_offer_addr): one class.
+template <bool WIDE, int LW, int NRC>
+__device__ __forceinline__ void nnd_select_group(uint32_t *__restrict__ knn_e, int k, int ks, int mc, int mcp, uint32_t it_seed,
+                                                 int32_t *__restrict__ cand, int64_t vv, bool act, uint32_t e, const uint32_t (&rwo)[NRC],
+                                                 const uint32_t (&rwn)[NRC], uint64_t *list, int j, int gb) {
     const uint32_t salt = nnd_offer_salt(it_seed, (uint32_t)vv);
-    const uint64_t rk0 = nnd_offer_key(rw0, salt), rk1 = nnd_offer_key(rw1, salt);
     const bool valid = e != NND_EMPTY_E;
     const uint32_t u = e & NND_IDX_MASK;
     const uint32_t cls = e >> 31;
     const uint64_t fkey = ((uint64_t)nnd_hash3(it_seed, (uint32_t)vv, u) << 32) | u;
-    const uint32_t below = (1u << j) - 1u;
-    int cnt[2];
-    uint32_t fmask1 = 0;  // forward new edges of my half
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const bool mine = valid && cls == (uint32_t)c;
-        const uint32_t hm = (uint32_t)(__ballot(mine) >> hb);
-        if (mine) sk[c][__popc(hm & below)] = fkey;
-        cnt[c] = __popc(hm);
-        if (c == 1) fmask1 = hm;
-    }
-    nnd_wave_lds_sync();
-    const int nf0 = cnt[0], nf1 = cnt[1];
-    int32_t *out = cand + vv * 2 * mcp;
-    int my_rank = 1 << 30;  // rank of this lane's forward new edge among the new offers
-    const int my_item = (valid && cls == 1u) ? __popc(fmask1 & below) : -1;
+    int32_t *out = cand + vv * 2 * mcp;  // layout [new | old]
+    int my_rank;  // rank of this lane's forward new edge among the new offers
     if constexpr (WIDE) {
-        // every forward edge is new (nf0 == 0): the items live in ONE list fl[0 .. M), forward edges first.  fl aliases
-        // sk[0] | sk[1]; the forward keys were written to sk[1] = fl + 64 above and move to the front here.
-        uint64_t *fl = &sk[0][0];
-        const uint64_t fk = j < nf1 ? sk[1][j] : NND_EMPTY_KEY;
-        nnd_wave_lds_sync();
-        if (j < nf1) fl[j] = fk;
-        nnd_wave_lds_sync();
-        bool ok0 = rw0 != NND_EMPTY_SLOT, ok1 = rw1 != NND_EMPTY_SLOT;
-        {
-            const int a0 = __builtin_amdgcn_readlane(nf1, 0), a1 = __builtin_amdgcn_readlane(nf1, 32);
-            const int nfm = a0 > a1 ? a0 : a1;  // wave-uniform trip count
-            const uint32_t s0 = (uint32_t)rk0, s1 = (uint32_t)rk1;
-            for (int q = 0; q < nfm; q++) {
-                const uint32_t f = (uint32_t)fl[q];
-                ok0 = ok0 && !(q < nf1 && f == s0);
-                ok1 = ok1 && !(q < nf1 && f == s1);
-            }
-        }
-        int M = nf1;
-        {   // bank order [old-class bank | new-class bank] = the order k_sample_select walks the 64 slots in
-            const uint32_t hm0 = (uint32_t)(__ballot(ok0) >> hb), hm1 = (uint32_t)(__ballot(ok1) >> hb);
-            if (ok0) fl[M + __popc(hm0 & below)] = rk0;
-            M += __popc(hm0);
-            if (ok1) fl[M + __popc(hm1 & below)] = rk1;
-            M += __popc(hm1);
-        }
-        nnd_wave_lds_sync();
-        const int m0 = __builtin_amdgcn_readlane(M, 0), m1 = __builtin_amdgcn_readlane(M, 32);
-        const int mm = m0 > m1 ? m0 : m1;  // wave-uniform trip count
-        const uint64_t key0 = j < M ? fl[j] : NND_EMPTY_KEY, key1 = 32 + j < M ? fl[32 + j] : NND_EMPTY_KEY, key2 = 64 + j < M ? fl[64 + j] : NND_EMPTY_KEY;
-        int r0 = 0, r1 = 0, r2 = 0;
-        for (int q = 0; q < mm; q++) {
-            const uint64_t kq = fl[q];
-            const bool in = q < M;
-            r0 += (in && kq < key0) ? 1 : 0;
-            r1 += (in && kq < key1) ? 1 : 0;
-            r2 += (in && kq < key2) ? 1 : 0;
-        }
-        if (act) {
-            if (j < M && r0 < mc) out[r0] = (int32_t)(uint32_t)key0;
-            if (32 + j < M && r1 < mc) out[r1] = (int32_t)(uint32_t)key1;
-            if (64 + j < M && r2 < mc) out[r2] = (int32_t)(uint32_t)key2;
-            const int filled = M < mc ? M : mc;
-            for (int q = filled + j; q < mcp; q += 32) out[q] = -1;
-            for (int q = j; q < mcp; q += 32) out[mcp + q] = -1;  // no old candidates yet
-        }
-        // forward item i < k <= 32 is item 0 of lane i of my half
-        const int got = __builtin_amdgcn_ds_bpermute((hb + (my_item >= 0 ? my_item : 0)) << 2, r0);
-        if (my_item >= 0) my_rank = got;
-        if (act && valid && cls == 1u && my_rank < mc) knn_e[vv * ks + j] = u;
-        return;
-    }
-    // utils.py:427-430: an id already in the list is not pushed again (a reverse offer that repeats a forward edge)
-    bool ok0 = rw0 != NND_EMPTY_SLOT, ok1 = rw1 != NND_EMPTY_SLOT;
-    {
-        const int a = nf0 > nf1 ? nf0 : nf1;
-        const int a0 = __builtin_amdgcn_readlane(a, 0), a1 = __builtin_amdgcn_readlane(a, 32);
-        const int nfm = a0 > a1 ? a0 : a1;  // wave-uniform trip count
-        const uint32_t s0 = (uint32_t)rk0, s1 = (uint32_t)rk1;
-        for (int q = 0; q < nfm; q++) {
-            const uint32_t f0 = (uint32_t)sk[0][q], f1 = (uint32_t)sk[1][q];
-            ok0 = ok0 && !(q < nf0 && f0 == s0);
-            ok1 = ok1 && !(q < nf1 && f1 == s1);
-        }
-    }
-    {
-        const uint32_t hm0 = (uint32_t)(__ballot(ok0) >> hb), hm1 = (uint32_t)(__ballot(ok1) >> hb);
-        if (ok0) sk[0][cnt[0] + __popc(hm0 & below)] = rk0;
-        if (ok1) sk[1][cnt[1] + __popc(hm1 & below)] = rk1;
-        cnt[0] += __popc(hm0);
-        cnt[1] += __popc(hm1);
-    }
-    nnd_wave_lds_sync();
-
+        bool rv[2 * NRC];
+        uint64_t rk[2 * NRC];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int M = cnt[c];
-        const int m0 = __builtin_amdgcn_readlane(M, 0), m1 = __builtin_amdgcn_readlane(M, 32);
-        const int mm = m0 > m1 ? m0 : m1;  // wave-uniform trip count
-        int32_t *dst = out + (c == 1 ? 0 : mcp);  // layout [new | old]
-        const uint64_t key0 = j < M ? sk[c][j] : NND_EMPTY_KEY, key1 = 32 + j < M ? sk[c][32 + j] : NND_EMPTY_KEY;
-        int r0 = 0, r1 = 0;
-        for (int q = 0; q < mm; q++) {
-            const uint64_t kq = sk[c][q];
-            const bool in = q < M;
-            r0 += (in && kq < key0) ? 1 : 0;
-            r1 += (in && kq < key1) ? 1 : 0;
+        for (int i = 0; i < NRC; i++) {
+            rv[i] = rwo[i] != NND_EMPTY_SLOT;
+            rk[i] = nnd_offer_key(rwo[i], salt);
+            rv[NRC + i] = rwn[i] != NND_EMPTY_SLOT;
+            rk[NRC + i] = nnd_offer_key(rwn[i], salt);
         }
-        if (act) {
-            if (j < M && r0 < mc) dst[r0] = (int32_t)(uint32_t)key0;
-            if (32 + j < M && r1 < mc) dst[r1] = (int32_t)(uint32_t)key1;
-            const int filled = M < mc ? M : mc;
-            for (int q = filled + j; q < mcp; q += 32) dst[q] = -1;
+        my_rank = nnd_select_class<LW, 2 * NRC>(act, valid, fkey, rv, rk, mc, mcp, out, list, j, gb);
+        if (act)
+            for (int q = j; q < mcp; q += LW) out[mcp + q] = -1;  // no old candidates yet
+    } else {
+        bool rv0[NRC], rv1[NRC];
+        uint64_t rk0[NRC], rk1[NRC];
+#pragma unroll
+        for (int i = 0; i < NRC; i++) {
+            rv0[i] = rwo[i] != NND_EMPTY_SLOT;
+            rk0[i] = nnd_offer_key(rwo[i], salt);
+            rv1[i] = rwn[i] != NND_EMPTY_SLOT;
+            rk1[i] = nnd_offer_key(rwn[i], salt);
         }
-        if (c == 1) {  // forward items sit at the front in lane order: item i < k <= 32 is item 0 of lane i of my half
-            const int got = __builtin_amdgcn_ds_bpermute((hb + (my_item >= 0 ? my_item : 0)) << 2, r0);
-            if (my_item >= 0) my_rank = got;
-        }
+        (void)nnd_select_class<LW, NRC>(act, valid && cls == 0u, fkey, rv0, rk0, mc, mcp, out + mcp, list, j, gb);
+        my_rank = nnd_select_class<LW, NRC>(act, valid && cls == 1u, fkey, rv1, rk1, mc, mcp, out, list, j, gb);
     }
     // flag reset (utils.py:311-318): a forward new edge that was sampled becomes old
     if (act && valid && cls == 1u && my_rank < mc) knn_e[vv * ks + j] = u;
@@ -439,7 +486,7 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
                                                          int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
                                                          const uint8_t *__restrict__ active) {
     constexpr int RCAP = 32;
-    __shared__ uint64_t skey[8][2][64];  // [half-wave of the workgroup][class][item] priority<<32 | id
+    __shared__ uint64_t skey[8][96];  // [half-wave of the workgroup][F: 32 forward keys | C: 64 survivors] priority<<32 | id
     const int lane = nnd_lane(), w = threadIdx.x >> 6, h = lane >> 5, j = lane & 31, hb = lane & 32;
     const int64_t v = own_lo + ((int64_t)blockIdx.x * 4 + w) * 2 + h;
     const bool von = v < own_hi;
@@ -447,7 +494,7 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
     if (von && !act)  // no new candidate can reach v: empty new list, nothing else to do (no offers were stored for it)
         for (int q = j; q < mcp; q += 32) cand[v * 2 * mcp + q] = -1;
     if (!__ballot(act)) return;  // wave-uniform
-    uint64_t(*sk)[64] = skey[w * 2 + h];
+    uint64_t *sk = skey[w * 2 + h];
     const int64_t vv = act ? v : own_lo;
 
     uint32_t e = NND_EMPTY_E;
@@ -460,7 +507,8 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
         if (rw0 != NND_EMPTY_SLOT) slots[j] = NND_EMPTY_SLOT;  // re-arm for the next iteration
         if (rw1 != NND_EMPTY_SLOT) slots[RCAP + j] = NND_EMPTY_SLOT;
     }
-    nnd_select_half<WIDE>(knn_e, k, ks, mc, mcp, it_seed, cand, vv, act, e, rw0, rw1, sk, j, hb);
+    const uint32_t rwo[1] = {rw0}, rwn[1] = {rw1};
+    nnd_select_group<WIDE, 32, 1>(knn_e, k, ks, mc, mcp, it_seed, cand, vv, act, e, rwo, rwn, sk, j, hb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -771,20 +819,21 @@ __global__ __launch_bounds__(1024) void k_rev_fill(rv_inbox ib, int64_t row0, in
 // runs the selection (nnd_select_half) for 8 of the bucket's targets in turn, the next one's k-list row requested while the
 // current one is ranked.  LDS: 32 KB banks + 16 KB selection lists: three workgroups = 24 waves per CU (measured against 1024
 // threads -- 4 targets per half-wave, 32 KB of lists, two workgroups = 32 waves per CU: 0.52 instead of 0.41 ms per launch).
-template <bool WIDE>
+template <bool WIDE, int LW>
 __global__ __launch_bounds__(RV_SEL_THREADS) void k_rev_select(rv_inbox ib, int64_t row0, int64_t n, const int32_t *__restrict__ order,
                                                     const uint8_t *__restrict__ active,
                                                     uint32_t *__restrict__ knn_e, int k, int ks, int mc, int mcp, uint32_t it_seed,
                                                     int32_t *__restrict__ cand) {
-    constexpr int RCAP = 32, NB = 128, ROW = 2 * RCAP, NT = RV_SEL_THREADS, NHW = NT / 32, PER = NB / NHW;
+    // LW lanes per target: 32 (k <= 32), or 16 -- four targets per wave -- when rows and candidate lists hold at most 16 entries
+    constexpr int RCAP = 32, NB = 128, ROW = 2 * RCAP, NT = RV_SEL_THREADS, NG = NT / LW, PER = NB / NG, NRC = RCAP / LW;
     constexpr int CAP = WIDE ? 2 * RCAP : RCAP;
     constexpr int NBANK = WIDE ? NB : 2 * NB;
     __shared__ uint32_t bank[NB * ROW];
     __shared__ uint32_t cnt[NBANK];
-    __shared__ uint64_t skey[NHW][2][64];
+    __shared__ uint64_t skey[NG][3 * LW];
     __shared__ int32_t vtx[NB];
     __shared__ int any_ovf;
-    const int tid = threadIdx.x, lane = tid & 63, hw = tid >> 5, j = lane & 31, hb = lane & 32;
+    const int tid = threadIdx.x, lane = tid & 63, grp = tid / LW, j = lane & (LW - 1), gb = lane & (64 - LW);
     const int64_t b = blockIdx.x;
     // the bucket's vertices: v >= 0 active, -2 - v inactive, -1 beyond the last vertex
     if (tid < NB) {
@@ -800,11 +849,11 @@ __global__ __launch_bounds__(RV_SEL_THREADS) void k_rev_select(rv_inbox ib, int6
     for (int i = tid; i < NBANK; i += NT) cnt[i] = 0;
     if (tid == 0) any_ovf = 0;
     __syncthreads();
-    // the k-list row of this half-wave's first target is requested now and lands during the fill phase; the next target's
+    // the k-list row of this group's first target is requested now and lands during the fill phase; the next target's
     // row is requested while the current one is ranked
     uint32_t pre_e = NND_EMPTY_E;
     {
-        const int32_t v0 = vtx[hw];
+        const int32_t v0 = vtx[grp];
         if (v0 >= 0 && j < k) pre_e = knn_e[(int64_t)v0 * ks + j];
     }
     rv_each_record(ib, b, tid, NT, [&](uint32_t w, uint32_t m) {
@@ -826,28 +875,33 @@ __global__ __launch_bounds__(RV_SEL_THREADS) void k_rev_select(rv_inbox ib, int6
         });
         __syncthreads();
     }
-    uint64_t(*sk)[64] = skey[hw];
+    uint64_t *sk = skey[grp];
 #pragma unroll 1
     for (int r = 0; r < PER; r++) {
-        const int tl = r * NHW + hw;
+        const int tl = r * NG + grp;
         const int32_t v = vtx[tl];
         const bool act = v >= 0;
         const uint32_t e = pre_e;
         pre_e = NND_EMPTY_E;
         if (r + 1 < PER) {
-            const int32_t vn = vtx[tl + NHW];
+            const int32_t vn = vtx[tl + NG];
             if (vn >= 0 && j < k) pre_e = knn_e[(int64_t)vn * ks + j];
         }
         if (v <= -2)  // no new candidate can reach the vertex: empty new list (its old list is never read)
-            for (int q = j; q < mcp; q += 32) cand[(int64_t)(-2 - v) * 2 * mcp + q] = -1;
+            for (int q = j; q < mcp; q += LW) cand[(int64_t)(-2 - v) * 2 * mcp + q] = -1;
         if (!__ballot(act)) continue;  // wave-uniform
-        const uint32_t rw0 = act ? bank[tl * ROW + j] : NND_EMPTY_SLOT, rw1 = act ? bank[tl * ROW + RCAP + j] : NND_EMPTY_SLOT;
+        uint32_t rwo[NRC], rwn[NRC];
+#pragma unroll
+        for (int i = 0; i < NRC; i++) {
+            rwo[i] = act ? bank[tl * ROW + i * LW + j] : NND_EMPTY_SLOT;
+            rwn[i] = act ? bank[tl * ROW + RCAP + i * LW + j] : NND_EMPTY_SLOT;
+        }
         nnd_wave_lds_sync();  // the previous target's lists are done with
 #ifdef NND_RV_NOSELECT  // timing experiments only: the kernel without the per-target selection
-        if (e == 0x12345u && rw0 == 7u && rw1 == 9u) cand[0] = 1;
+        if (e == 0x12345u && rwo[0] == 7u && rwn[0] == 9u) cand[0] = 1;
         continue;
 #endif
-        nnd_select_half<WIDE>(knn_e, k, ks, mc, mcp, it_seed, cand, act ? (int64_t)v : 0, act, e, rw0, rw1, sk, j, hb);
+        nnd_select_group<WIDE, LW, NRC>(knn_e, k, ks, mc, mcp, it_seed, cand, act ? (int64_t)v : 0, act, e, rwo, rwn, sk, j, gb);
     }
 }
 
@@ -1022,7 +1076,8 @@ static int launch_sample_bucketed(nnd_ctx *ctx, uint32_t it_seed, bool wide, con
     ib.ov = ctx->rv_ov;
     ib.ov_count = ov_count;
     if (fused) {
-        auto kern = wide ? k_rev_select<true> : k_rev_select<false>;
+        const bool q16 = ctx->ks == 16 && ctx->mc <= 16 && !(ctx->p.flags & NND_FLAG_TEST_SELECT_HALF);  // four targets per wave
+        auto kern = q16 ? (wide ? k_rev_select<true, 16> : k_rev_select<false, 16>) : (wide ? k_rev_select<true, 32> : k_rev_select<false, 32>);
         hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(RV_SEL_THREADS), 0, st, ib, row0, n_rows, order, ctx->active, ctx->knn_e, ctx->k, ctx->ks, ctx->mc, ctx->mcp,
                            it_seed, ctx->cand);
         return 0;

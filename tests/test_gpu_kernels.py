@@ -594,7 +594,7 @@ def test_sampling_falls_back_to_hashed_slots_when_the_record_regions_cannot_be_a
 
 
 @pytest.mark.parametrize("k,mc,stage,share_tol,fill_tol,tv_tol", [(15, 15, "first", 0.03, 0.01, 0.03), (15, 15, "mixed", 0.006, 0.002, 0.01),
-                                                                   (30, 30, "mixed", 0.04, 0.02, 0.2), (20, 10, "mixed", 0.03, 0.01, 0.03)])
+                                                                   (30, 30, "mixed", 0.02, 0.01, 0.06), (20, 10, "mixed", 0.03, 0.01, 0.03)])
 def test_candidate_lists_have_the_reference_algorithms_distribution(k, mc, stage, share_tol, fill_tol, tv_tol):
     """Round-5 review: the exact-sample test above checks the kernel against a host model of the LIBRARY'S OWN hashes; this one
     compares the lists with what the REFERENCE ALGORITHM (the oracle's new_build_candidates, pinned bit-exact to utils.py:222-320)
@@ -603,8 +603,8 @@ def test_candidate_lists_have_the_reference_algorithms_distribution(k, mc, stage
     Measured (round 6): where the lists are not full (k = mc = 15 after an iteration) every figure agrees to 0.002.  Two known
     deviations set the other tolerances: (1) FULL lists hold 2 points fewer forward entries than the reference's (0.757 vs 0.779
     on a first pass): the reference gives a mutual neighbour a second, order-dependent draw, the library keeps the forward draw
-    (sample.hip, before nnd_offer_salt: the order-independent alternative was measured and has the worse graph); (2) k = 30: a
-    quarter of the 32-slot old-class banks overflow and fall back to hashed minima -- 1.4 % fewer old candidates, 3 points more
+    (sample.hip, before nnd_offer_salt: the order-independent alternative was measured and has the worse graph); (2) k = 30: some
+    of the 32-slot old-class banks overflow and fall back to hashed minima -- 0.3 % fewer old candidates, 0.8 points more
     forward entries among them."""
     n = 60000
     x = clustered(n, 32, 8, 64, seed=5)
@@ -632,7 +632,8 @@ def test_candidate_lists_have_the_reference_algorithms_distribution(k, mc, stage
     every = np.arange(n)
     # the join skips a vertex without new candidates, and the library does not build its old list: compare the old lists
     # where both sides have new candidates
-    joined = np.nonzero((new[:, 0] >= 0) & (onew[:, 0] >= 0))[0]
+    # (the reference's lists are HEAPS: slot 0 is the root, filled last -- "has a candidate" is any(), not [:, 0])
+    joined = np.nonzero((new >= 0).any(1) & (onew >= 0).any(1))[0]
     assert len(joined) > 2000, len(joined)
     for name, g_l, o_l, rows in (("new", new, onew, every), ("old", old, oold, joined)):
         gm, gf, gh = stats(g_l, rows)
@@ -644,4 +645,6 @@ def test_candidate_lists_have_the_reference_algorithms_distribution(k, mc, stage
         assert abs(gf - of) <= share_tol, (name, gf, of)
         assert tv <= tv_tol, (name, tv)
     # the same vertices take part in the join (a vertex is active iff it has a new candidate)
-    assert abs(int((new[:, 0] >= 0).sum()) - int((onew[:, 0] >= 0).sum())) <= 0.002 * n
+    a_gpu, a_ref = int((new >= 0).any(1).sum()), int((onew >= 0).any(1).sum())
+    print("vertices with a new candidate: gpu %d reference %d of %d" % (a_gpu, a_ref, n))
+    assert abs(a_gpu - a_ref) <= 0.002 * n, (a_gpu, a_ref)
