@@ -534,6 +534,164 @@ __global__ __launch_bounds__(NW * 64, 2) void k_leaf_join_rb(const float *__rest
     }
 }
 
+// Rows of 17 .. 32 neighbours (k = 30, the reference's default, with leaves of up to 150 points), round 6.  k_leaf_join_rb above
+// gives every 64-row block of a leaf its own workgroup: the leaf's rows are staged once per block (three times at 150 points),
+// the Gram block is computed without symmetry (120 tiles for 55), and each row is merged by a whole wave (rank counting over
+// v_readlane broadcasts): 1.33 ms per tree at 1 M points even when nothing passes a threshold, 15.6 ms for eight trees
+// (profiles/r05_k30_per_tree.log).  Here ONE workgroup takes the whole leaf: rows staged once, the upper triangle of the Gram
+// block in registers (<= 7 tiles per wave), and the distance rows go to LDS 64 at a time -- a pass writes the rows of its block
+// from the tiles that hold them, directly or transposed, over the LDS the row tile occupied -- where two rows per wave are
+// merged by nnd_merge_rows_q32b (candidates compacted, then a 32-lane sorting network).  Rows of one leaf are owned by one
+// workgroup: no atomics.
+template <int NT, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NT <= 6 ? 4 : 3) void k_leaf_join_sym(const float *__restrict__ xp, int dp, const float *__restrict__ nrm, int metric,
+                                                          const int32_t *__restrict__ perm, const int32_t *__restrict__ wl_start,
+                                                          const int32_t *__restrict__ wl_len, int64_t leaf0, int64_t n_leaves, int k, int ks,
+                                                          uint32_t *__restrict__ knn_e, float *__restrict__ knn_d, float *__restrict__ th,
+                                                          long long *__restrict__ counters, int m_lo) {
+    constexpr int DC = 64, MP = NT * 16, RB = 64, DSTRIDE = MP + 1, NTHR = NW * 64;
+    constexpr int NTILES = NT * (NT + 1) / 2, TPW = (NTILES + NW - 1) / NW;
+    constexpr int NLD = (MP * (DC / 4) + NTHR - 1) / NTHR;  // 16-byte row chunks per thread and K block
+    constexpr int BIG = MP * DC > RB * DSTRIDE ? MP * DC : RB * DSTRIDE;
+    constexpr int SPW = RB / (2 * NW);                      // merge steps (two rows each) per wave and pass
+    __shared__ __attribute__((aligned(16))) float big[BIG];  // row tile, then 64 distance rows at a time
+    __shared__ int32_t ids[MP];
+    __shared__ float nrs[MP];
+    __shared__ uint2 qscr[NW * 2 * NND_Q32B_CAP];
+    const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
+    const int64_t leaf = leaf0 + blockIdx.x;
+    if (leaf >= n_leaves) return;
+    const int start = wl_start[leaf], m = wl_len[leaf];
+    if (m < 2) return;                    // no pairs
+    if (m <= m_lo || m > MP) return;      // a launch takes the leaves of ITS size class (run_leaf_rounds)
+    const int nt = (m + 15) >> 4, mp = nt << 4;
+    for (int r = tid; r < MP; r += NTHR) {
+        const int id = r < m ? perm[start + r] : -1;
+        ids[r] = id;
+        nrs[r] = nrm[id >= 0 ? id : 0];
+    }
+    __syncthreads();
+    f32x4 acc[TPW];
+    int tI[TPW], tJ[TPW];
+    bool tOn[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; q++) {
+        acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int t = w + q * NW, I = 0;
+        while (I < nt && t >= nt - I) {  // wave-uniform: row-major walk of the upper triangle
+            t -= nt - I;
+            I++;
+        }
+        tOn[q] = I < nt;
+        tI[q] = I < nt ? I : 0;
+        tJ[q] = I < nt ? I + t : 0;
+    }
+    float *Xs = big;
+    const int r16 = lane & 15, g = lane >> 4;
+    for (int c0 = 0; c0 < dp; c0 += DC) {
+        const int cw = (dp - c0) < DC ? (dp - c0) : DC;
+        const int nch = cw >> 2, total = mp * nch, nsh = cw == 64 ? 4 : 3;
+        f32x4 rv[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int idx = tid + q * NTHR, idc = idx < total ? idx : 0;
+            const int r = idc >> nsh, ch = idc & (nch - 1);
+            const int id = ids[r];
+            rv[q] = *(const f32x4 *)(xp + (int64_t)(id >= 0 ? id : 0) * dp + c0 + 4 * ch);
+        }
+        if (c0 > 0) __syncthreads();  // the previous block's operand reads are done
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int idx = tid + q * NTHR;
+            if (idx < total) {
+                const int r = idx >> nsh, ch = idx & (nch - 1);
+                *(f32x4 *)&Xs[nnd_swz<DC>(r, ch)] = rv[q];
+            }
+        }
+        __syncthreads();
+        for (int t = 0; t < (cw >> 4); t++) {
+            const int c = 4 * t + g;
+#pragma unroll
+            for (int q = 0; q < TPW; q++) {
+                if (!tOn[q]) continue;  // wave-uniform
+                const float4 a = *(const float4 *)&Xs[nnd_swz<DC>(tI[q] * 16 + r16, c)];
+                const float4 b = *(const float4 *)&Xs[nnd_swz<DC>(tJ[q] * 16 + r16, c)];
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[q], 0, 0, 0);
+            }
+        }
+    }
+    // Gram values -> distances, once (registers)
+#pragma unroll
+    for (int q = 0; q < TPW; q++) {
+        if (!tOn[q]) continue;
+        const float nj = nrs[tJ[q] * 16 + r16];
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[q][r] = nnd_gram_to_dist(metric, acc[q][r], nrs[tI[q] * 16 + 4 * g + r], nj);
+    }
+    float *Dm = big;  // RB x DSTRIDE: row il = leaf row p0 + il
+    int accepted = 0;
+    const int j32 = lane & 31, h = lane >> 5;
+    for (int p0 = 0; p0 < m; p0 += RB) {
+        // this wave's k-list rows of the pass: in flight while the distance rows are written
+        uint32_t pe[SPW];
+        float pd[SPW];
+#pragma unroll
+        for (int st = 0; st < SPW; st++) {
+            const int i = p0 + w * (2 * SPW) + 2 * st + h;
+            const bool on = i < m && j32 < k;
+            const int64_t v = ids[i < m ? i : 0];
+            const uint32_t ev = knn_e[v * ks + (on ? j32 : 0)];
+            const float dv = knn_d[v * ks + (on ? j32 : 0)];
+            pe[st] = on ? ev : NND_EMPTY_E;
+            pd[st] = on ? dv : INFINITY;
+        }
+        __syncthreads();  // Xs (first pass) / the previous pass's rows are done with
+#pragma unroll
+        for (int q = 0; q < TPW; q++) {
+            if (!tOn[q]) continue;
+            const int I = tI[q], J = tJ[q];
+            if (I * 16 >= p0 && I * 16 < p0 + RB) {  // the tile's rows belong to this pass
+#pragma unroll
+                for (int r = 0; r < 4; r++) Dm[(I * 16 + 4 * g + r - p0) * DSTRIDE + J * 16 + r16] = acc[q][r];
+            }
+            if (I != J && J * 16 >= p0 && J * 16 < p0 + RB) {  // ... and, transposed, its columns
+#pragma unroll
+                for (int r = 0; r < 4; r++) Dm[(J * 16 + r16 - p0) * DSTRIDE + I * 16 + 4 * g + r] = acc[q][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < SPW; st++) {
+            if (p0 + w * (2 * SPW) + 2 * st >= m) break;  // wave-uniform: no row left for this wave
+            const int i = p0 + w * (2 * SPW) + 2 * st + h;
+            const bool on = i < m;
+            const float *Drow = Dm + (on ? i - p0 : 0) * DSTRIDE;
+            const int64_t v = ids[on ? i : 0];
+            accepted += nnd_merge_rows_q32b(on, knn_e + v * ks, knn_d + v * ks, th + v, pe[st], pd[st], k, m,
+                                            [&](int c, uint32_t &id, float &dc) {
+                                                id = (uint32_t)ids[c];
+                                                dc = Drow[c];
+                                                return c != i;  // pynndescent_.py:97: p != q
+                                            }, qscr + w * 2 * NND_Q32B_CAP);
+        }
+    }
+    __syncthreads();
+    int *wacc = (int *)nrs;  // nrs is dead
+    if (lane == 0) wacc[w] = accepted;
+    __syncthreads();
+    if (tid == 0) {
+        long long a = 0;
+        for (int q = 0; q < NW; q++) a += wacc[q];
+        nnd_count(counters, CNT_ACCEPT, a);
+        nnd_count(counters, CNT_PAIRS, (long long)m * (m - 1) / 2);
+        nnd_count(counters, CNT_ROWS, m);
+        nnd_count(counters, CNT_MFMA, (long long)(nt * (nt + 1) / 2) * (dp >> 2));
+    }
+}
+
 // Work list: leaves longer than 256 points (possible only when max_depth cuts the recursion short,
 // rp_trees.py:2188) are cut into runs of <= 256 consecutive positions for seeding purposes.
 static constexpr int LEAF_MAX = 256;
@@ -559,7 +717,14 @@ static int run_leaf_rounds(nnd_ctx *ctx, const int32_t *perm, const int32_t *d_w
                 hipLaunchKernelGGL((k_leaf_join_rb<10, 8, true>), dim3((unsigned)cnt, 3), dim3(512), 0, ctx->stream, LEAF_ARGS);
             else
                 hipLaunchKernelGGL((k_leaf_join_rb<16, 8, true>), dim3((unsigned)cnt, 4), dim3(512), 0, ctx->stream, LEAF_ARGS);
-        } else if (maxlen <= 64 && qw)
+        }
+#ifndef NND_LEAF_OLD_K32
+        else if (!qw && ctx->k <= 32 && maxlen <= 160) {  // k = 17 .. 32: one workgroup per leaf, two rows per wave (k_leaf_join_sym)
+            hipLaunchKernelGGL((k_leaf_join_sym<6, 8>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 0);
+            if (maxlen > 96) hipLaunchKernelGGL((k_leaf_join_sym<10, 8>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 96);
+        }
+#endif
+        else if (maxlen <= 64 && qw)
             hipLaunchKernelGGL((k_leaf_join<4, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 0);
         else if (maxlen <= 64)
             hipLaunchKernelGGL((k_leaf_join<4, 8, 64>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 0);

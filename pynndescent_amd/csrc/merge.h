@@ -447,6 +447,135 @@ __device__ __forceinline__ int nnd_merge_rows_q16b(bool row_on, uint32_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same merge for rows of up to 32 neighbours (k = 30, the reference's default): TWO rows per wave, 32 lanes each (round 6).
+// Round 4 built two-rows-per-wave merges twice (insertion, rank counting) and measured no gain; what differs here is what
+// differed at k <= 16: the candidates are compacted first (a later tree leaves ~25 of ~87 leaf-mates under the threshold) and a
+// queue of up to 32 is folded by a sorting network over the row's 32 lanes -- 15 compare-exchange stages to sort the batch, the
+// elementwise min against the mirrored row, 5 half-cleaners.  Partners inside a 16-lane DPP row come by DPP, the three stages
+// that cross rows (lane ^ 31 twice, lane ^ 16) by ds_bpermute.
+#define NND_Q32B_CAP 64  // queue entries per row
+template <int PX>
+__device__ __forceinline__ uint32_t nnd_q32_partner(uint32_t v, int lane) {  // value of lane ^ PX (inside the 32-lane half)
+    if constexpr (PX == 1) return nnd_q16_partner<NND_DPP_QUAD_XOR1>(v);
+    else if constexpr (PX == 2) return nnd_q16_partner<NND_DPP_QUAD_XOR2>(v);
+    else if constexpr (PX == 3) return nnd_q16_partner<NND_DPP_QUAD_MIRROR>(v);
+    else if constexpr (PX == 4) return nnd_q16_partner<-1>(v);
+    else if constexpr (PX == 7) return nnd_q16_partner<NND_DPP_ROW_HALF_MIRROR>(v);
+    else if constexpr (PX == 8) return nnd_q16_partner<NND_DPP_ROW_ROR(8)>(v);
+    else if constexpr (PX == 15) return nnd_q16_partner<NND_DPP_ROW_MIRROR>(v);
+    else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ PX) << 2, (int)v);  // 16, 31: across the DPP rows
+}
+template <int PX>
+__device__ __forceinline__ void nnd_q32_cx(uint32_t &lo, uint32_t &hi, bool keep_max, int lane) {
+    const uint32_t plo = nnd_q32_partner<PX>(lo, lane), phi = nnd_q32_partner<PX>(hi, lane);
+    const bool take = ((((uint64_t)phi << 32) | plo) < (((uint64_t)hi << 32) | lo)) != keep_max;
+    lo = take ? plo : lo;
+    hi = take ? phi : hi;
+}
+template <int PX>
+__device__ __forceinline__ void nnd_q32_cx(uint32_t &lo, uint32_t &hi, uint32_t &fl, bool keep_max, int lane) {
+    const uint32_t plo = nnd_q32_partner<PX>(lo, lane), phi = nnd_q32_partner<PX>(hi, lane), pfl = nnd_q32_partner<PX>(fl, lane);
+    const bool take = ((((uint64_t)phi << 32) | plo) < (((uint64_t)hi << 32) | lo)) != keep_max;
+    lo = take ? plo : lo;
+    hi = take ? phi : hi;
+    fl = take ? pfl : fl;
+}
+
+template <typename CandFn>
+__device__ __forceinline__ int nnd_merge_rows_q32b(bool row_on, uint32_t *__restrict__ row_e, float *__restrict__ row_d,
+                                                   float *__restrict__ th_slot, uint32_t e, float d, int k, int ncand,
+                                                   CandFn cand, uint2 *wave_scr) {
+    const int lane = nnd_lane(), j = lane & 31, gb = lane & 32;
+    uint2 *my = wave_scr + (lane >> 5) * NND_Q32B_CAP;
+    const uint32_t e_in = e;
+    const float d_in = d;
+    uint32_t klo = e & NND_IDX_MASK, khi = __float_as_uint(d), flag = e & NND_NEW_BIT;  // key = khi:klo
+    if (e == NND_EMPTY_E) { klo = 0xFFFFFFFFu; khi = 0xFFFFFFFFu; flag = 0u; }
+    const bool any_list = __ballot(e != NND_EMPTY_E) != 0;
+    float th_cur = __int_as_float(__builtin_amdgcn_ds_bpermute((gb + k - 1) << 2, __float_as_int(d)));  // (+inf while the row is not full)
+    const bool b0 = (j & 1) != 0, b1 = (j & 2) != 0, b2 = (j & 4) != 0, b3 = (j & 8) != 0, b4 = (j & 16) != 0;
+    const uint32_t below = (1u << j) - 1u;
+    int fill = 0, pushed = 0;
+    const int nblk = (ncand + 31) >> 5;
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; blk++) {
+        const int c = blk * 32 + j;
+        uint32_t cid = 0;
+        float dc = 0.0f;
+        bool ok = row_on && c < ncand && cand(c, cid, dc);
+        ok = ok && (dc < th_cur);  // strict, utils.py:484
+        const unsigned long long cmask = __ballot(ok);
+        if (cmask) {
+            const uint32_t m32 = (uint32_t)(cmask >> gb);
+            if (ok) my[fill + __popc(m32 & below)] = make_uint2(cid, __float_as_uint(dc));
+            fill += __popc(m32);
+        }
+        const bool last = blk + 1 >= nblk;
+        if (!__ballot(fill > 32 || (fill > 0 && (last || th_cur == INFINITY)))) continue;
+        nnd_wave_lds_sync();
+#pragma unroll 1
+        for (int b = 0; b < NND_Q32B_CAP / 32; b++) {
+            if (!__ballot(fill > 32 * b)) break;  // wave-uniform
+            const uint2 s = my[32 * b + j];
+            bool sok = 32 * b + j < fill && __uint_as_float(s.y) < th_cur;  // queued against an older threshold: test again
+            if (any_list && __ballot(sok)) {  // utils.py:489-492 (every lane evaluates the rotations: see nnd_merge_rows_q16b)
+                const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)klo);
+                const bool dup0 = nnd_q16_any_eq<15>(klo, s.x), dup1 = nnd_q16_any_eq<15>(other, s.x);
+                const bool dup = dup0 || dup1;
+                sok = sok && !dup;
+            }
+            const unsigned long long mask = __ballot(sok);
+            if (!mask) continue;
+            pushed += __popcll(mask);
+            uint32_t slo = sok ? s.x : 0xFFFFFFFFu, shi = sok ? s.y : 0xFFFFFFFFu;
+            // bitonic sort of the batch, ascending over the row's 32 lanes
+            nnd_q32_cx<1>(slo, shi, b0, lane);
+            nnd_q32_cx<3>(slo, shi, b1, lane);
+            nnd_q32_cx<1>(slo, shi, b0, lane);
+            nnd_q32_cx<7>(slo, shi, b2, lane);
+            nnd_q32_cx<2>(slo, shi, b1, lane);
+            nnd_q32_cx<1>(slo, shi, b0, lane);
+            nnd_q32_cx<15>(slo, shi, b3, lane);
+            nnd_q32_cx<4>(slo, shi, b2, lane);
+            nnd_q32_cx<2>(slo, shi, b1, lane);
+            nnd_q32_cx<1>(slo, shi, b0, lane);
+            nnd_q32_cx<31>(slo, shi, b4, lane);
+            nnd_q32_cx<8>(slo, shi, b3, lane);
+            nnd_q32_cx<4>(slo, shi, b2, lane);
+            nnd_q32_cx<2>(slo, shi, b1, lane);
+            nnd_q32_cx<1>(slo, shi, b0, lane);
+            {   // the 32 smallest of row U batch: min(row[j], batch[31 - j]) is bitonic; five half-cleaners sort it
+                const uint32_t tlo = nnd_q32_partner<31>(slo, lane), thi = nnd_q32_partner<31>(shi, lane);
+                const bool take = (((uint64_t)thi << 32) | tlo) < (((uint64_t)khi << 32) | klo);
+                klo = take ? tlo : klo;
+                khi = take ? thi : khi;
+                flag = take ? NND_NEW_BIT : flag;
+            }
+            nnd_q32_cx<16>(klo, khi, flag, b4, lane);
+            nnd_q32_cx<8>(klo, khi, flag, b3, lane);
+            nnd_q32_cx<4>(klo, khi, flag, b2, lane);
+            nnd_q32_cx<2>(klo, khi, flag, b1, lane);
+            nnd_q32_cx<1>(klo, khi, flag, b0, lane);
+            if (j >= k) { klo = 0xFFFFFFFFu; khi = 0xFFFFFFFFu; flag = 0u; }  // k < 32: the row ends at slot k - 1
+            const uint32_t wk = (uint32_t)__builtin_amdgcn_ds_bpermute((gb + k - 1) << 2, (int)khi);
+            th_cur = wk == 0xFFFFFFFFu ? INFINITY : __uint_as_float(wk);
+        }
+        fill = 0;
+        nnd_wave_lds_sync();  // the queue is read: the next block may overwrite it
+    }
+    if (pushed == 0) return 0;
+    const bool empty = (klo & khi) == 0xFFFFFFFFu;
+    e = empty ? NND_EMPTY_E : (klo | flag);
+    d = empty ? INFINITY : __uint_as_float(khi);
+    if (row_on && j < k && (e != e_in || d != d_in)) {
+        row_e[j] = e;
+        row_d[j] = d;
+        if (j == k - 1) *th_slot = d;  // new worst distance of the row
+    }
+    return pushed;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Wide rows, 64 < k <= NND_WIDE_K = 256 (the reference has no bound on n_neighbors, utils.py:130-158; 256 is also the cap of its
 // default leaf size, rp_trees.py:2845): the row does not fit one entry per lane -- a lane holds entries lane, 64 + lane, ... --
 // so it is merged through LDS -- same result as nnd_merge_row_regs (the k smallest keys of row U {candidates

@@ -343,7 +343,7 @@ __device__ __forceinline__ int nnd_select_class(bool act, bool fvalid, uint64_t 
 #pragma unroll
     for (int i = 0; i < NR; i++) rp[i] = (uint32_t)(rkey[i] >> 32);
     uint32_t tau = 0xFFFFFFFFu, lo = 0u, hi = 0xFFFFFFFFu;
-    if (M > CAP || M > mc + 12) {
+    if (M > CAP || M > 2 * mc + 4) {  // (a list that is not much longer than what is kept is ranked whole: nothing to gain from a threshold)
         const float t = (float)(mc + 10) * 4294967296.0f / (float)M;
         tau = t >= 4294967040.0f ? 0xFFFFFFFFu : (uint32_t)t;
     }
