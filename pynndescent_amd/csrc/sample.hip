@@ -303,8 +303,149 @@ __global__ __launch_bounds__(256) void k_sample_select_wide(uint32_t *__restrict
 // The selection for one vertex per half-wave (both halves of the wave at once): forward edge word `e` of lane j, reverse slot
 // words rw0 (old-class bank, slot j) and rw1 (new-class bank) however the caller obtained them -- from rbuf
 // (k_sample_select_h) or from the LDS banks of the bucketed reverse pass (k_rev_select).  `sk`: the half-wave's LDS lists.
-// One class of one vertex per GROUP of LW lanes (round 6; LW = 32: two vertices per wave, LW = 16: four -- rows of up to 16
-// neighbours with up to 16 candidates per class, the BASELINE regime).  Rounds 2-5 ranked EVERY item of a class against every
+// k <= 32 with 32 reverse slots per class (max_candidates <= 32, the BASELINE regime): TWO vertices per wave, 32 lanes
+// each.  k_sample_select keeps ~30 of 64 lanes busy and is bound by instruction issue; here the loops (duplicate screen
+// over the forward ids, rank count over the items) run for both vertices at once.  Lane j of a half holds forward edge
+// j, reverse slots j (old class) and 32 + j (new class), and items j and 32 + j of each class's list (<= k + 32 <= 64
+// items).  Same keys, same duplicate rule, same ranks: the candidate lists are identical to k_sample_select's.
+// WIDE (the first pass of a build: every edge new, both banks hold new-class offers, nnd_offer_addr): one list of up to
+// k + 64 <= 96 items -- the two classes' LDS arrays of a half-wave are adjacent and are used as one, three items per lane.
+// The selection for one vertex per half-wave (both halves of the wave at once): forward edge word `e` of lane j, reverse slot
+// words rw0 (old-class bank, slot j) and rw1 (new-class bank) however the caller obtained them -- from rbuf
+// (k_sample_select_h) or from the LDS banks of the bucketed reverse pass (k_rev_select).  `sk`: the half-wave's LDS lists.
+template <bool WIDE>
+__device__ __forceinline__ void nnd_select_half(uint32_t *__restrict__ knn_e, int k, int ks, int mc, int mcp, uint32_t it_seed,
+                                                int32_t *__restrict__ cand, int64_t vv, bool act, uint32_t e, uint32_t rw0, uint32_t rw1,
+                                                uint64_t (*sk)[64], int j, int hb) {
+    const uint32_t salt = nnd_offer_salt(it_seed, (uint32_t)vv);
+    const uint64_t rk0 = nnd_offer_key(rw0, salt), rk1 = nnd_offer_key(rw1, salt);
+    const bool valid = e != NND_EMPTY_E;
+    const uint32_t u = e & NND_IDX_MASK;
+    const uint32_t cls = e >> 31;
+    const uint64_t fkey = ((uint64_t)nnd_hash3(it_seed, (uint32_t)vv, u) << 32) | u;
+    const uint32_t below = (1u << j) - 1u;
+    int cnt[2];
+    uint32_t fmask1 = 0;  // forward new edges of my half
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const bool mine = valid && cls == (uint32_t)c;
+        const uint32_t hm = (uint32_t)(__ballot(mine) >> hb);
+        if (mine) sk[c][__popc(hm & below)] = fkey;
+        cnt[c] = __popc(hm);
+        if (c == 1) fmask1 = hm;
+    }
+    nnd_wave_lds_sync();
+    const int nf0 = cnt[0], nf1 = cnt[1];
+    int32_t *out = cand + vv * 2 * mcp;
+    int my_rank = 1 << 30;  // rank of this lane's forward new edge among the new offers
+    const int my_item = (valid && cls == 1u) ? __popc(fmask1 & below) : -1;
+    if constexpr (WIDE) {
+        // every forward edge is new (nf0 == 0): the items live in ONE list fl[0 .. M), forward edges first.  fl aliases
+        // sk[0] | sk[1]; the forward keys were written to sk[1] = fl + 64 above and move to the front here.
+        uint64_t *fl = &sk[0][0];
+        const uint64_t fk = j < nf1 ? sk[1][j] : NND_EMPTY_KEY;
+        nnd_wave_lds_sync();
+        if (j < nf1) fl[j] = fk;
+        nnd_wave_lds_sync();
+        bool ok0 = rw0 != NND_EMPTY_SLOT, ok1 = rw1 != NND_EMPTY_SLOT;
+        {
+            const int a0 = __builtin_amdgcn_readlane(nf1, 0), a1 = __builtin_amdgcn_readlane(nf1, 32);
+            const int nfm = a0 > a1 ? a0 : a1;  // wave-uniform trip count
+            const uint32_t s0 = (uint32_t)rk0, s1 = (uint32_t)rk1;
+            for (int q = 0; q < nfm; q++) {
+                const uint32_t f = (uint32_t)fl[q];
+                ok0 = ok0 && !(q < nf1 && f == s0);
+                ok1 = ok1 && !(q < nf1 && f == s1);
+            }
+        }
+        int M = nf1;
+        {   // bank order [old-class bank | new-class bank] = the order k_sample_select walks the 64 slots in
+            const uint32_t hm0 = (uint32_t)(__ballot(ok0) >> hb), hm1 = (uint32_t)(__ballot(ok1) >> hb);
+            if (ok0) fl[M + __popc(hm0 & below)] = rk0;
+            M += __popc(hm0);
+            if (ok1) fl[M + __popc(hm1 & below)] = rk1;
+            M += __popc(hm1);
+        }
+        nnd_wave_lds_sync();
+        const int m0 = __builtin_amdgcn_readlane(M, 0), m1 = __builtin_amdgcn_readlane(M, 32);
+        const int mm = m0 > m1 ? m0 : m1;  // wave-uniform trip count
+        const uint64_t key0 = j < M ? fl[j] : NND_EMPTY_KEY, key1 = 32 + j < M ? fl[32 + j] : NND_EMPTY_KEY, key2 = 64 + j < M ? fl[64 + j] : NND_EMPTY_KEY;
+        int r0 = 0, r1 = 0, r2 = 0;
+        for (int q = 0; q < mm; q++) {
+            const uint64_t kq = fl[q];
+            const bool in = q < M;
+            r0 += (in && kq < key0) ? 1 : 0;
+            r1 += (in && kq < key1) ? 1 : 0;
+            r2 += (in && kq < key2) ? 1 : 0;
+        }
+        if (act) {
+            if (j < M && r0 < mc) out[r0] = (int32_t)(uint32_t)key0;
+            if (32 + j < M && r1 < mc) out[r1] = (int32_t)(uint32_t)key1;
+            if (64 + j < M && r2 < mc) out[r2] = (int32_t)(uint32_t)key2;
+            const int filled = M < mc ? M : mc;
+            for (int q = filled + j; q < mcp; q += 32) out[q] = -1;
+            for (int q = j; q < mcp; q += 32) out[mcp + q] = -1;  // no old candidates yet
+        }
+        // forward item i < k <= 32 is item 0 of lane i of my half
+        const int got = __builtin_amdgcn_ds_bpermute((hb + (my_item >= 0 ? my_item : 0)) << 2, r0);
+        if (my_item >= 0) my_rank = got;
+        if (act && valid && cls == 1u && my_rank < mc) knn_e[vv * ks + j] = u;
+        return;
+    }
+    // utils.py:427-430: an id already in the list is not pushed again (a reverse offer that repeats a forward edge)
+    bool ok0 = rw0 != NND_EMPTY_SLOT, ok1 = rw1 != NND_EMPTY_SLOT;
+    {
+        const int a = nf0 > nf1 ? nf0 : nf1;
+        const int a0 = __builtin_amdgcn_readlane(a, 0), a1 = __builtin_amdgcn_readlane(a, 32);
+        const int nfm = a0 > a1 ? a0 : a1;  // wave-uniform trip count
+        const uint32_t s0 = (uint32_t)rk0, s1 = (uint32_t)rk1;
+        for (int q = 0; q < nfm; q++) {
+            const uint32_t f0 = (uint32_t)sk[0][q], f1 = (uint32_t)sk[1][q];
+            ok0 = ok0 && !(q < nf0 && f0 == s0);
+            ok1 = ok1 && !(q < nf1 && f1 == s1);
+        }
+    }
+    {
+        const uint32_t hm0 = (uint32_t)(__ballot(ok0) >> hb), hm1 = (uint32_t)(__ballot(ok1) >> hb);
+        if (ok0) sk[0][cnt[0] + __popc(hm0 & below)] = rk0;
+        if (ok1) sk[1][cnt[1] + __popc(hm1 & below)] = rk1;
+        cnt[0] += __popc(hm0);
+        cnt[1] += __popc(hm1);
+    }
+    nnd_wave_lds_sync();
+
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int M = cnt[c];
+        const int m0 = __builtin_amdgcn_readlane(M, 0), m1 = __builtin_amdgcn_readlane(M, 32);
+        const int mm = m0 > m1 ? m0 : m1;  // wave-uniform trip count
+        int32_t *dst = out + (c == 1 ? 0 : mcp);  // layout [new | old]
+        const uint64_t key0 = j < M ? sk[c][j] : NND_EMPTY_KEY, key1 = 32 + j < M ? sk[c][32 + j] : NND_EMPTY_KEY;
+        int r0 = 0, r1 = 0;
+        for (int q = 0; q < mm; q++) {
+            const uint64_t kq = sk[c][q];
+            const bool in = q < M;
+            r0 += (in && kq < key0) ? 1 : 0;
+            r1 += (in && kq < key1) ? 1 : 0;
+        }
+        if (act) {
+            if (j < M && r0 < mc) dst[r0] = (int32_t)(uint32_t)key0;
+            if (32 + j < M && r1 < mc) dst[r1] = (int32_t)(uint32_t)key1;
+            const int filled = M < mc ? M : mc;
+            for (int q = filled + j; q < mcp; q += 32) dst[q] = -1;
+        }
+        if (c == 1) {  // forward items sit at the front in lane order: item i < k <= 32 is item 0 of lane i of my half
+            const int got = __builtin_amdgcn_ds_bpermute((hb + (my_item >= 0 ? my_item : 0)) << 2, r0);
+            if (my_item >= 0) my_rank = got;
+        }
+    }
+    // flag reset (utils.py:311-318): a forward new edge that was sampled becomes old
+    if (act && valid && cls == 1u && my_rank < mc) knn_e[vv * ks + j] = u;
+}
+
+// One class of one vertex per GROUP of LW lanes (round 6; used with LW = 16: FOUR vertices per wave -- rows of up to 16
+// neighbours with up to 16 candidates per class, the BASELINE regime; with 32 lanes per vertex and lists of up to 32 the form
+// measured 0.4 ms per build SLOWER than nnd_select_half above at k = 20 and k = 30, which therefore keeps those regimes).  Rounds 2-5 ranked EVERY item of a class against every
 // other one -- k forward edges + up to 32 (first pass: 64) reverse offers, two or three items per lane of a half-wave, a loop of
 // up to 47 (79) LDS broadcasts with a 64-bit compare per item: 400 of the 500 us of k_rev_select
 // (profiles/r06_sample_select_floor.log).  Only the max_candidates smallest keys matter, and the keys' priority words are
@@ -486,7 +627,7 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
                                                          int32_t *__restrict__ cand, int64_t own_lo, int64_t own_hi,
                                                          const uint8_t *__restrict__ active) {
     constexpr int RCAP = 32;
-    __shared__ uint64_t skey[8][96];  // [half-wave of the workgroup][F: 32 forward keys | C: 64 survivors] priority<<32 | id
+    __shared__ uint64_t skey[8][2][64];  // [half-wave of the workgroup][class][item] priority<<32 | id
     const int lane = nnd_lane(), w = threadIdx.x >> 6, h = lane >> 5, j = lane & 31, hb = lane & 32;
     const int64_t v = own_lo + ((int64_t)blockIdx.x * 4 + w) * 2 + h;
     const bool von = v < own_hi;
@@ -494,7 +635,7 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
     if (von && !act)  // no new candidate can reach v: empty new list, nothing else to do (no offers were stored for it)
         for (int q = j; q < mcp; q += 32) cand[v * 2 * mcp + q] = -1;
     if (!__ballot(act)) return;  // wave-uniform
-    uint64_t *sk = skey[w * 2 + h];
+    uint64_t(*sk)[64] = skey[w * 2 + h];
     const int64_t vv = act ? v : own_lo;
 
     uint32_t e = NND_EMPTY_E;
@@ -507,8 +648,7 @@ __global__ __launch_bounds__(256) void k_sample_select_h(uint32_t *__restrict__ 
         if (rw0 != NND_EMPTY_SLOT) slots[j] = NND_EMPTY_SLOT;  // re-arm for the next iteration
         if (rw1 != NND_EMPTY_SLOT) slots[RCAP + j] = NND_EMPTY_SLOT;
     }
-    const uint32_t rwo[1] = {rw0}, rwn[1] = {rw1};
-    nnd_select_group<WIDE, 32, 1>(knn_e, k, ks, mc, mcp, it_seed, cand, vv, act, e, rwo, rwn, sk, j, hb);
+    nnd_select_half<WIDE>(knn_e, k, ks, mc, mcp, it_seed, cand, vv, act, e, rw0, rw1, sk, j, hb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -830,7 +970,7 @@ __global__ __launch_bounds__(RV_SEL_THREADS) void k_rev_select(rv_inbox ib, int6
     constexpr int NBANK = WIDE ? NB : 2 * NB;
     __shared__ uint32_t bank[NB * ROW];
     __shared__ uint32_t cnt[NBANK];
-    __shared__ uint64_t skey[NG][3 * LW];
+    __shared__ uint64_t skey[NG][LW == 32 ? 128 : 3 * LW];  // LW = 32: the two 64-item class lists of nnd_select_half
     __shared__ int32_t vtx[NB];
     __shared__ int any_ovf;
     const int tid = threadIdx.x, lane = tid & 63, grp = tid / LW, j = lane & (LW - 1), gb = lane & (64 - LW);
@@ -901,7 +1041,10 @@ __global__ __launch_bounds__(RV_SEL_THREADS) void k_rev_select(rv_inbox ib, int6
         if (e == 0x12345u && rwo[0] == 7u && rwn[0] == 9u) cand[0] = 1;
         continue;
 #endif
-        nnd_select_group<WIDE, LW, NRC>(knn_e, k, ks, mc, mcp, it_seed, cand, act ? (int64_t)v : 0, act, e, rwo, rwn, sk, j, gb);
+        if constexpr (LW == 32)
+            nnd_select_half<WIDE>(knn_e, k, ks, mc, mcp, it_seed, cand, act ? (int64_t)v : 0, act, e, rwo[0], rwn[0], (uint64_t(*)[64])sk, j, gb);
+        else
+            nnd_select_group<WIDE, LW, NRC>(knn_e, k, ks, mc, mcp, it_seed, cand, act ? (int64_t)v : 0, act, e, rwo, rwn, sk, j, gb);
     }
 }
 
