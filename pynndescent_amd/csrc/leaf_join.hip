@@ -543,8 +543,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_leaf_join_rb(const float *__rest
 // from the tiles that hold them, directly or transposed, over the LDS the row tile occupied -- where two rows per wave are
 // merged by nnd_merge_rows_q32b (candidates compacted, then a 32-lane sorting network).  Rows of one leaf are owned by one
 // workgroup: no atomics.
+#ifndef NND_SYM_OCC_S
+#define NND_SYM_OCC_S 4
+#endif
+#ifndef NND_SYM_OCC_L
+#define NND_SYM_OCC_L 3
+#endif
 template <int NT, int NW = 8>
-__global__ __launch_bounds__(NW * 64, NT <= 6 ? 4 : 3) void k_leaf_join_sym(const float *__restrict__ xp, int dp, const float *__restrict__ nrm, int metric,
+__global__ __launch_bounds__(NW * 64, NT <= 6 ? NND_SYM_OCC_S : NND_SYM_OCC_L) void k_leaf_join_sym(const float *__restrict__ xp, int dp, const float *__restrict__ nrm, int metric,
                                                           const int32_t *__restrict__ perm, const int32_t *__restrict__ wl_start,
                                                           const int32_t *__restrict__ wl_len, int64_t leaf0, int64_t n_leaves, int k, int ks,
                                                           uint32_t *__restrict__ knn_e, float *__restrict__ knn_d, float *__restrict__ th,
