@@ -662,7 +662,7 @@ def run(args, world, rank, local_rank, share_gpu, wd):
         # HBM traffic per launch from the committed PMC passes (tools/pmc_traffic.py; separate --pmc runs, FETCH_SIZE
         # corrected by the factor calibrated for this access pattern); null if no profile of this kernel is committed
         traffic = traffic_from = None
-        for tname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 tj = json.load(open(tpath))

@@ -536,14 +536,15 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
         }
         if (lane == 0) nnewbuf[buf] = nn | (no << 8);
     };
-    f32x4 rt[NB][NT];  // this lane's chunks of its row in every tile (one K block)
+    f32x4 rt[NB][NT];   // this lane's chunks of its row in every tile (one K block)
+    f32x4 rt2[NB][NT];  // ... of the NEXT K block (round 6: requested before the MFMAs of the current one, not after them)
     float nx_nrm[RPL], nx_th[RPL];
     int nx_id[RPL];
     auto tile_live = [&](int t, int nn, int no) __attribute__((always_inline)) -> bool {
         return t < NA ? 16 * t < nn : 16 * (t - NA) < no;
     };
     // rows of K block [c0, c0 + cw) of the vertex whose ids are in cb[]; empty slots read row 0 (cache hit, masked later)
-    auto load_rows = [&](const int32_t *cb, int c0, int cw, int nn, int no) __attribute__((always_inline)) {
+    auto load_rows_into = [&](f32x4 (&dst)[NB][NT], const int32_t *cb, int c0, int cw, int nn, int no) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < NB; t++) {
             if (!tile_live(t, nn, no)) continue;
@@ -551,9 +552,10 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
             const float *pr = xp + (int64_t)(id >= 0 ? id : 0) * dp + c0 + 4 * gq;
 #pragma unroll
             for (int j = 0; j < NT; j++)
-                if (16 * j < cw) rt[t][j] = *(const f32x4 *)(pr + 16 * j);
+                if (16 * j < cw) dst[t][j] = *(const f32x4 *)(pr + 16 * j);
         }
     };
+    auto load_rows = [&](const int32_t *cb, int c0, int cw, int nn, int no) __attribute__((always_inline)) { load_rows_into(rt, cb, c0, cw, nn, no); };
     auto issue_gather = [&](int buf) __attribute__((always_inline)) {
         const int32_t *cb = cidbuf + buf * RV;
         const int cnt = nnewbuf[buf], nn = cnt & 255, no = cnt >> 8;
@@ -645,9 +647,10 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
         if (nn > 0) {
             land_gather();
             nnd_wave_lds_sync();
-            for (int c0 = 0; c0 < dp; c0 += DC) {
-                const int cw = (dp - c0) < DC ? (dp - c0) : DC;
-                if (c0 > 0) load_rows(cid, c0, cw, nn, no);  // later K blocks are fetched in turn
+            // K blocks, double-buffered in registers: the rows of block c + 1 are requested BEFORE the MFMAs of block c (rounds 1-5
+            // fetched them "in turn": three exposed gather latencies per vertex at d = 128 with 32-float blocks, and a wave is
+            // one of twelve on its CU)
+            auto gram_block = [&](const f32x4 (&r)[NB][NT], int c0, int cw) __attribute__((always_inline)) {
 #pragma unroll
                 for (int a = 0; a < NA; a++) {
                     if (!tile_live(a, nn, no)) continue;
@@ -658,13 +661,32 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
 #pragma unroll
                         for (int j = 0; j < NT; j++) {
                             if (16 * j >= cw) continue;
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(rt[a][j].x, rt[b][j].x, acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(rt[a][j].y, rt[b][j].y, acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(rt[a][j].z, rt[b][j].z, acc[a][b], 0, 0, 0);
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(rt[a][j].w, rt[b][j].w, acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[a][j].x, r[b][j].x, acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[a][j].y, r[b][j].y, acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[a][j].z, r[b][j].z, acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[a][j].w, r[b][j].w, acc[a][b], 0, 0, 0);
                         }
                     }
                 }
+            };
+            for (int c0 = 0; c0 < dp; c0 += 2 * DC) {
+                const int cw = (dp - c0) < DC ? (dp - c0) : DC;
+                const int c1 = c0 + DC, cw1 = (dp - c1) < DC ? (dp - c1) : DC;
+#ifndef NND_JW_NO_PIPELINE
+                if (c1 < dp) load_rows_into(rt2, cid, c1, cw1, nn, no);
+                gram_block(rt, c0, cw);
+                if (c1 < dp) {
+                    if (c1 + DC < dp) load_rows_into(rt, cid, c1 + DC, (dp - c1 - DC) < DC ? (dp - c1 - DC) : DC, nn, no);
+                    gram_block(rt2, c1, cw1);
+                }
+#else
+                gram_block(rt, c0, cw);
+                if (c1 < dp) {
+                    load_rows_into(rt2, cid, c1, cw1, nn, no);
+                    gram_block(rt2, c1, cw1);
+                    if (c1 + DC < dp) load_rows_into(rt, cid, c1 + DC, (dp - c1 - DC) < DC ? (dp - c1 - DC) : DC, nn, no);
+                }
+#endif
             }
         }
         // the row registers are free: the gather of this wave's next vertex flies during the epilogue

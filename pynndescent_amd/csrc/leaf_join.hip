@@ -743,7 +743,11 @@ static int run_leaf_rounds(nnd_ctx *ctx, const int32_t *perm, const int32_t *d_w
             hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 0);
 #else
             hipLaunchKernelGGL((k_leaf_join<4, 4, 64, true>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS, 0);
+#ifdef NND_LEAF_EMPTY_L  // timing experiment: what do the workgroups that leave at once cost?
+            hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 1000);
+#else
             hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 64);
+#endif
 #endif
         }
         else if (maxlen <= 80)
