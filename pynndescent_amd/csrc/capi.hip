@@ -467,7 +467,12 @@ static int h2d_parallel(nnd_ctx *ctx, void *dst_dev, const void *src, size_t byt
     std::lock_guard<std::mutex> lk(g_up_mu[dev]);
     API_HIP(hipSetDevice(dev));
     for (int b = 0; b < P; b++) {
-        if (!g_up_stage[dev][b]) API_HIP(hipHostMalloc((void **)&g_up_stage[dev][b], STAGE, hipHostMallocDefault));
+        if (!g_up_stage[dev][b] && hipHostMalloc((void **)&g_up_stage[dev][b], STAGE, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();  // no pinned memory for the staging buffers: the runtime's own pageable path
+            g_up_stage[dev][b] = nullptr;
+            API_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+            return 0;
+        }
         if (!g_up_ev[dev][b]) {
             API_HIP(hipEventCreateWithFlags(&g_up_ev[dev][b], hipEventDisableTiming));
         } else {

@@ -522,3 +522,35 @@ def test_wide_rows_up_to_256_neighbours(metric, k, n_trees):
     assert O.recall(tq, qi) >= 0.9, O.recall(tq, qi)
     with pytest.raises(NotImplementedError, match="n_neighbors <= 256"):
         NNDescent(x, metric, n_neighbors=257)
+
+
+def test_result_arrays_come_from_the_pinned_pool_and_are_recycled():
+    """Round 6 (include/pynnd_amd.h nnd_host_alloc, _capi.HostPool): the graph of a build lands in pinned host buffers that return
+    to the pool when the last numpy view of them dies; arrays handed to the caller are ordinary writable numpy arrays, two
+    indexes alive at the same time never share a buffer, and a build into pool memory equals a build into numpy memory."""
+    import gc
+
+    from pynndescent_amd import _capi
+
+    n, k = 90_000, 15  # 5.4 MB per array: above the pool's 4 MB floor
+    x = clustered(n, 32, 8, 64, seed=4)
+    a = NNDescent(x, "euclidean", n_neighbors=k, n_trees=4, random_state=5)
+    ia, da = a._neighbor_graph
+    assert not ia.flags.owndata and ia.flags.writeable and ia.flags.c_contiguous  # a view of a pool buffer
+    b = NNDescent(x, "euclidean", n_neighbors=k, n_trees=4, random_state=5)
+    ib, db = b._neighbor_graph
+    assert ia.ctypes.data != ib.ctypes.data and da.ctypes.data != db.ctypes.data
+    np.testing.assert_array_equal(ia, ib)  # same seed, same graph
+    np.testing.assert_array_equal(da, db)
+    g_idx, g_dist = a.neighbor_graph  # the copies come from the pool too
+    assert g_idx.ctypes.data != ia.ctypes.data and np.array_equal(g_idx, ia)
+    np.testing.assert_array_equal(g_dist, np.sqrt(da))
+    addr = {ib.ctypes.data, db.ctypes.data}
+    del b, ib, db
+    gc.collect()
+    c = NNDescent(x, "euclidean", n_neighbors=k, n_trees=4, random_state=5)
+    ic, dc = c._neighbor_graph
+    assert {ic.ctypes.data, dc.ctypes.data} & addr, "the released buffers were not reused"
+    np.testing.assert_array_equal(ic, ia)  # ... and `a`'s arrays were not touched by the reuse
+    _capi.host_pool.trim()  # (idle buffers go back to the runtime; buffers in use are untouched)
+    np.testing.assert_array_equal(ic, ia)
