@@ -220,22 +220,23 @@ def cpu_baseline(O, xs, k, n_trees, true_rows=None, true_idx=None):
     reference's own scheme would be on many cores.)"""
     cores = os.cpu_count() or 1
     O.build()
+    kind = O.build_native()  # -march=native on THIS box's cores when gcc is here (round-5 review: the shipped library is x86-64-v3)
     probe = xs[: min(200_000, xs.shape[0])]
     best_t, best = None, None
     for t in sorted({min(cores, c) for c in (32, 64, 128, 256, cores)}):
         t1 = time.perf_counter()
-        O.build_index(probe, "euclidean", n_neighbors=k, n_trees=n_trees, random_state=1234, n_threads=t, kind="fast")
+        O.build_index(probe, "euclidean", n_neighbors=k, n_trees=n_trees, random_state=1234, n_threads=t, kind=kind)
         dt = time.perf_counter() - t1
         if best is None or dt < best:
             best_t, best = t, dt
     t1 = time.perf_counter()
-    oidx, _ = O.build_index(xs, "euclidean", n_neighbors=k, n_trees=n_trees, random_state=1234, n_threads=best_t, kind="fast")
+    oidx, _ = O.build_index(xs, "euclidean", n_neighbors=k, n_trees=n_trees, random_state=1234, n_threads=best_t, kind=kind)
     dt = time.perf_counter() - t1
     rec = None
     if true_rows is not None:
         rec = round(float(O.recall(true_idx, oidx[true_rows])), 4)
     return {"value": round(xs.shape[0] / dt, 1), "unit": "points/s", "cores": best_t, "host_cores": cores, "kind": "port",
-            "seconds": round(dt, 2), "recall_at_10": rec,
+            "seconds": round(dt, 2), "recall_at_10": rec, "build_flags": "-O3 -ffast-math -fopenmp -march=%s" % ("native (compiled on this box)" if kind == "native" else "x86-64-v3"),
             "note": "PORT: a C/OpenMP restatement of the reference algorithm (oracle/), NOT the reference's numba code "
                     "(numba is not installable in this image)",
             "sample": "all %d points of the same set, same k/n_trees/defaults; gcc -O3 -ffast-math + OpenMP, %d threads "

@@ -46,6 +46,29 @@ def build(force=False):
     return libs
 
 
+def build_native():
+    """``liboracle_native.so``: the 'fast' flags with -march=native, compiled on the box that runs it (bench.py's cpu_baseline leg
+    on the GPU box's host; the library is never committed or shipped).  Returns 'native' when it could be built and loaded, else 'fast'."""
+    path = os.path.join(_HERE, "_build", "liboracle_native.so")
+    try:
+        import hashlib
+
+        src = os.path.join(_HERE, "nnd_oracle.c")
+        with open("/proc/cpuinfo") as fh:  # the library is only valid on the CPU it was compiled on: a copy that travelled is rebuilt
+            cpu = [ln for ln in fh.read().splitlines() if ln.startswith(("model name", "flags"))][:2]
+        tag = hashlib.sha1("\n".join(cpu).encode()).hexdigest()
+        stamp = path + ".cpu"
+        same = os.path.exists(stamp) and open(stamp).read().strip() == tag
+        if (not os.path.exists(path)) or not same or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            with open(stamp, "w") as fh:
+                fh.write(tag)
+        load("native")
+        return "native"
+    except Exception:
+        return "fast"
+
+
 _LIBS = {}
 
 
