@@ -129,3 +129,25 @@ def test_host_copy_and_sqrt_helpers_match_numpy():
     small = np.arange(10, dtype=np.float32)
     assert np.array_equal(_capi.host_sqrt(small), np.sqrt(small))
     assert np.array_equal(_capi.host_copy(a[::2]), a[::2])
+
+
+def test_host_pool_falls_back_to_numpy_without_a_device():
+    """_capi.HostPool (round 6): result arrays in pinned host memory -- without a HIP device nnd_host_alloc returns NULL and the
+    pool hands out ordinary numpy arrays; small requests never touch the library."""
+    import numpy as np
+    import torch
+
+    from pynndescent_amd import _capi
+
+    pool = _capi.HostPool()
+    small = pool.empty((10, 3), np.float32)
+    assert small.shape == (10, 3) and small.flags.owndata
+    big = pool.empty((1_200_000, 2), np.int32)  # 9.6 MB
+    assert big.shape == (1_200_000, 2) and big.dtype == np.int32 and big.flags.writeable and big.flags.c_contiguous
+    big[:] = 7
+    assert int(big.sum()) == 7 * big.size
+    if not torch.cuda.is_available():
+        assert big.flags.owndata  # numpy's own memory: nothing to return to the pool
+        lib = _capi.load_library()
+        assert not lib.nnd_host_alloc(1 << 20)
+    pool.trim()

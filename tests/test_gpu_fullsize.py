@@ -26,7 +26,7 @@ def _oracle(key, x_host, *unused, **unused_kw):
 _two_sided = two_sided
 
 
-def _build(x, metric, k, n_trees, seed=1, join_blocks=1):
+def _build(x, metric, k, n_trees, seed=1, join_blocks=0):  # 0: the library's schedule of sub-steps -- what the drop-in class runs
     n, d = x.shape
     rng_state, _, ts = O.draw_rng_states(seed, n_trees)
     b = _capi.Builder(n, d, O.METRICS[metric], k, n_trees, O.default_leaf_size(k), 200, min(60, k), O.default_n_iters(n),
@@ -206,7 +206,7 @@ def test_mid_recall_regime_iid_gaussian_200k(metric, d):
     ti, _ = O.brute_force_knn(x, 10, metric, rows=rows, kind="fast")
     r_gpu, r_cpu, its = [], [], []
     for seed in (1, 2, 3):
-        idx, dist, st = _build(xt, metric, 15, n_trees, seed=seed, join_blocks=0)
+        idx, dist, st = _build(xt, metric, 15, n_trees, seed=seed)
         r_gpu.append(O.recall(ti, idx.cpu().numpy()[rows]))
         its.append(st["n_iters_run"])
     for seed in (1, 2, 3, 4, 5):
