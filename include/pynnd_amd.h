@@ -106,6 +106,9 @@ typedef struct nnd_params {
 /* test hook: the fused candidate selection with 32 lanes per vertex where rows and candidate lists of at most 16 entries would
  * take 16 (four vertices per wave): the two forms must write identical lists (tests/test_gpu_kernels.py) */
 #define NND_FLAG_TEST_SELECT_HALF 4096
+/* test hook (row-sharded build): the per-iteration threshold / neighbour-id all-gather on the BUILD's channel, in front of the offer
+ * exchange (rounds 3-5), where it would run on the second channel beside the sampling: same graph either way (tests/test_gpu_sharded.py) */
+#define NND_FLAG_TEST_GATHER_INLINE 8192
 
 /* Run-time statistics for measurement (bench.py roofline). */
 typedef struct nnd_stats {
@@ -303,6 +306,12 @@ typedef struct nnd_shard_info {
     int32_t forest_by_cell;       /* 1: forest sharded by cell, 0: split by tree */
     int32_t n_sections_overlap;   /* the first sections of the build that need only this rank's rows: the point-set all-gather runs beside them */
     int64_t forest_positions;     /* point-trees this rank finished and seeded (forest by cell: ~ n_trees * n / ranks) */
+    /* ABI 6: the threshold / neighbour-id all-gather of every iteration runs on the SECOND channel beside the offer exchange and the
+     * second half of the sampling (only the join needs what it brings).  gather_bytes[i]: payload this rank sent in it;
+     * gather_section[i]: index of the compute section it runs beside (LOCAL serial mode times that section apart; -1: the gather ran on
+     * the build's channel, in front of the offer exchange, as it did through round 5) */
+    int64_t gather_bytes[64];
+    int32_t gather_section[64];
 } nnd_shard_info;
 int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, nnd_comm_t comm, const int64_t *shard_sizes);
 /* x_local_dev: this rank's rows, float32 (n_local, dim) on its GPU, complete when the call is made (or produced on

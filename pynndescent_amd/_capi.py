@@ -27,6 +27,7 @@ NND_FLAG_TEST_FAIL = 64  # test hook (sharded build): this rank returns an error
 NND_FLAG_TEST_VANISH = 128  # ... or returns there without telling anybody (a killed process)
 NND_FLAG_TEST_FOREST_FALLBACK_TOPS = 512  # test hook (sharded build): a rank reports that the by-cell forest cannot be built (at the tops)
 NND_FLAG_TEST_FOREST_FALLBACK_SHARE = 1024  # ... at the owners' shares; both flags: at the over-long cells
+NND_FLAG_TEST_GATHER_INLINE = 8192  # test hook (sharded build): the id / threshold gather on the build's channel instead of the second one
 NND_FLAG_TEST_SELECT_HALF = 4096  # test hook: the fused selection with 32 lanes per vertex where 16 would do (k <= 16, max_candidates <= 16)
 NND_FLAG_TEST_SAMPLE_NOMEM = 2048  # test hook: the sampler's record regions "cannot be allocated": the handle must fall back to the hashed slots
 NND_FLAG_TEST_SAMPLE_ATOMIC = 256  # test hook: reverse offers by one global atomicMin per edge (rounds 1-4) instead of the bucketed transposition
@@ -118,6 +119,8 @@ class NNDShardInfo(C.Structure):
         ("forest_by_cell", C.c_int32),
         ("n_sections_overlap", C.c_int32),
         ("forest_positions", C.c_int64),
+        ("gather_bytes", C.c_int64 * 64),
+        ("gather_section", C.c_int32 * 64),
     ]
 
     def as_dict(self):
@@ -134,7 +137,8 @@ class NNDShardInfo(C.Structure):
                 "section_ms": [float(v) for v in self.section_ms[:ns]],
                 "section_bytes": [int(v) for v in self.section_bytes[:ns]],
                 "forest_by_cell": bool(self.forest_by_cell), "n_sections_overlap": int(self.n_sections_overlap),
-                "forest_positions": int(self.forest_positions)}
+                "forest_positions": int(self.forest_positions),
+                "gather_bytes": [int(v) for v in self.gather_bytes[:it]], "gather_section": [int(v) for v in self.gather_section[:it]]}
 
 
 HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,

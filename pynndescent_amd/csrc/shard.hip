@@ -55,6 +55,7 @@ struct nnd_shard_s {
     int32_t *maps = nullptr;                     // small host-built tables (cell renumbering, roots, ...), grow-only
     int64_t maps_cap = 0;
     hipEvent_t ev_x = nullptr;                   // the point-set all-gather on the second channel has finished
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr; // per iteration: the owned rows are final / the id + threshold gather on the second channel is done
     nnd_shard_info info{};
     char err[512] = {0};
     void set_error(const char *fmt, ...) {
@@ -166,6 +167,8 @@ static void shard_free(nnd_shard_s *s) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->ev_x) (void)hipEventDestroy(s->ev_x);
+    if (s->ev_g0) (void)hipEventDestroy(s->ev_g0);
+    if (s->ev_g1) (void)hipEventDestroy(s->ev_g1);
     if (s->h) (void)nnd_destroy(s->h);
     delete s;
 }
@@ -250,6 +253,7 @@ extern "C" int32_t nnd_shard_create(nnd_shard_t *out, const nnd_params *params, 
     bool ok = hipSetDevice(p.device) == hipSuccess;
     ok = ok && hipMalloc((void **)&s->cvec, sizeof(long long) * (size_t)(NND_MAX_RANKS + 8)) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&s->ev_x, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&s->ev_g0, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->ev_g1, hipEventDisableTiming) == hipSuccess;
     if (ok && G > 1 && p.n_trees > 0) {
         ok = ok && hipMalloc((void **)&s->own_order, sizeof(int32_t) * (size_t)(n_own > 0 ? n_own : 1)) == hipSuccess;
         ok = ok && hipMalloc((void **)&s->order_cursor, sizeof(int)) == hipSuccess;
@@ -773,6 +777,8 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
     s->info.iters = 0;
     s->info.n_sections = 0;
     s->info.dropped_offers = 0;
+    memset(s->info.gather_bytes, 0, sizeof(s->info.gather_bytes));
+    for (int i = 0; i < 64; i++) s->info.gather_section[i] = -1;
     memset(s->info.c, 0, sizeof(s->info.c));
     memset(s->info.offer_records, 0, sizeof(s->info.offer_records));
     memset(s->info.proposal_records, 0, sizeof(s->info.proposal_records));
@@ -986,6 +992,12 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
         //     come back), an id that has entered since only lets a junk record through to the owner's own test.  So once
         //     an iteration changes under NND_GATHER_MIN of the entries (known here: the count wait above) the ids are not
         //     gathered again -- 4 * ks of the 4 + 4 * ks bytes per row, in the iterations where few rows changed.
+        //     Round 6: only the JOIN needs what this gather brings, so with a second channel it runs THERE, beside the offer
+        //     exchange and the second half of the sampling (which read and write this rank's own rows only; the peers read the
+        //     slices being sent while the sampling clears "new" flags in them -- the membership tests mask that bit), and the
+        //     build's stream waits for it in front of the join.  LOCAL serial mode (the critical-path tool) keeps the gather on
+        //     the build's channel -- nothing may run beside a timed section -- and reports it for the tool to price the overlap.
+        bool gather_async = false;
         if (G > 1) {
             const bool ids_now = s->gather_lists && (it == 0 || (double)c_prev >= NND_GATHER_MIN * (double)s->k * (double)s->n_total);
             size_t soff[NND_MAX_RANKS], scnt[NND_MAX_RANKS], roff[NND_MAX_RANKS], rcnt[NND_MAX_RANKS];
@@ -997,9 +1009,23 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
             }
             void *sb[2] = {h->th, h->knn_e}, *rb[2] = {h->th, h->knn_e};
             const int eb[2] = {4, 4 * s->ks};
-            const int64_t b0 = c->bytes_sent;
-            S_COMM(comm_alltoallv(c, st, ids_now ? 2 : 1, sb, rb, eb, soff, scnt, roff, rcnt));
-            note_bytes(s, b0);
+            gather_async = c->aux && c->aux_stream && !serial && !(s->gp.flags & NND_FLAG_TEST_GATHER_INLINE);
+            nnd_comm_s *gc = gather_async ? c->aux : c;
+            hipStream_t gs = gather_async ? c->aux_stream : st;
+            if (gather_async) {  // the second stream starts behind the merge that made this rank's rows final
+                S_HIP(hipEventRecord(s->ev_g0, st));
+                S_HIP(hipStreamWaitEvent(gs, s->ev_g0, 0));
+            }
+            const int64_t b0 = gc->bytes_sent;
+            if (comm_alltoallv(gc, gs, ids_now ? 2 : 1, sb, rb, eb, soff, scnt, roff, rcnt)) { s->set_error("id / threshold gather: %s", gc->err); return 1; }
+            const int64_t moved = gc->bytes_sent - b0;
+            if (gc != c) c->bytes_sent += moved;
+            if (gather_async) S_HIP(hipEventRecord(s->ev_g1, gs));
+            if (it < 64) {
+                s->info.gather_bytes[it] = moved;
+                s->info.gather_section[it] = -1;
+            }
+            if (!gather_async && !serial) note_bytes(s, b0);  // (serial mode: priced apart by the tool, see gather_section)
             h->lists_replicated = s->gather_lists;
         }
         s->info.dropped_offers += matrix[(size_t)me * nv + G + 1];
@@ -1010,11 +1036,17 @@ static int shard_build(nnd_shard_s *s, const float *x_local_dev, void *x_stream,
             note_bytes(s, b0);
         }
         if (it < 64) s->info.offer_records[it] = n_sent;
-        {
+        {   // the second half of the sampling: a section of its own since round 6 -- it is what the gather above runs beside
             section_timer sec(s);
             const int ts = t_begin(h);
             S_CTX(nnd_launch_sample_finish(h, s->in_t, (const uint32_t *)s->in_k, n_in));
             t_end(h, ts, ms_s, true);
+            if (G > 1 && it < 64 && (gather_async || serial)) s->info.gather_section[it] = s->info.n_sections;  // (the index this section gets)
+            sec.end();
+        }
+        if (gather_async) S_HIP(hipStreamWaitEvent(st, s->ev_g1, 0));  // thresholds and ids of the rows owned elsewhere are in place
+        {
+            section_timer sec(s);
             // (3) local join of the owned vertices
             S_CTX(nnd_zero_counters(h));
             // (rows of more than 64 neighbours: join_blocks sub-steps as in the one-GPU build, capi.hip auto_join_blocks -- the

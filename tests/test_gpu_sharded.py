@@ -549,3 +549,22 @@ def test_comm_self_test_moves_bytes_between_every_pair_of_ranks(world):
     errs = [lib.nnd_comm_last_error(grp[r]._h).decode() for r in range(world) if rcs[r] != 0]
     grp.close()
     assert rcs == [0] * world, errs
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_threshold_and_id_gather_on_the_second_channel_builds_the_same_graph(world):
+    """Round 6: the per-iteration all-gather of thresholds / neighbour ids (what a rank needs of the rows owned elsewhere for its
+    join's threshold and membership tests, utils.py:484-492 across processes) runs on the SECOND channel, beside the offer exchange
+    and the second half of the sampling.  NND_FLAG_TEST_GATHER_INLINE puts it back on the build's channel in front of them (rounds
+    3-5): the two orders must build the same graph, and the info block must say which one ran."""
+    x = clustered(40000, 32, 8, 64, seed=12)
+    xd = torch.from_numpy(x).cuda()
+    a_idx, a_dist, a_info = _run_local(xd, world, "euclidean", 15, n_trees=6, seed=5)
+    b_idx, b_dist, b_info = _run_local(xd, world, "euclidean", 15, n_trees=6, seed=5, flags=_capi.NND_FLAG_TEST_GATHER_INLINE)
+    assert a_info[0]["iters"] == b_info[0]["iters"] and a_info[0]["c"] == b_info[0]["c"]
+    assert torch.equal(a_idx, b_idx) and torch.equal(a_dist, b_dist)
+    it = a_info[0]["iters"]
+    assert all(g > 0 for g in a_info[0]["gather_bytes"][:it]) and a_info[0]["gather_bytes"][:it] == b_info[0]["gather_bytes"][:it]
+    assert all(s >= 0 for s in a_info[0]["gather_section"][:it]), a_info[0]["gather_section"]  # beside a compute section
+    assert all(s == -1 for s in b_info[0]["gather_section"][:it])
+    assert a_info[0]["bytes_sent"] == b_info[0]["bytes_sent"]

@@ -83,6 +83,22 @@ def main():
     egress = 7.0 * args.link_gbs * 1e9
     n_exch = int((byt.max(0) > 0).sum())
     exch_ms = float((byt.max(0) / egress).sum() * 1e3 + n_exch * args.latency_us * 1e-3)
+    # round 6: the threshold / neighbour-id gather of every iteration runs on the second channel beside the offer exchange and the
+    # second half of the sampling (section gather_section[i], timed apart in serial mode); what it exceeds them by is exposed
+    gth = np.array([i.get("gather_bytes", []) + [0] * 64 for i in infos])[:, :64].max(0)
+    gsec = infos[0].get("gather_section", [])
+    gather_inline_ms = gather_exposed_ms = 0.0
+    for i, gs in enumerate(gsec):
+        if gth[i] <= 0:
+            continue
+        g_ms = gth[i] / egress * 1e3 + args.latency_us * 1e-3
+        gather_inline_ms += g_ms
+        if gs >= 1 and gs < ns:
+            beside = float(sec.max(0)[gs]) + float(byt.max(0)[gs - 1] / egress * 1e3)  # the section + the offer exchange in front of it
+            gather_exposed_ms += max(0.0, g_ms - beside)
+        else:
+            gather_exposed_ms += g_ms
+    exch_ms += gather_exposed_ms
     # the point-set all-gather is not attached to a section.  Forest by cell: it runs on the second channel beside the first
     # n_sections_overlap sections (own rows + sample only) and the exchanges between them; what it exceeds them by is exposed
     allgather_bytes = (n - max(sizes)) * args.dim * 4  # received per rank; ring / direct: each link carries 1/7 of it
@@ -126,6 +142,7 @@ def main():
         "sections_min_ms": [round(float(v), 2) for v in sec.min(0)],
         "exchange_bytes_max_per_rank": [int(v) for v in byt.max(0)],
         "modelled_exchange_ms": round(exch_ms, 2),
+        "gather_ms_if_inline": round(gather_inline_ms, 2), "gather_exposed_ms": round(gather_exposed_ms, 2),
         "modelled_allgather_ms": round(allgather_full_ms, 2),
         "allgather_exposed_ms": round(allgather_ms, 2),
         "sections_beside_the_allgather": nov,
