@@ -94,8 +94,9 @@ def main():
         g_ms = gth[i] / egress * 1e3 + args.latency_us * 1e-3
         gather_inline_ms += g_ms
         if gs >= 1 and gs < ns:
-            beside = float(sec.max(0)[gs]) + float(byt.max(0)[gs - 1] / egress * 1e3)  # the section + the offer exchange in front of it
-            gather_exposed_ms += max(0.0, g_ms - beside)
+            # beside the SECTION only: the offer exchange in front of it runs at the same time too, but over the same links -- the
+            # bytes of both have to pass, so no credit is taken for that part of the overlap
+            gather_exposed_ms += max(0.0, g_ms - float(sec.max(0)[gs]))
         else:
             gather_exposed_ms += g_ms
     exch_ms += gather_exposed_ms
