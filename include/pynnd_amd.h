@@ -41,7 +41,7 @@ extern "C" {
 #define NND_METRIC_SQEUCLIDEAN 0 /* reference distances.py:63  squared_euclidean  */
 #define NND_METRIC_ALT_COSINE 1  /* reference distances.py:583 alternative_cosine */
 
-#define NND_ABI_VERSION 6 /* 6 (round 6): nnd_stats grew join_substeps[] at its end; nnd_host_alloc / nnd_host_free; 5: nnd_search_graph / nnd_search_graph_fetch */
+#define NND_ABI_VERSION 6 /* 6 (round 6): nnd_stats grew join_substeps[] and nnd_shard_info grew gather_bytes[] / gather_section[] at their ends; nnd_host_alloc / nnd_host_free; 5: nnd_search_graph / nnd_search_graph_fetch */
 
 typedef struct nnd_handle_s *nnd_handle_t;
 
