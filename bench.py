@@ -25,6 +25,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying, besides t
                          (+ oracle_recall_at_10: the CPU oracle on the same points and rows, outside the timed region)
   value_class_api      : wall time of the drop-in call itself, pynndescent_amd.NNDescent(x, ...).neighbor_graph (SURVEY 8d's metric)
   workload_k30         : the same points with the reference's default n_neighbors = 30 (+ oracle_recall_at_10, as above)
+  workload_c3 / _c5    : BASELINE configs[2] / configs[4] stand-ins (+ oracle_recall_at_10; _c5: + the graph diversification / prune pass)
   roofline.build       : whole-build algorithmic bytes (SURVEY 8d model with the measured counts) / wall time vs 8 TB/s
   recall_at_10         : recall vs exact brute force on a sample of points (reference-test convention)
 
@@ -137,7 +138,7 @@ def gather_rows(x, world):
     return torch.cat([o[:c] for o, c in zip(out, cnts)], dim=0).to(x.device)
 
 
-def other_config(_capi, name, device, local_rank):
+def other_config(_capi, name, device, local_rank, oracle=None, oracle_threads=64):
     """BASELINE configs[2] / configs[4] stand-ins (SURVEY 8d C3' / C5'): build time (device resident, best of 2 after a
     warm-up), recall@10 against exact cosine search, and for C5' the graph diversification / prune pass."""
     n, d, latent, seed, k, n_trees = {"c3": (1_200_000, 100, 24, 2, 15, 12), "c5": (290_000, 256, 32, 4, 15, 11)}[name]
@@ -181,14 +182,25 @@ def other_config(_capi, name, device, local_rank):
                  "what": "diversify + reverse diversify + union + degree prune + binarise (pynndescent_.py:1451-1611) on the device, on the handle "
                          "that built the graph: device arrays in, ONE device-to-host copy of the CSR pattern out (incl. the numpy / scipy wrap)"}
     b.close()
-    rows = torch.from_numpy(np.random.RandomState(0).choice(n, 1000, replace=False)).to(device)
-    rec = recall_at(exact_knn_cosine(x, rows, 10), oi[rows], 10)
+    rows_np = np.random.RandomState(0).choice(n, 1000, replace=False)
+    rows = torch.from_numpy(rows_np).to(device)
+    true10 = exact_knn_cosine(x, rows, 10)
+    rec = recall_at(true10, oi[rows], 10)
+    leg = None
+    if oracle is not None:  # the reference algorithm (CPU oracle) on the same points, recall on the same rows: outside every timed region
+        t1 = time.perf_counter()
+        oidx, _ = oracle.build_index(x.cpu().numpy(), "cosine", n_neighbors=k, n_trees=n_trees, random_state=1234, n_threads=oracle_threads, kind="fast")
+        leg = {"oracle_recall_at_10": round(float(oracle.recall(true10.cpu().numpy(), oidx[rows_np])), 4),
+               "oracle_seconds": round(time.perf_counter() - t1, 1), "oracle_threads": oracle_threads}
+        leg["recall_gap_to_oracle"] = round(rec - leg["oracle_recall_at_10"], 4)
     out = {"workload": {"c3": "BASELINE configs[2] stand-in (GloVe-like, SURVEY 8d C3'): %dx%d float32 cosine k=%d n_trees=%d",
                         "c5": "BASELINE configs[4] stand-in (NYTimes-like, SURVEY 8d C5'): %dx%d float32 cosine k=%d n_trees=%d + "
                               "graph diversification / prune pass"}[name] % (n, d, k, n_trees),
            "value": round(n / best, 1), "ms_per_step": round(best * 1e3, 3), "iters": st["n_iters_run"], "recall_at_10": round(rec, 4),
            "stage_ms": {"forest": round(st["ms_forest"], 3), "leaf_init": round(st["ms_leaf_init"], 3), "join": round(sum(st["ms_join"]), 3),
                         "sample": round(sum(st["ms_sample"]), 3), "merge": round(sum(st["ms_merge"]), 3), "finalize": round(st["ms_finalize"], 3)}}
+    if leg is not None:
+        out.update(leg)
     if name == "c5":
         from pynndescent_amd.search_graph import build_search_graph
 
@@ -776,8 +788,12 @@ def run(args, world, rank, local_rank, share_gpu, wd):
         if world == 1 and not args.no_extras and args.latent == 16 and args.data is None:
             builder.close()  # (its HBM is not needed any more; the other configurations get the GPU to themselves)
             _capi.load_library().nnd_release_pending()
-            c3 = other_config(_capi, "c3", device, local_rank)
-            c5 = other_config(_capi, "c5", device, local_rank)
+            orc = None
+            if not args.no_cpu_baseline:
+                from oracle import oracle as orc  # test infrastructure: the oracle legs only (outside every timed region)
+            othr = min(os.cpu_count() or 1, 256)
+            c3 = other_config(_capi, "c3", device, local_rank, orc, othr)
+            c5 = other_config(_capi, "c5", device, local_rank, orc, othr)
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O  # test infrastructure: the cpu_baseline leg only
 
