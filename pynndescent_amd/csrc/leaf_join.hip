@@ -21,7 +21,7 @@
 #include "state.h"
 
 #ifndef NND_LEAF_QW_OCC
-#define NND_LEAF_QW_OCC 7
+#define NND_LEAF_QW_OCC 6  // waves per SIMD of the 4-wave class: 80 VGPRs, no spills (7: 72 VGPRs with 7 spilled -- 0.1 GB of scratch traffic per tree and 2-5 % slower)
 #endif
 template <int NT, int NW, int DC, bool QW = false>
 struct leaf_cfg {
@@ -745,6 +745,8 @@ static int run_leaf_rounds(nnd_ctx *ctx, const int32_t *perm, const int32_t *d_w
             hipLaunchKernelGGL((k_leaf_join<4, 4, 64, true>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS, 0);
 #ifdef NND_LEAF_EMPTY_L  // timing experiment: what do the workgroups that leave at once cost?
             hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 1000);
+#elif defined(NND_LEAF_L_NW4)  // experiment: the large class with four waves too
+            hipLaunchKernelGGL((k_leaf_join<5, 4, 64, true>), grid, dim3(256), 0, ctx->stream, LEAF_ARGS, 64);
 #else
             hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 64);
 #endif
