@@ -737,7 +737,7 @@ static int run_leaf_rounds(nnd_ctx *ctx, const int32_t *perm, const int32_t *d_w
         else if (maxlen <= 80 && qw) {  // the default leaf_size (<= 75 points) with k <= 16
             // Two size classes, two launches over the tree's leaf table (a workgroup whose leaf belongs to the other class
             // leaves at once): leaves of <= 64 points -- 85 % of the leaves, 3/4 of the points -- get FOUR waves and 21 KB of LDS,
-            // so that 7 of them are in flight per CU instead of 4.  The kernel is bound by exposed latency, not by a pipe
+            // so that 6 of them are in flight per CU instead of 4.  The kernel is bound by exposed latency, not by a pipe
             // (profiles/r06_leaf_occupancy.log: 375 / 425 / 535 us per tree with 4 / 3 / 2 workgroups per CU).
 #ifdef NND_LEAF_ONE_CLASS
             hipLaunchKernelGGL((k_leaf_join<5, 8, 64, true>), grid, dim3(512), 0, ctx->stream, LEAF_ARGS, 0);
