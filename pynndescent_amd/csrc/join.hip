@@ -457,8 +457,14 @@ static int launch_join16_ks(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
 // the lists -- `new` rows from slots [new_off, new_off + 64), `old` rows from [old_off, old_off + 64) of a vertex's cstride slots;
 // SKIP_TRI leaves the new x new triangle out (the passes that meet a `new` block a second time, and the pass whose "old" block is
 // the second block of new candidates: every pair of the reference's join exactly once, pynndescent_.py:228-258).
-template <int MCP, int DC, bool SHARD, bool BLOCKED = false, bool SKIP_TRI = false>
-__global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_join_w(const float *__restrict__ xp, int dp,
+// ASEL >= 0 (round 6): the launch computes ONE tile row of new candidates (rows [16 ASEL, 16 ASEL + 16)) against its column tiles
+// and is followed by a launch for the other row(s): 4 + 3 tiles instead of 7 per wave -- 16 accumulator and 32 operand registers
+// a lane instead of 32 + 64 -- so that more waves are resident; a vertex with no candidate in the tile row is passed over.
+#ifndef NND_JW_WAVES_SPLIT
+#define NND_JW_WAVES_SPLIT 4
+#endif
+template <int MCP, int DC, bool SHARD, bool BLOCKED = false, bool SKIP_TRI = false, int ASEL = -1>
+__global__ __launch_bounds__(256, MCP == 32 ? (ASEL >= 0 ? NND_JW_WAVES_SPLIT : NND_JW_WAVES) : 2) void k_local_join_w(const float *__restrict__ xp, int dp,
                                                                        const float *__restrict__ nrm, int metric,
                                                                        const int32_t *__restrict__ cand,
                                                                        const int32_t *__restrict__ order, int64_t v_begin,
@@ -543,11 +549,16 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
     auto tile_live = [&](int t, int nn, int no) __attribute__((always_inline)) -> bool {
         return t < NA ? 16 * t < nn : 16 * (t - NA) < no;
     };
+    constexpr int A_LO = ASEL >= 0 ? ASEL : 0;        // first tile row of new candidates this launch computes
+    constexpr int NEW_MIN = 16 * A_LO;                // a vertex joins in this launch when it has more new candidates than this
+    auto tile_needed = [&](int t) __attribute__((always_inline)) -> bool {  // as an operand of this launch
+        return ASEL < 0 || t == ASEL || t >= (SKIP_TRI ? NA : ASEL);
+    };
     // rows of K block [c0, c0 + cw) of the vertex whose ids are in cb[]; empty slots read row 0 (cache hit, masked later)
     auto load_rows_into = [&](f32x4 (&dst)[NB][NT], const int32_t *cb, int c0, int cw, int nn, int no) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < NB; t++) {
-            if (!tile_live(t, nn, no)) continue;
+            if (!tile_needed(t) || !tile_live(t, nn, no)) continue;
             const int id = cb[16 * t + r16];
             const float *pr = xp + (int64_t)(id >= 0 ? id : 0) * dp + c0 + 4 * gq;
 #pragma unroll
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
     auto issue_gather = [&](int buf) __attribute__((always_inline)) {
         const int32_t *cb = cidbuf + buf * RV;
         const int cnt = nnewbuf[buf], nn = cnt & 255, no = cnt >> 8;
-        if (nn == 0) return;  // wave-uniform: no new candidate, no join (utils.py:611-613)
+        if (nn <= NEW_MIN) return;  // wave-uniform: no new candidate (in this launch's tile row), no join (utils.py:611-613)
         load_rows(cb, 0, dp < DC ? dp : DC, nn, no);
 #pragma unroll
         for (int u = 0; u < RPL; u++) {
@@ -644,7 +655,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
         for (int a = 0; a < NA; a++)
 #pragma unroll
             for (int b = 0; b < NB; b++) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (nn > 0) {
+        if (nn > NEW_MIN) {
             land_gather();
             nnd_wave_lds_sync();
             // K blocks, double-buffered in registers: the rows of block c + 1 are requested BEFORE the MFMAs of block c (rounds 1-5
@@ -653,7 +664,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
             auto gram_block = [&](const f32x4 (&r)[NB][NT], int c0, int cw) __attribute__((always_inline)) {
 #pragma unroll
                 for (int a = 0; a < NA; a++) {
-                    if (!tile_live(a, nn, no)) continue;
+                    if ((ASEL >= 0 && a != ASEL) || !tile_live(a, nn, no)) continue;
 #pragma unroll
                     for (int b = SKIP_TRI ? NA : a; b < NB; b++) {  // new x new from the diagonal tile up, then new x old
                         if (!tile_live(b, nn, no)) continue;
@@ -673,6 +684,15 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
                 const int cw = (dp - c0) < DC ? (dp - c0) : DC;
                 const int c1 = c0 + DC, cw1 = (dp - c1) < DC ? (dp - c1) : DC;
 #ifndef NND_JW_NO_PIPELINE
+                if constexpr (ASEL >= 0) {  // one register set: the point of the split launches is the register count
+                    if (c0 > 0) load_rows_into(rt, cid, c0, cw, nn, no);
+                    gram_block(rt, c0, cw);
+                    if (c1 < dp) {
+                        load_rows_into(rt, cid, c1, cw1, nn, no);
+                        gram_block(rt, c1, cw1);
+                    }
+                    continue;
+                }
                 if (c1 < dp) load_rows_into(rt2, cid, c1, cw1, nn, no);
                 gram_block(rt, c0, cw);
                 if (c1 < dp) {
@@ -691,10 +711,10 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
         }
         // the row registers are free: the gather of this wave's next vertex flies during the epilogue
         if (g + stride < n_v) issue_gather(cur ^ 1);
-        if (nn > 0) {
+        if (nn > NEW_MIN) {
 #pragma unroll
             for (int a = 0; a < NA; a++) {
-                if (!tile_live(a, nn, no)) continue;
+                if ((ASEL >= 0 && a != ASEL) || !tile_live(a, nn, no)) continue;
                 int pid4[4];
                 float pn4[4], pth4[4];
 #pragma unroll
@@ -737,9 +757,9 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
             for (int u = 0; u < RPL; u++) {
                 const int r = lane + 64 * u;
                 if (cflag[r]) pdirty[cid[r]] = 1;
-                tot_rows += cid[r] >= 0;
+                if (ASEL <= 0) tot_rows += cid[r] >= 0;  // (a vertex's rows and the vertex itself are counted by its first launch)
             }
-            if (lane == 0) tot_act += 1;
+            if (ASEL <= 0 && lane == 0) tot_act += 1;
         }
         nnd_wave_lds_sync();
         store_cand(cur, c2);
@@ -763,12 +783,12 @@ __global__ __launch_bounds__(256, MCP == 32 ? NND_JW_WAVES : 2) void k_local_joi
     }
 }
 
-template <int MCP, int DC, bool SHARD, bool BLOCKED = false, bool SKIP_TRI = false>
+template <int MCP, int DC, bool SHARD, bool BLOCKED = false, bool SKIP_TRI = false, int ASEL = -1>
 static int launch_join_w_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end, int cstride = 0, int new_off = 0, int old_off = 0) {
     constexpr int RV = 2 * MCP;
     constexpr int WAVE_BYTES = 512 * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + 8;
     size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
-    auto kern = k_local_join_w<MCP, DC, SHARD, BLOCKED, SKIP_TRI>;
+    auto kern = k_local_join_w<MCP, DC, SHARD, BLOCKED, SKIP_TRI, ASEL>;
     // function attributes and occupancy are per DEVICE: cached per device ordinal, not per process
     static int wg_per_cu_dev[64] = {0}, n_cu_dev[64] = {0};
     int &wg_per_cu = wg_per_cu_dev[ctx->p.device & 63], &n_cu = n_cu_dev[ctx->p.device & 63];
@@ -799,6 +819,16 @@ static int launch_join_w_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end, int cst
 
 template <int MCP, int DC>
 static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
+#ifdef NND_JW_SPLIT  // two launches, one tile row of new candidates each (k_local_join_w, ASEL)
+    if (MCP == 32) {
+        if (ctx->pbuf_r) {
+            if (launch_join_w_t<MCP, DC, true, false, false, 0>(ctx, v_begin, v_end)) return 1;
+            return launch_join_w_t<MCP, DC, true, false, false, 1>(ctx, v_begin, v_end);
+        }
+        if (launch_join_w_t<MCP, DC, false, false, false, 0>(ctx, v_begin, v_end)) return 1;
+        return launch_join_w_t<MCP, DC, false, false, false, 1>(ctx, v_begin, v_end);
+    }
+#endif
     return ctx->pbuf_r ? launch_join_w_t<MCP, DC, true>(ctx, v_begin, v_end) : launch_join_w_t<MCP, DC, false>(ctx, v_begin, v_end);
 }
 
