@@ -68,7 +68,11 @@ def test_forest_partitions(metric, n, d, k, T):
 
 
 @pytest.mark.parametrize("metric,n,d,k,T", [("euclidean", 4000, 32, 15, 3), ("cosine", 2500, 20, 10, 2),
-                                            ("euclidean", 1002, 5, 30, 2), ("euclidean", 1500, 130, 12, 2)])
+                                            ("euclidean", 1002, 5, 30, 2), ("euclidean", 1500, 130, 12, 2),
+                                            # round 6: the sorting-network merges at their edges -- k = 16 (every lane of a 16-lane row
+                                            # holds an entry), k = 17 / 20 / 32 (k_leaf_join_sym: both size classes, all 32 lanes), k = 8
+                                            ("euclidean", 5000, 40, 16, 3), ("euclidean", 3000, 16, 17, 2), ("cosine", 3000, 24, 20, 2),
+                                            ("euclidean", 6000, 32, 30, 3), ("euclidean", 4000, 24, 32, 2), ("cosine", 2000, 12, 8, 3)])
 def test_leaf_init_is_exact_topk_of_leafmates(metric, n, d, k, T):
     """After init_from_leaves every row must hold exactly the k nearest of the point's leaf-mates
     (what sequential checked_flagged_heap_push over all leaf pairs produces, pynndescent_.py:73-185)."""
