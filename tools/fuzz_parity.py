@@ -55,6 +55,20 @@ def main(count, seed):
             # routes a stuck graph gets; recall then moves by several percent from run to run on BOTH sides
             tol = 0.08 if (n_trees == 1 or n < 1000) else 0.03
             ok = abs(rg - ro) <= tol
+            if not ok:
+                # a stuck graph's recall has a standard deviation of 0.03-0.04 over build seeds on EITHER side (tools/fuzz_replay.py,
+                # profiles/r06_fuzz_replay60.log: one 0.93 vs 0.81 pair, means over 60 seeds 0.9346 vs 0.9304): a single pair beyond
+                # the tolerance is re-drawn 16 times and the MEANS are compared
+                from tools.fuzz_replay import gpu as gpu_build
+                gs, os_ = [], []
+                for q in range(16):
+                    s2 = s + 7919 * (q + 1)
+                    gi, lv, rst, emc2, nit2, _ = gpu_build(x, cfg, s2, 0)
+                    oi2, _ = O.nn_descent(x, k, rst.copy(), emc2, metric, nit2, 0.001, lv, n_threads=8)
+                    gs.append(O.recall(ti, gi)); os_.append(O.recall(ti, oi2))
+                ok = abs(float(np.mean(gs)) - float(np.mean(os_))) <= 0.03
+                print("     re-drawn over 16 seeds: gpu mean %.4f (sd %.4f)  oracle mean %.4f (sd %.4f)" % (
+                    np.mean(gs), np.std(gs), np.mean(os_), np.std(os_)))
             filled = idx >= 0
             big = np.where(filled, dist, np.inf)
             ok &= bool(np.all(big[:, 1:] >= big[:, :-1]))
