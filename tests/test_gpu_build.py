@@ -179,6 +179,16 @@ def test_leaf_size_larger_than_n(metric):
         assert set(idx[r].tolist()) <= set(range(10)) and len(set(idx[r].tolist())) == 9
 
 
+def test_tiny_inputs_every_k_up_to_n_plus_2():
+    """n = 1 .. 40 against every k in {1, 2, 3, n - 1, n, n + 2} (both metrics, d = 1 / 3 / 32): every row holds min(k, n) distinct
+    points in ascending order, or the call is refused up front with a message (tools/tiny_sizes.py)."""
+    from tools.tiny_sizes import run
+
+    n_ok, bad = run(verbose=False)
+    print("tiny inputs: %d builds ok, %d failures" % (n_ok, bad))
+    assert bad == 0 and n_ok > 300
+
+
 def test_bad_data_smoke_wide_rows():
     """tests/test_pynndescent_.py:750-756: 1011 x 3500, cosine, defaults (k=30)."""
     arr = np.load(os.path.join(GOLDEN, "reference_testdata_bad_data.npz"))["arr_0"]
