@@ -189,6 +189,14 @@ def test_tiny_inputs_every_k_up_to_n_plus_2():
     assert bad == 0 and n_ok > 300
 
 
+def test_builds_from_several_threads_equal_the_builds_made_alone():
+    """SURVEY 8b "re-entrant across independent handles": four Python threads build three indexes each at the same time on one device
+    (different sizes, metrics, k); every graph equals, bit for bit, the one the same call returns alone (tools/threads.py)."""
+    from tools.threads import run
+
+    assert run(4, 3, verbose=True) == 0
+
+
 def test_bad_data_smoke_wide_rows():
     """tests/test_pynndescent_.py:750-756: 1011 x 3500, cosine, defaults (k=30)."""
     arr = np.load(os.path.join(GOLDEN, "reference_testdata_bad_data.npz"))["arr_0"]
