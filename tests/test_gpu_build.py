@@ -207,6 +207,42 @@ def test_bad_data_smoke_wide_rows():
     _parity(data, "cosine", 30, idx, oidx, band=0.01)
 
 
+def test_random_state_none():
+    """tests/test_pynndescent_.py:261-276: random_state=None (a fresh global-RNG seed per call), positional metric_kwds and
+    n_neighbors: at least 99 % of the true 10 neighbours."""
+    x = nn_data_like()
+    idx, _ = NNDescent(x, "euclidean", {}, 10, random_state=None)._neighbor_graph
+    ti, _ = O.brute_force_knn(x, 10, "euclidean")
+    assert O.recall(ti, idx) >= 0.99
+    idx2, _ = NNDescent(x, "euclidean", {}, 10, random_state=None)._neighbor_graph
+    assert O.recall(ti, idx2) >= 0.99
+
+
+def test_no_output_when_verbose_is_false(capsys):
+    """tests/test_pynndescent_.py:390-405 on the reference's spatial_data shape (10 random rows + 2 zero rows x 20)."""
+    rs = np.random.RandomState(42)
+    x = np.vstack([rs.standard_normal((10, 20)), np.zeros((2, 20))]).astype(np.float32, order="C")
+    NNDescent(data=x, metric="euclidean", metric_kwds={}, n_neighbors=4, random_state=np.random.RandomState(7), n_trees=5, n_iters=2,
+              verbose=False)
+    assert capsys.readouterr().out.strip() == ""
+
+
+def test_one_dimensional_data():
+    """tests/test_pynndescent_.py:687-713 (the euclidean case): one column, tree_init=False, random_state=None, k = 20; prepare() and
+    query(k=10, epsilon=0.2) reach 95 % of the true neighbours."""
+    x = nn_data_like()
+    nnd = NNDescent(x[200:, :1], metric="euclidean", n_neighbors=20, random_state=None, tree_init=False)
+    nnd.prepare()
+    qi, _ = nnd.query(x[:200, :1], k=10, epsilon=0.2)
+    base = x[200:, :1].astype(np.float64)
+    d = np.abs(x[:200, :1].astype(np.float64) - base.T)
+    ti = np.argsort(d, axis=1, kind="stable")[:, :10]
+    # ties (duplicate coordinates, the two zero rows) count by DISTANCE: a returned point as close as the 10th true one is correct
+    kth = np.take_along_axis(d, ti[:, 9:10], axis=1)
+    got = np.take_along_axis(d, np.where(qi >= 0, qi, 0), axis=1)
+    assert ((got <= kth + 1e-12) & (qi >= 0)).sum() / (200 * 10) >= 0.95
+
+
 def test_init_graph_and_errors():
     x = clustered(1200, 10, 4, 6, seed=23)
     ti, _ = O.brute_force_knn(x, 10, "euclidean")
