@@ -109,6 +109,10 @@ typedef struct nnd_params {
 /* test hook (row-sharded build): the per-iteration threshold / neighbour-id all-gather on the BUILD's channel, in front of the offer
  * exchange (rounds 3-5), where it would run on the second channel beside the sampling: same graph either way (tests/test_gpu_sharded.py) */
 #define NND_FLAG_TEST_GATHER_INLINE 8192
+/* test hook: the local join of 17..32 candidates per class (k_local_join_w) reads the neighbour lists of its membership tests from
+ * global memory (rounds 3-5) where it would stage them in LDS (round 6, rows of <= 32 neighbours on one GPU): the two forms must
+ * build the same graph, entry for entry (tests/test_gpu_kernels.py) */
+#define NND_FLAG_TEST_JOIN_UNSTAGED 16384
 
 /* Run-time statistics for measurement (bench.py roofline). */
 typedef struct nnd_stats {

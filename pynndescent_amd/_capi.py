@@ -28,6 +28,7 @@ NND_FLAG_TEST_VANISH = 128  # ... or returns there without telling anybody (a ki
 NND_FLAG_TEST_FOREST_FALLBACK_TOPS = 512  # test hook (sharded build): a rank reports that the by-cell forest cannot be built (at the tops)
 NND_FLAG_TEST_FOREST_FALLBACK_SHARE = 1024  # ... at the owners' shares; both flags: at the over-long cells
 NND_FLAG_TEST_GATHER_INLINE = 8192  # test hook (sharded build): the id / threshold gather on the build's channel instead of the second one
+NND_FLAG_TEST_JOIN_UNSTAGED = 16384  # test hook: k_local_join_w with the membership lists read from global memory instead of staged in LDS
 NND_FLAG_TEST_SELECT_HALF = 4096  # test hook: the fused selection with 32 lanes per vertex where 16 would do (k <= 16, max_candidates <= 16)
 NND_FLAG_TEST_SAMPLE_NOMEM = 2048  # test hook: the sampler's record regions "cannot be allocated": the handle must fall back to the hashed slots
 NND_FLAG_TEST_SAMPLE_ATOMIC = 256  # test hook: reverse offers by one global atomicMin per edge (rounds 1-4) instead of the bucketed transposition

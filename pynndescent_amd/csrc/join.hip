@@ -451,7 +451,13 @@ static int launch_join16_ks(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
 #define NND_JW_WAVES 3
 #endif
 #ifndef NND_JW_DCW
-#define NND_JW_DCW 32
+#define NND_JW_DCW 16  // floats per K block, rows of >= 128 floats (round 6: 32 -> 16: no spilled register at three waves per SIMD; k = 30 join 18.4 -> 16.5 ms)
+#endif
+#ifndef NND_JW_DC
+#define NND_JW_DC 16   // ... narrower rows (32 -> 16: 14.7 -> 12.7 ms at d = 64, 16.6 -> 14.6 at d = 96, k = 30)
+#endif
+#ifndef NND_JW64_DC
+#define NND_JW64_DC 32 // ... the 64-slot kernel (max_candidates 33..64 and the blocked passes; 16: the same time)
 #endif
 // BLOCKED (max_candidates 65..128, candidate lists of [new(128) | old(128)] slots): the MCP = 64 kernel run over 64-slot blocks of
 // the lists -- `new` rows from slots [new_off, new_off + 64), `old` rows from [old_off, old_off + 64) of a vertex's cstride slots;
@@ -463,7 +469,25 @@ static int launch_join16_ks(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
 #ifndef NND_JW_WAVES_SPLIT
 #define NND_JW_WAVES_SPLIT 4
 #endif
-template <int MCP, int DC, bool SHARD, bool BLOCKED = false, bool SKIP_TRI = false, int ASEL = -1>
+// KL (round 6; MCP = 32, rows of <= 32 neighbours, one GPU): the neighbour lists of the vertex's 64 candidates ARE staged -- 8 KB a
+// wave, written by LDS-DMA (global_load_lds: no register on the way) when the vertex's ids land, i.e. before its MFMA phase, and
+// read by the membership tests of the drains after it.  The queue shrinks to 384 entries (a drain still takes full waves) so
+// that three workgroups keep fitting a CU: 12.8 KB a wave (the launcher checks the occupancy and falls back to the unstaged form).  Without it a drain step waits for two dependent list reads from L2.
+#ifndef NND_JW_KL_QCAP
+#define NND_JW_KL_QCAP 384  // 320: 18.9 ms, 384: 18.4, 416: 18.3 (k = 30 join at 1 M points); 448 no longer fits three workgroups a CU: 30 ms
+#endif
+template <bool KL>
+struct join_w_lds {
+    static constexpr int QCAP = KL ? NND_JW_KL_QCAP : 512;
+    static constexpr int KL_BYTES = KL ? 64 * 128 : 0;
+    static constexpr int wave_bytes(int RV) { return KL_BYTES + QCAP * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + 8; }
+};
+__device__ __forceinline__ void nnd_glds16(const void *src, void *lds_dst_wave_uniform) {  // 16 bytes per lane: LDS[dst + 16 lane] <- *src
+    const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dst_wave_uniform);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)src,
+                                     (__attribute__((address_space(3))) void *)off, 16, 0, 0);
+}
+template <int MCP, int DC, bool SHARD, bool BLOCKED = false, bool SKIP_TRI = false, int ASEL = -1, bool KL = false>
 __global__ __launch_bounds__(256, MCP == 32 ? (ASEL >= 0 ? NND_JW_WAVES_SPLIT : NND_JW_WAVES) : 2) void k_local_join_w(const float *__restrict__ xp, int dp,
                                                                        const float *__restrict__ nrm, int metric,
                                                                        const int32_t *__restrict__ cand,
@@ -479,13 +503,15 @@ __global__ __launch_bounds__(256, MCP == 32 ? (ASEL >= 0 ? NND_JW_WAVES_SPLIT : 
     constexpr int NA = MCP / 16, NB = 2 * NA, RV = 2 * MCP;
     constexpr int NT = DC / 16;                       // 16-byte chunks per lane, row and K block
     constexpr int RPL = RV / 64;                      // candidate slots per lane (1 or 2)
-    constexpr int QCAP = 512;
-    constexpr int WAVE_BYTES = QCAP * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + 8;
+    static_assert(!KL || (MCP == 32 && !SHARD && !BLOCKED && ASEL < 0), "staged neighbour lists: the plain 32-slot kernel only");
+    constexpr int QCAP = join_w_lds<KL>::QCAP;
+    constexpr int WAVE_BYTES = join_w_lds<KL>::wave_bytes(RV);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = nnd_lane(), w = tid >> 6;
     unsigned char *mine = smem + (size_t)w * ((WAVE_BYTES + 15) & ~15);
-    uint2 *queue = (uint2 *)mine;                       // QCAP
+    uint32_t *klist = (uint32_t *)mine;                 // KL: 64 rows x 32 words (row r at r * 128 bytes; rows of 16 words use the first half)
+    uint2 *queue = (uint2 *)(mine + join_w_lds<KL>::KL_BYTES);  // QCAP
     int32_t *cidbuf = (int32_t *)(queue + QCAP);        // 2 * RV
     int32_t *nnewbuf = cidbuf + 2 * RV;                 // 2
     int32_t *cid = nnewbuf + 2;                         // RV
@@ -608,6 +634,32 @@ __global__ __launch_bounds__(256, MCP == 32 ? (ASEL >= 0 ? NND_JW_WAVES_SPLIT : 
         }
         return present;
     };
+    // KL: the lists of the candidates in slots [0, nn) and [MCP, MCP + no), requested when the ids have landed: instruction i
+    // brings rows 8 i .. 8 i + 7 (lane = 8 * row + chunk), 1 KB of LDS each; lanes of empty slots / chunks beyond the row stay off
+    auto issue_lists = [&](int nn, int no) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (int i = 0; i < 8; i++) {  // (rolled: eight address pairs at once would be spilled -- the operand registers are live here)
+            if (!(8 * i < MCP ? 8 * i < nn : 8 * i - MCP < no)) continue;  // wave-uniform
+            const int row = 8 * i + (lane >> 3), c = lane & 7;
+            const int id = cid[row];
+            if (id >= 0 && c < kq) nnd_glds16(knn_e + (int64_t)id * ks + 4 * c, klist + i * 256);
+        }
+    };
+    auto list_has_lds = [&](int row, uint32_t id) __attribute__((always_inline)) -> bool {
+        const u32x4 *kl = (const u32x4 *)(klist + row * 32);
+        bool present = false;
+        for (int h = 0; h < kq; h += 4) {  // four chunks at a time (registers); rows start on different chunks (bank conflicts)
+            u32x4 wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) wv[j] = kl[h + ((j + row) & 3)];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32x4 m = wv[j] & NND_IDX_MASK;
+                present |= (m.x == id) | (m.y == id) | (m.z == id) | (m.w == id);
+            }
+        }
+        return present;
+    };
     int tot_pairs = 0, tot_prop = 0, tot_rows = 0, tot_act = 0, tot_tiles = 0;
     int qn = 0;
     auto drain = [&]() __attribute__((always_inline)) {
@@ -619,12 +671,12 @@ __global__ __launch_bounds__(256, MCP == 32 ? (ASEL >= 0 ? NND_JW_WAVES_SPLIT : 
                 const int a = en.x & 63, b = (en.x >> 6) & 127;
                 const float d = __uint_as_float(en.y);
                 const int pid = cid[a], qid = cid[b];
-                if ((en.x & (1u << 13)) && !list_has(pid, (uint32_t)qid)) {  // p <- q
+                if ((en.x & (1u << 13)) && !(KL ? list_has_lds(a, (uint32_t)qid) : list_has(pid, (uint32_t)qid))) {  // p <- q
                     atomicMin(prop_slot(pid, cslot[b]), (unsigned long long)nnd_make_key(d, (uint32_t)qid));
                     cflag[a] = 1;
                     tot_prop++;
                 }
-                if ((en.x & (1u << 14)) && !list_has(qid, (uint32_t)pid)) {  // q <- p
+                if ((en.x & (1u << 14)) && !(KL ? list_has_lds(b, (uint32_t)pid) : list_has(qid, (uint32_t)pid))) {  // q <- p
                     atomicMin(prop_slot(qid, cslot[a]), (unsigned long long)nnd_make_key(d, (uint32_t)pid));
                     cflag[b] = 1;
                     tot_prop++;
@@ -658,6 +710,7 @@ __global__ __launch_bounds__(256, MCP == 32 ? (ASEL >= 0 ? NND_JW_WAVES_SPLIT : 
         if (nn > NEW_MIN) {
             land_gather();
             nnd_wave_lds_sync();
+            if constexpr (KL) issue_lists(nn, no);  // in flight during the MFMA phase
             // K blocks, double-buffered in registers: the rows of block c + 1 are requested BEFORE the MFMAs of block c (rounds 1-5
             // fetched them "in turn": three exposed gather latencies per vertex at d = 128 with 32-float blocks, and a wave is
             // one of twelve on its CU)
@@ -710,6 +763,11 @@ __global__ __launch_bounds__(256, MCP == 32 ? (ASEL >= 0 ? NND_JW_WAVES_SPLIT : 
             }
         }
         // the row registers are free: the gather of this wave's next vertex flies during the epilogue
+        if constexpr (KL) {
+            // the lists were requested before the MFMA phase: they have landed (or nearly); waiting HERE, before the next vertex's
+            // gather is issued, keeps that gather out of the wait
+            if (nn > NEW_MIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (g + stride < n_v) issue_gather(cur ^ 1);
         if (nn > NEW_MIN) {
 #pragma unroll
@@ -783,12 +841,12 @@ __global__ __launch_bounds__(256, MCP == 32 ? (ASEL >= 0 ? NND_JW_WAVES_SPLIT : 
     }
 }
 
-template <int MCP, int DC, bool SHARD, bool BLOCKED = false, bool SKIP_TRI = false, int ASEL = -1>
+template <int MCP, int DC, bool SHARD, bool BLOCKED = false, bool SKIP_TRI = false, int ASEL = -1, bool KL = false>
 static int launch_join_w_t(nnd_ctx *ctx, int64_t v_begin, int64_t v_end, int cstride = 0, int new_off = 0, int old_off = 0) {
     constexpr int RV = 2 * MCP;
-    constexpr int WAVE_BYTES = 512 * 8 + 2 * RV * 4 + 2 * 4 + 5 * RV * 4 + 8;
+    constexpr int WAVE_BYTES = join_w_lds<KL>::wave_bytes(RV);
     size_t smem = 4 * (size_t)((WAVE_BYTES + 15) & ~15);
-    auto kern = k_local_join_w<MCP, DC, SHARD, BLOCKED, SKIP_TRI, ASEL>;
+    auto kern = k_local_join_w<MCP, DC, SHARD, BLOCKED, SKIP_TRI, ASEL, KL>;
     // function attributes and occupancy are per DEVICE: cached per device ordinal, not per process
     static int wg_per_cu_dev[64] = {0}, n_cu_dev[64] = {0};
     int &wg_per_cu = wg_per_cu_dev[ctx->p.device & 63], &n_cu = n_cu_dev[ctx->p.device & 63];
@@ -829,6 +887,27 @@ static int launch_join_w(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
         return launch_join_w_t<MCP, DC, false, false, false, 1>(ctx, v_begin, v_end);
     }
 #endif
+#ifndef NND_JW_NO_LDS_LISTS
+    if constexpr (MCP == 32) {  // rows of <= 32 neighbours on one GPU: the candidates' neighbour lists are staged in LDS (k_local_join_w, KL)
+        if (!ctx->pbuf_r && ctx->ks <= 32 && nnd_list_lo(ctx) <= 0 && nnd_list_hi(ctx) >= ctx->n && !(ctx->p.flags & NND_FLAG_TEST_JOIN_UNSTAGED)) {
+            // ... as long as three workgroups of it fit a CU (LDS): with two the kernel is 60 % slower than the unstaged form
+            static int kl_ok_dev[64] = {0};  // 0 unknown, 1 yes, -1 no (per device ordinal)
+            int &kl_ok = kl_ok_dev[ctx->p.device & 63];
+            if (kl_ok == 0) {
+                constexpr size_t smem = 4 * (size_t)((join_w_lds<true>::wave_bytes(2 * MCP) + 15) & ~15);
+                auto kern = k_local_join_w<MCP, DC, false, false, false, -1, true>;
+                int occ = 0;
+                if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, 256, smem) != hipSuccess) {
+                    (void)hipGetLastError();
+                    occ = 0;
+                }
+                kl_ok = occ >= 3 ? 1 : -1;
+            }
+            if (kl_ok > 0) return launch_join_w_t<MCP, DC, false, false, false, -1, true>(ctx, v_begin, v_end);
+        }
+    }
+#endif
     return ctx->pbuf_r ? launch_join_w_t<MCP, DC, true>(ctx, v_begin, v_end) : launch_join_w_t<MCP, DC, false>(ctx, v_begin, v_end);
 }
 
@@ -852,8 +931,8 @@ int nnd_launch_join(nnd_ctx *ctx, int64_t v_begin, int64_t v_end) {
 #define NND_J16_DCW 64
 #endif
         case 16: return wide ? launch_join16_ks<NND_J16_DCW>(ctx, v_begin, v_end) : launch_join16_ks<32>(ctx, v_begin, v_end);
-        case 32: return wide ? launch_join_w<32, NND_JW_DCW>(ctx, v_begin, v_end) : launch_join_w<32, 32>(ctx, v_begin, v_end);
-        case 64: return launch_join_w<64, 32>(ctx, v_begin, v_end);
+        case 32: return wide ? launch_join_w<32, NND_JW_DCW>(ctx, v_begin, v_end) : launch_join_w<32, NND_JW_DC>(ctx, v_begin, v_end);
+        case 64: return launch_join_w<64, NND_JW64_DC>(ctx, v_begin, v_end);
         case 128: return ctx->pbuf_r ? launch_join_blocked<true>(ctx, v_begin, v_end) : launch_join_blocked<false>(ctx, v_begin, v_end);
     }
     ctx->set_error("unsupported padded max_candidates %d", ctx->mcp);

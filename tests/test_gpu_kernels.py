@@ -483,6 +483,30 @@ def test_half_wave_select_equals_wave_select(k, mc):
     assert has_new.any()
 
 
+@pytest.mark.parametrize("metric,n,d,k,mc", [("euclidean", 40000, 128, 30, 30), ("cosine", 25000, 64, 20, 20), ("euclidean", 30000, 33, 16, 32),
+                                             ("euclidean", 20000, 100, 32, 17)])
+def test_join_with_staged_neighbour_lists_equals_the_unstaged_join(metric, n, d, k, mc):
+    """Round 6: k_local_join_w (17..32 candidates per class) stages the neighbour lists of a vertex's candidates in LDS by LDS-DMA
+    when rows hold <= 32 neighbours; NND_FLAG_TEST_JOIN_UNSTAGED keeps the membership tests on global memory (rounds 3-5).  The
+    proposals that leave a join are the same set either way, so whole builds are identical, entry for entry."""
+    from pynndescent_amd import _capi
+
+    x = clustered(n, d, 8, 30, seed=21)
+    outs = []
+    for flags in (0, _capi.NND_FLAG_TEST_JOIN_UNSTAGED):
+        b = make_builder(x, metric, k=k, n_trees=4, mc=mc, flags=flags, join_blocks=0)
+        b.make_forest()
+        b.init_from_leaves()
+        b.init_random()
+        cs = [b.descent_iter() for _ in range(4)]
+        idx, dist, fl = b.graph()
+        outs.append((np.asarray(cs), idx, dist, fl))
+        b.close()
+    assert outs[0][0][0] > 0
+    for a, c in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, c)
+
+
 @pytest.mark.parametrize("metric,n,d,T", [("euclidean", 300000, 128, 8), ("cosine", 200000, 100, 5), ("euclidean", 180000, 40, 12)])
 def test_coherent_routing_equals_plain_walk(metric, n, d, T):
     """The two-pass routing of the forest (top levels from LDS -> counting sort by bucket -> the bucket's subtree from
